@@ -1,0 +1,195 @@
+"""Pin the CPU oracle to the reference: every committed golden vector
+(tests/golden/*.npz, produced by importing /root/reference -- make_golden.py)
+must be reproduced by the restatement in oracle/.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub, rel_err, assert_grads_close
+from oracle import cnn, intops, mcep, augment
+
+TOL = 2e-5     # fp32, same torch build: restatement vs reference modules
+
+
+def _block_ids():
+    g = load_golden("ir_blocks.npz")
+    return sorted({k.split("/")[0] for k in g})
+
+
+@pytest.mark.parametrize("bid", _block_ids())
+def test_inverted_residual_eval_train_grads(bid):
+    g = load_golden("ir_blocks.npz")
+    cin, cout, k, s, res, B, T = (int(v) for v in g[bid + "/cfg"])
+    state = sub(g, bid + "/state/")
+    state = {"blk." + key: v for key, v in state.items()}
+    x = torch.from_numpy(g[bid + "/x"])
+    y = cnn.inverted_residual(x, state, "blk", k, s, bool(res), training=False)
+    assert rel_err(y, g[bid + "/y_eval"]) < TOL
+    # train mode: output, input grad, every parameter grad, running-stat updates
+    params = {key: v.clone().requires_grad_(True) for key, v in state.items()
+              if key.endswith("weight") or key.endswith("bias")}
+    st = dict(state); st.update(params)
+    xg = x.clone().requires_grad_(True)
+    upd = cnn.BNUpdates()
+    yt = cnn.inverted_residual(xg, st, "blk", k, s, bool(res), training=True, updates=upd)
+    assert rel_err(yt, g[bid + "/y_train"]) < TOL
+    (yt * torch.from_numpy(g[bid + "/gy"])).sum().backward()
+    assert rel_err(xg.grad, g[bid + "/gx"]) < 1e-4
+    assert_grads_close({key: p.grad for key, p in params.items()},
+                       {key: g[bid + "/grad/" + key[len("blk."):]] for key in params}, 2e-4)
+    for key, v in upd.items():
+        ref = g[bid + "/after/" + key[len("blk."):]]
+        assert rel_err(v, ref) < TOL, key
+
+
+def test_asr_tiny_logits_tokens_loss_grads():
+    g = load_golden("asr_tiny.npz")
+    state = sub(g, "state/")
+    audio = torch.from_numpy(g["audio"])
+    logits = cnn.audio_to_text_ctc_forward(audio, state, training=False)
+    assert rel_err(logits, g["logits_eval"]) < TOL
+    assert np.array_equal(logits.argmax(-1).numpy(), g["argmax_eval"])          # token ids: bit-exact
+    assert np.array_equal(cnn.encoder_output_length(torch.from_numpy(g["audio_len"])).numpy(), g["output_length"])
+    params = {k: v.clone().requires_grad_(True) for k, v in state.items()
+              if v.dtype.is_floating_point and "running" not in k}
+    st = dict(state); st.update(params)
+    upd = cnn.BNUpdates()
+    batch = ((audio, torch.from_numpy(g["audio_len"])), (torch.from_numpy(g["text"]), torch.from_numpy(g["text_len"])))
+    loss = cnn.audio_to_text_ctc_loss(batch, st, training=True, updates=upd)
+    assert abs(float(loss.detach()) - float(g["loss_train"])) < 1e-4 * abs(float(g["loss_train"]))
+    loss.backward()
+    assert_grads_close({k: p.grad for k, p in params.items()}, {k: g["grad/" + k] for k in params}, 2e-4)
+    for k, v in upd.items():
+        assert rel_err(v, g["after/" + k]) < TOL, k
+
+
+def test_asr_c1_full_size_seeded_init():
+    """BASELINE config 1: the oracle re-creates the full-size weights from
+    torch.manual_seed(1234) using stock nn layers in the reference's construction
+    order, checks the stored checksums, then must match the stored logits."""
+    g = load_golden("asr_c1.npz")
+    state = _seeded_asr_state(1234)
+    sums = np.array([float(v.double().sum()) for v in state.values() if v.dtype.is_floating_point])
+    if not np.allclose(sums, g["weight_sums"], rtol=0, atol=1e-9):
+        pytest.skip("torch RNG/init differs from the build container: seeded weights not reproducible here")
+    logits = cnn.audio_to_text_ctc_forward(torch.from_numpy(g["audio"]), state, training=False)
+    assert rel_err(logits, g["logits"]) < TOL
+    assert np.array_equal(logits.argmax(-1).numpy(), g["argmax"])
+
+
+def _seeded_asr_state(seed, audio_size=64, embed=512, vocab=29, hidden=512):
+    """Stock torch layers created in the order the reference creates them
+    (asr.py:45-53, 67-76, 89-91) so the default init consumes the RNG identically."""
+    from torch import nn
+    torch.manual_seed(seed)
+    state = {}
+    for i, (cin, cout, k, s, res) in enumerate(cnn.encoder_block_specs(audio_size, embed, hidden)):
+        hid = cin * 4
+        pre = f"encoder.layers.{i}.conv"
+        mods = [("0.0", nn.Conv1d(cin, hid, 1, bias=False)), ("0.1", nn.BatchNorm1d(hid)),
+                ("1.0", nn.Conv1d(hid, hid, k, stride=s, padding=(k - 1) // 2, groups=hid, bias=False)),
+                ("1.1", nn.BatchNorm1d(hid)), ("2", nn.Conv1d(hid, cout, 1, bias=False)), ("3", nn.BatchNorm1d(cout))]
+        for name, m in mods:
+            for key, v in m.state_dict().items():
+                state[f"{pre}.{name}.{key}"] = v
+    dec = nn.Conv1d(embed, vocab, 1, bias=True)
+    state["decoder.layers.1.weight"] = dec.weight.detach()
+    state["decoder.layers.1.bias"] = dec.bias.detach()
+    return {k: v.detach() for k, v in state.items()}
+
+
+@pytest.mark.parametrize("name,use_mcep", [("tts_tiny_logspc.npz", False), ("tts_tiny_mcep.npz", True)])
+def test_tts_audio_model(name, use_mcep):
+    g = load_golden(name)
+    state = sub(g, "state/")
+    at = torch.from_numpy(g["aligntext"])
+    fwd = cnn.align_text_to_audio_forward(at, state)
+    for v, key in zip(fwd, ("hasf0_logits", "f0_hat", "logspc_hat", "codeap_hat")):
+        assert v.shape == g["fwd/" + key].shape
+        assert rel_err(v, g["fwd/" + key]) < TOL, key
+    pred = cnn.align_text_to_audio_predict(at, state)
+    for v, key in zip(pred, ("f0", "logspc", "codeap")):
+        assert rel_err(v, g["predict/" + key]) < TOL, key
+    assert np.array_equal(pred[0].numpy() == 0, g["predict/f0"] == 0)           # F0 gating: exact
+    params = {k: v.clone().requires_grad_(True) for k, v in state.items()
+              if v.dtype.is_floating_point and "running" not in k and not k.startswith("norm.")}
+    st = dict(state); st.update(params)
+    batch = ((torch.from_numpy(g["target/f0"]), torch.from_numpy(g["target/f0_len"]),
+              torch.from_numpy(g["target/logspc"]), torch.from_numpy(g["target/codeap"])), (at, None))
+    losses = cnn.align_text_to_audio_loss(batch, st, use_mcep=use_mcep, training=True)
+    assert np.allclose(np.array([float(v.detach()) for v in losses]), g["losses_train"], rtol=1e-4)
+    sum(losses).backward()
+    assert_grads_close({k: p.grad for k, p in params.items()}, {k: g["grad/" + k] for k in params}, 2e-4)
+
+
+def test_align_model_and_integer_expansion():
+    g = load_golden("align_tiny.npz")
+    state = sub(g, "state/")
+    text = torch.from_numpy(g["text"])
+    assert rel_err(cnn.text_to_align_text_forward(text, state), g["pred_eval"]) < TOL
+    params = {k: v.clone().requires_grad_(True) for k, v in state.items()
+              if v.dtype.is_floating_point and "running" not in k}
+    st = dict(state); st.update(params)
+    batch = ((text, torch.from_numpy(g["text_len"])), (torch.from_numpy(g["align"]), torch.from_numpy(g["align_len"])))
+    loss = cnn.text_to_align_text_loss(batch, st, training=True)
+    assert abs(float(loss.detach()) - float(g["loss_train"])) < 1e-4 * abs(float(g["loss_train"]))
+    loss.backward()
+    assert_grads_close({k: p.grad for k, p in params.items()}, {k: g["grad/" + k] for k in params}, 2e-4)
+    for n in range(3):
+        got = intops.expand_align(g[f"align_case{n}/text"], g[f"align_case{n}/align"])
+        assert np.array_equal(got, g[f"align_case{n}/aligntext"])               # bit-exact
+
+
+def test_conv_transpose_golden():
+    g = load_golden("convtranspose.npz")
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    w = torch.from_numpy(g["weight"]).requires_grad_(True)
+    b = torch.from_numpy(g["bias"]).requires_grad_(True)
+    y = torch.nn.functional.conv_transpose1d(x, w, b, stride=2, padding=2)
+    assert y.shape[-1] == 2 * x.shape[-1] - 1
+    assert rel_err(y, g["y"]) < TOL
+    (y * torch.from_numpy(g["gy"])).sum().backward()
+    assert rel_err(x.grad, g["gx"]) < 1e-4 and rel_err(w.grad, g["gw"]) < 1e-4 and rel_err(b.grad, g["gb"]) < 1e-4
+
+
+def test_integer_tables_and_ctc_best_path():
+    g = load_golden("int_tables.npz")
+    assert np.array_equal(intops.output_length(g["output_length/in"]), g["output_length/out"])
+    assert np.array_equal(intops.padding_mask(9, g["padding_mask/len"]), g["padding_mask/mask"])
+    for n in range(3):
+        score, path, best = intops.ctc_best_path(g[f"ctc{n}/logits"], g[f"ctc{n}/labels"])
+        assert np.array_equal(path, g[f"ctc{n}/path"])
+        assert np.array_equal(best, g[f"ctc{n}/best_labels"])
+        assert np.isclose(score, g[f"ctc{n}/score"], rtol=1e-6)
+
+
+def test_mcep_matrices():
+    g = load_golden("mcep.npz")
+    # goldens carry float32 rounding from numpy>=2 irfft(float32) (see oracle/mcep.py)
+    assert np.abs(mcep.sp2mc_matrix(512, 24, 0.410) - g["sp2mc_16k"]).max() < 2e-7
+    assert np.abs(mcep.mc2sp_matrix(512, 24, 0.410) - g["mc2sp_16k"]).max() < 1e-9
+    assert np.abs(mcep.sp2mc_matrix(1024, 34, 0.455) - g["sp2mc_22k"]).max() < 2e-7
+    assert np.abs(mcep.mc2sp_matrix(1024, 34, 0.455) - g["mc2sp_22k"]).max() < 1e-9
+    with pytest.raises(ValueError):
+        mcep.vocoder_constants(8000)
+
+
+def test_augment_ops():
+    g = load_golden("augment.npz")
+    audio = torch.from_numpy(g["audio"]); alen = torch.from_numpy(g["audio_len"])
+    for n in range(3):
+        a, l = augment.timestretch(audio, alen, int(g[f"timestretch{n}/rate"]))
+        assert np.array_equal(a.numpy(), g[f"timestretch{n}/audio"]) and np.array_equal(l.numpy(), g[f"timestretch{n}/len"])
+    for n in range(2):
+        assert np.array_equal(augment.pitchshift(audio, float(g[f"pitchshift{n}/rate"])).numpy(), g[f"pitchshift{n}/audio"])
+    assert np.array_equal(augment.ampshift(audio, float(g["ampshift/rate"])).numpy(), g["ampshift/audio"])
+    for n in range(3):
+        spans = [(int(t), int(hw), float(a)) for t, hw, a in g[f"timemask{n}/spans"]]
+        assert np.array_equal(augment.timemask(audio, spans).numpy(), g[f"timemask{n}/audio"])
+        t, hw, a = g[f"freqmask{n}/params"]
+        assert np.array_equal(augment.freqmask(audio, int(t), int(hw), float(a)).numpy(), g[f"freqmask{n}/audio"])
+    low, high, std = (float(v) for v in g["mixnoise/params"])
+    got = augment.mixnoise(audio, low, high, std, torch.from_numpy(g["mixnoise/uniform"]))
+    assert rel_err(got, g["mixnoise/audio"]) < 1e-6
+    assert rel_err(augment.mixaudio(audio, alen), g["mixaudio/audio"]) < 1e-6
+    assert rel_err(augment.maskaudio(audio, alen), g["maskaudio/audio"]) < 1e-6
