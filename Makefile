@@ -1,0 +1,29 @@
+# Build the MI355X (gfx950) shared library of the Voice100 hot path and the CPU oracle helpers.
+#   make            -> voice100_amd/libvoice100_hip.so  (+ oracle/_build/libconv_ref.so)
+# No torch, no cmake: plain hipcc; the .so travels to the GPU box with the snapshot.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := voice100_amd/csrc
+OBJD  := build/obj
+SRCS  := $(wildcard $(CSRC)/*.hip)
+OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJD)/%.o,$(SRCS))
+LIB   := voice100_amd/libvoice100_hip.so
+HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wno-unused-result
+
+all: $(LIB) oracle
+
+$(OBJD)/%.o: $(CSRC)/%.hip $(CSRC)/common.h
+	@mkdir -p $(OBJD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

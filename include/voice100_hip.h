@@ -1,0 +1,119 @@
+/* voice100_hip.h -- C ABI of libvoice100_hip.so: the MI355X (gfx950) kernels behind the
+ * Voice100 non-autoregressive CNN hot path.
+ *
+ * The reference (kaiidams/voice100 v1.6.0) has no FFI of its own: the path is plain
+ * torch.nn modules.  Each entry point below therefore cites the
+ * reference call it stands in for; voice100_amd/ (Python, ctypes) mirrors the reference's
+ * module interface on top of these.  INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd / torch CUDA tensor storage), 16-byte
+ *     aligned, contiguous; activations are fp32 [B][C][T] unless stated otherwise;
+ *   - no allocation, no host synchronisation inside: outputs and workspaces ("stats",
+ *     "partial") are caller-allocated, `stream` is a hipStream_t (NULL = default stream);
+ *   - return value: 0 = launched; 1 = invalid/unsupported shape or mode; 2 = launch error;
+ *     3 = a required pointer is NULL.  The Python layer raises RuntimeError on != 0;
+ *   - re-entrant, no global state; one stream per process is the intended use.
+ */
+#ifndef VOICE100_HIP_H
+#define VOICE100_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- input-transform modes shared by the depthwise and pointwise kernels ------------------
+ *   0 NONE            v
+ *   1 AFFINE_RELU6    clamp(v*a[c] + b[c], 0, 6)      BatchNorm affine + ReLU6 of the producer
+ *                                                      (asr.py:36-37) applied on load
+ *   2 AFFINE2         a[c]*v + b[c]*v2 + c[c]         BatchNorm backward applied on load       */
+
+/* ---- K2 depthwise -------------------------------------------------------------------------
+ * y[b,c,t] = sum_j w[c][flip ? K-1-j : j] * in[b,c, t*stride - pad + j], zero padded, `in` being the
+ * transformed (and, for upsample U > 1, zero-stuffed by U) input.
+ * Replaces nn.Conv1d(groups=C) of ConvBNActivate, voice100/models/asr.py:31-35,49 (forward) and its
+ * autograd backward-data (flip=1, pad=K-1-pad; strided layers: stride=1, upsample=S).
+ * out_mode: 0 raw + stats(sum y, sum y^2)   1 clamp(y*out_a+out_b,0,6)  (eval-mode BN+ReLU6 folded)
+ *           2 y *= [0 < aux*out_a+out_b < 6] + stats(sum y, sum y*aux) (ReLU6 backward)   3 raw
+ * stats: [G][C][2] slab, G = v100_dw_num_groups(B, C). */
+int v100_dw_num_groups(int B, int C);
+int v100_dwconv(const float* x, const float* x2, const float* w, const float* in_a, const float* in_b,
+                const float* in_c, int in_mode, float* y, const float* aux, const float* out_a,
+                const float* out_b, int out_mode, float* stats, int G, int B, int C, int Tin, int Tout,
+                int K, int stride, int pad, int flip, int upsample, int force_generic, void* stream);
+
+/* dw[c][j] = sum_{b,t} g'[b,c,t] * x'[b,c, t*stride - pad + j]; g' / x' are g / x after g_mode / x_mode.
+ * Replaces the weight gradient of the same nn.Conv1d(groups=C).  partial: [G][C][K] workspace. */
+int v100_dwconv_wgrad(const float* g, const float* g2, const float* ga, const float* gb, const float* gc,
+                      int g_mode, const float* x, const float* xa, const float* xb, int x_mode,
+                      float* partial, float* dw, int G, int B, int C, int Tin, int Tout, int K, int stride,
+                      int pad, int force_generic, void* stream);
+
+/* ---- K1 pointwise (1x1 conv as GEMM on MFMA) ----------------------------------------------
+ * Y[b][m][t] = epilogue( sum_k A[m][k] * x'[b][k][t] (+ bias[m]) )
+ * Replaces nn.Conv1d(kernel_size=1): asr.py:47 (pw), :51 (pw-linear), :91 (LinearCharDecoder),
+ * tts.py:26,77 (heads); with A = W^T it is their backward-data.
+ * epi_mode: 0 store   1 store + stats(sum, sum^2)   2 clamp(y*ea+eb,0,6)   3 y*ea+eb (+R)
+ *           4 y *= [0 < R*ea+eb < 6] + stats(sum y, sum y*R)   5 y + R
+ * stats: [v100_pw_num_parts(B,T)][M][2].  use_bf16: operands rounded to bf16 (A_bf16 = bf16 copy of A),
+ * fp32 accumulate; 0 = exact fp32 MFMA. */
+int v100_pw_num_parts(int B, int T);
+int v100_pw_gemm(const float* A, const void* A_bf16, const float* X, const float* X2, const float* xa,
+                 const float* xb, const float* xc, int x_mode, float* Y, const float* bias, const float* ea,
+                 const float* eb, const float* R, int epi_mode, float* stats, int B, int M, int K, int T,
+                 int use_bf16, void* stream);
+
+/* dW[m][k] = sum_{b,t} g'[b][m][t] * x'[b][k][t]   (weight gradient of the same 1x1 conv).
+ * partial: [S][M][K] workspace, S = v100_pw_wgrad_splits(B, M, K). */
+int v100_pw_wgrad_splits(int B, int M, int K);
+int v100_pw_wgrad(const float* G, const float* G2, const float* ga, const float* gb, const float* gc, int g_mode,
+                  const float* X, const float* xa, const float* xb, int x_mode, float* partial, float* dW,
+                  int S, int B, int M, int K, int T, int use_bf16, void* stream);
+
+/* fp32 [rows][cols] weight -> optional bf16 copy, transposed fp32 copy, transposed bf16 copy. */
+int v100_weight_prep(const float* w, int rows, int cols, void* w_bf16, float* wt, void* wt_bf16, void* stream);
+
+/* ---- K3 BatchNorm1d (asr.py:36,52; eps 1e-5, momentum 0.1) ----------------------------------
+ * finalize_train: slab of (sum x, sum x^2) -> scale = gamma*rstd, shift = beta - mean*scale, saved
+ * mean/rstd, running stats (unbiased variance) and num_batches_tracked updated in place. */
+int v100_bn_finalize_train(const float* stats, int parts, long long count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                           float eps, float* scale, float* shift, float* save_mean, float* save_rstd, int C, void* stream);
+/* eval: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean*scale */
+int v100_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, float* scale, float* shift, int C, void* stream);
+/* backward: slab of (sum dz, sum dz*a) -> da = p*dz + q*a + r coefficients, dgamma, dbeta */
+int v100_bn_bwd_finalize(const float* partial, int parts, long long count, const float* gamma, const float* mean,
+                         const float* rstd, float* p, float* q, float* r, float* dgamma, float* dbeta, int C, void* stream);
+
+/* ---- per-channel elementwise / layout glue --------------------------------------------------*/
+/* partial[g][c] = (sum u, sum u*v) over (b in group g, t); v NULL -> sum u*u */
+int v100_chan_reduce2(const float* u, const float* v, float* partial, int G, int B, int C, int T, void* stream);
+int v100_slab_sum0(const float* partial, int parts, float* out, int C, void* stream);
+/* out = A[c]*u + Bc[c]*v + Cc[c]  (block output y = BN3(a3) + x, asr.py:55-59; BN3 backward) */
+int v100_chan_affine2(const float* u, const float* v, const float* A, const float* Bc, const float* Cc, float* out,
+                      int B, int C, int T, void* stream);
+/* out = u*m*s  (nn.Dropout(0.2) with a pre-drawn keep mask, asr.py:90) */
+int v100_mul_scale(const float* u, const float* m, float s, float* out, long long n, void* stream);
+/* [B][R][Cc] -> [B][Cc][R]  (torch.transpose(x,1,2) at the model edges, asr.py:111,114; tts.py:177,179) */
+int v100_transpose_last2(const float* in, float* out, int B, int R, int Cc, void* stream);
+/* out[b][c][t] = table[idx[b][t]][c]  (nn.Embedding + transpose, tts.py:81-83,176-177) and its backward */
+int v100_embedding_bct(const long long* idx, const float* table, float* out, int B, int V, int C, int T, void* stream);
+int v100_embedding_bwd(const long long* idx, const float* g, float* dtable, int B, int V, int C, int T, void* stream);
+
+
+/* ---- K8 log-mel batch augmentation ---------------------------------------------------------
+ * All of BatchSpectrogramAugumentation.forward (voice100/audio.py:27-108) in one pass over
+ * x [B][Tin][F] -> y [B][Tout][F]; the random decisions are drawn by the caller in the reference's
+ * order and passed as numbers (0 / 0.f = that op is off).  tm_s / tm_e / tm_a are HOST arrays of
+ * n_tmask (<= 3) normalised [start, end) time spans and fill values; len = int32 lengths after the
+ * stretch (device).  mix: 1 = mixaudio, 0 = maskaudio (one of the two always runs, audio.py:46-49). */
+int v100_augment_fused(const float* x, const int* len, const float* uniform, float* y, int B, int Tin, int Tout,
+                       int F, int stretch_rate, float pitch_rate, float amp, int n_tmask, const int* tm_s,
+                       const int* tm_e, const float* tm_a, int fm_on, int fm_s, int fm_e, float fm_a, int noise_on,
+                       float noise_low, float noise_high, float noise_std, int mix, float log_offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOICE100_HIP_H */

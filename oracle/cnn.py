@@ -85,7 +85,8 @@ def _batch_norm(x: torch.Tensor, state: State, prefix: str, training: bool,
 
 
 def relu6(x: torch.Tensor) -> torch.Tensor:
-    return torch.clamp(x, 0.0, 6.0)
+    """nn.ReLU6 = hardtanh(0, 6): gradient passes strictly inside (0, 6) (asr.py:37)."""
+    return F.relu6(x)
 
 
 def inverted_residual(x: torch.Tensor, state: State, prefix: str, kernel_size: int,

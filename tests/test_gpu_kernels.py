@@ -1,0 +1,248 @@
+"""Kernel-level parity (GPU): each C-ABI entry point against the CPU oracle / torch fp32 on
+seeded inputs.  Tolerance: <= 1e-4 relative (max-abs error / max-abs reference), fp32 paths;
+bf16 GEMM operands: <= 2e-2."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _native():
+    from voice100_amd import _native as N
+    return N
+
+
+def _dw_ref(x, w, stride, pad):
+    return F.conv1d(x, w[:, None, :], stride=stride, padding=pad, groups=x.shape[1])
+
+
+DW_CASES = [  # (B, C, T, K, stride, force_generic)
+    (3, 5, 700, 83, 1, 0), (2, 4, 1024, 59, 1, 0), (2, 3, 513, 19, 1, 0), (2, 6, 96, 11, 1, 0),
+    (2, 4, 1000, 11, 2, 0), (1, 3, 61, 11, 2, 0), (2, 3, 300, 7, 1, 0), (2, 3, 130, 13, 1, 0),
+    (2, 3, 257, 35, 1, 1), (1, 2, 40, 5, 1, 0), (4, 2, 2048, 51, 1, 0), (2, 2, 1023, 33, 1, 0),
+]
+
+
+@pytest.mark.parametrize("B,C,T,K,stride,generic", DW_CASES)
+def test_dwconv_forward_train_and_eval(cuda, B, C, T, K, stride, generic):
+    N = _native()
+    g = torch.Generator().manual_seed(K * 1000 + T)
+    x = torch.randn(B, C, T, generator=g)
+    w = torch.randn(C, K, generator=g) * 0.2
+    s = torch.rand(C, generator=g) + 0.5
+    sh = torch.randn(C, generator=g)
+    pad = (K - 1) // 2
+    h = torch.clamp(x * s[None, :, None] + sh[None, :, None], 0, 6)
+    ref = _dw_ref(h, w, stride, pad)
+    Tout = ref.shape[2]
+    G = N.helper("v100_dw_num_groups", B, C)
+    xd, wd, sd, shd = (t.to(cuda) for t in (x, w, s, sh))
+    y = torch.empty(B, C, Tout, device=cuda)
+    st = torch.zeros(G, C, 2, device=cuda)
+    N.call("v100_dwconv", xd, None, wd, sd, shd, None, 1, y, None, None, None, 0, st, G, B, C, T, Tout, K, stride, pad, 0, 1, generic)
+    assert rel_err(y, ref) < TOL
+    stats = st.sum(0).cpu()
+    assert rel_err(stats[:, 0], ref.sum((0, 2)), floor=1e-2) < 1e-3
+    assert rel_err(stats[:, 1], (ref * ref).sum((0, 2))) < 1e-4
+    # eval: plain input, folded BN + ReLU6 epilogue
+    oa, ob = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    ref2 = torch.clamp(_dw_ref(x, w, stride, pad) * oa[None, :, None] + ob[None, :, None], 0, 6)
+    y2 = torch.empty_like(y)
+    N.call("v100_dwconv", xd, None, wd, None, None, None, 0, y2, None, oa.to(cuda), ob.to(cuda), 1, None, G, B, C, T, Tout, K, stride, pad, 0, 1, generic)
+    assert rel_err(y2, ref2) < TOL
+
+
+@pytest.mark.parametrize("B,C,T,K,stride", [(2, 4, 600, 83, 1), (3, 3, 520, 27, 1), (2, 4, 1000, 11, 2), (2, 3, 77, 11, 2),
+                                           (2, 2, 90, 9, 1), (2, 3, 1023, 65, 1)])
+def test_dwconv_backward_data_and_weight(cuda, B, C, T, K, stride):
+    """The fused backward kernels against autograd through conv(relu6(bn-affine(a1))) with a BN-backward-shaped
+    incoming gradient (da2 = p*dz2 + q*a2 + r)."""
+    N = _native()
+    g = torch.Generator().manual_seed(K + T)
+    pad = (K - 1) // 2
+    a1 = torch.randn(B, C, T, generator=g) * 2
+    w = (torch.randn(C, K, generator=g) * 0.2)
+    s1, t1 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    a1g = a1.clone().requires_grad_(True)
+    wg = w.clone().requires_grad_(True)
+    h1 = torch.clamp(a1g * s1[None, :, None] + t1[None, :, None], 0, 6)
+    a2 = _dw_ref(h1, wg, stride, pad)
+    Tout = a2.shape[2]
+    dz2 = torch.randn(B, C, Tout, generator=g)
+    p, q, r = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    da2 = p[None, :, None] * dz2 + q[None, :, None] * a2.detach() + r[None, :, None]
+    a2.backward(da2)
+    pre = a1 * s1[None, :, None] + t1[None, :, None]
+    dh1_ref = a1g.grad / s1[None, :, None]           # undo the affine's chain factor: kernel returns dz1 = dh1 * mask
+    mask = ((pre > 0) & (pre < 6)).float()
+    G = N.helper("v100_dw_num_groups", B, C)
+    dev = lambda t: t.to(cuda).contiguous()
+    dz1 = torch.empty(B, C, T, device=cuda)
+    st = torch.zeros(G, C, 2, device=cuda)
+    N.call("v100_dwconv", dev(dz2), dev(a2.detach()), dev(w), dev(p), dev(q), dev(r), 2, dz1, dev(a1), dev(s1), dev(t1), 2, st, G,
+           B, C, Tout, T, K, 1, K - 1 - pad, 1, stride, 0)
+    assert rel_err(dz1, dh1_ref * mask) < TOL
+    stats = st.sum(0).cpu()
+    assert rel_err(stats[:, 0], (dh1_ref * mask).sum((0, 2)), floor=1e-2) < 1e-3
+    assert rel_err(stats[:, 1], (dh1_ref * mask * a1).sum((0, 2)), floor=1e-2) < 1e-3
+    partial = torch.empty(G, C, K, device=cuda)
+    dw = torch.empty(C, K, device=cuda)
+    N.call("v100_dwconv_wgrad", dev(dz2), dev(a2.detach()), dev(p), dev(q), dev(r), 2, dev(a1), dev(s1), dev(t1), 1, partial, dw,
+           G, B, C, T, Tout, K, stride, pad, 0)
+    assert rel_err(dw, wg.grad) < TOL
+    N.call("v100_dwconv_wgrad", dev(dz2), dev(a2.detach()), dev(p), dev(q), dev(r), 2, dev(a1), dev(s1), dev(t1), 1, partial, dw,
+           G, B, C, T, Tout, K, stride, pad, 1)
+    assert rel_err(dw, wg.grad) < TOL
+
+
+GEMM_CASES = [(2, 40, 24, 200), (3, 128, 64, 256), (1, 29, 512, 130), (2, 260, 256, 1023), (2, 256, 1024, 512), (1, 2, 8, 33)]
+
+
+@pytest.mark.parametrize("B,M,K,T", GEMM_CASES)
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_pw_gemm_modes(cuda, B, M, K, T, bf16):
+    N = _native()
+    g = torch.Generator().manual_seed(M * 7 + K)
+    tol = 2e-2 if bf16 else TOL
+    A = torch.randn(M, K, generator=g) / K ** 0.5
+    X = torch.randn(B, K, T, generator=g)
+    X2 = torch.randn(B, K, T, generator=g)
+    xa, xb, xc = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g), torch.randn(K, generator=g) * 0.1
+    ea, eb = torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g)
+    bias = torch.randn(M, generator=g)
+    R = torch.randn(B, M, T, generator=g) * 3
+    dev = lambda t: t.to(cuda).contiguous()
+    Ad = dev(A)
+    Abf = Ad.to(torch.bfloat16) if bf16 else None
+    parts = N.helper("v100_pw_num_parts", B, T)
+
+    def run(x_mode, epi, use_bias=False):
+        Y = torch.full((B, M, T), float("nan"), device=cuda)
+        st = torch.zeros(parts, M, 2, device=cuda)
+        N.call("v100_pw_gemm", Ad, Abf, dev(X), dev(X2), dev(xa), dev(xb), dev(xc), x_mode, Y, dev(bias) if use_bias else None,
+               dev(ea), dev(eb), dev(R), epi, st, B, M, K, T, bf16)
+        return Y.cpu(), st.sum(0).cpu()
+
+    xf = {0: X, 1: torch.clamp(X * xa[None, :, None] + xb[None, :, None], 0, 6),
+          2: xa[None, :, None] * X + xb[None, :, None] * X2 + xc[None, :, None]}
+    base = {m: torch.einsum("mk,bkt->bmt", A, v) for m, v in xf.items()}
+    y, _ = run(0, 0, use_bias=True)
+    assert rel_err(y, base[0] + bias[None, :, None]) < tol
+    y, st = run(1, 1)
+    assert rel_err(y, base[1]) < tol
+    assert rel_err(st[:, 0], base[1].sum((0, 2)), floor=1.0) < 10 * tol and rel_err(st[:, 1], (base[1] ** 2).sum((0, 2))) < 10 * tol
+    y, _ = run(0, 2)
+    assert rel_err(y, torch.clamp(base[0] * ea[None, :, None] + eb[None, :, None], 0, 6)) < tol
+    y, _ = run(1, 3)
+    assert rel_err(y, base[1] * ea[None, :, None] + eb[None, :, None] + R) < tol
+    y, st = run(0, 4)
+    pre = R * ea[None, :, None] + eb[None, :, None]
+    ref = base[0] * ((pre > 0) & (pre < 6)).float()
+    assert rel_err(y, ref) < tol
+    assert rel_err(st[:, 0], ref.sum((0, 2)), floor=1.0) < 10 * tol and rel_err(st[:, 1], (ref * R).sum((0, 2)), floor=1.0) < 10 * tol
+    y, _ = run(2, 5)
+    assert rel_err(y, base[2] + R) < tol
+
+
+@pytest.mark.parametrize("B,M,K,T", [(3, 40, 24, 200), (4, 256, 64, 512), (2, 29, 130, 77), (2, 130, 260, 1023)])
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_pw_wgrad(cuda, B, M, K, T, bf16):
+    N = _native()
+    g = torch.Generator().manual_seed(M + K + T)
+    tol = 2e-2 if bf16 else TOL
+    Gt = torch.randn(B, M, T, generator=g)
+    G2 = torch.randn(B, M, T, generator=g)
+    ga, gb, gc = torch.randn(M, generator=g), torch.randn(M, generator=g) * 0.2, torch.randn(M, generator=g) * 0.1
+    X = torch.randn(B, K, T, generator=g)
+    xa, xb = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    dev = lambda t: t.to(cuda).contiguous()
+    S = N.helper("v100_pw_wgrad_splits", B, M, K)
+    partial = torch.empty(S, M, K, device=cuda)
+    dW = torch.empty(M, K, device=cuda)
+    N.call("v100_pw_wgrad", dev(Gt), None, None, None, None, 0, dev(X), None, None, 0, partial, dW, S, B, M, K, T, bf16)
+    assert rel_err(dW, torch.einsum("bmt,bkt->mk", Gt, X)) < tol
+    gp = ga[None, :, None] * Gt + gb[None, :, None] * G2 + gc[None, :, None]
+    xp = torch.clamp(X * xa[None, :, None] + xb[None, :, None], 0, 6)
+    N.call("v100_pw_wgrad", dev(Gt), dev(G2), dev(ga), dev(gb), dev(gc), 2, dev(X), dev(xa), dev(xb), 1, partial, dW, S, B, M, K, T, bf16)
+    assert rel_err(dW, torch.einsum("bmt,bkt->mk", gp, xp)) < tol
+
+
+def test_bn_finalize_and_backward_coeffs(cuda):
+    N = _native()
+    g = torch.Generator().manual_seed(5)
+    B, C, T = 4, 7, 333
+    a = torch.randn(B, C, T, generator=g) * 2 + 1
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    ag = a.clone().requires_grad_(True)
+    y = bn(ag)
+    dz = torch.randn(B, C, T, generator=g)
+    y.backward(dz)
+    dev = lambda t: t.to(cuda).contiguous()
+    G = 2
+    part = torch.empty(G, C, 2, device=cuda)
+    N.call("v100_chan_reduce2", dev(a), None, part, G, B, C, T)
+    rmd, rvd, nbt = dev(rm), dev(rv), torch.zeros((), dtype=torch.int64, device=cuda)
+    sc, sh, mean, rstd = (torch.empty(C, device=cuda) for _ in range(4))
+    N.call("v100_bn_finalize_train", part, G, B * T, dev(gamma), dev(beta), rmd, rvd, nbt, 0.1, 1e-5, sc, sh, mean, rstd, C)
+    assert rel_err(dev(a) * sc[None, :, None] + sh[None, :, None], y) < TOL
+    assert rel_err(rmd, bn.running_mean) < 1e-5 and rel_err(rvd, bn.running_var) < 1e-5 and int(nbt) == 1
+    N.call("v100_chan_reduce2", dev(dz), dev(a), part, G, B, C, T)
+    p, q, r, dg, db = (torch.empty(C, device=cuda) for _ in range(5))
+    N.call("v100_bn_bwd_finalize", part, G, B * T, dev(gamma), mean, rstd, p, q, r, dg, db, C)
+    da = torch.empty(B, C, T, device=cuda)
+    N.call("v100_chan_affine2", dev(dz), dev(a), p, q, r, da, B, C, T)
+    assert rel_err(da, ag.grad) < TOL
+    assert rel_err(dg, bn.weight.grad) < TOL and rel_err(db, bn.bias.grad) < TOL
+    N.call("v100_bn_eval_coeffs", dev(gamma), dev(beta), dev(rm), dev(rv), 1e-5, sc, sh, C)
+    bn2 = torch.nn.BatchNorm1d(C).eval()
+    with torch.no_grad():
+        bn2.weight.copy_(gamma); bn2.bias.copy_(beta); bn2.running_mean.copy_(rm); bn2.running_var.copy_(rv)
+        assert rel_err(dev(a) * sc[None, :, None] + sh[None, :, None], bn2(a)) < TOL
+
+
+def test_layout_embedding_dropout(cuda):
+    from voice100_amd import functional as F_
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 101, 64, generator=g).to(cuda).requires_grad_(True)
+    y = F_.transpose_last2(x)
+    assert torch.equal(y.detach().cpu(), x.detach().cpu().transpose(1, 2))
+    gy = torch.randn(3, 64, 101, generator=g)
+    y.backward(gy.to(cuda))
+    assert torch.equal(x.grad.cpu(), gy.transpose(1, 2))
+    table = torch.randn(29, 48, generator=g).to(cuda).requires_grad_(True)
+    idx = torch.randint(0, 29, (2, 77), generator=g)
+    e = F_.embedding_bct(idx.to(cuda), table)
+    ref_t = table.detach().cpu().clone().requires_grad_(True)
+    ref = F.embedding(idx, ref_t).transpose(1, 2)
+    assert torch.equal(e.detach().cpu(), ref.detach())
+    ge = torch.randn(2, 48, 77, generator=g)
+    e.backward(ge.to(cuda)); ref.backward(ge)
+    assert rel_err(table.grad, ref_t.grad) < 1e-5
+    keep = (torch.rand(2, 8, 50, generator=g) > 0.2).float()
+    h = torch.randn(2, 8, 50, generator=g)
+    out = F_.dropout(h.to(cuda), 0.2, True, keep.to(cuda))
+    assert rel_err(out, h * keep / 0.8) < 1e-6
+
+
+def test_errors_are_loud(cuda):
+    N = _native()
+    x = torch.zeros(1, 2, 8, device=cuda)
+    with pytest.raises(RuntimeError):
+        N.call("v100_dwconv", x, None, None, None, None, None, 0, x, None, None, None, 3, None, 1, 1, 2, 8, 8, 3, 1, 1, 0, 1, 0)
+    with pytest.raises(RuntimeError):
+        N.call("v100_pw_gemm", None, None, x, None, None, None, None, 0, x, None, None, None, None, 0, None, 1, 2, 2, 8, 0)
+    with pytest.raises(RuntimeError):
+        N.call("v100_transpose_last2", torch.zeros(2, 2), torch.zeros(2, 2), 1, 2, 2)       # CPU tensors are refused
+    from voice100_amd.layers import InvertedResidual
+    with pytest.raises(RuntimeError):
+        InvertedResidual(4, 4, 5)(torch.zeros(1, 4, 16))                                     # no CPU fallback

@@ -1,0 +1,123 @@
+"""ASR side of the hot path: ConvVoiceEncoder, LinearCharDecoder, AudioToTextCTC.
+
+Drop-in for voice100/models/asr.py:62-196 -- same class names, constructor
+arguments, forward() layouts and state_dict keys -- with the convolution stacks
+running on the MI355X kernels.  pytorch_lightning is not required: the model is a
+plain nn.Module that also answers the LightningModule hooks the reference's
+trainers call (training_step / validation_step / test_step / configure_optimizers),
+see voice100_amd.trainer for the step loop that replaces `Trainer.fit`.
+"""
+from argparse import Namespace
+
+import torch
+from torch import nn
+
+from . import functional as F_
+from .audio import BatchSpectrogramAugumentation
+from .layers import InvertedResidual, PointwiseConv1d
+
+__all__ = ["ConvVoiceEncoder", "LinearCharDecoder", "AudioToTextCTC"]
+
+
+class ConvVoiceEncoder(nn.Module):
+    """9 inverted-residual blocks, k = 11 (stride 2), 19, 27, 35, 51, 59, 67, 75, 83 (asr.py:62-82)."""
+
+    def __init__(self, in_channels, out_channels, hidden_size):
+        super().__init__()
+        half = hidden_size // 2
+        spec = [  # (cin, cout, k, stride, residual)
+            (in_channels, half, 11, 2, False),
+            (half, half, 19, 1, True), (half, half, 27, 1, True), (half, half, 35, 1, True),
+            (half, hidden_size, 51, 1, False),
+            (hidden_size, hidden_size, 59, 1, True), (hidden_size, hidden_size, 67, 1, True),
+            (hidden_size, hidden_size, 75, 1, True),
+            (hidden_size, out_channels, 83, 1, False),
+        ]
+        self.layers = nn.Sequential(*[
+            InvertedResidual(ci, co, kernel_size=k, stride=s, use_residual=r) for ci, co, k, s, r in spec])
+
+    def forward(self, embed: torch.Tensor) -> torch.Tensor:
+        return self.layers(embed)
+
+    def output_length(self, embed_len: torch.Tensor) -> torch.Tensor:
+        return torch.div(embed_len + 1, 2, rounding_mode="trunc")
+
+
+class LinearCharDecoder(nn.Module):
+    """Dropout(0.2) then a biased 1x1 conv to the vocabulary (asr.py:85-94)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Dropout(0.2), PointwiseConv1d(in_channels, out_channels, bias=True))
+        self._keep_mask = None     # parity tests inject a fixed keep mask here
+
+    def forward(self, enc_out: torch.Tensor) -> torch.Tensor:
+        drop, conv = self.layers[0], self.layers[1]
+        x = F_.dropout(enc_out, drop.p, self.training, self._keep_mask)
+        return conv(x)
+
+
+class AudioToTextCTC(nn.Module):
+    """audio [B, T, audio_size] fp32 -> logits [B, (T+1)//2, vocab_size] (asr.py:97-196)."""
+
+    def __init__(self, audio_size, embed_size, vocab_size, hidden_size, learning_rate=0.001, weight_decay=0.00004):
+        super().__init__()
+        self.hparams = Namespace(audio_size=audio_size, embed_size=embed_size, vocab_size=vocab_size,
+                                 hidden_size=hidden_size, learning_rate=learning_rate, weight_decay=weight_decay)
+        self.embed_size = embed_size
+        self.encoder = ConvVoiceEncoder(audio_size, embed_size, hidden_size)
+        self.decoder = LinearCharDecoder(embed_size, vocab_size)
+        self.criterion = nn.CTCLoss(zero_infinity=True)     # K10 stays on PyTorch-ROCm
+        self.batch_augment = BatchSpectrogramAugumentation()
+        self.do_normalize = False
+
+    def forward(self, audio: torch.Tensor) -> torch.Tensor:
+        if torch.onnx.is_in_onnx_export():
+            raise RuntimeError("ONNX export needs a stock-op graph; export the reference module with this "
+                               "module's state_dict (identical keys) instead")
+        x = F_.transpose_last2(audio)            # [B,T,C] -> [B,C,T]
+        x = self.encoder(x)
+        x = self.decoder(x)
+        return F_.transpose_last2(x)             # [B,V,T'] -> [B,T',V]
+
+    def output_length(self, audio_len: torch.Tensor) -> torch.Tensor:
+        return self.encoder.output_length(audio_len)
+
+    def _calc_batch_loss(self, batch):
+        (audio, audio_len), (text, text_len) = batch
+        if self.training:
+            audio, audio_len = self.batch_augment(audio, audio_len)
+        logits = self.forward(audio)
+        logits_len = self.output_length(audio_len)
+        log_probs = nn.functional.log_softmax(torch.transpose(logits, 0, 1), dim=-1)
+        return self.criterion(log_probs, text, logits_len, text_len)
+
+    # LightningModule-style hooks the reference's trainers call (asr.py:154-178)
+    def training_step(self, batch, batch_idx=0):
+        return self._calc_batch_loss(batch)
+
+    def validation_step(self, batch, batch_idx=0):
+        return {"val_loss": self._calc_batch_loss(batch)}
+
+    def test_step(self, batch, batch_idx=0):
+        return {"test_loss": self._calc_batch_loss(batch)}
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.hparams.learning_rate,
+                                     weight_decay=self.hparams.weight_decay)
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=1, gamma=0.98)
+        return {"optimizer": optimizer, "lr_scheduler": scheduler}
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        parser = parent_parser.add_argument_group("voice100.models.asr.AudioToTextCTC")
+        parser.add_argument("--learning_rate", type=float, default=0.001)
+        parser.add_argument("--weight_decay", type=float, default=0.00004)
+        parser.add_argument("--hidden_size", type=float, default=512)    # sic: float in the reference (asr.py:185)
+        parser.add_argument("--embed_size", type=float, default=512)
+        return parent_parser
+
+    @staticmethod
+    def from_argparse_args(args, **kwargs):
+        return AudioToTextCTC(embed_size=int(args.embed_size), hidden_size=int(args.hidden_size),
+                              learning_rate=args.learning_rate, weight_decay=args.weight_decay, **kwargs)

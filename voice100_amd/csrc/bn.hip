@@ -1,0 +1,310 @@
+// K3 + glue: BatchNorm1d statistics finalisation (training), folded coefficients (eval), the
+// BatchNorm-backward reductions, and the small per-channel elementwise / layout kernels the
+// inverted-residual block needs between its GEMM and depthwise kernels.
+//
+// Reference semantics: nn.BatchNorm1d(eps=1e-5, momentum=0.1, affine, track_running_stats) as
+// instantiated at voice100/models/asr.py:36,52; batch statistics over (B, T); running_var takes
+// the unbiased batch variance; num_batches_tracked += 1 per training forward.
+//
+// The producers (pointwise.hip / depthwise.hip epilogues) leave per-channel partial sums in a
+// [parts][C][2] slab; the finalisers below reduce the slab in double (fixed order, deterministic)
+// and emit  scale = gamma * rstd,  shift = beta - mean * scale  for the consumer's prologue.
+#include "common.h"
+
+__global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int parts, double count,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         long long* __restrict__ num_batches_tracked, float momentum, float eps,
+                                         float* __restrict__ scale, float* __restrict__ shift,
+                                         float* __restrict__ save_mean, float* __restrict__ save_rstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int g = 0; g < parts; ++g) {
+        s0 += (double)stats[((size_t)g * C + c) * 2 + 0];
+        s1 += (double)stats[((size_t)g * C + c) * 2 + 1];
+    }
+    const double mean = s0 / count;
+    double var = s1 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_rstd) save_rstd[c] = rstd;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(running_var[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - running_mean[c] * sc;
+}
+
+// Backward of y = gamma * (a - mean) * rstd + beta given the slab of (sum dz, sum dz*a):
+//   dgamma = rstd * (sum dz*a - mean * sum dz),  dbeta = sum dz
+//   da = p*dz + q*a + r   with  p = gamma*rstd,  q = -gamma*rstd^2 * dgamma/n,
+//                               r = -gamma*rstd*dbeta/n - q*mean
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int parts, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, float* __restrict__ p, float* __restrict__ q,
+                                       float* __restrict__ r, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int g = 0; g < parts; ++g) {
+        s0 += (double)partial[((size_t)g * C + c) * 2 + 0];
+        s1 += (double)partial[((size_t)g * C + c) * 2 + 1];
+    }
+    const double mu = mean[c], rs = rstd[c], ga = gamma[c];
+    const double dg = rs * (s1 - mu * s0);
+    const double pp = ga * rs;
+    const double qq = -ga * rs * rs * dg / count;
+    const double rr = -pp * s0 / count - qq * mu;
+    p[c] = (float)pp;
+    q[c] = (float)qq;
+    r[c] = (float)rr;
+    if (dgamma) dgamma[c] = (float)dg;
+    if (dbeta) dbeta[c] = (float)s0;
+}
+
+// partial[g][c] = (sum u, sum u*v) over this group's batches and all t; v may be null (then sum u*u)
+__global__ __launch_bounds__(256) void chan_reduce2_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                           float* __restrict__ partial, int B, int C, int T, int G) {
+    __shared__ float red[4][2];
+    const int c = blockIdx.x, g = blockIdx.y;
+    const int bper = (B + G - 1) / G;
+    const int b0 = g * bper, b1 = min(B, b0 + bper);
+    float s0 = 0.f, s1 = 0.f;
+    const bool vec = (T & 3) == 0;
+    for (int b = b0; b < b1; ++b) {
+        const size_t ro = ((size_t)b * C + c) * T;
+        if (vec) {
+            for (int t = threadIdx.x * 4; t < T; t += 1024) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(u + ro + t);
+                const f32x4 w = v ? *reinterpret_cast<const f32x4*>(v + ro + t) : a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s0 += a[e]; s1 = fmaf(a[e], w[e], s1); }
+            }
+        } else {
+            for (int t = threadIdx.x; t < T; t += 256) {
+                const float a = u[ro + t];
+                const float w = v ? v[ro + t] : a;
+                s0 += a; s1 = fmaf(a, w, s1);
+            }
+        }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[((size_t)g * C + c) * 2 + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        partial[((size_t)g * C + c) * 2 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+// out[c] = sum_g partial[g][c][0]   (bias gradients)
+__global__ void slab_sum0_kernel(const float* __restrict__ partial, int parts, float* __restrict__ out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int g = 0; g < parts; ++g) s += (double)partial[((size_t)g * C + c) * 2];
+    out[c] = (float)s;
+}
+
+// out = A[c]*u + Bc[c]*v + Cc[c]   (v / Bc / Cc optional: missing Bc = 1, missing v or Cc = 0)
+//   forward block output:  y = scale3*a3 + shift3 (+ x)        (asr.py:55-59)
+//   backward:              da3 = p*dy + q*a3 + r
+__global__ __launch_bounds__(256) void chan_affine2_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                           const float* __restrict__ A, const float* __restrict__ Bc,
+                                                           const float* __restrict__ Cc, float* __restrict__ out,
+                                                           int C, int T, long total) {
+    const bool vec = (T & 3) == 0;
+    if (vec) {
+        const long n4 = total >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            const long e0 = i << 2;
+            const int c = (int)((e0 / T) % C);
+            const float a = A ? A[c] : 1.f, b = Bc ? Bc[c] : 1.f, cc = Cc ? Cc[c] : 0.f;
+            const f32x4 x = *reinterpret_cast<const f32x4*>(u + e0);
+            f32x4 o;
+            if (v) {
+                const f32x4 y = *reinterpret_cast<const f32x4*>(v + e0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(x[e], a, fmaf(y[e], b, cc));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(x[e], a, cc);
+            }
+            *reinterpret_cast<f32x4*>(out + e0) = o;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int c = (int)((i / T) % C);
+            const float a = A ? A[c] : 1.f, b = Bc ? Bc[c] : 1.f, cc = Cc ? Cc[c] : 0.f;
+            out[i] = fmaf(u[i], a, (v ? v[i] * b : 0.f) + cc);
+        }
+    }
+}
+
+// out = u * m * s   (inverted dropout with a pre-drawn keep mask; asr.py:90)
+__global__ void mul_scale_kernel(const float* __restrict__ u, const float* __restrict__ m, float s, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = u[i] * m[i] * s;
+}
+
+// [B][R][Cc] -> [B][Cc][R]   (model-edge layouts: asr.py:111,114; tts.py:177,179)
+__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const float* src = in + (size_t)b * R * Cc;
+    float* dst = out + (size_t)b * R * Cc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < R && c < Cc) tile[ty + 8 * i][tx] = src[(size_t)r * Cc + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < R && c < Cc) dst[(size_t)c * R + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+// K6: out[b][c][t] = table[idx[b][t]][c]   (nn.Embedding + transpose(1,2): tts.py:81-83, 176-177)
+__global__ __launch_bounds__(256) void embedding_bct_kernel(const long long* __restrict__ idx, const float* __restrict__ table,
+                                                            float* __restrict__ out, int V, int C, int T) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + 8 * i, c = c0 + tx;
+        if (t < T && c < C) {
+            long long id = idx[(size_t)b * T + t];
+            if (id < 0) id = 0;
+            if (id >= V) id = V - 1;
+            tile[ty + 8 * i][tx] = table[(size_t)id * C + c];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, t = t0 + tx;
+        if (t < T && c < C) out[((size_t)b * C + c) * T + t] = tile[tx][ty + 8 * i];
+    }
+}
+
+// d_table[idx[b][t]][c] += g[b][c][t]  (embedding backward; vocab is tiny so fp32 atomics per row)
+__global__ void embedding_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ g, float* __restrict__ dtable,
+                                     int V, int C, int T, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const int c = (int)((i / T) % C);
+        const int b = (int)(i / ((long)T * C));
+        long long id = idx[(size_t)b * T + t];
+        if (id >= 0 && id < V) atomicAdd(&dtable[(size_t)id * C + c], g[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int v100_bn_finalize_train(const float* stats, int parts, long long count, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                                      float eps, float* scale, float* shift, float* save_mean, float* save_rstd, int C, void* stream) {
+    if (!stats || !gamma || !beta || !scale || !shift) return V100_ERR_NULL;
+    if (C <= 0 || parts <= 0 || count <= 0) return V100_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, parts, (double)count,
+                       gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean, save_rstd, C);
+    return v100_launch_status();
+}
+
+extern "C" int v100_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                   float eps, float* scale, float* shift, int C, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) return V100_ERR_NULL;
+    if (C <= 0) return V100_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, eps, scale, shift, C);
+    return v100_launch_status();
+}
+
+extern "C" int v100_bn_bwd_finalize(const float* partial, int parts, long long count, const float* gamma, const float* mean,
+                                    const float* rstd, float* p, float* q, float* r, float* dgamma, float* dbeta, int C, void* stream) {
+    if (!partial || !gamma || !mean || !rstd || !p || !q || !r) return V100_ERR_NULL;
+    if (C <= 0 || parts <= 0 || count <= 0) return V100_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, partial, parts, (double)count,
+                       gamma, mean, rstd, p, q, r, dgamma, dbeta, C);
+    return v100_launch_status();
+}
+
+extern "C" int v100_chan_reduce2(const float* u, const float* v, float* partial, int G, int B, int C, int T, void* stream) {
+    if (!u || !partial) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || G > B) return V100_ERR_SHAPE;
+    hipLaunchKernelGGL(chan_reduce2_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, u, v, partial, B, C, T, G);
+    return v100_launch_status();
+}
+
+extern "C" int v100_slab_sum0(const float* partial, int parts, float* out, int C, void* stream) {
+    if (!partial || !out) return V100_ERR_NULL;
+    if (parts <= 0 || C <= 0) return V100_ERR_SHAPE;
+    hipLaunchKernelGGL(slab_sum0_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, partial, parts, out, C);
+    return v100_launch_status();
+}
+
+extern "C" int v100_chan_affine2(const float* u, const float* v, const float* A, const float* Bc, const float* Cc, float* out,
+                                 int B, int C, int T, void* stream) {
+    if (!u || !out) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || T <= 0) return V100_ERR_SHAPE;
+    const long total = (long)B * C * T;
+    long blocks = (total / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(chan_affine2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, u, v, A, Bc, Cc, out, C, T, total);
+    return v100_launch_status();
+}
+
+extern "C" int v100_mul_scale(const float* u, const float* m, float s, float* out, long long n, void* stream) {
+    if (!u || !m || !out) return V100_ERR_NULL;
+    if (n <= 0) return V100_ERR_SHAPE;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mul_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, u, m, s, out, (long)n);
+    return v100_launch_status();
+}
+
+extern "C" int v100_transpose_last2(const float* in, float* out, int B, int R, int Cc, void* stream) {
+    if (!in || !out) return V100_ERR_NULL;
+    if (B <= 0 || R <= 0 || Cc <= 0) return V100_ERR_SHAPE;
+    hipLaunchKernelGGL(transpose_last2_kernel, dim3(ceil_div(Cc, 32), ceil_div(R, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, R, Cc);
+    return v100_launch_status();
+}
+
+extern "C" int v100_embedding_bct(const long long* idx, const float* table, float* out, int B, int V, int C, int T, void* stream) {
+    if (!idx || !table || !out) return V100_ERR_NULL;
+    if (B <= 0 || V <= 0 || C <= 0 || T <= 0) return V100_ERR_SHAPE;
+    hipLaunchKernelGGL(embedding_bct_kernel, dim3(ceil_div(C, 32), ceil_div(T, 32), B), dim3(256), 0, (hipStream_t)stream, idx, table, out, V, C, T);
+    return v100_launch_status();
+}
+
+extern "C" int v100_embedding_bwd(const long long* idx, const float* g, float* dtable, int B, int V, int C, int T, void* stream) {
+    if (!idx || !g || !dtable) return V100_ERR_NULL;
+    if (B <= 0 || V <= 0 || C <= 0 || T <= 0) return V100_ERR_SHAPE;
+    const long total = (long)B * C * T;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipMemsetAsync(dtable, 0, (size_t)V * C * sizeof(float), (hipStream_t)stream);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, idx, g, dtable, V, C, T, total);
+    return v100_launch_status();
+}

@@ -1,0 +1,44 @@
+// Shared helpers for the gfx950 (MI355X / CDNA4) kernels of the Voice100 hot path.
+// Wave = 64 lanes everywhere in this tree; nothing here is portable on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define V100_OK 0
+#define V100_ERR_SHAPE 1       // invalid / unsupported shape or argument
+#define V100_ERR_LAUNCH 2      // hipGetLastError() after a launch
+#define V100_ERR_NULL 3        // required pointer is null
+
+#define V100_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+static inline int v100_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? V100_OK : V100_ERR_LAUNCH;
+}
+
+__device__ __forceinline__ float relu6f(float v) {
+    return __builtin_fminf(__builtin_fmaxf(v, 0.0f), 6.0f);   // v_med3-able clamp
+}
+
+// full-wave sum, result in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// fp32 -> bf16 round-to-nearest-even; plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ u16 f2bf(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(u16, h);
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,360 @@
+"""Autograd functions that run the Voice100 CNN blocks on the HIP kernels.
+
+Every function here launches kernels of libvoice100_hip.so on torch's current
+stream; there is no CPU or stock-PyTorch fallback.  Activations are fp32
+[B, C, T]; `precision` selects the matrix-core path of the 1x1 convolutions:
+"fp32" (exact fp32 MFMA, the parity path) or "bf16" (operands rounded to bf16
+while staging, fp32 accumulate).
+
+Data flow of one InvertedResidual block (reference: voice100/models/asr.py:40-59)
+in training mode -- raw conv outputs a1/a2/a3 are the only large tensors written;
+BatchNorm + ReLU6 are applied by the *consumer* while it loads its input:
+
+    x --pw GEMM--> a1 (+stats) --dw (BN1+ReLU6 on load)--> a2 (+stats)
+      --pw GEMM (BN2+ReLU6 on load)--> a3 (+stats) --affine(+x)--> y
+"""
+from typing import Optional
+
+import torch
+
+from . import _native as N
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+_PRECISION = "fp32"
+
+
+def set_matmul_precision(p: str) -> None:
+    """"fp32" (default, parity path) or "bf16" (throughput path) for the 1x1 GEMMs."""
+    global _PRECISION
+    if p not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    _PRECISION = p
+
+
+def get_matmul_precision() -> str:
+    return _PRECISION
+
+
+def _f32(*shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _check(x: torch.Tensor, name: str):
+    if not x.is_cuda:
+        raise RuntimeError(f"{name}: voice100_amd runs on the GPU only (got a {x.device} tensor); "
+                           "there is no CPU fallback -- see oracle/ for the CPU checker")
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {x.dtype}")
+
+
+def conv_out_len(t: int, k: int, stride: int) -> int:
+    pad = (k - 1) // 2
+    return (t + 2 * pad - k) // stride + 1
+
+
+class _Weights:
+    """fp32 [M, K] weight plus the copies a step needs (bf16 and/or transposed)."""
+
+    def __init__(self, w2d: torch.Tensor, bf16: bool, transposed: bool):
+        self.w = w2d
+        m, k = w2d.shape
+        self.w_bf = torch.empty((m, k), dtype=torch.bfloat16, device=w2d.device) if bf16 else None
+        self.wt = _f32(k, m, like=w2d) if (transposed and not bf16) else None
+        self.wt_bf = torch.empty((k, m), dtype=torch.bfloat16, device=w2d.device) if (transposed and bf16) else None
+        if self.w_bf is not None or self.wt is not None or self.wt_bf is not None:
+            N.call("v100_weight_prep", w2d, m, k, self.w_bf, self.wt, self.wt_bf)
+
+
+def _pw_gemm(a_f32, a_bf, x, y, m, k, t, b, bf16, x2=None, xa=None, xb=None, xc=None, x_mode=0, bias=None,
+             ea=None, eb=None, r=None, epi=0, stats=None):
+    N.call("v100_pw_gemm", a_f32, a_bf, x, x2, xa, xb, xc, x_mode, y, bias, ea, eb, r, epi, stats, b, m, k, t, int(bf16))
+
+
+def _bn_train(stats, parts, count, bn_w, bn_b, rm, rv, nbt, c, like):
+    scale, shift, mean, rstd = (_f32(c, like=like) for _ in range(4))
+    N.call("v100_bn_finalize_train", stats, parts, count, bn_w, bn_b, rm, rv, nbt, BN_MOMENTUM, BN_EPS, scale, shift, mean, rstd, c)
+    return scale, shift, mean, rstd
+
+
+def _bn_eval(bn_w, bn_b, rm, rv, c, like):
+    scale, shift = _f32(c, like=like), _f32(c, like=like)
+    N.call("v100_bn_eval_coeffs", bn_w, bn_b, rm, rv, BN_EPS, scale, shift, c)
+    return scale, shift
+
+
+def _bn_bwd(partial, parts, count, gamma, mean, rstd, c, like):
+    p, q, r, dg, db = (_f32(c, like=like) for _ in range(5))
+    N.call("v100_bn_bwd_finalize", partial, parts, count, gamma, mean, rstd, p, q, r, dg, db, c)
+    return p, q, r, dg, db
+
+
+class InvertedResidualTrainFn(torch.autograd.Function):
+    """Training-mode InvertedResidual (asr.py:40-59): batch statistics, running-stat update, autograd."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, wd, g2, b2, w3, g3, b3, rm1, rv1, nbt1, rm2, rv2, nbt2, rm3, rv3, nbt3,
+                kernel_size, stride, use_residual, precision):
+        _check(x, "InvertedResidual")
+        x = x.contiguous()
+        B, cin, T = x.shape
+        hid, cout = w1.shape[0], w3.shape[0]
+        k = int(kernel_size)
+        pad = (k - 1) // 2
+        T2 = conv_out_len(T, k, stride)
+        bf16 = precision == "bf16"
+        W1 = _Weights(w1.detach().reshape(hid, cin), bf16, False)
+        W3 = _Weights(w3.detach().reshape(cout, hid), bf16, False)
+        wd2 = wd.detach().reshape(hid, k).contiguous()
+
+        # pw: a1 = W1 x, with the partial sums for BN1
+        parts1 = N.helper("v100_pw_num_parts", B, T)
+        a1 = _f32(B, hid, T, like=x)
+        st = _f32(parts1, hid, 2, like=x)
+        _pw_gemm(W1.w, W1.w_bf, x, a1, hid, cin, T, B, bf16, epi=1, stats=st)
+        s1, t1, mean1, rstd1 = _bn_train(st, parts1, B * T, g1.detach(), b1.detach(), rm1, rv1, nbt1, hid, x)
+
+        # dw: a2 = dwconv(relu6(s1*a1+t1)), with the partial sums for BN2
+        G = N.helper("v100_dw_num_groups", B, hid)
+        a2 = _f32(B, hid, T2, like=x)
+        st = _f32(G, hid, 2, like=x)
+        N.call("v100_dwconv", a1, None, wd2, s1, t1, None, 1, a2, None, None, None, 0, st, G, B, hid, T, T2, k, stride, pad, 0, 1, 0)
+        s2, t2, mean2, rstd2 = _bn_train(st, G, B * T2, g2.detach(), b2.detach(), rm2, rv2, nbt2, hid, x)
+
+        # pw-linear: a3 = W3 relu6(s2*a2+t2), with the partial sums for BN3
+        parts3 = N.helper("v100_pw_num_parts", B, T2)
+        a3 = _f32(B, cout, T2, like=x)
+        st = _f32(parts3, cout, 2, like=x)
+        _pw_gemm(W3.w, W3.w_bf, a2, a3, cout, hid, T2, B, bf16, xa=s2, xb=t2, x_mode=1, epi=1, stats=st)
+        s3, t3, mean3, rstd3 = _bn_train(st, parts3, B * T2, g3.detach(), b3.detach(), rm3, rv3, nbt3, cout, x)
+
+        # y = BN3(a3) (+ x)
+        y = _f32(B, cout, T2, like=x)
+        N.call("v100_chan_affine2", a3, x if use_residual else None, s3, None, t3, y, B, cout, T2)
+
+        ctx.save_for_backward(x, a1, a2, a3, w1, wd, w3, g1, g2, g3, s1, t1, mean1, rstd1, s2, t2, mean2, rstd2, mean3, rstd3)
+        ctx.cfg = (k, int(stride), bool(use_residual), bf16)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, a1, a2, a3, w1, wd, w3, g1, g2, g3, s1, t1, mean1, rstd1, s2, t2, mean2, rstd2, mean3, rstd3) = ctx.saved_tensors
+        k, stride, use_residual, bf16 = ctx.cfg
+        dy = dy.contiguous()
+        B, cin, T = x.shape
+        hid, cout = a1.shape[1], a3.shape[1]
+        T2 = a2.shape[2]
+        pad = (k - 1) // 2
+        W1 = _Weights(w1.detach().reshape(hid, cin), bf16, True)
+        W3 = _Weights(w3.detach().reshape(cout, hid), bf16, True)
+        wd2 = wd.detach().reshape(hid, k).contiguous()
+
+        # BN3 backward: reductions over (dy, a3), then da3 = p*dy + q*a3 + r
+        Gr = N.helper("v100_dw_num_groups", B, cout)
+        part = _f32(Gr, cout, 2, like=x)
+        N.call("v100_chan_reduce2", dy, a3, part, Gr, B, cout, T2)
+        p3, q3, r3, dg3, db3 = _bn_bwd(part, Gr, B * T2, g3.detach(), mean3, rstd3, cout, x)
+        da3 = _f32(B, cout, T2, like=x)
+        N.call("v100_chan_affine2", dy, a3, p3, q3, r3, da3, B, cout, T2)
+
+        # pw-linear weight grad: dW3 = da3 . relu6(s2*a2+t2)^T
+        S = N.helper("v100_pw_wgrad_splits", B, cout, hid)
+        partial = _f32(S, cout, hid, like=x)
+        dW3 = _f32(cout, hid, like=x)
+        N.call("v100_pw_wgrad", da3, None, None, None, None, 0, a2, s2, t2, 1, partial, dW3, S, B, cout, hid, T2, int(bf16))
+
+        # pw-linear data grad through ReLU6: dz2 = (W3^T da3) * [0 < s2*a2+t2 < 6], with BN2-backward sums
+        parts = N.helper("v100_pw_num_parts", B, T2)
+        dz2 = _f32(B, hid, T2, like=x)
+        st = _f32(parts, hid, 2, like=x)
+        _pw_gemm(W3.wt, W3.wt_bf, da3, dz2, hid, cout, T2, B, bf16, ea=s2, eb=t2, r=a2, epi=4, stats=st)
+        p2, q2, r2, dg2, db2 = _bn_bwd(st, parts, B * T2, g2.detach(), mean2, rstd2, hid, x)
+
+        # depthwise weight grad: dWd = corr(da2, relu6(s1*a1+t1)),  da2 = p2*dz2 + q2*a2 + r2
+        G = N.helper("v100_dw_num_groups", B, hid)
+        partial = _f32(G, hid, k, like=x)
+        dWd = _f32(hid, k, like=x)
+        N.call("v100_dwconv_wgrad", dz2, a2, p2, q2, r2, 2, a1, s1, t1, 1, partial, dWd, G, B, hid, T, T2, k, stride, pad, 0)
+
+        # depthwise data grad through ReLU6: dz1 = convT(da2) * [0 < s1*a1+t1 < 6], with BN1-backward sums
+        dz1 = _f32(B, hid, T, like=x)
+        st = _f32(G, hid, 2, like=x)
+        N.call("v100_dwconv", dz2, a2, wd2, p2, q2, r2, 2, dz1, a1, s1, t1, 2, st, G, B, hid, T2, T, k, 1, k - 1 - pad, 1, stride, 0)
+        p1, q1, r1, dg1, db1 = _bn_bwd(st, G, B * T, g1.detach(), mean1, rstd1, hid, x)
+
+        # pw weight grad: dW1 = da1 . x^T,  da1 = p1*dz1 + q1*a1 + r1
+        S = N.helper("v100_pw_wgrad_splits", B, hid, cin)
+        partial = _f32(S, hid, cin, like=x)
+        dW1 = _f32(hid, cin, like=x)
+        N.call("v100_pw_wgrad", dz1, a1, p1, q1, r1, 2, x, None, None, 0, partial, dW1, S, B, hid, cin, T, int(bf16))
+
+        # pw data grad: dx = W1^T da1 (+ dy through the residual)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _f32(B, cin, T, like=x)
+            _pw_gemm(W1.wt, W1.wt_bf, dz1, dx, cin, hid, T, B, bf16, x2=a1, xa=p1, xb=q1, xc=r1, x_mode=2,
+                     r=dy if use_residual else None, epi=5 if use_residual else 0)
+
+        return (dx, dW1.view_as(w1), dg1, db1, dWd.view_as(wd), dg2, db2, dW3.view_as(w3), dg3, db3) + (None,) * 13
+
+
+def inverted_residual_eval(x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3,
+                           kernel_size, stride, use_residual, precision):
+    """Eval-mode InvertedResidual: BatchNorm folded to per-channel scale/shift inside the three kernels."""
+    _check(x, "InvertedResidual")
+    x = x.contiguous()
+    B, cin, T = x.shape
+    hid, cout = w1.shape[0], w3.shape[0]
+    k = int(kernel_size)
+    pad = (k - 1) // 2
+    T2 = conv_out_len(T, k, stride)
+    bf16 = precision == "bf16"
+    W1 = _Weights(w1.detach().reshape(hid, cin), bf16, False)
+    W3 = _Weights(w3.detach().reshape(cout, hid), bf16, False)
+    s1, t1 = _bn_eval(g1, b1, rm1, rv1, hid, x)
+    s2, t2 = _bn_eval(g2, b2, rm2, rv2, hid, x)
+    s3, t3 = _bn_eval(g3, b3, rm3, rv3, cout, x)
+    h1 = _f32(B, hid, T, like=x)
+    _pw_gemm(W1.w, W1.w_bf, x, h1, hid, cin, T, B, bf16, ea=s1, eb=t1, epi=2)
+    h2 = _f32(B, hid, T2, like=x)
+    G = N.helper("v100_dw_num_groups", B, hid)
+    N.call("v100_dwconv", h1, None, wd.detach().reshape(hid, k).contiguous(), None, None, None, 0, h2, None, s2, t2, 1, None, G,
+           B, hid, T, T2, k, stride, pad, 0, 1, 0)
+    y = _f32(B, cout, T2, like=x)
+    _pw_gemm(W3.w, W3.w_bf, h2, y, cout, hid, T2, B, bf16, ea=s3, eb=t3, r=x if use_residual else None, epi=3)
+    return y
+
+
+class PointwiseConvFn(torch.autograd.Function):
+    """nn.Conv1d(kernel_size=1, bias optional) on the GEMM kernel (asr.py:91; tts.py:26,77)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, precision):
+        _check(x, "pointwise_conv1d")
+        x = x.contiguous()
+        B, cin, T = x.shape
+        cout = w.shape[0]
+        bf16 = precision == "bf16"
+        W = _Weights(w.detach().reshape(cout, cin), bf16, False)
+        y = _f32(B, cout, T, like=x)
+        _pw_gemm(W.w, W.w_bf, x, y, cout, cin, T, B, bf16, bias=bias.detach() if bias is not None else None, epi=0)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        ctx.bf16 = bf16
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, cin, T = x.shape
+        cout = w.shape[0]
+        bf16 = ctx.bf16
+        W = _Weights(w.detach().reshape(cout, cin), bf16, True)
+        S = N.helper("v100_pw_wgrad_splits", B, cout, cin)
+        partial = _f32(S, cout, cin, like=x)
+        dW = _f32(cout, cin, like=x)
+        N.call("v100_pw_wgrad", dy, None, None, None, None, 0, x, None, None, 0, partial, dW, S, B, cout, cin, T, int(bf16))
+        db = None
+        if ctx.has_bias:
+            G = N.helper("v100_dw_num_groups", B, cout)
+            part = _f32(G, cout, 2, like=x)
+            N.call("v100_chan_reduce2", dy, None, part, G, B, cout, T)
+            db = _f32(cout, like=x)
+            N.call("v100_slab_sum0", part, G, db, cout)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _f32(B, cin, T, like=x)
+            _pw_gemm(W.wt, W.wt_bf, dy, dx, cin, cout, T, B, bf16, epi=0)
+        return dx, dW.view_as(w), db, None
+
+
+def pointwise_conv1d(x, w, bias=None, precision: Optional[str] = None):
+    return PointwiseConvFn.apply(x, w, bias, precision or _PRECISION)
+
+
+class TransposeLast2Fn(torch.autograd.Function):
+    """torch.transpose(x, 1, 2) materialised ([B,R,C] -> [B,C,R]); asr.py:111,114."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _check(x, "transpose_last2")
+        x = x.contiguous()
+        B, R, C = x.shape
+        y = _f32(B, C, R, like=x)
+        N.call("v100_transpose_last2", x, y, B, R, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        B, C, R = dy.shape
+        dx = _f32(B, R, C, like=dy)
+        N.call("v100_transpose_last2", dy, dx, B, C, R)
+        return dx
+
+
+def transpose_last2(x):
+    return TransposeLast2Fn.apply(x)
+
+
+class DropoutMaskFn(torch.autograd.Function):
+    """y = x * keep / (1 - p) with a caller-supplied keep mask (nn.Dropout(0.2), asr.py:90)."""
+
+    @staticmethod
+    def forward(ctx, x, keep, scale):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        N.call("v100_mul_scale", x, keep, float(scale), y, x.numel())
+        ctx.save_for_backward(keep)
+        ctx.scale = float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (keep,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        N.call("v100_mul_scale", dy, keep, ctx.scale, dx, dy.numel())
+        return dx, None, None
+
+
+def dropout(x, p: float, training: bool, keep: Optional[torch.Tensor] = None):
+    """Inverted dropout. `keep` (0/1 float mask) can be injected for reproducible parity runs."""
+    if not training or p == 0.0:
+        return x
+    if keep is None:
+        keep = (torch.rand(x.shape, device=x.device) >= p).to(torch.float32)
+    return DropoutMaskFn.apply(x, keep, 1.0 / (1.0 - p))
+
+
+class EmbeddingBCTFn(torch.autograd.Function):
+    """nn.Embedding followed by transpose(1,2): idx [B,T] int64 -> [B,C,T] (tts.py:81-83,176-177)."""
+
+    @staticmethod
+    def forward(ctx, idx, table):
+        if not idx.is_cuda:
+            raise RuntimeError("embedding: voice100_amd runs on the GPU only")
+        idx = idx.contiguous().to(torch.int64)
+        B, T = idx.shape
+        V, C = table.shape
+        out = _f32(B, C, T, like=table)
+        N.call("v100_embedding_bct", idx, table.detach().contiguous(), out, B, V, C, T)
+        ctx.save_for_backward(idx)
+        ctx.vc = (V, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        V, C = ctx.vc
+        dy = dy.contiguous()
+        B, _, T = dy.shape
+        dtable = _f32(V, C, like=dy)
+        N.call("v100_embedding_bwd", idx, dy, dtable, B, V, C, T)
+        return None, dtable
+
+
+def embedding_bct(idx, table):
+    return EmbeddingBCTFn.apply(idx, table)

@@ -1,0 +1,86 @@
+"""Parameter-holding building blocks with the reference's state_dict layout.
+
+Reference: voice100/models/asr.py:27-59 (ConvBNActivate, InvertedResidual).
+The sub-modules here only OWN the parameters / buffers (so that
+`conv.0.0.weight`, `conv.0.1.running_mean`, ... `conv.3.bias` load from a
+reference checkpoint with strict=True); the arithmetic of a block runs as one
+fused chain of HIP kernels (voice100_amd.functional), never through the
+sub-modules' own forward().
+"""
+import torch
+from torch import nn
+
+from . import functional as F_
+
+
+class ConvBNActivate(nn.ModuleList):
+    """Conv1d(bias=False) + BatchNorm1d + ReLU6 parameter group (asr.py:27-37).
+
+    Index 0 = conv, 1 = batch norm, 2 = ReLU6 (no parameters), as in the reference's
+    nn.Sequential, so the keys are `0.weight`, `1.weight`, `1.running_mean`, ...
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, dilation=1, groups=1):
+        if dilation != 1:
+            raise NotImplementedError("dilation != 1 is never used by the reference networks")
+        padding = (kernel_size - 1) // 2
+        super().__init__([
+            nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                      groups=groups, bias=False),
+            nn.BatchNorm1d(out_channels),
+            nn.ReLU6(inplace=True),
+        ])
+
+    def forward(self, x):
+        raise RuntimeError("ConvBNActivate is a parameter group; run it through InvertedResidual "
+                           "(fused HIP path) -- voice100_amd has no unfused fallback")
+
+
+class InvertedResidual(nn.Module):
+    """1x1 expand -> depthwise k -> 1x1 project, BatchNorm after each, ReLU6 after the first two,
+    optional identity skip (asr.py:40-59).  x [B, Cin, T] fp32 on the GPU -> [B, Cout, T/stride]."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, expand_ratio=4, use_residual=True):
+        super().__init__()
+        hidden_size = in_channels * expand_ratio
+        self.use_residual = use_residual
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.conv = nn.ModuleList([
+            ConvBNActivate(in_channels, hidden_size, kernel_size=1),
+            ConvBNActivate(hidden_size, hidden_size, kernel_size=kernel_size, stride=stride, groups=hidden_size),
+            nn.Conv1d(hidden_size, out_channels, kernel_size=1, bias=False),
+            nn.BatchNorm1d(out_channels),
+        ])
+        if use_residual and (in_channels != out_channels or stride != 1):
+            raise ValueError("use_residual needs in_channels == out_channels and stride == 1")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        pw, dw, pl, bn3 = self.conv[0], self.conv[1], self.conv[2], self.conv[3]
+        bn1, bn2 = pw[1], dw[1]
+        prec = F_.get_matmul_precision()
+        if self.training:
+            return F_.InvertedResidualTrainFn.apply(
+                x, pw[0].weight, bn1.weight, bn1.bias, dw[0].weight, bn2.weight, bn2.bias, pl.weight, bn3.weight, bn3.bias,
+                bn1.running_mean, bn1.running_var, bn1.num_batches_tracked,
+                bn2.running_mean, bn2.running_var, bn2.num_batches_tracked,
+                bn3.running_mean, bn3.running_var, bn3.num_batches_tracked,
+                self.kernel_size, self.stride, self.use_residual, prec)
+        # eval mode: frozen statistics, inference only (autograd through eval-mode BN is not on the
+        # reference's training path and is not built)
+        with torch.no_grad():
+            return F_.inverted_residual_eval(
+                x, pw[0].weight, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                dw[0].weight, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
+                pl.weight, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var,
+                self.kernel_size, self.stride, self.use_residual, prec)
+
+
+class PointwiseConv1d(nn.Conv1d):
+    """nn.Conv1d(kernel_size=1) whose forward/backward run on the GEMM kernel (asr.py:91; tts.py:26,77)."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__(in_channels, out_channels, kernel_size=1, padding=0, bias=bias)
+
+    def forward(self, x):
+        return F_.pointwise_conv1d(x, self.weight, self.bias)
