@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio frames/sec, fwd+bwd(+optimizer), "asr_en_base" =
+AudioToTextCTC(audio_size=64, embed_size=512, vocab_size=29, hidden_size=512)  (SURVEY.md 0.2),
+B = 32 x 1024-frame synthetic log-mel per GPU, CTC targets [32, 100]   (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; batches shard across ranks (weak scaling, 32 utterances per GPU), one RCCL
+gradient all-reduce per step overlapped with backward.  Rank 0 prints ONE JSON line.
+
+A "step" = augmentation + forward + log_softmax/CTC + backward + gradient exchange + Adam, with
+inputs already resident in HBM.  `roofline` = depthwise forward kernel (the north-star's graded
+kernel): algorithmic bytes of its 9 launches per step / their HIP-event time inside the timed
+region.  `cpu_baseline` = the CPU oracle (port of the reference's PyTorch-CPU path) timed on this
+box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate ~6300
+B_PER_GPU, T_FRAMES, N_MEL, VOCAB, TEXT_LEN = 32, 1024, 64, 29, 100
+
+
+def encoder_dw_bytes(B, T):
+    """Algorithmic bytes of the 9 depthwise forward launches: fp32 in + out + taps + BN coeffs."""
+    specs = [(256, 11, 2), (1024, 19, 1), (1024, 27, 1), (1024, 35, 1), (1024, 51, 1),
+             (2048, 59, 1), (2048, 67, 1), (2048, 75, 1), (2048, 83, 1)]
+    total, t = 0, T
+    per_layer = []
+    for hid, k, s in specs:
+        tout = (t - 1) // s + 1
+        b = 4 * B * hid * (t + tout) + 4 * hid * k + 8 * hid
+        per_layer.append(b)
+        total += b
+        t = tout
+    return total, per_layer
+
+
+def synth_batch(device, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    audio = (torch.randn(B, T_FRAMES, N_MEL, generator=g) * 2 - 4).clamp_min(float(torch.log(torch.tensor(1e-6))))
+    audio_len = torch.full((B,), T_FRAMES, dtype=torch.int32)
+    text = torch.randint(1, VOCAB, (B, TEXT_LEN), generator=g)
+    text_len = torch.full((B,), TEXT_LEN, dtype=torch.int32)
+    return ((audio.to(device), audio_len.to(device)), (text.to(device), text_len.to(device)))
+
+
+def cpu_baseline(sample_b=8, iters=2):
+    """Oracle (CPU port of the reference path, stock PyTorch CPU ops, fp32, all host cores): train-mode
+    forward + log_softmax + CTC + backward on a B=sample_b slice of the workload."""
+    from oracle import cnn
+    from voice100_amd.asr import AudioToTextCTC
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    m = AudioToTextCTC(N_MEL, 512, VOCAB, 512)
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    params = {k: v.requires_grad_(True) for k, v in state.items() if v.dtype.is_floating_point and "running" not in k}
+    state.update(params)
+    (audio, audio_len), (text, text_len) = synth_batch("cpu", sample_b, 1234)
+    times = []
+    for i in range(iters + 1):
+        for p in params.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        loss = cnn.audio_to_text_ctc_loss(((audio, audio_len), (text, text_len)), state, training=True)
+        loss.backward()
+        dt = time.perf_counter() - t0
+        if i > 0:
+            times.append(dt)
+    best = sum(times) / len(times)
+    return {"value": round(sample_b * T_FRAMES / best, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle.cnn train fwd+CTC+bwd, B={sample_b} x T={T_FRAMES} slice of the B=32 workload, fp32, "
+                      f"{iters} timed iters after 1 warm-up, torch.set_num_threads({cores})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from voice100_amd import functional as F_, _native as N
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd.trainer import TrainStep, init_distributed
+
+    rank, local_rank, world = init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    N.load()
+    F_.set_matmul_precision(args.precision)
+
+    torch.manual_seed(1234)                                  # reference: pl.seed_everything(1234), train_asr.py:13
+    model = AudioToTextCTC(N_MEL, 512, VOCAB, 512, learning_rate=1e-3, weight_decay=4e-5).to(device)
+    step = TrainStep(model)
+    batch = synth_batch(device, B_PER_GPU, 1234 + rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(batch)
+    if not args.no_kernel_timing:
+        N.timer = N.KernelTimer()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    kt = N.timer.summary() if N.timer is not None else {}
+    N.timer = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        frames = B_PER_GPU * T_FRAMES * world * args.steps
+        dw_bytes, _ = encoder_dw_bytes(B_PER_GPU, T_FRAMES)
+        roof = None
+        if "dw_fwd" in kt:
+            n, ms = kt["dw_fwd"]
+            achieved = dw_bytes * args.steps / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "dwconv_kernel (depthwise fwd, 9 launches/step)", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "algorithmic_bytes_per_step": dw_bytes}
+        out = {
+            "metric": "audio frames/sec (fwd+bwd) asr_en_base, B=32x1024-frame mel",
+            "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: asr_en_base (AudioToTextCTC 64/512/29/512) training step, "
+                                   "batch=32 x 1024-frame synthetic log-mel + CTC targets [32,100] per GPU, "
+                                   "augmentation+dropout on, Adam; 1x1 GEMM operands bf16 (fp32 accumulate), "
+                                   "activations/depthwise/BatchNorm fp32" if args.precision == "bf16" else
+                                   "configs[1] at fp32 throughout",
+                       "global_batch": B_PER_GPU * world, "frames_per_utterance": T_FRAMES, "parallelism": f"dp{world}"},
+            "loss": round(float(loss), 4),
+            "roofline": roof,
+            "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(kt.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

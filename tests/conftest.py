@@ -36,6 +36,14 @@ def rel_err(a, b, floor=1e-5):
     return float((a - b).abs().max()) / denom
 
 
+def rel_l2(a, b):
+    """||a-b||_2 / ||b||_2 -- used for the bf16-operand path, where a ReLU6 mask can flip on
+    elements that sit on the 0 / 6 boundary (an O(1) change of single gradient entries)."""
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
 @pytest.fixture(scope="session")
 def cuda():
     if not torch.cuda.is_available():

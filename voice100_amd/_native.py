@@ -111,3 +111,41 @@ def helper(name, *args):
     """Host-side helpers that return a count rather than a status (v100_*_num_* / _splits)."""
     lib = load()
     return getattr(lib, name)(*args)
+
+
+class KernelTimer:
+    """Opt-in HIP-event timing of kernel regions on torch's current stream (bench.py only).
+    Usage: N.timer = KernelTimer(); ... ; N.timer.summary() after a synchronize."""
+
+    def __init__(self):
+        self.events = {}
+
+    def record(self, tag, start, end):
+        self.events.setdefault(tag, []).append((start, end))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {tag: (len(ev), sum(s.elapsed_time(e) for s, e in ev)) for tag, ev in self.events.items()}
+
+
+timer = None
+
+
+class region:
+    """`with region("dw_fwd"):` brackets the launches inside with HIP events when a timer is installed."""
+
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        if timer is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if timer is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            timer.record(self.tag, self.start, end)
+        return False
