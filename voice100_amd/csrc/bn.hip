@@ -17,14 +17,18 @@ __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int pa
                                          long long* __restrict__ num_batches_tracked, float momentum, float eps,
                                          float* __restrict__ scale, float* __restrict__ shift,
                                          float* __restrict__ save_mean, float* __restrict__ save_rstd, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-    if (c >= C) return;
+    // one wave per channel: lanes stride over the slab rows, fixed-order butterfly in double
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (c == 0 && lane == 0 && num_batches_tracked) *num_batches_tracked += 1;
     double s0 = 0.0, s1 = 0.0;
-    for (int g = 0; g < parts; ++g) {
+    for (int g = lane; g < parts; g += 64) {
         s0 += (double)stats[((size_t)g * C + c) * 2 + 0];
         s1 += (double)stats[((size_t)g * C + c) * 2 + 1];
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+    if (lane != 0) return;
     const double mean = s0 / count;
     double var = s1 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -59,13 +63,16 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int pa
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, float* __restrict__ p, float* __restrict__ q,
                                        float* __restrict__ r, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
     double s0 = 0.0, s1 = 0.0;
-    for (int g = 0; g < parts; ++g) {
+    for (int g = lane; g < parts; g += 64) {
         s0 += (double)partial[((size_t)g * C + c) * 2 + 0];
         s1 += (double)partial[((size_t)g * C + c) * 2 + 1];
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+    if (lane != 0) return;
     const double mu = mean[c], rs = rstd[c], ga = gamma[c];
     const double dg = rs * (s1 - mu * s0);
     const double pp = ga * rs;
@@ -226,7 +233,7 @@ extern "C" int v100_bn_finalize_train(const float* stats, int parts, long long c
                                       float eps, float* scale, float* shift, float* save_mean, float* save_rstd, int C, void* stream) {
     if (!stats || !gamma || !beta || !scale || !shift) return V100_ERR_NULL;
     if (C <= 0 || parts <= 0 || count <= 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, parts, (double)count,
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, parts, (double)count,
                        gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean, save_rstd, C);
     return v100_launch_status();
 }
@@ -244,7 +251,7 @@ extern "C" int v100_bn_bwd_finalize(const float* partial, int parts, long long c
                                     const float* rstd, float* p, float* q, float* r, float* dgamma, float* dbeta, int C, void* stream) {
     if (!partial || !gamma || !mean || !rstd || !p || !q || !r) return V100_ERR_NULL;
     if (C <= 0 || parts <= 0 || count <= 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, partial, parts, (double)count,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, parts, (double)count,
                        gamma, mean, rstd, p, q, r, dgamma, dbeta, C);
     return v100_launch_status();
 }

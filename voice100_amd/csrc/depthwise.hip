@@ -15,280 +15,7 @@
 // computes.  Per-channel sums for the consumer BatchNorm (training statistics, or the two
 // BN-backward reductions) are accumulated in registers and written once per workgroup to a
 // [G][C][2] slab -- deterministic, no atomics.
-#include "common.h"
-
-enum { DW_IN_NONE = 0, DW_IN_AFFINE_RELU6 = 1, DW_IN_AFFINE2 = 2 };
-enum { DW_OUT_RAW_STATS = 0, DW_OUT_AFFINE_RELU6 = 1, DW_OUT_MASK_STATS = 2, DW_OUT_RAW = 3 };
-
-struct DwParams {
-    const float* x;      // [B,C,Tin]
-    const float* x2;     // [B,C,Tin]   second stream for DW_IN_AFFINE2
-    const float* w;      // [C,K]
-    const float* in_a;   // [C] scale (AFFINE_RELU6) / p (AFFINE2)
-    const float* in_b;   // [C] shift            / q
-    const float* in_c;   // [C]                  / r
-    float* y;            // [B,C,Tout]
-    const float* aux;    // [B,C,Tout]  pre-activation tensor for DW_OUT_MASK_STATS
-    const float* out_a;  // [C]
-    const float* out_b;  // [C]
-    float* stats;        // [G][C][2]
-    int B, C, Tin, Tout, K, stride, pad, flip, upsample, G, in_mode, out_mode;
-};
-
-struct DwWgradParams {
-    const float* g;      // [B,C,Tout] upstream gradient stream 1
-    const float* g2;     // [B,C,Tout] stream 2 for AFFINE2
-    const float* ga; const float* gb; const float* gc;   // [C] each
-    const float* x;      // [B,C,Tin]  conv input (pre-activation when x_mode = AFFINE_RELU6)
-    const float* xa; const float* xb;                     // [C] each
-    float* partial;      // [G][C][K]
-    int B, C, Tin, Tout, K, stride, pad, G, g_mode, x_mode;
-};
-
-__device__ __forceinline__ float dw_in_transform(int mode, float v, float v2, float a, float b, float c) {
-    if (mode == DW_IN_AFFINE_RELU6) return relu6f(fmaf(v, a, b));
-    if (mode == DW_IN_AFFINE2) return fmaf(v, a, fmaf(v2, b, c));
-    return v;
-}
-
-// R consecutive floats starting at ptr (t0 .. t0+R-1 of a row of length T), zero past the end.
-template <int R>
-__device__ __forceinline__ void dw_load_run(float (&out)[R], const float* __restrict__ ptr, int t0, int T, bool vec) {
-    if (vec) {
-#pragma unroll
-        for (int q = 0; q < R / 4; ++q) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t0 + 4 * q < T) v = *reinterpret_cast<const f32x4*>(ptr + 4 * q);
-            out[4 * q] = v[0]; out[4 * q + 1] = v[1]; out[4 * q + 2] = v[2]; out[4 * q + 3] = v[3];
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) out[r] = (t0 + r < T) ? ptr[r] : 0.f;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Staging: one wave copies the input span of one tile into its LDS row.
-//   LDS index i  <->  input position in0 + i,   in0 = out0*S - pad (may be negative)
-// Global reads are 16-byte aligned float4 when the row length is a multiple of 4.
-template <int NV>
-struct DwRaw {
-    f32x4 v[NV];
-    f32x4 v2[NV];
-};
-
-template <int NV, int SPAN>
-__device__ __forceinline__ void dw_issue_loads(DwRaw<NV>& raw, const float* __restrict__ row, const float* __restrict__ row2,
-                                               int in0, int Tin, bool two, int lane) {
-    const int in0a = in0 & ~3;            // floor to a multiple of 4 (two's complement: also for negatives)
-    const bool aligned = (Tin & 3) == 0;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int ia = in0a + 4 * (lane + 64 * v);
-        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-        if (ia < in0 + SPAN) {
-            if (aligned) {
-                if (ia >= 0 && ia < Tin) {
-                    a = *reinterpret_cast<const f32x4*>(row + ia);
-                    if (two) b = *reinterpret_cast<const f32x4*>(row2 + ia);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int t = ia + e;
-                    if (t >= 0 && t < Tin) {
-                        a[e] = row[t];
-                        if (two) b[e] = row2[t];
-                    }
-                }
-            }
-        }
-        raw.v[v] = a;
-        raw.v2[v] = b;
-    }
-}
-
-template <int NV, int SPAN>
-__device__ __forceinline__ void dw_stage_to_lds(const DwRaw<NV>& raw, float* lds, int in0, int Tin, int mode,
-                                                float ca, float cb, float cc, int lane) {
-    const int in0a = in0 & ~3;
-    const int off = in0 - in0a;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int ia = in0a + 4 * (lane + 64 * v);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int t = ia + e;
-            const int i = 4 * (lane + 64 * v) + e - off;
-            float val = 0.f;
-            if (t >= 0 && t < Tin) val = dw_in_transform(mode, raw.v[v][e], raw.v2[v][e], ca, cb, cc);
-            if (i >= 0 && i < SPAN) lds[i] = val;
-        }
-    }
-}
-
-template <int K, int S, int R>
-struct DwGeom {
-    static_assert((R * S) % 4 == 0, "lane window must start on a 16-byte LDS boundary");
-    static constexpr int TILE = 64 * R;
-    static constexpr int WIN = (R - 1) * S + K;               // inputs one lane touches
-    static constexpr int SPAN = (TILE - 1) * S + K;           // inputs one tile touches
-    static constexpr int SPAN4 = (SPAN + 3) & ~3;
-    static constexpr int NV = (SPAN + 3 + 3) / 4 / 64 + 1;    // float4 loads per lane covering [in0a, in0+SPAN)
-    static constexpr int NCH = (WIN + 3) / 4;                 // window chunks
-    static constexpr int NTC = (K + 3) / 4;                   // tap chunks
-    static constexpr int PD = 2;                              // LDS prefetch distance (chunks)
-};
-
-// ---------------------------------------------------------------------------------------------
-// Forward / backward-data kernel.  K, stride S and outputs-per-lane R are compile time so the
-// window walk is fully unrolled with static register indices.
-template <int K, int S, int R>
-__global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
-    using G_ = DwGeom<K, S, R>;
-    constexpr int TILE = G_::TILE, WIN = G_::WIN, SPAN = G_::SPAN, NV = G_::NV, NCH = G_::NCH, NTC = G_::NTC, PD = G_::PD;
-
-    __shared__ __attribute__((aligned(16))) float lds_all[4][G_::SPAN4 + 8];
-    __shared__ __attribute__((aligned(16))) float lds_w[NTC * 4];
-    __shared__ float lds_red[4][2];
-
-    const int c = blockIdx.x;
-    const int g = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    float* lds = lds_all[wave];
-
-    for (int j = threadIdx.x; j < NTC * 4; j += 256)
-        lds_w[j] = j < K ? p.w[(size_t)c * K + (p.flip ? (K - 1 - j) : j)] : 0.f;
-    __syncthreads();
-
-    const int in_mode = p.in_mode, out_mode = p.out_mode;
-    float ca = 1.f, cb = 0.f, cc = 0.f, oa = 1.f, ob = 0.f;
-    if (in_mode != DW_IN_NONE) { ca = p.in_a[c]; cb = p.in_b[c]; }
-    if (in_mode == DW_IN_AFFINE2) cc = p.in_c[c];
-    if (out_mode == DW_OUT_AFFINE_RELU6 || out_mode == DW_OUT_MASK_STATS) { oa = p.out_a[c]; ob = p.out_b[c]; }
-
-    const int Tin = p.Tin, Tout = p.Tout;
-    const int bper = (p.B + p.G - 1) / p.G;
-    const int b0 = g * bper;
-    const int nb = min(p.B, b0 + bper) - b0;
-    const int ntiles = (Tout + TILE - 1) / TILE;
-    const int nitems = nb > 0 ? nb * ntiles : 0;
-    const bool two = in_mode == DW_IN_AFFINE2;
-    const bool out_vec = (Tout & 3) == 0;
-
-    float s0 = 0.f, s1 = 0.f;
-    DwRaw<NV> raw;
-    int item = wave;
-    if (item < nitems) {
-        const int b = b0 + item / ntiles, tile = item % ntiles;
-        const size_t ro = ((size_t)b * p.C + c) * Tin;
-        dw_issue_loads<NV, SPAN>(raw, p.x + ro, two ? p.x2 + ro : p.x, tile * TILE * S - p.pad, Tin, two, lane);
-    }
-    for (; item < nitems; item += 4) {
-        const int b = b0 + item / ntiles, tile = item % ntiles;
-        const int out0 = tile * TILE;
-        const int in0 = out0 * S - p.pad;
-        dw_stage_to_lds<NV, SPAN>(raw, lds, in0, Tin, in_mode, ca, cb, cc, lane);
-
-        // prefetch the next item's input while this one computes
-        const int nitem = item + 4;
-        if (nitem < nitems) {
-            const int nb_ = b0 + nitem / ntiles, ntile = nitem % ntiles;
-            const size_t ro = ((size_t)nb_ * p.C + c) * Tin;
-            dw_issue_loads<NV, SPAN>(raw, p.x + ro, two ? p.x2 + ro : p.x, ntile * TILE * S - p.pad, Tin, two, lane);
-        }
-
-        const int t0 = out0 + lane * R;
-        const size_t oo = ((size_t)b * p.C + c) * Tout + t0;
-        float auxv[R];
-        if (out_mode == DW_OUT_MASK_STATS) dw_load_run<R>(auxv, p.aux + oo, t0, Tout, out_vec);
-
-        float acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.f;
-        const float* win = lds + lane * (R * S);
-        // The tap reads are loop-invariant; hide that from LICM (an opaque zero offset per item) or
-        // hipcc hoists all K taps into registers for the whole kernel.
-        int opaque = 0;
-        asm volatile("" : "+s"(opaque));
-        const float* wl = lds_w + opaque;
-        // Software-pipelined walk: chunk ch of the window and of the taps are fetched PD steps ahead;
-        // the sched_barrier stops hipcc from hoisting every ds_read to the top of the unrolled body
-        // (WIN + K live registers, which halves occupancy for K >= 51).
-        f32x4 inc[NCH];
-        f32x4 tapc[NTC];
-#pragma unroll
-        for (int q = 0; q < PD; ++q) {
-            if (q < NCH) inc[q] = *reinterpret_cast<const f32x4*>(win + 4 * q);
-            if (q < NTC) tapc[q] = *reinterpret_cast<const f32x4*>(wl + 4 * q);
-        }
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            if (ch + PD < NCH) inc[ch + PD] = *reinterpret_cast<const f32x4*>(win + 4 * (ch + PD));
-            if (ch + PD < NTC) tapc[ch + PD] = *reinterpret_cast<const f32x4*>(wl + 4 * (ch + PD));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = 4 * ch + e;
-                if (i < WIN) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int j = i - r * S;
-                        if (j >= 0 && j < K) acc[r] = fmaf(tapc[j >> 2][j & 3], inc[ch][e], acc[r]);
-                    }
-                }
-            }
-            // pin this chunk's FMAs in front of the barrier (pure ops otherwise sink below it)
-#pragma unroll
-            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acc[r]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-        // epilogue
-        float outv[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool valid = t0 + r < Tout;
-            float yv = acc[r];
-            if (out_mode == DW_OUT_RAW_STATS) {
-                if (valid) { s0 += yv; s1 = fmaf(yv, yv, s1); }
-            } else if (out_mode == DW_OUT_AFFINE_RELU6) {
-                yv = relu6f(fmaf(yv, oa, ob));
-            } else if (out_mode == DW_OUT_MASK_STATS) {
-                const float pre = fmaf(auxv[r], oa, ob);
-                yv = (pre > 0.f && pre < 6.f) ? yv : 0.f;
-                if (valid) { s0 += yv; s1 = fmaf(yv, auxv[r], s1); }
-            }
-            outv[r] = yv;
-        }
-        if (out_vec) {
-#pragma unroll
-            for (int q = 0; q < R / 4; ++q) {
-                if (t0 + 4 * q < Tout) {
-                    f32x4 o = {outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(p.y + oo + 4 * q) = o;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (t0 + r < Tout) p.y[oo + r] = outv[r];
-        }
-    }
-
-    if (out_mode == DW_OUT_RAW_STATS || out_mode == DW_OUT_MASK_STATS) {
-        s0 = wave_sum(s0);
-        s1 = wave_sum(s1);
-        if (lane == 0) { lds_red[wave][0] = s0; lds_red[wave][1] = s1; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float a = (lds_red[0][0] + lds_red[1][0]) + (lds_red[2][0] + lds_red[3][0]);
-            const float b = (lds_red[0][1] + lds_red[1][1]) + (lds_red[2][1] + lds_red[3][1]);
-            p.stats[((size_t)g * p.C + c) * 2 + 0] = a;
-            p.stats[((size_t)g * p.C + c) * 2 + 1] = b;
-        }
-    }
-}
+#include "depthwise_common.h"
 
 // ---------------------------------------------------------------------------------------------
 // Generic fallback: any K / stride / zero-upsampled input (backward-data of a strided conv).
@@ -350,7 +77,8 @@ __global__ __launch_bounds__(256) void dwconv_generic_kernel(DwParams p) {
 // Backward-weight: dW[c][j] = sum_{b,t} g[b,c,t] * xin[b,c,t*S - pad + j].
 // Same staging of xin (with its BN affine + ReLU6 recomputed on the way in); each lane keeps K
 // partial sums in registers across all its tiles and the wave reduces them once at the end.
-template <int K, int S, int R>
+// Specialised for the training combination: g = BN-backward affine of (dz2, a2), xin = relu6(bn(a1)).
+template <int K, int S, int R, bool AL>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradParams p) {
     using G_ = DwGeom<K, S, R>;
     constexpr int TILE = G_::TILE, WIN = G_::WIN, SPAN = G_::SPAN, NV = G_::NV, NCH = G_::NCH, PD = G_::PD;
@@ -361,11 +89,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradParams p) {
     const int c = blockIdx.x, g = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* lds = lds_all[wave];
-    const int x_mode = p.x_mode, g_mode = p.g_mode;
-    float xa = 1.f, xb = 0.f, ga = 1.f, gb = 0.f, gc = 0.f;
-    if (x_mode != DW_IN_NONE) { xa = p.xa[c]; xb = p.xb[c]; }
-    if (g_mode != DW_IN_NONE) { ga = p.ga[c]; gb = p.gb[c]; }
-    if (g_mode == DW_IN_AFFINE2) gc = p.gc[c];
+    const float xa = p.xa[c], xb = p.xb[c], ga = p.ga[c], gb = p.gb[c], gc = p.gc[c];
 
     const int Tin = p.Tin, Tout = p.Tout;
     const int bper = (p.B + p.G - 1) / p.G;
@@ -373,38 +97,37 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradParams p) {
     const int nb = min(p.B, b0 + bper) - b0;
     const int ntiles = (Tout + TILE - 1) / TILE;
     const int nitems = nb > 0 ? nb * ntiles : 0;
-    const bool g_vec = (Tout & 3) == 0;
 
     float accw[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) accw[j] = 0.f;
 
-    DwRaw<NV> raw;
+    DwRaw<NV, false> raw;
     int item = wave;
     if (item < nitems) {
         const int b = b0 + item / ntiles, tile = item % ntiles;
         const size_t ro = ((size_t)b * p.C + c) * Tin;
-        dw_issue_loads<NV, SPAN>(raw, p.x + ro, p.x + ro, tile * TILE * S - p.pad, Tin, false, lane);
+        dw_issue_loads<NV, SPAN, false, AL>(raw, p.x + ro, p.x + ro, tile * TILE * S - p.pad, Tin, lane);
     }
     for (; item < nitems; item += 4) {
         const int b = b0 + item / ntiles, tile = item % ntiles;
         const int out0 = tile * TILE;
         const int in0 = out0 * S - p.pad;
-        dw_stage_to_lds<NV, SPAN>(raw, lds, in0, Tin, x_mode, xa, xb, 0.f, lane);
+        dw_stage_to_lds<NV, SPAN, DW_IN_AFFINE_RELU6, false>(raw, lds, in0, Tin, xa, xb, 0.f, lane);
         const int nitem = item + 4;
         if (nitem < nitems) {
             const int nb_ = b0 + nitem / ntiles, ntile = nitem % ntiles;
             const size_t ro = ((size_t)nb_ * p.C + c) * Tin;
-            dw_issue_loads<NV, SPAN>(raw, p.x + ro, p.x + ro, ntile * TILE * S - p.pad, Tin, false, lane);
+            dw_issue_loads<NV, SPAN, false, AL>(raw, p.x + ro, p.x + ro, ntile * TILE * S - p.pad, Tin, lane);
         }
         const int t0 = out0 + lane * R;
         const size_t oo = ((size_t)b * p.C + c) * Tout + t0;
         float gv[R], gv2[R];
-        dw_load_run<R>(gv, p.g + oo, t0, Tout, g_vec);
-        if (g_mode == DW_IN_AFFINE2) dw_load_run<R>(gv2, p.g2 + oo, t0, Tout, g_vec);
+        dw_load_run<R, AL>(gv, p.g + oo, t0, Tout);
+        dw_load_run<R, AL>(gv2, p.g2 + oo, t0, Tout);
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            gv[r] = (t0 + r < Tout) ? dw_in_transform(g_mode, gv[r], g_mode == DW_IN_AFFINE2 ? gv2[r] : 0.f, ga, gb, gc) : 0.f;
+            gv[r] = (t0 + r < Tout) ? fmaf(gv[r], ga, fmaf(gv2[r], gb, gc)) : 0.f;
 
         const float* win = lds + lane * (R * S);
         f32x4 inc[NCH];
@@ -489,21 +212,13 @@ __global__ void slab_reduce_kernel(const float* __restrict__ partial, float* __r
 
 // ---------------------------------------------------------------------------------------------
 template <int K, int S>
-static void launch_dw(const DwParams& p, hipStream_t st) {
-    dim3 grid(p.C, p.G);
-    if (p.Tout > 256) hipLaunchKernelGGL((dwconv_kernel<K, S, 8>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((dwconv_kernel<K, S, 4>), grid, dim3(256), 0, st, p);
-}
-template <int K, int S>
 static void launch_dw_wgrad(const DwWgradParams& p, hipStream_t st) {
     dim3 grid(p.C, p.G);
     // R = 8 only: the R = 4 instantiations of K >= 67 fall out of registers (hipcc 7.2 leaves the
     // accumulator array in scratch), and short rows are not the case this kernel is tuned for.
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<K, S, 8>), grid, dim3(256), 0, st, p);
+    if (((p.Tin & 3) == 0) && ((p.Tout & 3) == 0)) hipLaunchKernelGGL((dwconv_wgrad_kernel<K, S, 8, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((dwconv_wgrad_kernel<K, S, 8, false>), grid, dim3(256), 0, st, p);
 }
-
-// kernel sizes used by the reference's networks: asr.py:68-76, tts.py:18-25, 73-76
-#define V100_DW_SPECIALISED(X) X(5) X(7) X(11) X(17) X(19) X(27) X(29) X(33) X(35) X(51) X(59) X(65) X(67) X(75) X(83)
 
 extern "C" int v100_dw_num_groups(int B, int C) {
     // enough workgroups to fill 256 CUs several times over, but as few slabs as possible
@@ -531,10 +246,9 @@ extern "C" int v100_dwconv(const float* x, const float* x2, const float* w, cons
     hipStream_t st = (hipStream_t)stream;
     bool done = false;
     if (!force_generic && upsample == 1) {
-#define X(KK) if (!done && K == KK && stride == 1) { launch_dw<KK, 1>(p, st); done = true; }
-        V100_DW_SPECIALISED(X)
-#undef X
-        if (!done && K == 11 && stride == 2) { launch_dw<11, 2>(p, st); done = true; }
+        if (in_mode == DW_IN_AFFINE_RELU6 && out_mode == DW_OUT_RAW_STATS) done = dw_launch_fwd_train(p, st);
+        else if (in_mode == DW_IN_NONE && out_mode == DW_OUT_AFFINE_RELU6) done = dw_launch_fwd_eval(p, st);
+        else if (in_mode == DW_IN_AFFINE2 && out_mode == DW_OUT_MASK_STATS) done = dw_launch_bwd_data(p, st);
     }
     if (!done) hipLaunchKernelGGL(dwconv_generic_kernel, dim3(C, G), dim3(256), K * sizeof(float), st, p);
     return v100_launch_status();
@@ -553,7 +267,7 @@ extern "C" int v100_dwconv_wgrad(const float* g, const float* g2, const float* g
     DwWgradParams p{g, g2, ga, gb, gc, x, xa, xb, partial, B, C, Tin, Tout, K, stride, pad, G, g_mode, x_mode};
     hipStream_t st = (hipStream_t)stream;
     bool done = false;
-    if (!force_generic) {
+    if (!force_generic && g_mode == DW_IN_AFFINE2 && x_mode == DW_IN_AFFINE_RELU6) {
 #define X(KK) if (!done && K == KK && stride == 1) { launch_dw_wgrad<KK, 1>(p, st); done = true; }
         V100_DW_SPECIALISED(X)
 #undef X

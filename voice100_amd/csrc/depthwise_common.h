@@ -1,0 +1,337 @@
+// K2: depthwise Conv1d (groups == channels) for gfx950, fp32 activations in [B, C, T].
+//
+// Replaces nn.Conv1d(groups=hidden) + nn.BatchNorm1d + nn.ReLU6 of the reference's
+// ConvBNActivate "dw" stage (voice100/models/asr.py:27-37, 49) and, with flipped taps,
+// its backward-data; dwconv_wgrad is its backward-weight.
+//
+// Design (DESIGN.md "K2"): HBM-bound for k <~ 51, at the fp32-VALU/HBM balance point for
+// k >= 59.  One workgroup = one channel x a group of batch rows, so the taps are wave-uniform.
+// Each wave streams (row, tile) items: a tile is 64 lanes x R consecutive outputs; the input
+// span (+halo) is staged once through a per-wave LDS row with the producer's BatchNorm affine +
+// ReLU6 (or the BN-backward affine of two tensors) applied on the way in, then every lane slides
+// a register window over it: R*K v_fmac per lane against ~(R*S+K)/4 window + K/4 tap
+// ds_read_b128 (taps are broadcast reads streamed next to the window, so the register footprint
+// does not grow with K).  The next tile's global loads are in flight while the current tile
+// computes.  Per-channel sums for the consumer BatchNorm (training statistics, or the two
+// BN-backward reductions) are accumulated in registers and written once per workgroup to a
+// [G][C][2] slab -- deterministic, no atomics.
+#pragma once
+#include "common.h"
+
+enum { DW_IN_NONE = 0, DW_IN_AFFINE_RELU6 = 1, DW_IN_AFFINE2 = 2 };
+enum { DW_OUT_RAW_STATS = 0, DW_OUT_AFFINE_RELU6 = 1, DW_OUT_MASK_STATS = 2, DW_OUT_RAW = 3 };
+
+struct DwParams {
+    const float* x;      // [B,C,Tin]
+    const float* x2;     // [B,C,Tin]   second stream for DW_IN_AFFINE2
+    const float* w;      // [C,K]
+    const float* in_a;   // [C] scale (AFFINE_RELU6) / p (AFFINE2)
+    const float* in_b;   // [C] shift            / q
+    const float* in_c;   // [C]                  / r
+    float* y;            // [B,C,Tout]
+    const float* aux;    // [B,C,Tout]  pre-activation tensor for DW_OUT_MASK_STATS
+    const float* out_a;  // [C]
+    const float* out_b;  // [C]
+    float* stats;        // [G][C][2]
+    int B, C, Tin, Tout, K, stride, pad, flip, upsample, G, in_mode, out_mode;
+};
+
+struct DwWgradParams {
+    const float* g;      // [B,C,Tout] upstream gradient stream 1
+    const float* g2;     // [B,C,Tout] stream 2 for AFFINE2
+    const float* ga; const float* gb; const float* gc;   // [C] each
+    const float* x;      // [B,C,Tin]  conv input (pre-activation when x_mode = AFFINE_RELU6)
+    const float* xa; const float* xb;                     // [C] each
+    float* partial;      // [G][C][K]
+    int B, C, Tin, Tout, K, stride, pad, G, g_mode, x_mode;
+};
+
+__device__ __forceinline__ float dw_in_transform(int mode, float v, float v2, float a, float b, float c) {
+    if (mode == DW_IN_AFFINE_RELU6) return relu6f(fmaf(v, a, b));
+    if (mode == DW_IN_AFFINE2) return fmaf(v, a, fmaf(v2, b, c));
+    return v;
+}
+
+// Branch-free loads: a load inside a conditional makes hipcc wait for it at the join, serialising a
+// tile's loads one latency after another.  Every load below is unconditional (address clamped to
+// the row start when out of range), the value is selected afterwards.
+
+// R consecutive floats ptr[0..R-1] (positions t0..t0+R-1 of a row of length T), zero past the end.
+template <int R, bool AL>
+__device__ __forceinline__ void dw_load_run(float (&out)[R], const float* __restrict__ ptr, int t0, int T) {
+    if constexpr (AL) {
+#pragma unroll
+        for (int q = 0; q < R / 4; ++q) {
+            const bool ok = t0 + 4 * q < T;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? ptr + 4 * q : ptr - t0);
+            out[4 * q] = ok ? v[0] : 0.f; out[4 * q + 1] = ok ? v[1] : 0.f; out[4 * q + 2] = ok ? v[2] : 0.f; out[4 * q + 3] = ok ? v[3] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = t0 + r < T;
+            const float v = ptr[ok ? r : -t0];
+            out[r] = ok ? v : 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Staging: one wave copies the input span of one tile into its LDS row.
+//   LDS index i  <->  input position in0 + i,   in0 = out0*S - pad (may be negative)
+// Global reads are 16-byte aligned float4 when the row length is a multiple of 4 (AL).
+template <int NV, bool TWO>
+struct DwRaw {
+    f32x4 v[NV];
+    f32x4 v2[TWO ? NV : 1];
+};
+
+template <int NV, int SPAN, bool TWO, bool AL>
+__device__ __forceinline__ void dw_issue_loads(DwRaw<NV, TWO>& raw, const float* __restrict__ row, const float* __restrict__ row2,
+                                               int in0, int Tin, int lane) {
+    const int in0a = in0 & ~3;            // floor to a multiple of 4 (two's complement: also for negatives)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int ia = in0a + 4 * (lane + 64 * v);
+        if constexpr (AL) {
+            const bool ok = ia >= 0 && ia < Tin && ia < in0 + SPAN;
+            const int idx = ok ? ia : 0;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(row + idx);
+            raw.v[v] = ok ? a : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (TWO) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(row2 + idx);
+                raw.v2[v] = ok ? b : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = ia + e;
+                const bool ok = t >= 0 && t < Tin && ia < in0 + SPAN;
+                const int idx = ok ? t : 0;
+                const float a = row[idx];
+                raw.v[v][e] = ok ? a : 0.f;
+                if constexpr (TWO) {
+                    const float b = row2[idx];
+                    raw.v2[v][e] = ok ? b : 0.f;
+                }
+            }
+        }
+    }
+}
+
+template <int NV, int SPAN, int MODE, bool TWO>
+__device__ __forceinline__ void dw_stage_to_lds(const DwRaw<NV, TWO>& raw, float* lds, int in0, int Tin,
+                                                float ca, float cb, float cc, int lane) {
+    const int in0a = in0 & ~3;
+    const int off = in0 - in0a;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int ia = in0a + 4 * (lane + 64 * v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = ia + e;
+            const int i = 4 * (lane + 64 * v) + e - off;
+            float val;
+            if constexpr (MODE == DW_IN_AFFINE_RELU6) val = relu6f(fmaf(raw.v[v][e], ca, cb));
+            else if constexpr (MODE == DW_IN_AFFINE2) val = fmaf(raw.v[v][e], ca, fmaf(raw.v2[v][e], cb, cc));
+            else val = raw.v[v][e];
+            val = (t >= 0 && t < Tin) ? val : 0.f;      // zero padding applies to the TRANSFORMED tensor
+            if (i >= 0 && i < SPAN) lds[i] = val;
+        }
+    }
+}
+
+template <int K, int S, int R>
+struct DwGeom {
+    static_assert((R * S) % 4 == 0, "lane window must start on a 16-byte LDS boundary");
+    static constexpr int TILE = 64 * R;
+    static constexpr int WIN = (R - 1) * S + K;               // inputs one lane touches
+    static constexpr int SPAN = (TILE - 1) * S + K;           // inputs one tile touches
+    static constexpr int SPAN4 = (SPAN + 3) & ~3;
+    static constexpr int NV = (SPAN + 3 + 3) / 4 / 64 + 1;    // float4 loads per lane covering [in0a, in0+SPAN)
+    static constexpr int NCH = (WIN + 3) / 4;                 // window chunks
+    static constexpr int NTC = (K + 3) / 4;                   // tap chunks
+    static constexpr int PD = 2;                              // LDS prefetch distance (chunks)
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// Forward / backward-data kernel.  K, stride S, outputs-per-lane R, the input/output modes and the
+// alignment class (AL: Tin and Tout multiples of 4 -> float4 global accesses) are compile time, so
+// the window walk is fully unrolled with static register indices and the staging is branch-free.
+template <int K, int S, int R, int IM, int OM, bool AL>
+__global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
+    using G_ = DwGeom<K, S, R>;
+    constexpr int TILE = G_::TILE, WIN = G_::WIN, SPAN = G_::SPAN, NV = G_::NV, NCH = G_::NCH, NTC = G_::NTC, PD = G_::PD;
+    constexpr bool TWO = IM == DW_IN_AFFINE2;
+    constexpr bool STATS = (OM == DW_OUT_RAW_STATS || OM == DW_OUT_MASK_STATS);
+
+    __shared__ __attribute__((aligned(16))) float lds_all[4][G_::SPAN4 + 8];
+    __shared__ __attribute__((aligned(16))) float lds_w[NTC * 4];
+    __shared__ float lds_red[4][2];
+
+    const int c = blockIdx.x;
+    const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float* lds = lds_all[wave];
+
+    // taps -> LDS (zero padded to a multiple of 4); streamed through registers next to the window
+    for (int j = threadIdx.x; j < NTC * 4; j += 256)
+        lds_w[j] = j < K ? p.w[(size_t)c * K + (p.flip ? (K - 1 - j) : j)] : 0.f;
+    __syncthreads();
+
+    float ca = 1.f, cb = 0.f, cc = 0.f, oa = 1.f, ob = 0.f;
+    if constexpr (IM != DW_IN_NONE) { ca = p.in_a[c]; cb = p.in_b[c]; }
+    if constexpr (IM == DW_IN_AFFINE2) cc = p.in_c[c];
+    if constexpr (OM == DW_OUT_AFFINE_RELU6 || OM == DW_OUT_MASK_STATS) { oa = p.out_a[c]; ob = p.out_b[c]; }
+
+    const int Tin = p.Tin, Tout = p.Tout;
+    const int bper = (p.B + p.G - 1) / p.G;
+    const int b0 = g * bper;
+    const int nb = min(p.B, b0 + bper) - b0;
+    const int ntiles = (Tout + TILE - 1) / TILE;
+    const int nitems = nb > 0 ? nb * ntiles : 0;
+
+    float s0 = 0.f, s1 = 0.f;
+    DwRaw<NV, TWO> raw;
+    int item = wave;
+    if (item < nitems) {
+        const int b = b0 + item / ntiles, tile = item % ntiles;
+        const size_t ro = ((size_t)b * p.C + c) * Tin;
+        dw_issue_loads<NV, SPAN, TWO, AL>(raw, p.x + ro, TWO ? p.x2 + ro : p.x, tile * TILE * S - p.pad, Tin, lane);
+    }
+    for (; item < nitems; item += 4) {
+        const int b = b0 + item / ntiles, tile = item % ntiles;
+        const int out0 = tile * TILE;
+        const int in0 = out0 * S - p.pad;
+        dw_stage_to_lds<NV, SPAN, IM, TWO>(raw, lds, in0, Tin, ca, cb, cc, lane);
+
+        // prefetch the next item's input while this one computes
+        const int nitem = item + 4;
+        if (nitem < nitems) {
+            const int nb_ = b0 + nitem / ntiles, ntile = nitem % ntiles;
+            const size_t ro = ((size_t)nb_ * p.C + c) * Tin;
+            dw_issue_loads<NV, SPAN, TWO, AL>(raw, p.x + ro, TWO ? p.x2 + ro : p.x, ntile * TILE * S - p.pad, Tin, lane);
+        }
+
+        const int t0 = out0 + lane * R;
+        const size_t oo = ((size_t)b * p.C + c) * Tout + t0;
+        float auxv[R];
+        if constexpr (OM == DW_OUT_MASK_STATS) dw_load_run<R, AL>(auxv, p.aux + oo, t0, Tout);
+
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        const float* win = lds + lane * (R * S);
+        // The tap reads are loop-invariant; hide that from LICM (an opaque zero offset per item) or
+        // hipcc hoists all K taps into registers for the whole kernel.
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const float* wl = lds_w + opaque;
+        // Software-pipelined walk: chunk ch of the window and of the taps are fetched PD steps ahead;
+        // the sched_barrier stops hipcc from hoisting every ds_read to the top of the unrolled body
+        // (WIN + K live registers, which halves occupancy for K >= 51).
+        f32x4 inc[NCH];
+        f32x4 tapc[NTC];
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+            if (q < NCH) inc[q] = *reinterpret_cast<const f32x4*>(win + 4 * q);
+            if (q < NTC) tapc[q] = *reinterpret_cast<const f32x4*>(wl + 4 * q);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch + PD < NCH) inc[ch + PD] = *reinterpret_cast<const f32x4*>(win + 4 * (ch + PD));
+            if (ch + PD < NTC) tapc[ch + PD] = *reinterpret_cast<const f32x4*>(wl + 4 * (ch + PD));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * ch + e;
+                if (i < WIN) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int j = i - r * S;
+                        if (j >= 0 && j < K) acc[r] = fmaf(tapc[j >> 2][j & 3], inc[ch][e], acc[r]);
+                    }
+                }
+            }
+            // pin this chunk's FMAs in front of the barrier (pure ops otherwise sink below it)
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acc[r]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // epilogue
+        float outv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool valid = t0 + r < Tout;
+            float yv = acc[r];
+            if constexpr (OM == DW_OUT_RAW_STATS) {
+                if (valid) { s0 += yv; s1 = fmaf(yv, yv, s1); }
+            } else if constexpr (OM == DW_OUT_AFFINE_RELU6) {
+                yv = relu6f(fmaf(yv, oa, ob));
+            } else if constexpr (OM == DW_OUT_MASK_STATS) {
+                const float pre = fmaf(auxv[r], oa, ob);
+                yv = (pre > 0.f && pre < 6.f) ? yv : 0.f;
+                if (valid) { s0 += yv; s1 = fmaf(yv, auxv[r], s1); }
+            }
+            outv[r] = yv;
+        }
+        if constexpr (AL) {
+#pragma unroll
+            for (int q = 0; q < R / 4; ++q) {
+                if (t0 + 4 * q < Tout) {
+                    f32x4 o = {outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(p.y + oo + 4 * q) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (t0 + r < Tout) p.y[oo + r] = outv[r];
+        }
+    }
+
+    if constexpr (STATS) {
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) { lds_red[wave][0] = s0; lds_red[wave][1] = s1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float a = (lds_red[0][0] + lds_red[1][0]) + (lds_red[2][0] + lds_red[3][0]);
+            const float b = (lds_red[0][1] + lds_red[1][1]) + (lds_red[2][1] + lds_red[3][1]);
+            p.stats[((size_t)g * p.C + c) * 2 + 0] = a;
+            p.stats[((size_t)g * p.C + c) * 2 + 1] = b;
+        }
+    }
+}
+
+// kernel sizes used by the reference's networks: asr.py:68-76, tts.py:18-25, 73-76
+#define V100_DW_SPECIALISED(X) X(5) X(7) X(11) X(17) X(19) X(27) X(29) X(33) X(35) X(51) X(59) X(65) X(67) X(75) X(83)
+
+// One launcher per (input mode, output mode) pair, each in its own translation unit (they compile
+// in parallel).  Returns false when (K, stride) has no specialisation.
+template <int IM, int OM>
+static bool dw_launch_specialised(const DwParams& p, hipStream_t st) {
+    dim3 grid(p.C, p.G);
+    const bool al = ((p.Tin & 3) == 0) && ((p.Tout & 3) == 0);
+    const bool big = p.Tout > 256;
+#define DW_GO(KK, SS)                                                                                             \
+    do {                                                                                                          \
+        if (big) { if (al) hipLaunchKernelGGL((dwconv_kernel<KK, SS, 8, IM, OM, true>), grid, dim3(256), 0, st, p);  \
+                   else hipLaunchKernelGGL((dwconv_kernel<KK, SS, 8, IM, OM, false>), grid, dim3(256), 0, st, p); }  \
+        else     { if (al) hipLaunchKernelGGL((dwconv_kernel<KK, SS, 4, IM, OM, true>), grid, dim3(256), 0, st, p);  \
+                   else hipLaunchKernelGGL((dwconv_kernel<KK, SS, 4, IM, OM, false>), grid, dim3(256), 0, st, p); }  \
+        return true;                                                                                              \
+    } while (0)
+#define X(KK) if (p.K == KK && p.stride == 1) DW_GO(KK, 1);
+    V100_DW_SPECIALISED(X)
+#undef X
+    if (p.K == 11 && p.stride == 2) DW_GO(11, 2);
+#undef DW_GO
+    return false;
+}
+
+bool dw_launch_fwd_train(const DwParams& p, hipStream_t st);   // in AFFINE_RELU6, out RAW_STATS
+bool dw_launch_fwd_eval(const DwParams& p, hipStream_t st);    // in NONE,         out AFFINE_RELU6
+bool dw_launch_bwd_data(const DwParams& p, hipStream_t st);    // in AFFINE2,      out MASK_STATS

@@ -12,9 +12,10 @@
 // backward reductions) into a deterministic [parts][M][2] slab.
 //
 // Two precisions of the same tiling (DESIGN.md "K1"):
-//   PREC_F32  : v_mfma_f32_32x32x2_f32, exact fp32 (bitwise an fmaf chain)  -- parity path
-//   PREC_BF16 : v_mfma_f32_32x32x16_bf16, operands rounded to bf16 while staging, fp32 accumulate
+//   fp32 : v_mfma_f32_32x32x2_f32, exact fp32 (bitwise an fmaf chain)  -- parity path
+//   bf16 : v_mfma_f32_32x32x16_bf16, operands rounded to bf16 while staging, fp32 accumulate
 // 128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles (64 acc VGPRs).
+// 1-D grid with an XCD-aware remap: the M-tiles that share one X tile run on one XCD (one L2).
 #include "common.h"
 
 enum { PW_X_NONE = 0, PW_X_AFFINE_RELU6 = 1, PW_X_AFFINE2 = 2 };
@@ -25,7 +26,7 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 
 struct PwParams {
     const float* A;       // [M][K] fp32 weights
-    const u16* Abf;       // [M][K] bf16 weights (PREC_BF16)
+    const u16* Abf;       // [M][K] bf16 weights (bf16 path)
     const float* X;       // [B][K][T]
     const float* X2;      // [B][K][T]  (PW_X_AFFINE2)
     const float* xa; const float* xb; const float* xc;   // [K]
@@ -33,8 +34,8 @@ struct PwParams {
     const float* bias;    // [M] or null
     const float* ea; const float* eb;                     // [M]
     const float* R;       // [B][M][T] residual / pre-activation tensor
-    float* stats;         // [B * gridDim.x][M][2]
-    int B, M, K, T, x_mode, epi_mode;
+    float* stats;         // [B * n_ttiles][M][2]
+    int B, M, K, T, x_mode, epi_mode, n_mtiles, n_ttiles;
 };
 
 __device__ __forceinline__ float pw_x_transform(int mode, float v, float v2, float a, float b, float c) {
@@ -49,32 +50,51 @@ __device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 l
     return v;
 }
 
-// load 4 consecutive floats src[0..3] (element index i0 of a row of length n), zero outside
-__device__ __forceinline__ f32x4 load4(const float* __restrict__ row, int i0, int n, bool vec) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (vec) {
-        if (i0 < n) v = *reinterpret_cast<const f32x4*>(row + i0);
+// Branch-free tile loads.  A conditional load inside a branch makes hipcc wait for it (vmcnt(0)) at
+// the join, which serialises a tile's loads one memory latency after another; here every load is
+// unconditional (address clamped to the tensor base when out of range) and the value is selected
+// afterwards, so a tile's loads are all in flight together.
+//   elements i0..i0+3 of the row starting at base + row_off (row length n), zero where invalid
+template <bool VEC>
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ base, size_t row_off, int i0, int n, bool row_ok) {
+    f32x4 v;
+    if constexpr (VEC) {
+        const bool ok = row_ok && i0 < n;
+        v = *reinterpret_cast<const f32x4*>(base + (ok ? row_off + i0 : 0));
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (i0 + e < n) v[e] = row[i0 + e];
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = row_ok && (i0 + e) < n;
+            const float x = base[ok ? row_off + i0 + e : 0];
+            v[e] = ok ? x : 0.f;
+        }
     }
     return v;
 }
 
-// =============================================================================================
-// fp32 path
-// =============================================================================================
-#define F32_BK 16
-#define F32_LD (128 + 4)
+__device__ __forceinline__ float ldc(const float* __restrict__ c, int i, bool ok, float dflt) {   // coefficient, predicated
+    const float v = c[ok ? i : 0];
+    return ok ? v : dflt;
+}
+
+// XCD-aware work-item index: consecutive block ids are dealt round-robin over the 8 XCDs, so give
+// each XCD a contiguous chunk of the work list (blocks that share an operand tile then share an L2).
+// Bijective for any grid size (cdna_hip_programming.md T1).
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, slot = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
 
 // Shared epilogue for the NN kernels. acc[i][j] is the 32x32 tile (i: m sub-tile, j: t sub-tile);
 // element r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
-__device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[2][2], int b, int m0, int t0, int wm, int wn,
+__device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[2][2], int b, int m0, int t0, int tt, int wm, int wn,
                                             int lane, float (*red)[2][64][2]) {
     const int epi = p.epi_mode;
     const int col = lane & 31, half = lane >> 5;
     const bool do_stats = (epi == PW_EPI_STATS || epi == PW_EPI_MASK_STATS);
+    const bool use_e = (epi == PW_EPI_AFFINE_RELU6 || epi == PW_EPI_AFFINE_RES || epi == PW_EPI_MASK_STATS);
+    const bool use_r = (epi == PW_EPI_MASK_STATS || epi == PW_EPI_ADD || (epi == PW_EPI_AFFINE_RES && p.R));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -82,32 +102,30 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[2][
             const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;    // row inside the wave's 64
             const int m = m0 + wm * 64 + rl;
             const bool mv = m < p.M;
-            float ea = 1.f, eb = 0.f, bs = 0.f;
-            if (mv) {
-                if (epi == PW_EPI_AFFINE_RELU6 || epi == PW_EPI_AFFINE_RES || epi == PW_EPI_MASK_STATS) { ea = p.ea[m]; eb = p.eb[m]; }
-                if (p.bias) bs = p.bias[m];
-            }
+            const float ea = use_e ? ldc(p.ea, m, mv, 1.f) : 1.f;
+            const float eb = use_e ? ldc(p.eb, m, mv, 0.f) : 0.f;
+            const float bs = p.bias ? ldc(p.bias, m, mv, 0.f) : 0.f;
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int t = t0 + wn * 64 + j * 32 + col;
                 const bool ok = mv && t < p.T;
                 const size_t o = ((size_t)b * p.M + m) * p.T + t;
+                float rv = 0.f;
+                if (use_r) { rv = p.R[ok ? o : 0]; rv = ok ? rv : 0.f; }
                 float v = acc[i][j][r] + bs;
                 if (epi == PW_EPI_STATS) {
                     if (ok) { s0 += v; s1 = fmaf(v, v, s1); }
                 } else if (epi == PW_EPI_AFFINE_RELU6) {
                     v = relu6f(fmaf(v, ea, eb));
                 } else if (epi == PW_EPI_AFFINE_RES) {
-                    v = fmaf(v, ea, eb);
-                    if (p.R && ok) v += p.R[o];
+                    v = fmaf(v, ea, eb) + rv;
                 } else if (epi == PW_EPI_MASK_STATS) {
-                    const float a = ok ? p.R[o] : 0.f;
-                    const float pre = fmaf(a, ea, eb);
+                    const float pre = fmaf(rv, ea, eb);
                     v = (pre > 0.f && pre < 6.f) ? v : 0.f;
-                    if (ok) { s0 += v; s1 = fmaf(v, a, s1); }
+                    if (ok) { s0 += v; s1 = fmaf(v, rv, s1); }
                 } else if (epi == PW_EPI_ADD) {
-                    if (ok) v += p.R[o];
+                    v += rv;
                 }
                 if (ok) p.Y[o] = v;
             }
@@ -125,7 +143,7 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[2][
             const int m = m0 + tid;
             if (m < p.M) {
                 const int w = tid >> 6, rl = tid & 63;
-                const size_t part = (size_t)b * gridDim.x + blockIdx.x;
+                const size_t part = (size_t)b * p.n_ttiles + tt;
                 p.stats[(part * p.M + m) * 2 + 0] = red[w][0][rl][0] + red[w][1][rl][0];
                 p.stats[(part * p.M + m) * 2 + 1] = red[w][0][rl][1] + red[w][1][rl][1];
             }
@@ -133,6 +151,22 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[2][
     }
 }
 
+// work item -> (b, t-tile, m-tile), m-tile fastest
+__device__ __forceinline__ void pw_work(const PwParams& p, int& b, int& tt, int& mt) {
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    mt = w % p.n_mtiles;
+    const int rest = w / p.n_mtiles;
+    tt = rest % p.n_ttiles;
+    b = rest / p.n_ttiles;
+}
+
+// =============================================================================================
+// fp32 path
+// =============================================================================================
+#define F32_BK 16
+#define F32_LD (128 + 4)
+
+template <bool TV, bool KV>
 __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(PwParams p) {
     __shared__ __attribute__((aligned(16))) float As[2][F32_BK][F32_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][F32_BK][F32_LD];
@@ -140,11 +174,11 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(PwParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.z, m0 = blockIdx.y * PW_BM, t0 = blockIdx.x * PW_BN;
+    int b, tt, mt;
+    pw_work(p, b, tt, mt);
+    const int m0 = mt * PW_BM, t0 = tt * PW_BN;
     const int M = p.M, K = p.K, T = p.T, x_mode = p.x_mode;
-    const float* Xb = p.X + (size_t)b * K * T;
-    const float* X2b = (x_mode == PW_X_AFFINE2) ? p.X2 + (size_t)b * K * T : Xb;
-    const bool kvec = (K & 3) == 0, tvec = (T & 3) == 0;
+    const size_t xoff = (size_t)b * K * T;
 
     const int a_k = (tid & 3) * 4;          // + k0, 4 consecutive k
     const int a_m = tid >> 2;               // + 64*i
@@ -152,19 +186,18 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(PwParams p) {
     const int b_k = tid >> 5;               // + 8*i
 
     f32x4 ra[2], rb[2], rb2[2];
+    float ca[2], cb[2], cc[2];
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + a_m + 64 * i;
-            ra[i] = (m < M) ? load4(p.A + (size_t)m * K, k0 + a_k, K, kvec) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[i] = ld4<KV>(p.A, (size_t)m * K, k0 + a_k, K, m < M);
             const int k = k0 + b_k + 8 * i;
-            if (k < K) {
-                rb[i] = load4(Xb + (size_t)k * T, t0 + b_t, T, tvec);
-                if (x_mode == PW_X_AFFINE2) rb2[i] = load4(X2b + (size_t)k * T, t0 + b_t, T, tvec);
-            } else {
-                rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                rb2[i] = rb[i];
-            }
+            const bool kv = k < K;
+            rb[i] = ld4<TV>(p.X, xoff + (size_t)k * T, t0 + b_t, T, kv);
+            if (x_mode == PW_X_AFFINE2) rb2[i] = ld4<TV>(p.X2, xoff + (size_t)k * T, t0 + b_t, T, kv);
+            if (x_mode != PW_X_NONE) { ca[i] = ldc(p.xa, k, kv, 1.f); cb[i] = ldc(p.xb, k, kv, 0.f); }
+            if (x_mode == PW_X_AFFINE2) cc[i] = ldc(p.xc, k, kv, 0.f);
         }
     };
     auto store_tiles = [&](int buf, int k0) {
@@ -174,11 +207,10 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(PwParams p) {
             for (int e = 0; e < 4; ++e) As[buf][a_k + e][a_m + 64 * i] = ra[i][e];
             const int k = k0 + b_k + 8 * i;
             f32x4 v = rb[i];
-            if (x_mode != PW_X_NONE && k < K) {
-                const float ca = p.xa[k], cb = p.xb[k], cc = (x_mode == PW_X_AFFINE2) ? p.xc[k] : 0.f;
+            if (x_mode != PW_X_NONE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    v[e] = (t0 + b_t + e < T) ? pw_x_transform(x_mode, rb[i][e], rb2[i][e], ca, cb, cc) : 0.f;
+                    v[e] = (k < K && t0 + b_t + e < T) ? pw_x_transform(x_mode, rb[i][e], rb2[i][e], ca[i], cb[i], cc[i]) : 0.f;
             }
             *reinterpret_cast<f32x4*>(&Bs[buf][b_k + 8 * i][b_t]) = v;
         }
@@ -214,7 +246,7 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(PwParams p) {
         if (kt + 1 < nk) store_tiles(cur ^ 1, (kt + 1) * F32_BK);
         __syncthreads();
     }
-    pw_epilogue(p, acc, b, m0, t0, wm, wn, lane, red);
+    pw_epilogue(p, acc, b, m0, t0, tt, wm, wn, lane, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -224,17 +256,28 @@ struct WgParams {
     const float* G;  const float* G2;  const float* ga; const float* gb; const float* gc;   // A operand [B][M][T], coeffs [M]
     const float* X;  const float* xa; const float* xb;                                        // B operand [B][K][T], coeffs [K]
     float* partial;  // [S][M][K]
-    int B, M, K, T, S, g_mode, x_mode;
+    int B, M, K, T, S, g_mode, x_mode, n_mtiles, n_ktiles;
 };
 
+// work item -> (split, m-tile, k-tile), k-tile fastest: one split's tiles sit on one XCD
+__device__ __forceinline__ void wg_work(const WgParams& p, int& s, int& mt, int& kt) {
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    kt = w % p.n_ktiles;
+    const int rest = w / p.n_ktiles;
+    mt = rest % p.n_mtiles;
+    s = rest / p.n_mtiles;
+}
+
+template <bool TV>
 __global__ __launch_bounds__(256) void pw_wgrad_f32_kernel(WgParams p) {
     __shared__ __attribute__((aligned(16))) float As[2][F32_BK][F32_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][F32_BK][F32_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int s = blockIdx.z, m0 = blockIdx.y * PW_BM, n0 = blockIdx.x * PW_BN;
+    int s, mt, ktile;
+    wg_work(p, s, mt, ktile);
+    const int m0 = mt * PW_BM, n0 = ktile * PW_BN;
     const int M = p.M, K = p.K, T = p.T, g_mode = p.g_mode, x_mode = p.x_mode;
-    const bool tvec = (T & 3) == 0;
     const int bper = (p.B + p.S - 1) / p.S;
     const int b_lo = s * bper, b_hi = min(p.B, b_lo + bper);
 
@@ -243,14 +286,16 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32_kernel(WgParams p) {
 
     // per-row prologue coefficients are fixed for the whole kernel
     float ga[2], gb[2], gc[2], xa[2], xb[2];
+    bool mv[2], kv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + l_r + 64 * i, k = n0 + l_r + 64 * i;
-        ga[i] = (g_mode != PW_X_NONE && m < M) ? p.ga[m] : 1.f;
-        gb[i] = (g_mode != PW_X_NONE && m < M) ? p.gb[m] : 0.f;
-        gc[i] = (g_mode == PW_X_AFFINE2 && m < M) ? p.gc[m] : 0.f;
-        xa[i] = (x_mode != PW_X_NONE && k < K) ? p.xa[k] : 1.f;
-        xb[i] = (x_mode != PW_X_NONE && k < K) ? p.xb[k] : 0.f;
+        mv[i] = m < M; kv[i] = k < K;
+        ga[i] = (g_mode != PW_X_NONE) ? ldc(p.ga, m, mv[i], 1.f) : 1.f;
+        gb[i] = (g_mode != PW_X_NONE) ? ldc(p.gb, m, mv[i], 0.f) : 0.f;
+        gc[i] = (g_mode == PW_X_AFFINE2) ? ldc(p.gc, m, mv[i], 0.f) : 0.f;
+        xa[i] = (x_mode != PW_X_NONE) ? ldc(p.xa, k, kv[i], 1.f) : 1.f;
+        xb[i] = (x_mode != PW_X_NONE) ? ldc(p.xb, k, kv[i], 0.f) : 0.f;
     }
 
     f32x4 ra[2], ra2[2], rb[2];
@@ -258,21 +303,19 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32_kernel(WgParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + l_r + 64 * i, k = n0 + l_r + 64 * i;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[i] = (m < M) ? load4(p.G + ((size_t)b * M + m) * T, t0 + l_t, T, tvec) : z;
-            ra2[i] = (g_mode == PW_X_AFFINE2 && m < M) ? load4(p.G2 + ((size_t)b * M + m) * T, t0 + l_t, T, tvec) : z;
-            rb[i] = (k < K) ? load4(p.X + ((size_t)b * K + k) * T, t0 + l_t, T, tvec) : z;
+            ra[i] = ld4<TV>(p.G, ((size_t)b * M + m) * T, t0 + l_t, T, mv[i]);
+            if (g_mode == PW_X_AFFINE2) ra2[i] = ld4<TV>(p.G2, ((size_t)b * M + m) * T, t0 + l_t, T, mv[i]);
+            rb[i] = ld4<TV>(p.X, ((size_t)b * K + k) * T, t0 + l_t, T, kv[i]);
         }
     };
     auto store_tiles = [&](int buf, int t0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const bool mv = (m0 + l_r + 64 * i) < M, kv = (n0 + l_r + 64 * i) < K;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool tv = t0 + l_t + e < T;
-                As[buf][l_t + e][l_r + 64 * i] = (mv && tv) ? pw_x_transform(g_mode, ra[i][e], ra2[i][e], ga[i], gb[i], gc[i]) : 0.f;
-                Bs[buf][l_t + e][l_r + 64 * i] = (kv && tv) ? pw_x_transform(x_mode, rb[i][e], 0.f, xa[i], xb[i], 0.f) : 0.f;
+                As[buf][l_t + e][l_r + 64 * i] = (mv[i] && tv) ? pw_x_transform(g_mode, ra[i][e], ra2[i][e], ga[i], gb[i], gc[i]) : 0.f;
+                Bs[buf][l_t + e][l_r + 64 * i] = (kv[i] && tv) ? pw_x_transform(x_mode, rb[i][e], 0.f, xa[i], xb[i], 0.f) : 0.f;
             }
         }
     };
@@ -337,6 +380,28 @@ __device__ __forceinline__ int bf_off(int row, int chunk) {          // byte off
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// 8 consecutive bf16 of A[m][k..k+7] (zero where invalid), branch-free
+template <bool KV>
+__device__ __forceinline__ uint4 ld8bf(const u16* __restrict__ base, size_t row_off, int k, int K, bool row_ok) {
+    uint4 v;
+    if constexpr (KV) {
+        const bool ok = row_ok && k < K;
+        v = *reinterpret_cast<const uint4*>(base + (ok ? row_off + k : 0));
+        if (!ok) v = uint4{0u, 0u, 0u, 0u};
+    } else {
+        unsigned t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = row_ok && (k + e) < K;
+            const unsigned x = base[ok ? row_off + k + e : 0];
+            t[e] = ok ? x : 0u;
+        }
+        v.x = t[0] | (t[1] << 16); v.y = t[2] | (t[3] << 16); v.z = t[4] | (t[5] << 16); v.w = t[6] | (t[7] << 16);
+    }
+    return v;
+}
+
+template <bool TV, bool KV>
 __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(PwParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char As[2][128 * 128];   // [m][k] bf16, 16 KB per buffer
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][128 * 128];   // [t][k] bf16
@@ -344,11 +409,11 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(PwParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.z, m0 = blockIdx.y * PW_BM, t0 = blockIdx.x * PW_BN;
+    int b, tt, mt;
+    pw_work(p, b, tt, mt);
+    const int m0 = mt * PW_BM, t0 = tt * PW_BN;
     const int M = p.M, K = p.K, T = p.T, x_mode = p.x_mode;
-    const float* Xb = p.X + (size_t)b * K * T;
-    const float* X2b = (x_mode == PW_X_AFFINE2) ? p.X2 + (size_t)b * K * T : Xb;
-    const bool kvec = (K & 7) == 0, tvec = (T & 3) == 0;
+    const size_t xoff = (size_t)b * K * T;
 
     // A tile: 128 rows x 8 chunks(8 bf16) = 1024 16-byte pieces, 4 per thread
     // B tile: 64 k x 128 t fp32; thread owns 8 consecutive k (one chunk) x 4 consecutive t
@@ -357,36 +422,22 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(PwParams p) {
 
     uint4 ra[4];
     f32x4 rb[8], rb2[8];
+    float ca[8], cb[8], cc[8];
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int piece = tid + 256 * i;
             const int row = piece >> 3, ch = piece & 7;
-            const int m = m0 + row, k = k0 + ch * 8;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (m < M && k < K) {
-                const u16* src = p.Abf + (size_t)m * K + k;
-                if (kvec) v = *reinterpret_cast<const uint4*>(src);
-                else {
-                    u16 tmp[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) tmp[e] = (k + e < K) ? src[e] : (u16)0;
-                    v.x = tmp[0] | (tmp[1] << 16); v.y = tmp[2] | (tmp[3] << 16);
-                    v.z = tmp[4] | (tmp[5] << 16); v.w = tmp[6] | (tmp[7] << 16);
-                }
-            }
-            ra[i] = v;
+            ra[i] = ld8bf<KV>(p.Abf, (size_t)(m0 + row) * K, k0 + ch * 8, K, (m0 + row) < M);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + b_kc * 8 + e;
-            if (k < K) {
-                rb[e] = load4(Xb + (size_t)k * T, t0 + b_tq, T, tvec);
-                if (x_mode == PW_X_AFFINE2) rb2[e] = load4(X2b + (size_t)k * T, t0 + b_tq, T, tvec);
-            } else {
-                rb[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-                rb2[e] = rb[e];
-            }
+            const bool kv = k < K;
+            rb[e] = ld4<TV>(p.X, xoff + (size_t)k * T, t0 + b_tq, T, kv);
+            if (x_mode == PW_X_AFFINE2) rb2[e] = ld4<TV>(p.X2, xoff + (size_t)k * T, t0 + b_tq, T, kv);
+            if (x_mode != PW_X_NONE) { ca[e] = ldc(p.xa, k, kv, 1.f); cb[e] = ldc(p.xb, k, kv, 0.f); }
+            if (x_mode == PW_X_AFFINE2) cc[e] = ldc(p.xc, k, kv, 0.f);
         }
     };
     auto store_tiles = [&](int buf, int k0) {
@@ -400,11 +451,12 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(PwParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + b_kc * 8 + e;
-            float ca = 1.f, cb = 0.f, cc = 0.f;
-            if (x_mode != PW_X_NONE && k < K) { ca = p.xa[k]; cb = p.xb[k]; if (x_mode == PW_X_AFFINE2) cc = p.xc[k]; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                v[e][q] = (k < K && t0 + b_tq + q < T) ? pw_x_transform(x_mode, rb[e][q], rb2[e][q], ca, cb, cc) : 0.f;
+            for (int q = 0; q < 4; ++q) {
+                float x = rb[e][q];
+                if (x_mode != PW_X_NONE) x = (k < K && t0 + b_tq + q < T) ? pw_x_transform(x_mode, x, rb2[e][q], ca[e], cb[e], cc[e]) : 0.f;
+                v[e][q] = x;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -446,23 +498,39 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(PwParams p) {
         if (kt + 1 < nk) store_tiles(cur ^ 1, (kt + 1) * BF_BK);
         __syncthreads();
     }
-    pw_epilogue(p, acc, b, m0, t0, wm, wn, lane, red);
+    pw_epilogue(p, acc, b, m0, t0, tt, wm, wn, lane, red);
 }
 
 // Backward-weight, bf16: contraction index is t; both operands are read as 8 consecutive t
 // (two float4), transformed, rounded and written as one 16-byte chunk of a [row][t] image.
+template <bool TV>
 __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char As[2][128 * 128];   // [m][t] bf16
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][128 * 128];   // [k][t] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int s = blockIdx.z, m0 = blockIdx.y * PW_BM, n0 = blockIdx.x * PW_BN;
+    int s, mt, ktile;
+    wg_work(p, s, mt, ktile);
+    const int m0 = mt * PW_BM, n0 = ktile * PW_BN;
     const int M = p.M, K = p.K, T = p.T, g_mode = p.g_mode, x_mode = p.x_mode;
-    const bool tvec = (T & 3) == 0;
     const int bper = (p.B + p.S - 1) / p.S;
     const int b_lo = s * bper, b_hi = min(p.B, b_lo + bper);
 
-    // 128 rows x 8 chunks per operand = 1024 pieces, 4 per thread: piece = tid + 256*i
+    // 128 rows x 8 chunks per operand = 1024 pieces, 4 per thread: piece = tid + 256*i (row = piece>>3, chunk = piece&7)
+    float ga[4], gb[4], gc[4], xa[4], xb[4];
+    bool mv[4], kv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid + 256 * i) >> 3;
+        const int m = m0 + row, k = n0 + row;
+        mv[i] = m < M; kv[i] = k < K;
+        ga[i] = (g_mode != PW_X_NONE) ? ldc(p.ga, m, mv[i], 1.f) : 1.f;
+        gb[i] = (g_mode != PW_X_NONE) ? ldc(p.gb, m, mv[i], 0.f) : 0.f;
+        gc[i] = (g_mode == PW_X_AFFINE2) ? ldc(p.gc, m, mv[i], 0.f) : 0.f;
+        xa[i] = (x_mode != PW_X_NONE) ? ldc(p.xa, k, kv[i], 1.f) : 1.f;
+        xb[i] = (x_mode != PW_X_NONE) ? ldc(p.xb, k, kv[i], 0.f) : 0.f;
+    }
+
     f32x4 ra[4][2], ra2[4][2], rb[4][2];
     auto load_tiles = [&](int b, int t0) {
 #pragma unroll
@@ -470,12 +538,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgParams p) {
             const int piece = tid + 256 * i;
             const int row = piece >> 3, ch = piece & 7;
             const int m = m0 + row, k = n0 + row, t = t0 + ch * 8;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                ra[i][h] = (m < M) ? load4(p.G + ((size_t)b * M + m) * T, t + 4 * h, T, tvec) : z;
-                ra2[i][h] = (g_mode == PW_X_AFFINE2 && m < M) ? load4(p.G2 + ((size_t)b * M + m) * T, t + 4 * h, T, tvec) : z;
-                rb[i][h] = (k < K) ? load4(p.X + ((size_t)b * K + k) * T, t + 4 * h, T, tvec) : z;
+                ra[i][h] = ld4<TV>(p.G, ((size_t)b * M + m) * T, t + 4 * h, T, mv[i]);
+                if (g_mode == PW_X_AFFINE2) ra2[i][h] = ld4<TV>(p.G2, ((size_t)b * M + m) * T, t + 4 * h, T, mv[i]);
+                rb[i][h] = ld4<TV>(p.X, ((size_t)b * K + k) * T, t + 4 * h, T, kv[i]);
             }
         }
     };
@@ -484,16 +551,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgParams p) {
         for (int i = 0; i < 4; ++i) {
             const int piece = tid + 256 * i;
             const int row = piece >> 3, ch = piece & 7;
-            const int m = m0 + row, k = n0 + row, t = t0 + ch * 8;
-            float ga = 1.f, gb = 0.f, gc = 0.f, xa = 1.f, xb = 0.f;
-            if (g_mode != PW_X_NONE && m < M) { ga = p.ga[m]; gb = p.gb[m]; if (g_mode == PW_X_AFFINE2) gc = p.gc[m]; }
-            if (x_mode != PW_X_NONE && k < K) { xa = p.xa[k]; xb = p.xb[k]; }
+            const int t = t0 + ch * 8;
             float va[8], vb[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const bool tv = t + e < T;
-                va[e] = (m < M && tv) ? pw_x_transform(g_mode, ra[i][e >> 2][e & 3], ra2[i][e >> 2][e & 3], ga, gb, gc) : 0.f;
-                vb[e] = (k < K && tv) ? pw_x_transform(x_mode, rb[i][e >> 2][e & 3], 0.f, xa, xb, 0.f) : 0.f;
+                va[e] = (mv[i] && tv) ? pw_x_transform(g_mode, ra[i][e >> 2][e & 3], ra2[i][e >> 2][e & 3], ga[i], gb[i], gc[i]) : 0.f;
+                vb[e] = (kv[i] && tv) ? pw_x_transform(x_mode, rb[i][e >> 2][e & 3], 0.f, xa[i], xb[i], 0.f) : 0.f;
             }
             uint4 oa, ob;
             oa.x = pack_bf16(va[0], va[1]); oa.y = pack_bf16(va[2], va[3]); oa.z = pack_bf16(va[4], va[5]); oa.w = pack_bf16(va[6], va[7]);
@@ -606,10 +670,26 @@ extern "C" int v100_pw_gemm(const float* A, const void* A_bf16, const float* X, 
     if ((epi_mode == PW_EPI_AFFINE_RELU6 || epi_mode == PW_EPI_AFFINE_RES || epi_mode == PW_EPI_MASK_STATS) && (!ea || !eb)) return V100_ERR_NULL;
     if ((epi_mode == PW_EPI_MASK_STATS || epi_mode == PW_EPI_ADD) && !R) return V100_ERR_NULL;
     if ((epi_mode == PW_EPI_STATS || epi_mode == PW_EPI_MASK_STATS) && !stats) return V100_ERR_NULL;
-    PwParams p{A, (const u16*)A_bf16, X, X2, xa, xb, xc, Y, bias, ea, eb, R, stats, B, M, K, T, x_mode, epi_mode};
-    dim3 grid(ceil_div(T, PW_BN), ceil_div(M, PW_BM), B);
-    if (use_bf16) hipLaunchKernelGGL(pw_gemm_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(pw_gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    const int nmt = ceil_div(M, PW_BM), ntt = ceil_div(T, PW_BN);
+    PwParams p{A, (const u16*)A_bf16, X, X2, xa, xb, xc, Y, bias, ea, eb, R, stats, B, M, K, T, x_mode, epi_mode, nmt, ntt};
+    const long nwg = (long)nmt * ntt * B;
+    if (nwg > 0x7fffffffL) return V100_ERR_SHAPE;
+    dim3 grid((unsigned)nwg);
+    hipStream_t st = (hipStream_t)stream;
+    const bool tv = (T & 3) == 0;
+    if (use_bf16) {
+        const bool kv = (K & 7) == 0;
+        if (tv && kv) hipLaunchKernelGGL((pw_gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, p);
+        else if (tv) hipLaunchKernelGGL((pw_gemm_bf16_kernel<true, false>), grid, dim3(256), 0, st, p);
+        else if (kv) hipLaunchKernelGGL((pw_gemm_bf16_kernel<false, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((pw_gemm_bf16_kernel<false, false>), grid, dim3(256), 0, st, p);
+    } else {
+        const bool kv = (K & 3) == 0;
+        if (tv && kv) hipLaunchKernelGGL((pw_gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, p);
+        else if (tv) hipLaunchKernelGGL((pw_gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, p);
+        else if (kv) hipLaunchKernelGGL((pw_gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((pw_gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, p);
+    }
     return v100_launch_status();
 }
 
@@ -622,11 +702,19 @@ extern "C" int v100_pw_wgrad(const float* G, const float* G2, const float* ga, c
     if (g_mode != PW_X_NONE && (!ga || !gb)) return V100_ERR_NULL;
     if (g_mode == PW_X_AFFINE2 && (!G2 || !gc)) return V100_ERR_NULL;
     if (x_mode != PW_X_NONE && (!xa || !xb)) return V100_ERR_NULL;
-    WgParams p{G, G2, ga, gb, gc, X, xa, xb, partial, B, M, K, T, S, g_mode, x_mode};
-    dim3 grid(ceil_div(K, PW_BN), ceil_div(M, PW_BM), S);
-    if (use_bf16) hipLaunchKernelGGL(pw_wgrad_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(pw_wgrad_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    const int nmt = ceil_div(M, PW_BM), nkt = ceil_div(K, PW_BN);
+    WgParams p{G, G2, ga, gb, gc, X, xa, xb, partial, B, M, K, T, S, g_mode, x_mode, nmt, nkt};
+    dim3 grid((unsigned)(nmt * nkt * S));
+    hipStream_t st = (hipStream_t)stream;
+    const bool tv = (T & 3) == 0;
+    if (use_bf16) {
+        if (tv) hipLaunchKernelGGL((pw_wgrad_bf16_kernel<true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((pw_wgrad_bf16_kernel<false>), grid, dim3(256), 0, st, p);
+    } else {
+        if (tv) hipLaunchKernelGGL((pw_wgrad_f32_kernel<true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((pw_wgrad_f32_kernel<false>), grid, dim3(256), 0, st, p);
+    }
     const long n = (long)M * K;
-    hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, dW, S, n);
+    hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, dW, S, n);
     return v100_launch_status();
 }
