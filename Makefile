@@ -12,7 +12,7 @@ HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wno
 
 all: $(LIB) oracle
 
-$(OBJD)/%.o: $(CSRC)/%.hip $(CSRC)/common.h
+$(OBJD)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h)
 	@mkdir -p $(OBJD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -1,0 +1,314 @@
+// bf16-operand instantiations of the pointwise GEMM kernels (see pointwise_common.h / pointwise.hip).
+#include "pointwise_common.h"
+
+// =============================================================================================
+// bf16 path: operands rounded to bf16 while staging, fp32 accumulate (v_mfma_f32_32x32x16_bf16).
+// LDS images are [row][k] with k contiguous (64 bf16 = 128 B per row) and a 16-byte-chunk XOR
+// swizzle chunk ^= (row >> 1) & 7 so the fragment ds_read_b128 of 32 consecutive rows is
+// conflict-free (bank rule (a/4) % 64, 16-lane groups).
+// =============================================================================================
+#define BF_BK 64
+
+__device__ __forceinline__ int bf_off(int row, int chunk) {          // byte offset inside a [128][64] bf16 tile
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// 8 consecutive bf16 of A[m][k..k+7], RAW (address clamped when out of range; mask8bf at the use)
+template <bool KV>
+__device__ __forceinline__ uint4 ld8bf(const u16* __restrict__ base, size_t row_off, int k, int K, bool row_ok) {
+    uint4 v;
+    if constexpr (KV) {
+        const bool ok = row_ok && k < K;
+        v = *reinterpret_cast<const uint4*>(base + (ok ? row_off + k : 0));
+    } else {
+        unsigned t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = row_ok && (k + e) < K;
+            t[e] = base[ok ? row_off + k + e : 0];
+        }
+        v.x = t[0] | (t[1] << 16); v.y = t[2] | (t[3] << 16); v.z = t[4] | (t[5] << 16); v.w = t[6] | (t[7] << 16);
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint4 mask8bf(uint4 v, int k, int K, bool row_ok) {
+    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned lo = (row_ok && (k + 2 * e) < K) ? 0xffffu : 0u;
+        const unsigned hi = (row_ok && (k + 2 * e + 1) < K) ? 0xffff0000u : 0u;
+        w[e] &= (lo | hi);
+    }
+    return uint4{w[0], w[1], w[2], w[3]};
+}
+
+template <int XM_, int EPI_, bool TV, bool KV>
+__global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(PwParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][128 * 128];   // [m][k] bf16, 16 KB per buffer
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][128 * 128];   // [t][k] bf16
+    __shared__ float red[2][2][64][2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int b, tt, mt;
+    pw_work(p, b, tt, mt);
+    const int m0 = mt * PW_BM, t0 = tt * PW_BN;
+    const int M = p.M, K = p.K, T = p.T;
+    const int x_mode = PW_MODE(XM_, p.x_mode);
+    const size_t xoff = (size_t)b * K * T;
+
+    // A tile: 128 rows x 8 chunks(8 bf16) = 1024 16-byte pieces, 4 per thread
+    // B tile: 64 k x 128 t fp32; thread owns 8 consecutive k (one chunk) x 4 consecutive t
+    const int b_tq = (tid & 31) * 4;       // t offset in tile
+    const int b_kc = tid >> 5;             // chunk 0..7  -> k = 8*b_kc .. +7
+
+    uint4 ra[4];
+    f32x4 rb[8], rb2[8];
+    float ca[8], cb[8], cc[8];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = tid + 256 * i;
+            const int row = piece >> 3, ch = piece & 7;
+            ra[i] = ld8bf<KV>(p.Abf, (size_t)(m0 + row) * K, k0 + ch * 8, K, (m0 + row) < M);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + b_kc * 8 + e;
+            const bool kv = k < K;
+            rb[e] = ld4<TV>(p.X, xoff + (size_t)k * T, t0 + b_tq, T, kv);
+            if (x_mode == PW_X_AFFINE2) rb2[e] = ld4<TV>(p.X2, xoff + (size_t)k * T, t0 + b_tq, T, kv);
+            if (x_mode != PW_X_NONE) { ca[e] = ldc(p.xa, k, kv, 1.f); cb[e] = ldc(p.xb, k, kv, 0.f); }
+            if (x_mode == PW_X_AFFINE2) cc[e] = ldc(p.xc, k, kv, 0.f);
+        }
+    };
+    auto store_tiles = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = tid + 256 * i;
+            const int row = piece >> 3, ch = piece & 7;
+            *reinterpret_cast<uint4*>(&As[buf][bf_off(row, ch)]) = mask8bf(ra[i], k0 + ch * 8, K, (m0 + row) < M);
+        }
+        float v[8][4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + b_kc * 8 + e;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[e][q] = (k < K && t0 + b_tq + q < T) ? pw_x_transform(x_mode, rb[e][q], rb2[e][q], ca[e], cb[e], cc[e]) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 o;
+            o.x = pack_bf16(v[0][q], v[1][q]); o.y = pack_bf16(v[2][q], v[3][q]);
+            o.z = pack_bf16(v[4][q], v[5][q]); o.w = pack_bf16(v[6][q], v[7][q]);
+            *reinterpret_cast<uint4*>(&Bs[buf][bf_off(b_tq + q, b_kc)]) = o;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (K + BF_BK - 1) / BF_BK;
+    load_tiles(0);
+    store_tiles(0, 0);
+    __syncthreads();
+    const int lr = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * BF_BK);
+        __builtin_amdgcn_sched_barrier(0);      // loads are issued before the MFMA block ...
+#pragma unroll
+        for (int ks = 0; ks < BF_BK / 16; ++ks) {          // 16 k per MFMA: lane half lh holds k = 16*ks + 8*lh .. +7
+            const int ch = ks * 2 + lh;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[cur][bf_off(wm * 64 + lr, ch)]);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[cur][bf_off(wm * 64 + 32 + lr, ch)]);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[cur][bf_off(wn * 64 + lr, ch)]);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[cur][bf_off(wn * 64 + 32 + lr, ch)]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        // ... and first USED after it: without this fence hipcc hoists the staging arithmetic (and the
+        // vmcnt wait it needs) above the MFMAs, which exposes the whole memory latency every k-step.
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]));
+        if (x_mode == PW_X_AFFINE2)
+            asm volatile("" : "+v"(rb2[0]), "+v"(rb2[1]), "+v"(rb2[2]), "+v"(rb2[3]), "+v"(rb2[4]), "+v"(rb2[5]), "+v"(rb2[6]), "+v"(rb2[7]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) store_tiles(cur ^ 1, (kt + 1) * BF_BK);
+        __syncthreads();
+    }
+    pw_epilogue<EPI_>(p, acc, b, m0, t0, tt, wm, wn, lane, red);
+}
+
+// Backward-weight, bf16: contraction index is t; both operands are read as 8 consecutive t
+// (two float4), transformed, rounded and written as one 16-byte chunk of a [row][t] image.
+template <int GM_, int XM_, bool TV>
+__global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][128 * 128];   // [m][t] bf16
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][128 * 128];   // [k][t] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int s, mt, ktile;
+    wg_work(p, s, mt, ktile);
+    const int m0 = mt * PW_BM, n0 = ktile * PW_BN;
+    const int M = p.M, K = p.K, T = p.T;
+    const int g_mode = PW_MODE(GM_, p.g_mode), x_mode = PW_MODE(XM_, p.x_mode);
+    const int bper = (p.B + p.S - 1) / p.S;
+    const int b_lo = s * bper, b_hi = min(p.B, b_lo + bper);
+
+    // 128 rows x 8 chunks per operand = 1024 pieces, 4 per thread: piece = tid + 256*i (row = piece>>3, chunk = piece&7)
+    float ga[4], gb[4], gc[4], xa[4], xb[4];
+    bool mv[4], kv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid + 256 * i) >> 3;
+        const int m = m0 + row, k = n0 + row;
+        mv[i] = m < M; kv[i] = k < K;
+        ga[i] = (g_mode != PW_X_NONE) ? ldc(p.ga, m, mv[i], 1.f) : 1.f;
+        gb[i] = (g_mode != PW_X_NONE) ? ldc(p.gb, m, mv[i], 0.f) : 0.f;
+        gc[i] = (g_mode == PW_X_AFFINE2) ? ldc(p.gc, m, mv[i], 0.f) : 0.f;
+        xa[i] = (x_mode != PW_X_NONE) ? ldc(p.xa, k, kv[i], 1.f) : 1.f;
+        xb[i] = (x_mode != PW_X_NONE) ? ldc(p.xb, k, kv[i], 0.f) : 0.f;
+    }
+
+    f32x4 ra[4][2], ra2[4][2], rb[4][2];
+    auto load_tiles = [&](int b, int t0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = tid + 256 * i;
+            const int row = piece >> 3, ch = piece & 7;
+            const int m = m0 + row, k = n0 + row, t = t0 + ch * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ra[i][h] = ld4<TV>(p.G, ((size_t)b * M + m) * T, t + 4 * h, T, mv[i]);
+                if (g_mode == PW_X_AFFINE2) ra2[i][h] = ld4<TV>(p.G2, ((size_t)b * M + m) * T, t + 4 * h, T, mv[i]);
+                rb[i][h] = ld4<TV>(p.X, ((size_t)b * K + k) * T, t + 4 * h, T, kv[i]);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf, int t0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = tid + 256 * i;
+            const int row = piece >> 3, ch = piece & 7;
+            const int t = t0 + ch * 8;
+            float va[8], vb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool tv = t + e < T;
+                va[e] = (mv[i] && tv) ? pw_x_transform(g_mode, ra[i][e >> 2][e & 3], ra2[i][e >> 2][e & 3], ga[i], gb[i], gc[i]) : 0.f;
+                vb[e] = (kv[i] && tv) ? pw_x_transform(x_mode, rb[i][e >> 2][e & 3], 0.f, xa[i], xb[i], 0.f) : 0.f;
+            }
+            uint4 oa, ob;
+            oa.x = pack_bf16(va[0], va[1]); oa.y = pack_bf16(va[2], va[3]); oa.z = pack_bf16(va[4], va[5]); oa.w = pack_bf16(va[6], va[7]);
+            ob.x = pack_bf16(vb[0], vb[1]); ob.y = pack_bf16(vb[2], vb[3]); ob.z = pack_bf16(vb[4], vb[5]); ob.w = pack_bf16(vb[6], vb[7]);
+            *reinterpret_cast<uint4*>(&As[buf][bf_off(row, ch)]) = oa;
+            *reinterpret_cast<uint4*>(&Bs[buf][bf_off(row, ch)]) = ob;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = (T + BF_BK - 1) / BF_BK;
+    const int nsteps = (b_hi > b_lo) ? (b_hi - b_lo) * nt : 0;
+    const int lr = lane & 31, lh = lane >> 5;
+    if (nsteps > 0) {
+        load_tiles(b_lo, 0);
+        store_tiles(0, 0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        const int nxt = st + 1;
+        const int nb = b_lo + nxt / nt, ntt = (nxt % nt) * BF_BK;
+        if (nxt < nsteps) load_tiles(nb, ntt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < BF_BK / 16; ++ks) {
+            const int ch = ks * 2 + lh;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[cur][bf_off(wm * 64 + lr, ch)]);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[cur][bf_off(wm * 64 + 32 + lr, ch)]);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[cur][bf_off(wn * 64 + lr, ch)]);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[cur][bf_off(wn * 64 + 32 + lr, ch)]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        // ... and first USED after it: without this fence hipcc hoists the staging arithmetic (and the
+        // vmcnt wait it needs) above the MFMAs, which exposes the whole memory latency every k-step.
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            asm volatile("" : "+v"(ra[i][0]), "+v"(ra[i][1]), "+v"(rb[i][0]), "+v"(rb[i][1]));
+            if (g_mode == PW_X_AFFINE2) asm volatile("" : "+v"(ra2[i][0]), "+v"(ra2[i][1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt < nsteps) store_tiles(cur ^ 1, ntt);
+        __syncthreads();
+    }
+    const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int k = n0 + wn * 64 + j * 32 + col;
+                if (m < M && k < K) p.partial[((size_t)s * M + m) * K + k] = acc[i][j][r];
+            }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Dispatch: fast kernels (modes fixed at compile time, aligned K) for the combinations the networks
+// use; everything else goes to the generic instantiation (run-time modes, scalar-safe loads).
+#define PW_NN_COMBOS(X) X(0, 0) X(0, 1) X(1, 1) X(0, 2) X(0, 3) X(0, 4) X(2, 0) X(2, 5)
+#define PW_WG_COMBOS(X) X(0, 0) X(0, 1) X(2, 0)
+
+void pw_launch_gemm_bf16(const PwParams& p, dim3 grid, hipStream_t st) {
+    const bool tv = (p.T & 3) == 0, kv = (p.K & 7) == 0;
+    if (kv) {
+#define X(XM, EP)                                                                                                   \
+        if (p.x_mode == XM && p.epi_mode == EP) {                                                                   \
+            if (tv) hipLaunchKernelGGL((pw_gemm_bf16_kernel<XM, EP, true, true>), grid, dim3(256), 0, st, p);          \
+            else hipLaunchKernelGGL((pw_gemm_bf16_kernel<XM, EP, false, true>), grid, dim3(256), 0, st, p);            \
+            return;                                                                                                 \
+        }
+        PW_NN_COMBOS(X)
+#undef X
+    }
+    if (tv && kv) hipLaunchKernelGGL((pw_gemm_bf16_kernel<-1, -1, true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pw_gemm_bf16_kernel<-1, -1, false, false>), grid, dim3(256), 0, st, p);
+}
+
+void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
+    const bool tv = (p.T & 3) == 0;
+#define X(GM, XM)                                                                                                   \
+    if (p.g_mode == GM && p.x_mode == XM) {                                                                         \
+        if (tv) hipLaunchKernelGGL((pw_wgrad_bf16_kernel<GM, XM, true>), grid, dim3(256), 0, st, p);                   \
+        else hipLaunchKernelGGL((pw_wgrad_bf16_kernel<GM, XM, false>), grid, dim3(256), 0, st, p);                     \
+        return;                                                                                                     \
+    }
+    PW_WG_COMBOS(X)
+#undef X
+    if (tv) hipLaunchKernelGGL((pw_wgrad_bf16_kernel<-1, -1, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pw_wgrad_bf16_kernel<-1, -1, false>), grid, dim3(256), 0, st, p);
+}

@@ -1,0 +1,193 @@
+// K1: pointwise (1x1) Conv1d as a per-utterance GEMM on the MI355X matrix cores.
+//
+//   forward / backward-data ("NN"):  Y[b][m][t] = sum_k A[m][k] * f(X[b][k][t])
+//   backward-weight          ("NT"):  dW[m][k]   = sum_{b,t} g(G[b][m][t]) * f(X[b][k][t])
+//
+// Replaces nn.Conv1d(kernel_size=1) (+ BatchNorm1d / ReLU6 / residual add around it) of the
+// reference's ConvBNActivate "pw" and "pw-linear" stages (voice100/models/asr.py:47,51-52) and the
+// 1x1 heads (asr.py:91, tts.py:26,77).  Activations stay fp32 [B, C, T] in HBM; f() is applied
+// while staging the tile into LDS, so the BatchNorm affine + ReLU6 of the producer (forward) or the
+// BatchNorm-backward affine of two tensors (backward) never round-trips through HBM.  The epilogue
+// emits the per-channel partial sums the next BatchNorm needs (training statistics or the two
+// backward reductions) into a deterministic [parts][M][2] slab.
+//
+// Two precisions of the same tiling (DESIGN.md "K1"):
+//   fp32 : v_mfma_f32_32x32x2_f32, exact fp32 (bitwise an fmaf chain)  -- parity path
+//   bf16 : v_mfma_f32_32x32x16_bf16, operands rounded to bf16 while staging, fp32 accumulate
+// 128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles (64 acc VGPRs).
+// 1-D grid with an XCD-aware remap: the M-tiles that share one X tile run on one XCD (one L2).
+#pragma once
+#include "common.h"
+
+enum { PW_X_NONE = 0, PW_X_AFFINE_RELU6 = 1, PW_X_AFFINE2 = 2 };
+enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFINE_RES = 3, PW_EPI_MASK_STATS = 4, PW_EPI_ADD = 5 };
+
+#define PW_BM 128
+#define PW_BN 128
+
+struct PwParams {
+    const float* A;       // [M][K] fp32 weights
+    const u16* Abf;       // [M][K] bf16 weights (bf16 path)
+    const float* X;       // [B][K][T]
+    const float* X2;      // [B][K][T]  (PW_X_AFFINE2)
+    const float* xa; const float* xb; const float* xc;   // [K]
+    float* Y;             // [B][M][T]
+    const float* bias;    // [M] or null
+    const float* ea; const float* eb;                     // [M]
+    const float* R;       // [B][M][T] residual / pre-activation tensor
+    float* stats;         // [B * n_ttiles][M][2]
+    int B, M, K, T, x_mode, epi_mode, n_mtiles, n_ttiles;
+};
+
+__device__ __forceinline__ float pw_x_transform(int mode, float v, float v2, float a, float b, float c) {
+    if (mode == PW_X_AFFINE_RELU6) return relu6f(fmaf(v, a, b));
+    if (mode == PW_X_AFFINE2) return fmaf(v, a, fmaf(v2, b, c));
+    return v;
+}
+
+__device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 lanes sharing lane>>5
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Branch-free tile loads.  A conditional load inside a branch makes hipcc wait for it (vmcnt(0)) at
+// the join, which serialises a tile's loads one memory latency after another; here every load is
+// unconditional (address clamped to the tensor base when out of range) and the value is selected
+// afterwards, so a tile's loads are all in flight together.
+//   elements i0..i0+3 of the row starting at base + row_off (row length n), zero where invalid
+template <bool VEC>
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ base, size_t row_off, int i0, int n, bool row_ok) {
+    // RAW load: the caller masks invalid elements later (mask4), at the point of use -- a select right
+    // here would be a use of the loaded value and pull the vmcnt wait up to the issue point.
+    f32x4 v;
+    if constexpr (VEC) {
+        const bool ok = row_ok && i0 < n;
+        v = *reinterpret_cast<const f32x4*>(base + (ok ? row_off + i0 : 0));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = row_ok && (i0 + e) < n;
+            v[e] = base[ok ? row_off + i0 + e : 0];
+        }
+    }
+    return v;
+}
+
+__device__ __forceinline__ f32x4 mask4(f32x4 v, int i0, int n, bool row_ok) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (row_ok && (i0 + e) < n) ? v[e] : 0.f;
+    return v;
+}
+
+// per-channel coefficient, address clamped; the value is only meaningful when ok (callers zero the
+// element it multiplies otherwise)
+__device__ __forceinline__ float ldc(const float* __restrict__ c, int i, bool ok, float dflt) {
+    (void)dflt;
+    return c[ok ? i : 0];
+}
+
+// XCD-aware work-item index: consecutive block ids are dealt round-robin over the 8 XCDs, so give
+// each XCD a contiguous chunk of the work list (blocks that share an operand tile then share an L2).
+// Bijective for any grid size (cdna_hip_programming.md T1).
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, slot = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// Shared epilogue for the NN kernels. acc[i][j] is the 32x32 tile (i: m sub-tile, j: t sub-tile);
+// element r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
+template <int EPI_>
+__device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[2][2], int b, int m0, int t0, int tt, int wm, int wn,
+                                            int lane, float (*red)[2][64][2]) {
+    const int epi = EPI_ >= 0 ? EPI_ : p.epi_mode;
+    const int col = lane & 31, half = lane >> 5;
+    const bool do_stats = (epi == PW_EPI_STATS || epi == PW_EPI_MASK_STATS);
+    const bool use_e = (epi == PW_EPI_AFFINE_RELU6 || epi == PW_EPI_AFFINE_RES || epi == PW_EPI_MASK_STATS);
+    const bool use_r = (epi == PW_EPI_MASK_STATS || epi == PW_EPI_ADD || (epi == PW_EPI_AFFINE_RES && p.R));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;    // row inside the wave's 64
+            const int m = m0 + wm * 64 + rl;
+            const bool mv = m < p.M;
+            const float ea = use_e ? ldc(p.ea, m, mv, 1.f) : 1.f;
+            const float eb = use_e ? ldc(p.eb, m, mv, 0.f) : 0.f;
+            const float bs = p.bias ? ldc(p.bias, m, mv, 0.f) : 0.f;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int t = t0 + wn * 64 + j * 32 + col;
+                const bool ok = mv && t < p.T;
+                const size_t o = ((size_t)b * p.M + m) * p.T + t;
+                float rv = 0.f;
+                if (use_r) { rv = p.R[ok ? o : 0]; rv = ok ? rv : 0.f; }
+                float v = acc[i][j][r] + bs;
+                if (epi == PW_EPI_STATS) {
+                    if (ok) { s0 += v; s1 = fmaf(v, v, s1); }
+                } else if (epi == PW_EPI_AFFINE_RELU6) {
+                    v = relu6f(fmaf(v, ea, eb));
+                } else if (epi == PW_EPI_AFFINE_RES) {
+                    v = fmaf(v, ea, eb) + rv;
+                } else if (epi == PW_EPI_MASK_STATS) {
+                    const float pre = fmaf(rv, ea, eb);
+                    v = (pre > 0.f && pre < 6.f) ? v : 0.f;
+                    if (ok) { s0 += v; s1 = fmaf(v, rv, s1); }
+                } else if (epi == PW_EPI_ADD) {
+                    v += rv;
+                }
+                if (ok) p.Y[o] = v;
+            }
+            if (do_stats) {
+                s0 = half_wave_sum(s0);
+                s1 = half_wave_sum(s1);
+                if (col == 0) { red[wm][wn][rl][0] = s0; red[wm][wn][rl][1] = s1; }
+            }
+        }
+    }
+    if (do_stats) {
+        __syncthreads();
+        const int tid = threadIdx.x;
+        if (tid < 128) {
+            const int m = m0 + tid;
+            if (m < p.M) {
+                const int w = tid >> 6, rl = tid & 63;
+                const size_t part = (size_t)b * p.n_ttiles + tt;
+                p.stats[(part * p.M + m) * 2 + 0] = red[w][0][rl][0] + red[w][1][rl][0];
+                p.stats[(part * p.M + m) * 2 + 1] = red[w][0][rl][1] + red[w][1][rl][1];
+            }
+        }
+    }
+}
+
+// work item -> (b, t-tile, m-tile), m-tile fastest
+__device__ __forceinline__ void pw_work(const PwParams& p, int& b, int& tt, int& mt) {
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    mt = w % p.n_mtiles;
+    const int rest = w / p.n_mtiles;
+    tt = rest % p.n_ttiles;
+    b = rest / p.n_ttiles;
+}
+
+struct WgParams {
+    const float* G;  const float* G2;  const float* ga; const float* gb; const float* gc;   // A operand [B][M][T], coeffs [M]
+    const float* X;  const float* xa; const float* xb;                                        // B operand [B][K][T], coeffs [K]
+    float* partial;  // [S][M][K]
+    int B, M, K, T, S, g_mode, x_mode, n_mtiles, n_ktiles;
+};
+
+
+// work item -> (split, m-tile, k-tile), k-tile fastest: one split's tiles sit on one XCD
+__device__ __forceinline__ void wg_work(const WgParams& p, int& s, int& mt, int& kt) {
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    kt = w % p.n_ktiles;
+    const int rest = w / p.n_ktiles;
+    mt = rest % p.n_mtiles;
+    s = rest / p.n_mtiles;
+}
+
+
+// Mode template parameters: >= 0 fixes the mode at compile time (branch-free staging, the fast
+// kernels); -1 reads it from the params at run time (the generic kernel for odd shapes).
+#define PW_MODE(TPL, RUNTIME) ((TPL) >= 0 ? (TPL) : (RUNTIME))
