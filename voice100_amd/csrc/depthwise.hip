@@ -96,29 +96,26 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradParams p) {
     const int b0 = g * bper;
     const int nb = min(p.B, b0 + bper) - b0;
     const int ntiles = (Tout + TILE - 1) / TILE;
-    const int nitems = nb > 0 ? nb * ntiles : 0;
 
     float accw[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) accw[j] = 0.f;
 
     DwRaw<NV, false> raw;
-    int item = wave;
-    if (item < nitems) {
-        const int b = b0 + item / ntiles, tile = item % ntiles;
-        const size_t ro = ((size_t)b * p.C + c) * Tin;
-        dw_issue_loads<NV, SPAN, false, AL>(raw, p.x + ro, p.x + ro, tile * TILE * S - p.pad, Tin, lane);
+    for (int tile = 0; tile < ntiles; ++tile) {
+    const int out0 = tile * TILE;
+    const int in0 = out0 * S - p.pad;
+    int bi = wave;
+    if (bi < nb) {
+        const size_t ro = ((size_t)(b0 + bi) * p.C + c) * Tin;
+        dw_issue_loads<NV, SPAN, false, AL>(raw, p.x + ro, p.x + ro, in0, Tin, lane);
     }
-    for (; item < nitems; item += 4) {
-        const int b = b0 + item / ntiles, tile = item % ntiles;
-        const int out0 = tile * TILE;
-        const int in0 = out0 * S - p.pad;
+    for (; bi < nb; bi += 4) {
+        const int b = b0 + bi;
         dw_stage_to_lds<NV, SPAN, DW_IN_AFFINE_RELU6, false>(raw, lds, in0, Tin, xa, xb, 0.f, lane);
-        const int nitem = item + 4;
-        if (nitem < nitems) {
-            const int nb_ = b0 + nitem / ntiles, ntile = nitem % ntiles;
-            const size_t ro = ((size_t)nb_ * p.C + c) * Tin;
-            dw_issue_loads<NV, SPAN, false, AL>(raw, p.x + ro, p.x + ro, ntile * TILE * S - p.pad, Tin, lane);
+        if (bi + 4 < nb) {
+            const size_t ro = ((size_t)(b + 4) * p.C + c) * Tin;
+            dw_issue_loads<NV, SPAN, false, AL>(raw, p.x + ro, p.x + ro, in0, Tin, lane);
         }
         const int t0 = out0 + lane * R;
         const size_t oo = ((size_t)b * p.C + c) * Tout + t0;
@@ -157,6 +154,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    }   // tile
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const float s = wave_sum(accw[j]);

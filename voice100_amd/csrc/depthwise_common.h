@@ -191,28 +191,28 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
     const int b0 = g * bper;
     const int nb = min(p.B, b0 + bper) - b0;
     const int ntiles = (Tout + TILE - 1) / TILE;
-    const int nitems = nb > 0 ? nb * ntiles : 0;
 
     float s0 = 0.f, s1 = 0.f;
     DwRaw<NV, TWO> raw;
-    int item = wave;
-    if (item < nitems) {
-        const int b = b0 + item / ntiles, tile = item % ntiles;
-        const size_t ro = ((size_t)b * p.C + c) * Tin;
-        dw_issue_loads<NV, SPAN, TWO, AL>(raw, p.x + ro, TWO ? p.x2 + ro : p.x, tile * TILE * S - p.pad, Tin, lane);
+    // Tile outer, batch row inner: everything that depends only on the tile (bounds masks, LDS
+    // indices, in-row offsets) is loop-invariant for the inner loop and hoisted out of it; the
+    // per-row work is loads + transform + select + ds_write.
+    for (int tile = 0; tile < ntiles; ++tile) {
+    const int out0 = tile * TILE;
+    const int in0 = out0 * S - p.pad;
+    int bi = wave;
+    if (bi < nb) {
+        const size_t ro = ((size_t)(b0 + bi) * p.C + c) * Tin;
+        dw_issue_loads<NV, SPAN, TWO, AL>(raw, p.x + ro, TWO ? p.x2 + ro : p.x, in0, Tin, lane);
     }
-    for (; item < nitems; item += 4) {
-        const int b = b0 + item / ntiles, tile = item % ntiles;
-        const int out0 = tile * TILE;
-        const int in0 = out0 * S - p.pad;
+    for (; bi < nb; bi += 4) {
+        const int b = b0 + bi;
         dw_stage_to_lds<NV, SPAN, IM, TWO>(raw, lds, in0, Tin, ca, cb, cc, lane);
 
-        // prefetch the next item's input while this one computes
-        const int nitem = item + 4;
-        if (nitem < nitems) {
-            const int nb_ = b0 + nitem / ntiles, ntile = nitem % ntiles;
-            const size_t ro = ((size_t)nb_ * p.C + c) * Tin;
-            dw_issue_loads<NV, SPAN, TWO, AL>(raw, p.x + ro, TWO ? p.x2 + ro : p.x, ntile * TILE * S - p.pad, Tin, lane);
+        // prefetch the next row's input while this one computes
+        if (bi + 4 < nb) {
+            const size_t ro = ((size_t)(b + 4) * p.C + c) * Tin;
+            dw_issue_loads<NV, SPAN, TWO, AL>(raw, p.x + ro, TWO ? p.x2 + ro : p.x, in0, Tin, lane);
         }
 
         const int t0 = out0 + lane * R;
@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
                 if (t0 + r < Tout) p.y[oo + r] = outv[r];
         }
     }
+    }   // tile
 
     if constexpr (STATS) {
         s0 = wave_sum(s0);
