@@ -113,6 +113,29 @@ int v100_augment_fused(const float* x, const int* len, const float* uniform, flo
                        const int* tm_e, const float* tm_a, int fm_on, int fm_s, int fm_e, float fm_a, int noise_on,
                        float noise_low, float noise_high, float noise_std, int mix, float log_offset, void* stream);
 
+/* ---- K4 / K7 / K9 glue (csrc/features.hip) -------------------------------------------------
+ * shift_copy: out[b][out_coff+c][u*out_mul+out_add] (=|+=) in[b][in_coff+c][u*in_mul+in_add] (0 when that
+ * index is out of range) + bias[c], u in [0,n).  Builds the tap-stacked GEMM operand of
+ * nn.ConvTranspose1d(512,256,k=5,stride=2,padding=2) (voice100/models/tts.py:22), interleaves its even/odd
+ * output phases, and the inverse moves for its backward. */
+int v100_shift_copy(const float* in, float* out, const float* bias, int B, int C, int Tin, int Tout, int in_ctot,
+                    int in_coff, int out_ctot, int out_coff, int in_mul, int in_add, int out_mul, int out_add, int n,
+                    int accumulate, void* stream);
+/* frames[b][n][t] = x[b][reflect(t*hop + n + (n_fft-win)/2 - n_fft/2)]: torchaudio Spectrogram(center=True,
+ * pad_mode="reflect") framing used by MelSpectrogramAudioTransform, voice100/data_modules.py:276-281 */
+int v100_stft_frames(const float* x, float* frames, int B, int N, int T, int hop, int win, int n_fft, void* stream);
+/* pw[b][f][t] = spec[b][f][t]^2 + spec[b][F+f][t]^2 */
+int v100_power_spectrum(const float* spec, float* pw, int B, int F, int T, void* stream);
+/* out[b][t][c] = log(in[b][c][t] + offset)   (data_modules.py:290-291) */
+int v100_log_transpose(const float* in, float* out, int B, int C, int T, float offset, void* stream);
+/* AlignTextToAudioModel.predict epilogue (tts.py:197-200, _layers_v1.py:132-138): x [B][T][2+S+Cap] ->
+ * f0 = gate(x0 < 0 ? 0 : x1*std+mean), logspc, codeap un-normalised */
+int v100_world_unnormalize(const float* x, float* f0, float* logspc, float* codeap, const float* f0_mean, const float* f0_std,
+                           const float* ls_mean, const float* ls_std, const float* ca_mean, const float* ca_std,
+                           int B, int T, int S, int Cap, void* stream);
+/* y = max(exp(x) - offset, 0)   (WORLDVocoder.decode, voice100/vocoder.py:99) */
+int v100_exp_clip(const float* x, float* y, float offset, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

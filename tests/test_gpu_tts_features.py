@@ -1,0 +1,143 @@
+"""TTS models, ConvTranspose1d, log-mel front-end and WORLD glue on the GPU vs golden vectors / the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub, rel_err, assert_grads_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_conv_transpose_golden(cuda):
+    from voice100_amd import functional as F_
+    g = load_golden("convtranspose.npz")
+    x = torch.from_numpy(g["x"]).to(cuda).requires_grad_(True)
+    w = torch.from_numpy(g["weight"]).to(cuda).requires_grad_(True)
+    b = torch.from_numpy(g["bias"]).to(cuda).requires_grad_(True)
+    y = F_.conv_transpose1d_k5s2(x, w, b)
+    assert y.shape == g["y"].shape and rel_err(y, g["y"]) < 1e-4
+    y.backward(torch.from_numpy(g["gy"]).to(cuda))
+    assert rel_err(x.grad, g["gx"]) < 1e-4 and rel_err(w.grad, g["gw"]) < 1e-4 and rel_err(b.grad, g["gb"]) < 1e-4
+
+
+def test_conv_transpose_c_oracle(cuda):
+    """Independent check against the plain-C restatement (oracle/conv_ref.c), odd sizes."""
+    import ctypes, os
+    from voice100_amd import functional as F_
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "oracle", "_build", "libconv_ref.so"))
+    g = torch.Generator().manual_seed(3)
+    B, cin, cout, L = 2, 12, 20, 37
+    x = torch.randn(B, cin, L, generator=g); w = torch.randn(cin, cout, 5, generator=g) * 0.3; b = torch.randn(cout, generator=g)
+    ref = np.zeros((B, cout, 2 * L - 1), dtype=np.float32)
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    xn, wn, bn = x.numpy().copy(), w.numpy().copy(), b.numpy().copy()
+    lib.ref_conv_transpose1d(fp(xn), fp(wn), fp(bn), fp(ref), B, cin, cout, L, 5, 2, 2)
+    y = F_.conv_transpose1d_k5s2(x.to(cuda), w.to(cuda), b.to(cuda))
+    assert rel_err(y, ref) < 1e-4
+
+
+@pytest.mark.parametrize("name,use_mcep", [("tts_tiny_logspc.npz", False), ("tts_tiny_mcep.npz", True)])
+def test_align_text_to_audio_golden(cuda, name, use_mcep):
+    from voice100_amd.tts import AlignTextToAudioModel
+    g = load_golden(name)
+    m = AlignTextToAudioModel(vocab_size=29, hidden_size=32, use_mcep=use_mcep)
+    m.load_state_dict(sub(g, "state/"), strict=True)
+    m = m.to(cuda).eval()
+    at = torch.from_numpy(g["aligntext"]).to(cuda)
+    with torch.no_grad():
+        fwd = m(at)
+    for v, key in zip(fwd, ("hasf0_logits", "f0_hat", "logspc_hat", "codeap_hat")):
+        assert v.shape == g["fwd/" + key].shape
+        assert rel_err(v, g["fwd/" + key]) < 1e-4, key
+    pred = m.predict(at)
+    for v, key in zip(pred, ("f0", "logspc", "codeap")):
+        assert rel_err(v, g["predict/" + key]) < 1e-4, key
+    assert np.array_equal(pred[0].cpu().numpy() == 0, g["predict/f0"] == 0)          # F0 gate: exact
+    m.train()
+    dev = lambda k: torch.from_numpy(g[k]).to(cuda)
+    batch = ((dev("target/f0"), dev("target/f0_len"), dev("target/logspc"), dev("target/codeap")), (at, None))
+    losses = m._calc_batch_loss(batch)
+    assert np.allclose(np.array([float(v.detach()) for v in losses]), g["losses_train"], rtol=2e-4)
+    sum(losses).backward()
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert_grads_close(grads, {k: g["grad/" + k] for k in grads}, 2e-3)
+
+
+def test_text_to_align_text_golden(cuda):
+    from voice100_amd.tts import TextToAlignTextModel
+    g = load_golden("align_tiny.npz")
+    m = TextToAlignTextModel(vocab_size=29, hidden_size=32)
+    m.load_state_dict(sub(g, "state/"), strict=True)
+    m = m.to(cuda).eval()
+    text = torch.from_numpy(g["text"]).to(cuda)
+    with torch.no_grad():
+        assert rel_err(m(text), g["pred_eval"]) < 1e-4
+    m.train()
+    dev = lambda k: torch.from_numpy(g[k]).to(cuda)
+    loss = m._calc_batch_loss(((text, dev("text_len")), (dev("align"), dev("align_len"))))
+    assert abs(float(loss.detach()) - float(g["loss_train"])) < 2e-4 * abs(float(g["loss_train"]))
+    loss.backward()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert_grads_close(grads, {k: g["grad/" + k] for k in grads}, 2e-3)
+    for n in range(3):                                                               # integer expansion: bit-exact
+        got = m.align(torch.from_numpy(g[f"align_case{n}/text"]), torch.from_numpy(g[f"align_case{n}/align"]))
+        assert np.array_equal(got.numpy(), g[f"align_case{n}/aligntext"])
+
+
+def test_tts_config3_shape(cuda):
+    """BASELINE configs[2] shapes: B=16 aligned text of 512 -> 1023 WORLD frames; batch independence + finiteness."""
+    from voice100_amd.tts import AlignTextToAudioModel
+    torch.manual_seed(1234)
+    m = AlignTextToAudioModel(vocab_size=29, hidden_size=512).to(cuda).eval()
+    at = torch.randint(0, 29, (16, 512), device=cuda)
+    f0, logspc, codeap = m.predict(at)
+    assert f0.shape == (16, 1023) and logspc.shape == (16, 1023, 257) and codeap.shape == (16, 1023, 1)
+    assert torch.isfinite(logspc).all()
+    f0b, logspcb, _ = m.predict(at[3:5].contiguous())
+    assert rel_err(logspcb, logspc[3:5]) < 1e-5
+
+
+def test_log_mel_vs_oracle_and_torch_stft(cuda):
+    """PARITY UNPINNED vs torchaudio (absent): checked against oracle/mel.py (numpy restatement of torchaudio 0.13.1's
+    definition) and against torch.stft for the spectrogram stage.  fp32 tolerance 1e-4 relative on the log-mel values."""
+    from voice100_amd.mel import MelSpectrogramAudioTransform
+    from oracle import mel as O
+    tr = MelSpectrogramAudioTransform().to(cuda)
+    g = torch.Generator().manual_seed(11)
+    for n in (16000, 4321, 800):
+        wav = (torch.rand(n, generator=g) * 2 - 1)
+        got = tr(wav.to(cuda)).cpu()
+        ref = O.log_mel(wav.numpy())
+        assert got.shape == ref.shape == (1 + n // 160, 64)
+        assert rel_err(got, ref) < 1e-4
+        spec = torch.stft(wav, 512, hop_length=160, win_length=400, window=torch.hann_window(400), center=True,
+                          pad_mode="reflect", return_complex=True).abs() ** 2
+        fb = torch.from_numpy(O.melscale_fbanks())
+        ref2 = torch.log(spec.T @ fb + 1e-6)
+        assert rel_err(got, ref2) < 1e-4
+    batch = torch.rand(3, 16000, generator=g) * 2 - 1
+    out = tr(batch.to(cuda))
+    assert out.shape == (3, 101, 64)
+    assert rel_err(out[1], O.log_mel(batch[1].numpy())) < 1e-4
+
+
+def test_world_glue(cuda):
+    from voice100_amd.vocoder import WORLDVocoder, create_sp2mc_matrix, create_mc2sp_matrix
+    g = load_golden("mcep.npz")
+    assert np.abs(create_sp2mc_matrix(512, 24, 0.410) - g["sp2mc_16k"]).max() < 2e-7
+    assert np.abs(create_mc2sp_matrix(512, 24, 0.410) - g["mc2sp_16k"]).max() < 1e-9
+    assert np.abs(create_sp2mc_matrix(1024, 34, 0.455) - g["sp2mc_22k"]).max() < 2e-7
+    assert np.abs(create_mc2sp_matrix(1024, 34, 0.455) - g["mc2sp_22k"]).max() < 1e-9
+    with pytest.raises(ValueError):
+        WORLDVocoder(sample_rate=8000)
+    v = WORLDVocoder(use_mcep=True).to(cuda)
+    rng = np.random.RandomState(0)
+    logspc = (rng.randn(77, 257) - 5).astype(np.float32)
+    mc = v.logspc_to_mcep(torch.from_numpy(logspc).to(cuda))
+    assert rel_err(mc, logspc.astype(np.float64) @ g["sp2mc_16k"]) < 1e-4
+    back = v.mcep_to_logspc(mc)
+    assert rel_err(back, mc.cpu().numpy().astype(np.float64) @ g["mc2sp_16k"]) < 1e-4
+    spc = v.logspc_to_spc(torch.from_numpy(logspc).to(cuda))
+    assert rel_err(spc, np.maximum(np.exp(logspc.astype(np.float64)) - 1e-15, 0)) < 1e-5
+    with pytest.raises(RuntimeError):
+        v.encode(torch.zeros(1600))          # pyworld is not part of this path

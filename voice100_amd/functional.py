@@ -364,3 +364,118 @@ class EmbeddingBCTFn(torch.autograd.Function):
 
 def embedding_bct(idx, table):
     return EmbeddingBCTFn.apply(idx, table)
+
+
+class ConvTranspose1dK5S2Fn(torch.autograd.Function):
+    """nn.ConvTranspose1d(Cin, Cout, kernel_size=5, stride=2, padding=2, bias) -- tts.py:22.
+
+    Output length 2L-1.  Even outputs y[2u] use taps 0/2/4 on x[u+1], x[u], x[u-1]; odd outputs y[2u+1]
+    use taps 1/3 on x[u+1], x[u]: two dense GEMMs (K = 3*Cin and 2*Cin) over tap-stacked copies of x, run
+    on the pointwise MFMA kernel, then interleaved (+bias).
+    """
+
+    @staticmethod
+    def _stack(x):
+        B, cin, L = x.shape
+        xe = _f32(B, 3 * cin, L, like=x)
+        xo = _f32(B, 2 * cin, L, like=x)
+        for tap, d in enumerate((1, 0, -1)):
+            N.call("v100_shift_copy", x, xe, None, B, cin, L, L, cin, 0, 3 * cin, tap * cin, 1, d, 1, 0, L, 0)
+        for tap, d in enumerate((1, 0)):
+            N.call("v100_shift_copy", x, xo, None, B, cin, L, L, cin, 0, 2 * cin, tap * cin, 1, d, 1, 0, L, 0)
+        return xe, xo
+
+    @staticmethod
+    def _mats(w):
+        # w [Cin][Cout][5] -> Ae [Cout][3*Cin] (taps 0,2,4), Ao [Cout][2*Cin] (taps 1,3); tiny, layout only
+        wt = w.detach().permute(1, 2, 0)                      # [Cout][5][Cin]
+        ae = wt[:, [0, 2, 4], :].reshape(w.shape[1], -1).contiguous()
+        ao = wt[:, [1, 3], :].reshape(w.shape[1], -1).contiguous()
+        return ae, ao
+
+    @staticmethod
+    def forward(ctx, x, w, bias, precision):
+        _check(x, "conv_transpose1d")
+        if w.shape[2] != 5:
+            raise RuntimeError("conv_transpose1d: only kernel_size=5, stride=2, padding=2 is built (tts.py:22)")
+        x = x.contiguous()
+        B, cin, L = x.shape
+        cout = w.shape[1]
+        bf16 = precision == "bf16"
+        xe, xo = ConvTranspose1dK5S2Fn._stack(x)
+        ae, ao = ConvTranspose1dK5S2Fn._mats(w)
+        We, Wo = _Weights(ae, bf16, False), _Weights(ao, bf16, False)
+        ye, yo = _f32(B, cout, L, like=x), _f32(B, cout, L, like=x)
+        _pw_gemm(We.w, We.w_bf, xe, ye, cout, 3 * cin, L, B, bf16)
+        _pw_gemm(Wo.w, Wo.w_bf, xo, yo, cout, 2 * cin, L, B, bf16)
+        T = 2 * L - 1
+        y = _f32(B, cout, T, like=x)
+        b = bias.detach() if bias is not None else None
+        N.call("v100_shift_copy", ye, y, b, B, cout, L, T, cout, 0, cout, 0, 1, 0, 2, 0, L, 0)
+        if L > 1:
+            N.call("v100_shift_copy", yo, y, b, B, cout, L, T, cout, 0, cout, 0, 1, 0, 2, 1, L - 1, 0)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        ctx.bf16 = bf16
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, cin, L = x.shape
+        cout = w.shape[1]
+        T = 2 * L - 1
+        bf16 = ctx.bf16
+        dye, dyo = _f32(B, cout, L, like=x), torch.zeros((B, cout, L), dtype=torch.float32, device=x.device)
+        N.call("v100_shift_copy", dy, dye, None, B, cout, T, L, cout, 0, cout, 0, 2, 0, 1, 0, L, 0)
+        if L > 1:
+            N.call("v100_shift_copy", dy, dyo, None, B, cout, T, L, cout, 0, cout, 0, 2, 1, 1, 0, L - 1, 0)
+        xe, xo = ConvTranspose1dK5S2Fn._stack(x)
+        ae, ao = ConvTranspose1dK5S2Fn._mats(w)
+        We, Wo = _Weights(ae, bf16, True), _Weights(ao, bf16, True)
+        # weight gradients: dAe = dye . xe^T, dAo = dyo . xo^T, scattered back to [Cin][Cout][5]
+        dae, dao = _f32(cout, 3 * cin, like=x), _f32(cout, 2 * cin, like=x)
+        for g, xs, out, kk in ((dye, xe, dae, 3 * cin), (dyo, xo, dao, 2 * cin)):
+            S = N.helper("v100_pw_wgrad_splits", B, cout, kk)
+            partial = _f32(S, cout, kk, like=x)
+            N.call("v100_pw_wgrad", g, None, None, None, None, 0, xs, None, None, 0, partial, out, S, B, cout, kk, L, int(bf16))
+        dw = torch.empty_like(w)
+        dw[:, :, [0, 2, 4]] = dae.view(cout, 3, cin).permute(2, 0, 1)
+        dw[:, :, [1, 3]] = dao.view(cout, 2, cin).permute(2, 0, 1)
+        db = None
+        if ctx.has_bias:
+            G = N.helper("v100_dw_num_groups", B, cout)
+            part = _f32(G, cout, 2, like=x)
+            N.call("v100_chan_reduce2", dy, None, part, G, B, cout, T)
+            db = _f32(cout, like=x)
+            N.call("v100_slab_sum0", part, G, db, cout)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxe, dxo = _f32(B, 3 * cin, L, like=x), _f32(B, 2 * cin, L, like=x)
+            _pw_gemm(We.wt, We.wt_bf, dye, dxe, 3 * cin, cout, L, B, bf16)
+            _pw_gemm(Wo.wt, Wo.wt_bf, dyo, dxo, 2 * cin, cout, L, B, bf16)
+            dx = torch.zeros_like(x)
+            for tap, d in enumerate((1, 0, -1)):        # xe tap block held x[u+d]  ->  dx[t] += dxe[tap][t-d]
+                N.call("v100_shift_copy", dxe, dx, None, B, cin, L, L, 3 * cin, tap * cin, cin, 0, 1, -d, 1, 0, L, 1)
+            for tap, d in enumerate((1, 0)):
+                N.call("v100_shift_copy", dxo, dx, None, B, cin, L, L, 2 * cin, tap * cin, cin, 0, 1, -d, 1, 0, L, 1)
+        return dx, dw, db, None
+
+
+def conv_transpose1d_k5s2(x, w, bias=None, precision: Optional[str] = None):
+    return ConvTranspose1dK5S2Fn.apply(x, w, bias, precision or _PRECISION)
+
+
+def world_unnormalize_gate(x_bta, f0_mean, f0_std, ls_mean, ls_std, ca_mean, ca_std):
+    """x [B,T,2+S+Cap] -> (f0 [B,T], logspc [B,T,S], codeap [B,T,Cap]); tts.py:192-201."""
+    _check(x_bta, "world_unnormalize")
+    x_bta = x_bta.contiguous()
+    B, T, A = x_bta.shape
+    S, cap = ls_mean.shape[0], ca_mean.shape[0]
+    assert A == 2 + S + cap
+    f0 = _f32(B, T, like=x_bta)
+    logspc = _f32(B, T, S, like=x_bta)
+    codeap = _f32(B, T, cap, like=x_bta)
+    N.call("v100_world_unnormalize", x_bta, f0, logspc, codeap, f0_mean, f0_std, ls_mean, ls_std, ca_mean, ca_std, B, T, S, cap)
+    return f0, logspc, codeap
