@@ -13,7 +13,8 @@
  *     "partial") are caller-allocated, `stream` is a hipStream_t (NULL = default stream);
  *   - return value: 0 = launched; 1 = invalid/unsupported shape or mode; 2 = launch error;
  *     3 = a required pointer is NULL.  The Python layer raises RuntimeError on != 0;
- *   - re-entrant, no global state; one stream per process is the intended use.
+ *   - re-entrant; the only global state is the opt-in timing table below; one stream per process is the
+ *     intended use.
  */
 #ifndef VOICE100_HIP_H
 #define VOICE100_HIP_H
@@ -135,6 +136,12 @@ int v100_world_unnormalize(const float* x, float* f0, float* logspc, float* code
                            int B, int T, int S, int Cap, void* stream);
 /* y = max(exp(x) - offset, 0)   (WORLDVocoder.decode, voice100/vocoder.py:99) */
 int v100_exp_clip(const float* x, float* y, float offset, long long n, void* stream);
+
+/* ---- opt-in kernel timing (bench.py roofline): HIP events on the launch stream around the hot kernels.
+ * tags: 0 depthwise fwd, 1 depthwise bwd-data, 2 depthwise bwd-weight, 3 pointwise GEMM, 4 pointwise bwd-weight.
+ * enable(1) clears the counters; read() synchronises the device and returns the summed ms / launch count. */
+int v100_timing_enable(int on);
+int v100_timing_read(int tag, double* ms, long long* count);
 
 #ifdef __cplusplus
 }

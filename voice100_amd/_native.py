@@ -91,17 +91,24 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+_fast = {}
+
+
 def call(name, *args):
-    """Launch `name` on torch's current stream (the trailing `stream` argument is appended here)."""
-    lib = load()
-    fn = getattr(lib, name)
-    params = _protos[name]
-    full = list(args)
-    if params and params[-1][1] == "stream" and len(full) == len(params) - 1:
-        full.append(stream_ptr())
-    if len(full) != len(params):
-        raise TypeError(f"{name}: expected {len(params)} arguments, got {len(full)}")
-    conv = [(_ptr(a) if t is ctypes.c_void_p else a) for a, (t, _) in zip(full, params)]
+    """Launch `name` on torch's current stream (the trailing `stream` argument is appended here).
+    Tensors must be contiguous CUDA tensors (checked); None is a NULL pointer."""
+    ent = _fast.get(name)
+    if ent is None:
+        lib = load()
+        params = _protos[name]
+        ent = _fast[name] = (getattr(lib, name), [t is ctypes.c_void_p for t, _ in params],
+                             bool(params) and params[-1][1] == "stream", len(params))
+    fn, is_ptr, wants_stream, nparams = ent
+    if wants_stream and len(args) == nparams - 1:
+        args = args + (torch.cuda.current_stream().cuda_stream,)
+    if len(args) != nparams:
+        raise TypeError(f"{name}: expected {nparams} arguments, got {len(args)}")
+    conv = [(_ptr(a) if (p and a is not None and not isinstance(a, int)) else a) for a, p in zip(args, is_ptr)]
     rc = fn(*conv)
     if rc != 0:
         raise RuntimeError(f"{name} failed: {STATUS.get(rc, rc)} (status {rc})")
@@ -113,39 +120,21 @@ def helper(name, *args):
     return getattr(lib, name)(*args)
 
 
-class KernelTimer:
-    """Opt-in HIP-event timing of kernel regions on torch's current stream (bench.py only).
-    Usage: N.timer = KernelTimer(); ... ; N.timer.summary() after a synchronize."""
-
-    def __init__(self):
-        self.events = {}
-
-    def record(self, tag, start, end):
-        self.events.setdefault(tag, []).append((start, end))
-
-    def summary(self):
-        torch.cuda.synchronize()
-        return {tag: (len(ev), sum(s.elapsed_time(e) for s, e in ev)) for tag, ev in self.events.items()}
+TIMING_TAGS = {"dw_fwd": 0, "dw_bwd_data": 1, "dw_wgrad": 2, "pw_gemm": 3, "pw_wgrad": 4}
 
 
-timer = None
+def timing_enable(on: bool) -> None:
+    """Opt-in HIP-event timing inside the library (see include/voice100_hip.h); bench.py only."""
+    load().v100_timing_enable(int(on))
 
 
-class region:
-    """`with region("dw_fwd"):` brackets the launches inside with HIP events when a timer is installed."""
-
-    def __init__(self, tag):
-        self.tag = tag
-
-    def __enter__(self):
-        if timer is not None:
-            self.start = torch.cuda.Event(enable_timing=True)
-            self.start.record()
-        return self
-
-    def __exit__(self, *exc):
-        if timer is not None:
-            end = torch.cuda.Event(enable_timing=True)
-            end.record()
-            timer.record(self.tag, self.start, end)
-        return False
+def timing_read():
+    """{tag: (launches, total_ms)} recorded since timing_enable(True)."""
+    lib = load()
+    out = {}
+    for name, tag in TIMING_TAGS.items():
+        ms, n = ctypes.c_double(0.0), ctypes.c_longlong(0)
+        lib.v100_timing_read(tag, ctypes.byref(ms), ctypes.byref(n))
+        if n.value:
+            out[name] = (n.value, ms.value)
+    return out

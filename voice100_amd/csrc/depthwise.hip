@@ -16,6 +16,7 @@
 // BN-backward reductions) are accumulated in registers and written once per workgroup to a
 // [G][C][2] slab -- deterministic, no atomics.
 #include "depthwise_common.h"
+#include "timing.h"
 
 // ---------------------------------------------------------------------------------------------
 // Generic fallback: any K / stride / zero-upsampled input (backward-data of a strided conv).
@@ -242,6 +243,7 @@ extern "C" int v100_dwconv(const float* x, const float* x2, const float* w, cons
     DwParams p{x, x2, w, in_a, in_b, in_c, y, aux, out_a, out_b, stats,
                B, C, Tin, Tout, K, stride, pad, flip, upsample, G, in_mode, out_mode};
     hipStream_t st = (hipStream_t)stream;
+    V100TimedRegion timed(out_mode == DW_OUT_MASK_STATS ? V100_T_DW_BWD_DATA : V100_T_DW_FWD, st);
     bool done = false;
     if (!force_generic && upsample == 1) {
         if (in_mode == DW_IN_AFFINE_RELU6 && out_mode == DW_OUT_RAW_STATS) done = dw_launch_fwd_train(p, st);
@@ -264,6 +266,7 @@ extern "C" int v100_dwconv_wgrad(const float* g, const float* g2, const float* g
     if (x_mode != DW_IN_NONE && (!xa || !xb)) return V100_ERR_NULL;
     DwWgradParams p{g, g2, ga, gb, gc, x, xa, xb, partial, B, C, Tin, Tout, K, stride, pad, G, g_mode, x_mode};
     hipStream_t st = (hipStream_t)stream;
+    V100TimedRegion timed(V100_T_DW_WGRAD, st);
     bool done = false;
     if (!force_generic && g_mode == DW_IN_AFFINE2 && x_mode == DW_IN_AFFINE_RELU6) {
 #define X(KK) if (!done && K == KK && stride == 1) { launch_dw_wgrad<KK, 1>(p, st); done = true; }

@@ -17,6 +17,7 @@
 // 128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles (64 acc VGPRs).
 // 1-D grid with an XCD-aware remap: the M-tiles that share one X tile run on one XCD (one L2).
 #include "pointwise_common.h"
+#include "timing.h"
 
 void pw_launch_gemm_f32(const PwParams& p, dim3 grid, hipStream_t st);
 void pw_launch_gemm_bf16(const PwParams& p, dim3 grid, hipStream_t st);
@@ -83,6 +84,7 @@ extern "C" int v100_pw_gemm(const float* A, const void* A_bf16, const float* X, 
     if (nwg > 0x7fffffffL) return V100_ERR_SHAPE;
     dim3 grid((unsigned)nwg);
     hipStream_t st = (hipStream_t)stream;
+    V100TimedRegion timed(V100_T_PW_GEMM, st);
     if (use_bf16) pw_launch_gemm_bf16(p, grid, st);
     else pw_launch_gemm_f32(p, grid, st);
     return v100_launch_status();
@@ -101,6 +103,7 @@ extern "C" int v100_pw_wgrad(const float* G, const float* G2, const float* ga, c
     WgParams p{G, G2, ga, gb, gc, X, xa, xb, partial, B, M, K, T, S, g_mode, x_mode, nmt, nkt};
     dim3 grid((unsigned)(nmt * nkt * S));
     hipStream_t st = (hipStream_t)stream;
+    V100TimedRegion timed(V100_T_PW_WGRAD, st);
     if (use_bf16) pw_launch_wgrad_bf16(p, grid, st);
     else pw_launch_wgrad_f32(p, grid, st);
     const long n = (long)M * K;

@@ -1,0 +1,61 @@
+// Opt-in HIP-event timing of the hot kernels, for bench.py's roofline line: events are recorded on the
+// stream the kernel is launched on, inside the timed region, at ~1 us of host cost per event (torch.cuda.Event
+// pairs from Python cost ~10 us each and distorted the step).  Off by default; no effect on results.
+#include "common.h"
+#include "timing.h"
+#include <vector>
+#include <mutex>
+
+namespace {
+struct Pair { hipEvent_t a, b; int tag; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Pair> g_pairs;
+size_t g_used = 0;
+const size_t kMaxPairs = 16384;
+}
+
+void v100_timing_begin(int tag, hipStream_t st, int* slot) {
+    *slot = -1;
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_used >= kMaxPairs) return;
+    if (g_used >= g_pairs.size()) {
+        Pair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+        g_pairs.push_back(p);
+    }
+    g_pairs[g_used].tag = tag;
+    (void)hipEventRecord(g_pairs[g_used].a, st);
+    *slot = (int)g_used++;
+}
+
+void v100_timing_end(int slot, hipStream_t st) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipEventRecord(g_pairs[slot].b, st);
+}
+
+extern "C" int v100_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    if (on) g_used = 0;
+    return V100_OK;
+}
+
+// Sum of elapsed ms and number of launches recorded under `tag` since the last enable(1). Synchronises the device.
+extern "C" int v100_timing_read(int tag, double* ms, long long* count) {
+    if (!ms || !count) return V100_ERR_NULL;
+    if (hipDeviceSynchronize() != hipSuccess) return V100_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lk(g_mu);
+    double total = 0.0;
+    long long n = 0;
+    for (size_t i = 0; i < g_used; ++i) {
+        if (g_pairs[i].tag != tag) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_pairs[i].a, g_pairs[i].b) == hipSuccess) { total += t; ++n; }
+    }
+    *ms = total;
+    *count = n;
+    return V100_OK;
+}

@@ -69,8 +69,7 @@ class _Weights:
 
 def _pw_gemm(a_f32, a_bf, x, y, m, k, t, b, bf16, x2=None, xa=None, xb=None, xc=None, x_mode=0, bias=None,
              ea=None, eb=None, r=None, epi=0, stats=None):
-    with N.region("pw_gemm"):
-        N.call("v100_pw_gemm", a_f32, a_bf, x, x2, xa, xb, xc, x_mode, y, bias, ea, eb, r, epi, stats, b, m, k, t, int(bf16))
+    N.call("v100_pw_gemm", a_f32, a_bf, x, x2, xa, xb, xc, x_mode, y, bias, ea, eb, r, epi, stats, b, m, k, t, int(bf16))
 
 
 def _bn_train(stats, parts, count, bn_w, bn_b, rm, rv, nbt, c, like):
@@ -120,8 +119,7 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         G = N.helper("v100_dw_num_groups", B, hid)
         a2 = _f32(B, hid, T2, like=x)
         st = _f32(G, hid, 2, like=x)
-        with N.region("dw_fwd"):
-            N.call("v100_dwconv", a1, None, wd2, s1, t1, None, 1, a2, None, None, None, 0, st, G, B, hid, T, T2, k, stride, pad, 0, 1, 0)
+        N.call("v100_dwconv", a1, None, wd2, s1, t1, None, 1, a2, None, None, None, 0, st, G, B, hid, T, T2, k, stride, pad, 0, 1, 0)
         s2, t2, mean2, rstd2 = _bn_train(st, G, B * T2, g2.detach(), b2.detach(), rm2, rv2, nbt2, hid, x)
 
         # pw-linear: a3 = W3 relu6(s2*a2+t2), with the partial sums for BN3
@@ -164,8 +162,7 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         S = N.helper("v100_pw_wgrad_splits", B, cout, hid)
         partial = _f32(S, cout, hid, like=x)
         dW3 = _f32(cout, hid, like=x)
-        with N.region("pw_wgrad"):
-            N.call("v100_pw_wgrad", da3, None, None, None, None, 0, a2, s2, t2, 1, partial, dW3, S, B, cout, hid, T2, int(bf16))
+        N.call("v100_pw_wgrad", da3, None, None, None, None, 0, a2, s2, t2, 1, partial, dW3, S, B, cout, hid, T2, int(bf16))
 
         # pw-linear data grad through ReLU6: dz2 = (W3^T da3) * [0 < s2*a2+t2 < 6], with BN2-backward sums
         parts = N.helper("v100_pw_num_parts", B, T2)
@@ -178,22 +175,19 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         G = N.helper("v100_dw_num_groups", B, hid)
         partial = _f32(G, hid, k, like=x)
         dWd = _f32(hid, k, like=x)
-        with N.region("dw_wgrad"):
-            N.call("v100_dwconv_wgrad", dz2, a2, p2, q2, r2, 2, a1, s1, t1, 1, partial, dWd, G, B, hid, T, T2, k, stride, pad, 0)
+        N.call("v100_dwconv_wgrad", dz2, a2, p2, q2, r2, 2, a1, s1, t1, 1, partial, dWd, G, B, hid, T, T2, k, stride, pad, 0)
 
         # depthwise data grad through ReLU6: dz1 = convT(da2) * [0 < s1*a1+t1 < 6], with BN1-backward sums
         dz1 = _f32(B, hid, T, like=x)
         st = _f32(G, hid, 2, like=x)
-        with N.region("dw_bwd_data"):
-            N.call("v100_dwconv", dz2, a2, wd2, p2, q2, r2, 2, dz1, a1, s1, t1, 2, st, G, B, hid, T2, T, k, 1, k - 1 - pad, 1, stride, 0)
+        N.call("v100_dwconv", dz2, a2, wd2, p2, q2, r2, 2, dz1, a1, s1, t1, 2, st, G, B, hid, T2, T, k, 1, k - 1 - pad, 1, stride, 0)
         p1, q1, r1, dg1, db1 = _bn_bwd(st, G, B * T, g1.detach(), mean1, rstd1, hid, x)
 
         # pw weight grad: dW1 = da1 . x^T,  da1 = p1*dz1 + q1*a1 + r1
         S = N.helper("v100_pw_wgrad_splits", B, hid, cin)
         partial = _f32(S, hid, cin, like=x)
         dW1 = _f32(hid, cin, like=x)
-        with N.region("pw_wgrad"):
-            N.call("v100_pw_wgrad", dz1, a1, p1, q1, r1, 2, x, None, None, 0, partial, dW1, S, B, hid, cin, T, int(bf16))
+        N.call("v100_pw_wgrad", dz1, a1, p1, q1, r1, 2, x, None, None, 0, partial, dW1, S, B, hid, cin, T, int(bf16))
 
         # pw data grad: dx = W1^T da1 (+ dy through the residual)
         dx = None
