@@ -12,6 +12,9 @@
 #define V100_WAVE 64
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 4-byte-aligned variant: global memory on gfx950 takes dword-aligned dwordx4 accesses, so rows whose length is
+// not a multiple of 4 can still be streamed with 16-byte loads/stores (the tail is masked by the caller)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;

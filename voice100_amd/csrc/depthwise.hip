@@ -103,20 +103,22 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradParams p) {
     for (int j = 0; j < K; ++j) accw[j] = 0.f;
 
     DwRaw<NV, false> raw;
+    const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, (unsigned)((size_t)p.B * p.C * Tin * 4));
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     for (int tile = 0; tile < ntiles; ++tile) {
     const int out0 = tile * TILE;
     const int in0 = out0 * S - p.pad;
-    int bi = wave;
+    int bi = wave_u;
     if (bi < nb) {
-        const size_t ro = ((size_t)(b0 + bi) * p.C + c) * Tin;
-        dw_issue_loads<NV, SPAN, false, AL>(raw, p.x + ro, p.x + ro, in0, Tin, lane);
+        const unsigned rb = (unsigned)(((size_t)(b0 + bi) * p.C + c) * Tin * 4);
+        dw_issue_loads<NV, SPAN, false, AL>(raw, rx, rx, rb, in0, Tin, lane);
     }
     for (; bi < nb; bi += 4) {
         const int b = b0 + bi;
         dw_stage_to_lds<NV, SPAN, DW_IN_AFFINE_RELU6, false>(raw, lds, in0, Tin, xa, xb, 0.f, lane);
         if (bi + 4 < nb) {
-            const size_t ro = ((size_t)(b + 4) * p.C + c) * Tin;
-            dw_issue_loads<NV, SPAN, false, AL>(raw, p.x + ro, p.x + ro, in0, Tin, lane);
+            const unsigned rb = (unsigned)(((size_t)(b + 4) * p.C + c) * Tin * 4);
+            dw_issue_loads<NV, SPAN, false, AL>(raw, rx, rx, rb, in0, Tin, lane);
         }
         const int t0 = out0 + lane * R;
         const size_t oo = ((size_t)b * p.C + c) * Tout + t0;
@@ -215,8 +217,7 @@ static void launch_dw_wgrad(const DwWgradParams& p, hipStream_t st) {
     dim3 grid(p.C, p.G);
     // R = 8 only: the R = 4 instantiations of K >= 67 fall out of registers (hipcc 7.2 leaves the
     // accumulator array in scratch), and short rows are not the case this kernel is tuned for.
-    if (((p.Tin & 3) == 0) && ((p.Tout & 3) == 0)) hipLaunchKernelGGL((dwconv_wgrad_kernel<K, S, 8, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((dwconv_wgrad_kernel<K, S, 8, false>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<K, S, 8, true>), grid, dim3(256), 0, st, p);
 }
 
 extern "C" int v100_dw_num_groups(int B, int C) {
@@ -245,7 +246,8 @@ extern "C" int v100_dwconv(const float* x, const float* x2, const float* w, cons
     hipStream_t st = (hipStream_t)stream;
     V100TimedRegion timed(out_mode == DW_OUT_MASK_STATS ? V100_T_DW_BWD_DATA : V100_T_DW_FWD, st);
     bool done = false;
-    if (!force_generic && upsample == 1) {
+    const bool fits = (size_t)B * C * Tin * 4 < 0x7fffff00ull;
+    if (!force_generic && upsample == 1 && fits) {
         if (in_mode == DW_IN_AFFINE_RELU6 && out_mode == DW_OUT_RAW_STATS) done = dw_launch_fwd_train(p, st);
         else if (in_mode == DW_IN_NONE && out_mode == DW_OUT_AFFINE_RELU6) done = dw_launch_fwd_eval(p, st);
         else if (in_mode == DW_IN_AFFINE2 && out_mode == DW_OUT_MASK_STATS) done = dw_launch_bwd_data(p, st);
@@ -268,7 +270,7 @@ extern "C" int v100_dwconv_wgrad(const float* g, const float* g2, const float* g
     hipStream_t st = (hipStream_t)stream;
     V100TimedRegion timed(V100_T_DW_WGRAD, st);
     bool done = false;
-    if (!force_generic && g_mode == DW_IN_AFFINE2 && x_mode == DW_IN_AFFINE_RELU6) {
+    if (!force_generic && g_mode == DW_IN_AFFINE2 && x_mode == DW_IN_AFFINE_RELU6 && (size_t)B * C * Tin * 4 < 0x7fffff00ull) {
 #define X(KK) if (!done && K == KK && stride == 1) { launch_dw_wgrad<KK, 1>(p, st); done = true; }
         V100_DW_SPECIALISED(X)
 #undef X

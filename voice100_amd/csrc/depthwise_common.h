@@ -62,9 +62,10 @@ __device__ __forceinline__ void dw_load_run(float (&out)[R], const float* __rest
     if constexpr (AL) {
 #pragma unroll
         for (int q = 0; q < R / 4; ++q) {
-            const bool ok = t0 + 4 * q < T;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? ptr + 4 * q : ptr - t0);
-            out[4 * q] = ok ? v[0] : 0.f; out[4 * q + 1] = ok ? v[1] : 0.f; out[4 * q + 2] = ok ? v[2] : 0.f; out[4 * q + 3] = ok ? v[3] : 0.f;
+            const bool ok = t0 + 4 * q < T;                  // first element in range: the 16-byte load is safe to issue
+            const f32x4 v = *reinterpret_cast<const f32x4u*>(ok ? ptr + 4 * q : ptr - t0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[4 * q + e] = (t0 + 4 * q + e < T) ? v[e] : 0.f;
         }
     } else {
 #pragma unroll
@@ -86,36 +87,26 @@ struct DwRaw {
     f32x4 v2[TWO ? NV : 1];
 };
 
+typedef unsigned int dw_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dw_make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// Buffer loads over the whole [B,C,T] tensor: the row offset is a scalar (soffset), the in-row offset a
+// per-lane voffset; positions outside the row's [0, Tin) window get an out-of-range voffset and come back
+// as zero from the hardware bounds check (no select, no fault at the tensor's end, any row alignment).
 template <int NV, int SPAN, bool TWO, bool AL>
-__device__ __forceinline__ void dw_issue_loads(DwRaw<NV, TWO>& raw, const float* __restrict__ row, const float* __restrict__ row2,
-                                               int in0, int Tin, int lane) {
+__device__ __forceinline__ void dw_issue_loads(DwRaw<NV, TWO>& raw, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rx2,
+                                               unsigned row_bytes, int in0, int Tin, int lane) {
     const int in0a = in0 & ~3;            // floor to a multiple of 4 (two's complement: also for negatives)
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int ia = in0a + 4 * (lane + 64 * v);
-        if constexpr (AL) {
-            const bool ok = ia >= 0 && ia < Tin && ia < in0 + SPAN;
-            const int idx = ok ? ia : 0;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(row + idx);
-            raw.v[v] = ok ? a : f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (TWO) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(row2 + idx);
-                raw.v2[v] = ok ? b : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int t = ia + e;
-                const bool ok = t >= 0 && t < Tin && ia < in0 + SPAN;
-                const int idx = ok ? t : 0;
-                const float a = row[idx];
-                raw.v[v][e] = ok ? a : 0.f;
-                if constexpr (TWO) {
-                    const float b = row2[idx];
-                    raw.v2[v][e] = ok ? b : 0.f;
-                }
-            }
-        }
+        const bool ok = ia >= 0 && ia < Tin && ia < in0 + SPAN;
+        const int vo = ok ? ia * 4 : 0x7ffffff0;
+        raw.v[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, (int)row_bytes, 0));
+        if constexpr (TWO) raw.v2[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, vo, (int)row_bytes, 0));
     }
 }
 
@@ -194,16 +185,20 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
 
     float s0 = 0.f, s1 = 0.f;
     DwRaw<NV, TWO> raw;
+    const unsigned xbytes = (unsigned)((size_t)p.B * p.C * Tin * 4);
+    const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, xbytes);
+    const __amdgpu_buffer_rsrc_t rx2 = dw_make_rsrc(TWO ? p.x2 : p.x, xbytes);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // provably wave-uniform row index
     // Tile outer, batch row inner: everything that depends only on the tile (bounds masks, LDS
     // indices, in-row offsets) is loop-invariant for the inner loop and hoisted out of it; the
     // per-row work is loads + transform + select + ds_write.
     for (int tile = 0; tile < ntiles; ++tile) {
     const int out0 = tile * TILE;
     const int in0 = out0 * S - p.pad;
-    int bi = wave;
+    int bi = wave_u;
     if (bi < nb) {
-        const size_t ro = ((size_t)(b0 + bi) * p.C + c) * Tin;
-        dw_issue_loads<NV, SPAN, TWO, AL>(raw, p.x + ro, TWO ? p.x2 + ro : p.x, in0, Tin, lane);
+        const unsigned rb = (unsigned)(((size_t)(b0 + bi) * p.C + c) * Tin * 4);
+        dw_issue_loads<NV, SPAN, TWO, AL>(raw, rx, rx2, rb, in0, Tin, lane);
     }
     for (; bi < nb; bi += 4) {
         const int b = b0 + bi;
@@ -211,8 +206,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
 
         // prefetch the next row's input while this one computes
         if (bi + 4 < nb) {
-            const size_t ro = ((size_t)(b + 4) * p.C + c) * Tin;
-            dw_issue_loads<NV, SPAN, TWO, AL>(raw, p.x + ro, TWO ? p.x2 + ro : p.x, in0, Tin, lane);
+            const unsigned rb = (unsigned)(((size_t)(b + 4) * p.C + c) * Tin * 4);
+            dw_issue_loads<NV, SPAN, TWO, AL>(raw, rx, rx2, rb, in0, Tin, lane);
         }
 
         const int t0 = out0 + lane * R;
@@ -280,9 +275,13 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
         if constexpr (AL) {
 #pragma unroll
             for (int q = 0; q < R / 4; ++q) {
-                if (t0 + 4 * q < Tout) {
+                if (t0 + 4 * q + 3 < Tout) {
                     f32x4 o = {outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(p.y + oo + 4 * q) = o;
+                    *reinterpret_cast<f32x4u*>(p.y + oo + 4 * q) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (t0 + 4 * q + e < Tout) p.y[oo + 4 * q + e] = outv[4 * q + e];
                 }
             }
         } else {
@@ -315,14 +314,12 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
 template <int IM, int OM>
 static bool dw_launch_specialised(const DwParams& p, hipStream_t st) {
     dim3 grid(p.C, p.G);
-    const bool al = ((p.Tin & 3) == 0) && ((p.Tout & 3) == 0);
     const bool big = p.Tout > 256;
+    // rows of any length take the 16-byte (dword-aligned) global path; tails are masked per element
 #define DW_GO(KK, SS)                                                                                             \
     do {                                                                                                          \
-        if (big) { if (al) hipLaunchKernelGGL((dwconv_kernel<KK, SS, 8, IM, OM, true>), grid, dim3(256), 0, st, p);  \
-                   else hipLaunchKernelGGL((dwconv_kernel<KK, SS, 8, IM, OM, false>), grid, dim3(256), 0, st, p); }  \
-        else     { if (al) hipLaunchKernelGGL((dwconv_kernel<KK, SS, 4, IM, OM, true>), grid, dim3(256), 0, st, p);  \
-                   else hipLaunchKernelGGL((dwconv_kernel<KK, SS, 4, IM, OM, false>), grid, dim3(256), 0, st, p); }  \
+        if (big) hipLaunchKernelGGL((dwconv_kernel<KK, SS, 8, IM, OM, true>), grid, dim3(256), 0, st, p);         \
+        else hipLaunchKernelGGL((dwconv_kernel<KK, SS, 4, IM, OM, true>), grid, dim3(256), 0, st, p);             \
         return true;                                                                                              \
     } while (0)
 #define X(KK) if (p.K == KK && p.stride == 1) DW_GO(KK, 1);

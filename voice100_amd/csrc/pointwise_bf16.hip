@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = K / BF_BK;
+    const int nk = (K + BF_BK - 1) / BF_BK;
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgParams p) {
 
 // Fast path of the backward-weight kernel for T % 64 == 0: buffer loads with per-batch descriptors
 // (rows past M / K read as zero in hardware), per-lane offsets computed once.
-template <int GM, int XM>
+template <int GM, int XM, bool TAIL>
 __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char As[2][128 * 128];   // [m][t] bf16
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][128 * 128];   // [k][t] bf16
@@ -472,7 +472,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int t0) {
+        const bool tail = TAIL && (t0 + BF_BK > T);        // contraction index past T must contribute zero
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float va[8], vb[8];
@@ -498,6 +499,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
             if constexpr (XM != PW_X_NONE) { if (voX[i] >= K * T * 4) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) vb[e] = 0.f; } }
+            if constexpr (TAIL) if (tail) {
+                const int tb = t0 + (((tid + 256 * i) & 7) << 3);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { if (tb + e >= T) { va[e] = 0.f; vb[e] = 0.f; } }
+            }
             u32x4 oa, ob;
             oa[0] = pack_bf16(va[0], va[1]); oa[1] = pack_bf16(va[2], va[3]); oa[2] = pack_bf16(va[4], va[5]); oa[3] = pack_bf16(va[6], va[7]);
             ob[0] = pack_bf16(vb[0], vb[1]); ob[1] = pack_bf16(vb[2], vb[3]); ob[2] = pack_bf16(vb[4], vb[5]); ob[3] = pack_bf16(vb[6], vb[7]);
@@ -514,14 +520,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nt = T / BF_BK;
+    const int nt = (T + BF_BK - 1) / BF_BK;
     const int nsteps = (b_hi > b_lo) ? (b_hi - b_lo) * nt : 0;
     const int lr = lane & 31, lh = lane >> 5;
     const int sw = (lr >> 1) & 7;
     const int rdA0 = (wm * 64 + lr) * 128, rdB0 = (wn * 64 + lr) * 128;
     if (nsteps > 0) {
         load_tiles(b_lo, 0);
-        store_tiles(0);
+        store_tiles(0, 0);
     }
     __syncthreads();
     for (int st = 0; st < nsteps; ++st) {
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
             if constexpr (GM == PW_X_AFFINE2) asm volatile("" : "+v"(ra2[i][0]), "+v"(ra2[i][1]));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (nxt < nsteps) store_tiles(cur ^ 1);
+        if (nxt < nsteps) store_tiles(cur ^ 1, (nxt % nt) * BF_BK);
         __syncthreads();
     }
     const int col = lane & 31, half = lane >> 5;
@@ -572,7 +578,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
 
 void pw_launch_gemm_bf16(const PwParams& p, dim3 grid, hipStream_t st) {
     const bool tv = (p.T & 3) == 0, kv = (p.K & 7) == 0;
-    const bool full = (p.K % BF_BK) == 0 && (p.T % PW_BN) == 0 && (long)p.K * p.T * 4 < 0x7fffffffL && (long)p.M * p.K * 2 < 0x7fffffffL;
+    // Any M, K, T: rows / columns past the tensor fall outside the buffer descriptors and read as zero; columns
+    // t >= T inside a row read the next row's (finite) values, which only reach output columns that are never
+    // stored; k >= K rows of X are zero, so whatever A holds there is multiplied by zero.
+    const bool full = (p.K & 1) == 0 && (long)(p.K + 64) * p.T * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL;
     if (full) {
 #define X(XM, EP)                                                                                                   \
         if (p.x_mode == XM && p.epi_mode == EP) {                                                                   \
@@ -598,11 +607,12 @@ void pw_launch_gemm_bf16(const PwParams& p, dim3 grid, hipStream_t st) {
 
 void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
     const bool tv = (p.T & 3) == 0;
-    const bool full = (p.T % BF_BK) == 0 && (long)(p.M + 128) * p.T * 4 < 0x7fffffffL && (long)(p.K + 128) * p.T * 4 < 0x7fffffffL;
+    const bool full = (long)(p.M + 128) * p.T * 4 < 0x7fffffffL && (long)(p.K + 128) * p.T * 4 < 0x7fffffffL;
     if (full) {
 #define X(GM, XM)                                                                                                   \
         if (p.g_mode == GM && p.x_mode == XM) {                                                                     \
-            hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<GM, XM>), grid, dim3(256), 0, st, p);                     \
+            if (p.T % BF_BK == 0) hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<GM, XM, false>), grid, dim3(256), 0, st, p); \
+            else hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<GM, XM, true>), grid, dim3(256), 0, st, p);          \
             return;                                                                                                 \
         }
         PW_WG_COMBOS(X)
