@@ -246,3 +246,29 @@ def test_errors_are_loud(cuda):
     from voice100_amd.layers import InvertedResidual
     with pytest.raises(RuntimeError):
         InvertedResidual(4, 4, 5)(torch.zeros(1, 4, 16))                                     # no CPU fallback
+
+
+@pytest.mark.parametrize("B,T,V,L", [(3, 40, 29, 7), (4, 130, 71, 30), (2, 9, 5, 6), (5, 64, 29, 1)])
+def test_ctc_loss_fused(cuda, B, T, V, L):
+    """Fused log_softmax + CTC (value and gradient) vs torch's CPU F.ctc_loss, ragged lengths, repeated labels,
+    an infeasible utterance (zero_infinity) and an empty target."""
+    from voice100_amd import functional as F_
+    g = torch.Generator().manual_seed(B * 100 + T)
+    logits = torch.randn(B, T, V, generator=g) * 2
+    targets = torch.randint(1, V, (B, L), generator=g)
+    if L > 2:
+        targets[0, 1] = targets[0, 0]                      # repeated label needs a blank in between
+    in_len = torch.randint(min(2 * L + 1, T), T + 1, (B,), generator=g).to(torch.int32)
+    tgt_len = torch.randint(1, L + 1, (B,), generator=g).to(torch.int32)
+    if B >= 4:
+        in_len[1] = max(1, int(tgt_len[1]) - 1)            # too short: infinite loss -> zeroed
+        tgt_len[2] = 0                                      # empty target
+    ref_in = logits.clone().requires_grad_(True)
+    ref = F.ctc_loss(F.log_softmax(ref_in.transpose(0, 1), dim=-1), targets, in_len, tgt_len, blank=0, reduction="mean",
+                     zero_infinity=True)
+    ref.backward()
+    x = logits.to(cuda).requires_grad_(True)
+    loss = F_.ctc_loss(x, targets.to(cuda), in_len.to(cuda), tgt_len.to(cuda))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-4 * max(1.0, abs(float(ref.detach())))
+    assert rel_err(x.grad, ref_in.grad) < 2e-4

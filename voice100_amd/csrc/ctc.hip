@@ -1,0 +1,195 @@
+// K10: log_softmax + CTC loss + its gradient w.r.t. the logits, fused (asr.py:148-152:
+// F.log_softmax(dim=-1) then nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True)).
+//
+// The stock PyTorch-ROCm CTC kernels cost ~1.6 ms per step at the benchmark shape (T'=512, B=32, L=100),
+// almost all of it latency of a 512-step serial recursion.  Here one workgroup owns one (utterance,
+// direction): the alpha (forward) and beta (backward) lattices run concurrently, log-probabilities are
+// staged through LDS 64 frames at a time, one __syncthreads per frame.  The gradient
+//   dL/dlogit[t][c] = softmax[t][c] - exp(logsumexp_{s: ext[s]=c}(alpha+beta)[t] + nll - logprob[t][c])
+// (log_softmax's backward is the identity here because that expression sums to zero over c) is formed by one
+// wave per frame with LDS float atomics into the <= 128 class bins.
+#include "common.h"
+#include <math.h>
+
+#define CTC_CHUNK 64
+#define CTC_MAXV 128
+#define NEG_INF (-INFINITY)
+
+__device__ __forceinline__ float lse2(float a, float b) {
+    const float m = fmaxf(a, b);
+    if (m == NEG_INF) return NEG_INF;
+    return m + logf(expf(a - m) + expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+    const float m = fmaxf(fmaxf(a, b), c);
+    if (m == NEG_INF) return NEG_INF;
+    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// lse[b][t] = logsumexp_c logits[b][t][c]
+__global__ void ctc_lse_kernel(const float* __restrict__ logits, float* __restrict__ lse, long rows, int V) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = logits + r * V;
+    float m = NEG_INF;
+    for (int c = 0; c < V; ++c) m = fmaxf(m, p[c]);
+    float s = 0.f;
+    for (int c = 0; c < V; ++c) s += expf(p[c] - m);
+    lse[r] = m + logf(s);
+}
+
+// grid (B, 2): y = 0 alpha, y = 1 beta.  lattice[b][t][s] written for t < in_len[b], s < 2*tgt_len[b]+1.
+__global__ __launch_bounds__(256) void ctc_lattice_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                          const long long* __restrict__ targets, const int* __restrict__ in_len,
+                                                          const int* __restrict__ tgt_len, float* __restrict__ alpha,
+                                                          float* __restrict__ beta, float* __restrict__ nll, int T, int V, int Lmax,
+                                                          int Smax, int blank) {
+    extern __shared__ float sm[];
+    float* lp = sm;                                  // [CTC_CHUNK][V] log-probs of the current chunk
+    float* row = sm + CTC_CHUNK * V;                 // [2][Smax + 4] previous / current lattice row (with guard cells)
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    int Tb = in_len[b];
+    if (Tb > T) Tb = T;
+    int L = tgt_len[b];
+    if (L > Lmax) L = Lmax;
+    const int S = 2 * L + 1;
+    float* lat = (dir == 0 ? alpha : beta) + (size_t)b * T * Smax;
+    const long long* tg = targets + (size_t)b * Lmax;
+    const int rs = Smax + 4;
+    // guard cells (index 0,1 and S+2,S+3 of the padded row) stay -inf
+    for (int i = tid; i < 2 * rs; i += 256) row[i] = NEG_INF;
+    __syncthreads();
+    if (Tb <= 0) { if (dir == 0 && tid == 0) nll[b] = INFINITY; return; }
+
+    // states handled by this thread: s = tid, tid + 256, ... ; class and skip permission per state
+    const int NS = 2;                                // up to 512 states per utterance
+    int cls[NS]; bool skip[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int s = tid + 256 * k;
+        cls[k] = blank; skip[k] = false;
+        if (s < S && (s & 1)) {
+            cls[k] = (int)tg[s >> 1];
+            if (dir == 0) skip[k] = s >= 2 && tg[s >> 1] != tg[(s >> 1) - 1];
+            else skip[k] = s + 2 < S && tg[s >> 1] != tg[(s >> 1) + 1];
+        }
+        if (cls[k] < 0 || cls[k] >= V) cls[k] = blank;
+    }
+
+    const int nchunks = (Tb + CTC_CHUNK - 1) / CTC_CHUNK;
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int c0 = dir == 0 ? ci * CTC_CHUNK : (nchunks - 1 - ci) * CTC_CHUNK;     // first frame of the chunk
+        const int cn = min(CTC_CHUNK, Tb - c0);
+        __syncthreads();
+        for (int i = tid; i < cn * V; i += 256) {
+            const int tt = i / V, c = i - tt * V;
+            lp[i] = logits[((size_t)b * T + c0 + tt) * V + c] - lse[(size_t)b * T + c0 + tt];
+        }
+        __syncthreads();
+        for (int j = 0; j < cn; ++j) {
+            const int tl = dir == 0 ? j : cn - 1 - j;
+            const int t = c0 + tl;
+            const bool first = dir == 0 ? (t == 0) : (t == Tb - 1);
+            const int cur = t & 1, prv = cur ^ 1;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int s = tid + 256 * k;
+                if (s < S) {
+                    const float e = lp[tl * V + cls[k]];
+                    float v;
+                    if (first) {
+                        const bool start = dir == 0 ? (s <= 1) : (s >= S - 2);
+                        v = start ? e : NEG_INF;
+                    } else if (dir == 0) {
+                        const float* pr = row + prv * rs + 2 + s;
+                        v = e + lse3(pr[0], pr[-1], skip[k] ? pr[-2] : NEG_INF);
+                    } else {
+                        const float* pr = row + prv * rs + 2 + s;
+                        v = e + lse3(pr[0], pr[1], skip[k] ? pr[2] : NEG_INF);
+                    }
+                    row[cur * rs + 2 + s] = v;
+                    lat[(size_t)t * Smax + s] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (dir == 0 && tid == 0) {
+        const float* last = row + ((Tb - 1) & 1) * rs + 2;
+        const float ll = S >= 2 ? lse2(last[S - 1], last[S - 2]) : last[S - 1];
+        nll[b] = -ll;
+    }
+}
+
+// one wave per (b, t): grad[b][t][c] = softmax - exp(lcab + nll - logprob); zero for padded frames / infeasible utterances
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                       const long long* __restrict__ targets, const int* __restrict__ in_len,
+                                                       const int* __restrict__ tgt_len, const float* __restrict__ alpha,
+                                                       const float* __restrict__ beta, const float* __restrict__ nll,
+                                                       float* __restrict__ grad, int B, int T, int V, int Lmax, int Smax, int blank) {
+    __shared__ float bins[4][CTC_MAXV];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long w = (long)blockIdx.x * 4 + wave;
+    if (w >= (long)B * T) return;
+    const int b = (int)(w / T), t = (int)(w % T);
+    float* g = grad + ((size_t)b * T + t) * V;
+    const float n = nll[b];
+    int Tb = in_len[b];
+    if (Tb > T) Tb = T;
+    if (t >= Tb || !(n < INFINITY)) {                 // padded frame, or zero_infinity
+        for (int c = lane; c < V; c += 64) g[c] = 0.f;
+        return;
+    }
+    int L = tgt_len[b];
+    if (L > Lmax) L = Lmax;
+    const int S = 2 * L + 1;
+    const float* al = alpha + ((size_t)b * T + t) * Smax;
+    const float* be = beta + ((size_t)b * T + t) * Smax;
+    const long long* tg = targets + (size_t)b * Lmax;
+    for (int c = lane; c < V; c += 64) bins[wave][c] = 0.f;
+    float m = NEG_INF;
+    for (int s = lane; s < S; s += 64) m = fmaxf(m, al[s] + be[s]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    __builtin_amdgcn_wave_barrier();
+    if (m > NEG_INF) {
+        for (int s = lane; s < S; s += 64) {
+            int c = (s & 1) ? (int)tg[s >> 1] : blank;
+            if (c < 0 || c >= V) c = blank;
+            atomicAdd(&bins[wave][c], expf(al[s] + be[s] - m));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float z = lse[(size_t)b * T + t];
+    const float* lg = logits + ((size_t)b * T + t) * V;
+    for (int c = lane; c < V; c += 64) {
+        const float lpc = lg[c] - z;
+        const float acc = bins[wave][c];
+        const float occ = (acc > 0.f) ? expf(m + logf(acc) + n - lpc) : 0.f;
+        g[c] = expf(lpc) - occ;
+    }
+}
+
+extern "C" int v100_ctc_workspace_floats(int B, int T, int Lmax) {      // alpha + beta + lse
+    const long n = 2L * B * T * (2 * Lmax + 1) + (long)B * T;
+    return n > 0x7fffffffL ? -1 : (int)n;
+}
+
+extern "C" int v100_ctc_loss(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace,
+                             float* nll, float* grad, int B, int T, int V, int Lmax, int blank, void* stream) {
+    if (!logits || !targets || !in_len || !tgt_len || !workspace || !nll || !grad) return V100_ERR_NULL;
+    if (B <= 0 || T <= 0 || V <= 0 || V > CTC_MAXV || Lmax < 0 || 2 * Lmax + 1 > 512 || blank < 0 || blank >= V) return V100_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int Smax = 2 * Lmax + 1;
+    float* alpha = workspace;
+    float* beta = alpha + (size_t)B * T * Smax;
+    float* lse = beta + (size_t)B * T * Smax;
+    const long rows = (long)B * T;
+    hipLaunchKernelGGL(ctc_lse_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logits, lse, rows, V);
+    const size_t shmem = (size_t)(CTC_CHUNK * V + 2 * (Smax + 4)) * sizeof(float);
+    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(B, 2), dim3(256), shmem, st, logits, lse, targets, in_len, tgt_len, alpha, beta, nll,
+                       T, V, Lmax, Smax, blank);
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len,
+                       alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank);
+    return v100_launch_status();
+}

@@ -4,8 +4,8 @@ The reference has no collective call site of its own; under Lightning's DDP it g
 bucketed gradient all-reduce (mean) once per step, per-rank BatchNorm statistics and
 rank-local metrics.  This module reproduces exactly that exchange:
 
-* all gradients live in ONE flat fp32 buffer (p.grad are views into it), cut into
-  buckets in reverse parameter order (the order backward produces them);
+* gradients are exchanged through ONE flat fp32 buffer cut into buckets in reverse parameter
+  order (the order backward produces them); a bucket is packed with one multi-tensor copy;
 * a post-accumulate hook per parameter launches the bucket's all-reduce as soon as its
   last gradient is written, so the exchange overlaps the rest of backward;
 * xGMI is point-to-point (7 links/GPU), the whole message is 46.5 MB, so a few large
@@ -20,6 +20,16 @@ import torch.distributed as dist
 
 
 class FlatGradBuckets:
+    """Bucketed gradient mean over the process group.
+
+    Parameters are cut into buckets in reverse order (the order backward produces gradients).  A
+    post-accumulate hook per parameter counts a bucket down; when its last gradient has been written the
+    bucket's gradients are packed into the flat buffer with one multi-tensor copy and its all-reduce is
+    launched asynchronously, so the exchange overlaps the rest of backward.  After finish_step() every
+    p.grad is a view into the (averaged) flat buffer.  With a single process nothing is registered and
+    gradients stay where autograd put them (no extra kernels on the step).
+    """
+
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 16 << 20, process_group=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
@@ -29,25 +39,24 @@ class FlatGradBuckets:
             raise ValueError("parameters must share one device and dtype")
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=dt, device=dev)
-        # reverse order: the last layers' gradients are ready first
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev) if self.world > 1 else None
         order = list(reversed(self.params))
         self._bucket_of = {}
-        self.buckets = []          # (start, end, n_params)
-        off, start, count = 0, 0, 0
-        itemsize = self.flat.element_size()
+        self.buckets = []          # (start, end, [params])
+        off, start, members = 0, 0, []
+        itemsize = 4 if self.flat is None else self.flat.element_size()
+        self._view = {}
         for p in order:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self._view[p] = (off, off + n)
             self._bucket_of[p] = len(self.buckets)
             off += n
-            count += 1
+            members.append(p)
             if (off - start) * itemsize >= bucket_bytes:
-                self.buckets.append((start, off, count))
-                start, count = off, 0
-        if count:
-            self.buckets.append((start, off, count))
+                self.buckets.append((start, off, members))
+                start, members = off, []
+        if members:
+            self.buckets.append((start, off, members))
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._hooks = []
@@ -57,37 +66,36 @@ class FlatGradBuckets:
         self.begin_step()
 
     def begin_step(self):
-        """Zero the flat buffer (one memset) and re-arm the bucket counters; call before backward."""
-        self.flat.zero_()
-        for i, (_, _, n) in enumerate(self.buckets):
-            self._pending[i] = n
+        """Drop last step's gradients (autograd then assigns instead of accumulating) and re-arm the buckets."""
+        for p in self.params:
+            p.grad = None
+        for i, (_, _, members) in enumerate(self.buckets):
+            self._pending[i] = len(members)
         self._handles = []
+
+    def _launch(self, b):
+        s, e, members = self.buckets[b]
+        views = [self.flat[self._view[p][0]:self._view[p][1]].view_as(p) for p in members]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in members]
+        torch._foreach_copy_(views, grads)
+        for p, v in zip(members, views):
+            p.grad = v
+        self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._pending[b] = -1
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
-        if p.grad.data_ptr() != self.flat.data_ptr() + self._offset_bytes(p):
-            # autograd replaced the view (first backward with a None grad cannot happen: grads are preset)
-            raise RuntimeError("parameter gradient no longer aliases the flat buffer")
         self._pending[b] -= 1
         if self._pending[b] == 0:
-            s, e, _ = self.buckets[b]
-            self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-
-    def _offset_bytes(self, p):
-        return p.grad.storage_offset() * self.flat.element_size()
+            self._launch(b)
 
     def finish_step(self):
         """Wait for the exchange and turn the sum into DDP's mean.  Call after backward."""
         if self.world == 1:
             return
-        if any(n != 0 for n in self._pending):      # a parameter produced no gradient this step
-            for h in self._handles:
-                h.wait()
-            self._handles = [dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
-            # buckets already reduced would be summed twice: rescale them
-            for b, (s, e, _) in enumerate(self.buckets):
-                if self._pending[b] == 0:
-                    self.flat[s:e].div_(self.world)
+        for b in range(len(self.buckets)):
+            if self._pending[b] >= 0:          # some parameter of this bucket produced no gradient this step
+                self._launch(b)
         for h in self._handles:
             h.wait()
         self.flat.div_(self.world)

@@ -473,3 +473,41 @@ def world_unnormalize_gate(x_bta, f0_mean, f0_std, ls_mean, ls_std, ca_mean, ca_
     codeap = _f32(B, T, cap, like=x_bta)
     N.call("v100_world_unnormalize", x_bta, f0, logspc, codeap, f0_mean, f0_std, ls_mean, ls_std, ca_mean, ca_std, B, T, S, cap)
     return f0, logspc, codeap
+
+
+
+class CTCLossFn(torch.autograd.Function):
+    """log_softmax(dim=-1) + CTCLoss(blank=0, reduction='mean', zero_infinity=True) on logits [B, T, V]
+    (asr.py:146-152), forward and gradient in one pass of the HIP lattice kernels."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, input_lengths, target_lengths, blank):
+        _check(logits, "ctc_loss")
+        logits = logits.contiguous()
+        B, T, V = logits.shape
+        targets = targets.to(device=logits.device, dtype=torch.int64).contiguous()
+        lmax = targets.shape[1]
+        il = input_lengths.to(device=logits.device, dtype=torch.int32).contiguous()
+        tl = target_lengths.to(device=logits.device, dtype=torch.int32).contiguous()
+        nws = N.helper("v100_ctc_workspace_floats", B, T, lmax)
+        if nws < 0:
+            raise RuntimeError("ctc_loss: workspace too large")
+        ws = _f32(nws, like=logits)
+        nll = _f32(B, like=logits)
+        grad = torch.empty_like(logits)
+        N.call("v100_ctc_loss", logits, targets, il, tl, ws, nll, grad, B, T, V, lmax, int(blank))
+        finite = torch.isfinite(nll)
+        denom = tl.clamp_min(1).to(torch.float32)
+        loss = (torch.where(finite, nll, torch.zeros_like(nll)) / denom).mean()
+        ctx.save_for_backward(grad, denom)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        grad, denom = ctx.saved_tensors
+        scale = (gout / (denom * denom.shape[0]))[:, None, None]
+        return grad * scale, None, None, None, None
+
+
+def ctc_loss(logits_btv, targets, input_lengths, target_lengths, blank: int = 0):
+    return CTCLossFn.apply(logits_btv, targets, input_lengths, target_lengths, blank)
