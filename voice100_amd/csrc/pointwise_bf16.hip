@@ -164,9 +164,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 
 template <int XM, int EPI>
 __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char As[2][128 * 128];   // [m][k] bf16
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][128 * 128];   // [t][k] bf16
-    __shared__ float red[2][2][64][2];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 128 * 128];    // 64 KB: 2 x (A, B) stages; reused by the epilogue
+    unsigned char (*As)[128 * 128] = reinterpret_cast<unsigned char (*)[128 * 128]>(smem);               // [2][m][k] bf16
+    unsigned char (*Bs)[128 * 128] = reinterpret_cast<unsigned char (*)[128 * 128]>(smem + 2 * 128 * 128);  // [2][t][k] bf16
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
         if (kt + 1 < nk) store_tiles(cur ^ 1);
         __syncthreads();
     }
-    pw_epilogue<EPI>(p, acc, b, m0, t0, tt, wm, wn, lane, red);
+    pw_epilogue_lds<EPI>(p, acc, reinterpret_cast<float*>(smem), b, m0, t0, tt, wm, wn, tid);
 }
 
 // Backward-weight, bf16: contraction index is t; both operands are read as 8 consecutive t
@@ -581,7 +581,8 @@ void pw_launch_gemm_bf16(const PwParams& p, dim3 grid, hipStream_t st) {
     // Any M, K, T: rows / columns past the tensor fall outside the buffer descriptors and read as zero; columns
     // t >= T inside a row read the next row's (finite) values, which only reach output columns that are never
     // stored; k >= K rows of X are zero, so whatever A holds there is multiplied by zero.
-    const bool full = (p.K & 1) == 0 && (long)(p.K + 64) * p.T * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL;
+    const bool full = (p.K & 1) == 0 && (long)(p.K + 64) * p.T * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL &&
+                      (long)p.B * p.M * p.T * 4 < 0x7fffff00L;
     if (full) {
 #define X(XM, EP)                                                                                                   \
         if (p.x_mode == XM && p.epi_mode == EP) {                                                                   \

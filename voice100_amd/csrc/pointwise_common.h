@@ -161,6 +161,96 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, f32x16 (&acc)[2][
     }
 }
 
+// Sum over the 32 lanes that share lane>>5, on the DPP path (5 VALU ops, no LDS crossbar).  The total is
+// valid in the upper 16 lanes of each half (lanes 16-31 and 48-63).
+__device__ __forceinline__ float half_wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));  // row_bcast:15 into rows 1,3
+    return v;
+}
+
+// Epilogue through LDS: the 128x128 fp32 accumulator tile is parked in the (now idle) 64 KB staging buffers,
+// then every half-wave streams one output row per pass as 16-byte accesses (R read, Y write: 512 B contiguous
+// per row) and reduces the row's BatchNorm partial sums with DPP.  `ct` = 128*128 floats of LDS.
+template <int EPI_>
+__device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)[2][2], float* ct, int b, int m0, int t0, int tt,
+                                                int wm, int wn, int tid) {
+    constexpr int epi = EPI_;
+    const int lane = tid & 63, col = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                ct[row * 128 + wn * 64 + j * 32 + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    constexpr bool do_stats = (epi == PW_EPI_STATS || epi == PW_EPI_MASK_STATS);
+    constexpr bool use_e = (epi == PW_EPI_AFFINE_RELU6 || epi == PW_EPI_AFFINE_RES || epi == PW_EPI_MASK_STATS);
+    const bool use_r = (epi == PW_EPI_MASK_STATS || epi == PW_EPI_ADD || (epi == PW_EPI_AFFINE_RES && p.R != nullptr));
+    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_r ? p.R : p.X), 0,
+                                                                       (int)((size_t)p.B * p.M * p.T * 4), 0x00020000);
+    const int wave = tid >> 6;
+    const int t = t0 + col * 4;
+    const size_t part = (size_t)b * p.n_ttiles + tt;
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+        const int row = pass * 8 + wave * 2 + half;
+        const int m = m0 + row;
+        const bool mv = m < p.M;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ct + row * 128 + col * 4);
+        const float ea = use_e ? p.ea[mv ? m : 0] : 1.f;
+        const float eb = use_e ? p.eb[mv ? m : 0] : 0.f;
+        const float bs = p.bias ? p.bias[mv ? m : 0] : 0.f;
+        const size_t o = ((size_t)b * p.M + m) * p.T + t;
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+        if (use_r) rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, (mv && t < p.T) ? (int)(o * 4) : 0x7ffffff0, 0, 0));
+        f32x4 v;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = mv && (t + e) < p.T;
+            float x = a[e] + bs;
+            const float r = ok ? rv[e] : 0.f;
+            if constexpr (epi == PW_EPI_STATS) {
+                if (ok) { s0 += x; s1 = fmaf(x, x, s1); }
+            } else if constexpr (epi == PW_EPI_AFFINE_RELU6) {
+                x = relu6f(fmaf(x, ea, eb));
+            } else if constexpr (epi == PW_EPI_AFFINE_RES) {
+                x = fmaf(x, ea, eb) + r;
+            } else if constexpr (epi == PW_EPI_MASK_STATS) {
+                const float pre = fmaf(r, ea, eb);
+                x = (pre > 0.f && pre < 6.f) ? x : 0.f;
+                if (ok) { s0 += x; s1 = fmaf(x, r, s1); }
+            } else if constexpr (epi == PW_EPI_ADD) {
+                x += r;
+            }
+            v[e] = x;
+        }
+        if (mv) {
+            if (t + 3 < p.T) *reinterpret_cast<f32x4u*>(p.Y + o) = v;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (t + e < p.T) p.Y[o + e] = v[e];
+            }
+        }
+        if constexpr (do_stats) {
+            s0 = half_wave_sum_dpp(s0);
+            s1 = half_wave_sum_dpp(s1);
+            if (col == 31 && mv) {
+                p.stats[(part * p.M + m) * 2 + 0] = s0;
+                p.stats[(part * p.M + m) * 2 + 1] = s1;
+            }
+        }
+    }
+}
+
 // work item -> (b, t-tile, m-tile), m-tile fastest
 __device__ __forceinline__ void pw_work(const PwParams& p, int& b, int& tt, int& mt) {
     const int w = xcd_remap(blockIdx.x, gridDim.x);
