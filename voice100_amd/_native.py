@@ -34,7 +34,7 @@ def parse_header(path=HEADER_PATH):
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\bint\s+(v100_\w+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"\b(?:int|long long)\s+(v100_\w+)\s*\(([^)]*)\)\s*;", text):
         name, args = m.group(1), m.group(2)
         params = []
         for a in args.split(","):
@@ -67,7 +67,7 @@ def load():
         for name, params in protos.items():
             fn = getattr(lib, name)        # AttributeError if the header declares a symbol the .so lacks
             fn.argtypes = [t for t, _ in params]
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_longlong if name.endswith("_bytes") else ctypes.c_int
         _lib, _protos = lib, protos
         return lib
 

@@ -1,0 +1,165 @@
+// Block executor: one host call runs the whole kernel chain of an InvertedResidual block
+// (voice100/models/asr.py:40-59) forward (training mode) or backward on the given stream.
+// Pure host code: it sequences the kernel entry points of this library (no allocation: the caller
+// passes the outputs, the tensors saved for backward and ONE workspace blob that is carved here).
+// This replaces ~12 (forward) / ~20 (backward) Python->C crossings per block with one.
+#include "common.h"
+#include "../../include/voice100_hip.h"
+
+namespace {
+struct Carver {
+    char* p; size_t used;
+    explicit Carver(void* base) : p((char*)base), used(0) {}
+    template <class T> T* take(size_t n) {
+        used = (used + 255) & ~size_t(255);
+        T* r = p ? (T*)(p + used) : nullptr;
+        used += n * sizeof(T);
+        return r;
+    }
+};
+inline int conv_out(int t, int k, int s) { return (t + 2 * ((k - 1) / 2) - k) / s + 1; }
+const float kMom = 0.1f, kEps = 1e-5f;
+}
+
+// shape = {B, Cin, hid, Cout, T, K, stride, residual, bf16}
+// coef  = 12 vectors of `hid` floats: s1 t1 mean1 rstd1 s2 t2 mean2 rstd2 s3 t3 mean3 rstd3
+enum { IR_B, IR_CIN, IR_HID, IR_COUT, IR_T, IR_K, IR_STRIDE, IR_RES, IR_BF16, IR_NSHAPE };
+
+static size_t ir_fwd_carve(const int* sh, void* base, void** w1bf, void** w3bf, float** stats) {
+    const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T];
+    const int T2 = conv_out(T, sh[IR_K], sh[IR_STRIDE]);
+    Carver c(base);
+    *w1bf = c.take<u16>((size_t)hid * cin);
+    *w3bf = c.take<u16>((size_t)cout * hid);
+    size_t n = (size_t)v100_pw_num_parts(B, T) * hid * 2;
+    const size_t n2 = (size_t)v100_dw_num_groups(B, hid) * hid * 2;
+    const size_t n3 = (size_t)v100_pw_num_parts(B, T2) * cout * 2;
+    if (n2 > n) n = n2;
+    if (n3 > n) n = n3;
+    *stats = c.take<float>(n);
+    return c.used + 256;
+}
+
+extern "C" long long v100_ir_fwd_workspace_bytes(const int* shape) {
+    void *a, *b; float* s;
+    return (long long)ir_fwd_carve(shape, nullptr, &a, &b, &s);
+}
+
+// ptrs: 0 x | 1 w1 2 g1 3 b1 4 rm1 5 rv1 6 nbt1 | 7 wd 8 g2 9 b2 10 rm2 11 rv2 12 nbt2 | 13 w3 14 g3 15 b3 16 rm3 17 rv3 18 nbt3 |
+//       19 a1 20 a2 21 a3 22 y 23 coef 24 workspace
+extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stream) {
+    if (!sh || !P) return V100_ERR_NULL;
+    const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T], K = sh[IR_K], S = sh[IR_STRIDE];
+    const int res = sh[IR_RES], bf = sh[IR_BF16];
+    const int pad = (K - 1) / 2, T2 = conv_out(T, K, S);
+    const float* x = (const float*)P[0];
+    const float* w1 = (const float*)P[1]; const float* wd = (const float*)P[7]; const float* w3 = (const float*)P[13];
+    float* a1 = (float*)P[19]; float* a2 = (float*)P[20]; float* a3 = (float*)P[21]; float* y = (float*)P[22];
+    float* coef = (float*)P[23];
+    const int mc = hid > cout ? hid : cout;          // coef vector stride
+    float *s1 = coef, *t1 = coef + mc, *m1 = coef + 2 * mc, *r1 = coef + 3 * mc, *s2 = coef + 4 * mc, *t2 = coef + 5 * mc,
+          *m2 = coef + 6 * mc, *r2 = coef + 7 * mc, *s3 = coef + 8 * mc, *t3 = coef + 9 * mc, *m3 = coef + 10 * mc, *r3 = coef + 11 * mc;
+    void *w1bf, *w3bf; float* st;
+    ir_fwd_carve(sh, const_cast<void*>(P[24]), &w1bf, &w3bf, &st);
+    int rc;
+#define CK(call) do { rc = (call); if (rc) return rc; } while (0)
+    if (bf) {
+        CK(v100_weight_prep(w1, hid, cin, w1bf, nullptr, nullptr, stream));
+        CK(v100_weight_prep(w3, cout, hid, w3bf, nullptr, nullptr, stream));
+    }
+    const int parts1 = v100_pw_num_parts(B, T), parts3 = v100_pw_num_parts(B, T2), G = v100_dw_num_groups(B, hid);
+    CK(v100_pw_gemm(w1, w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, bf, stream));
+    CK(v100_bn_finalize_train(st, parts1, (long long)B * T, (const float*)P[2], (const float*)P[3], (float*)P[4], (float*)P[5], (long long*)P[6],
+                              kMom, kEps, s1, t1, m1, r1, hid, stream));
+    CK(v100_dwconv(a1, nullptr, wd, s1, t1, nullptr, 1, a2, nullptr, nullptr, nullptr, 0, st, G, B, hid, T, T2, K, S, pad, 0, 1, 0, stream));
+    CK(v100_bn_finalize_train(st, G, (long long)B * T2, (const float*)P[8], (const float*)P[9], (float*)P[10], (float*)P[11], (long long*)P[12],
+                              kMom, kEps, s2, t2, m2, r2, hid, stream));
+    CK(v100_pw_gemm(w3, w3bf, a2, nullptr, s2, t2, nullptr, 1, a3, nullptr, nullptr, nullptr, nullptr, 1, st, B, cout, hid, T2, bf, stream));
+    CK(v100_bn_finalize_train(st, parts3, (long long)B * T2, (const float*)P[14], (const float*)P[15], (float*)P[16], (float*)P[17], (long long*)P[18],
+                              kMom, kEps, s3, t3, m3, r3, cout, stream));
+    CK(v100_chan_affine2(a3, res ? x : nullptr, s3, nullptr, t3, y, B, cout, T2, stream));
+    return V100_OK;
+}
+
+struct IrBwdWs {
+    void *w1t_bf, *w3t_bf; float *w1t, *w3t;
+    float *part, *da3, *dz2, *dz1, *slab, *pqr;
+};
+static size_t ir_bwd_carve(const int* sh, void* base, IrBwdWs& w) {
+    const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T], K = sh[IR_K];
+    const int T2 = conv_out(T, K, sh[IR_STRIDE]);
+    Carver c(base);
+    w.w1t_bf = c.take<u16>((size_t)hid * cin); w.w3t_bf = c.take<u16>((size_t)cout * hid);
+    w.w1t = c.take<float>((size_t)hid * cin);  w.w3t = c.take<float>((size_t)cout * hid);
+    size_t n = (size_t)v100_dw_num_groups(B, cout) * cout * 2;
+    size_t m = (size_t)v100_pw_num_parts(B, T2) * hid * 2; if (m > n) n = m;
+    m = (size_t)v100_dw_num_groups(B, hid) * hid * 2; if (m > n) n = m;
+    w.part = c.take<float>(n);
+    w.da3 = c.take<float>((size_t)B * cout * T2);
+    w.dz2 = c.take<float>((size_t)B * hid * T2);
+    w.dz1 = c.take<float>((size_t)B * hid * T);
+    n = (size_t)v100_pw_wgrad_splits(B, cout, hid) * cout * hid;
+    m = (size_t)v100_pw_wgrad_splits(B, hid, cin) * hid * cin; if (m > n) n = m;
+    m = (size_t)v100_dw_num_groups(B, hid) * hid * K; if (m > n) n = m;
+    w.slab = c.take<float>(n);
+    w.pqr = c.take<float>((size_t)3 * (hid > cout ? hid : cout));
+    return c.used + 256;
+}
+
+extern "C" long long v100_ir_bwd_workspace_bytes(const int* shape) {
+    IrBwdWs w;
+    return (long long)ir_bwd_carve(shape, nullptr, w);
+}
+
+// ptrs: 0 x 1 a1 2 a2 3 a3 | 4 w1 5 wd 6 w3 | 7 g1 8 g2 9 g3 | 10 coef | 11 dy | 12 dx (may be NULL) |
+//       13 dW1 14 dg1 15 db1 16 dWd 17 dg2 18 db2 19 dW3 20 dg3 21 db3 | 22 workspace
+extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
+    if (!sh || !P) return V100_ERR_NULL;
+    const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T], K = sh[IR_K], S = sh[IR_STRIDE];
+    const int res = sh[IR_RES], bf = sh[IR_BF16];
+    const int pad = (K - 1) / 2, T2 = conv_out(T, K, S);
+    const float *x = (const float*)P[0], *a1 = (const float*)P[1], *a2 = (const float*)P[2], *a3 = (const float*)P[3];
+    const float *w1 = (const float*)P[4], *wd = (const float*)P[5], *w3 = (const float*)P[6];
+    const float *g1 = (const float*)P[7], *g2 = (const float*)P[8], *g3 = (const float*)P[9];
+    const float* coef = (const float*)P[10];
+    const int mc = hid > cout ? hid : cout;
+    const float *s1 = coef, *t1 = coef + mc, *m1 = coef + 2 * mc, *r1 = coef + 3 * mc, *s2 = coef + 4 * mc, *t2 = coef + 5 * mc,
+                *m2 = coef + 6 * mc, *r2 = coef + 7 * mc, *m3 = coef + 10 * mc, *r3 = coef + 11 * mc;
+    const float* dy = (const float*)P[11];
+    float* dx = (float*)P[12];
+    IrBwdWs w;
+    ir_bwd_carve(sh, const_cast<void*>(P[22]), w);
+    float *pp = w.pqr, *qq = w.pqr + mc, *rr = w.pqr + 2 * mc;
+    int rc;
+    if (bf) {
+        CK(v100_weight_prep(w1, hid, cin, nullptr, nullptr, w.w1t_bf, stream));
+        CK(v100_weight_prep(w3, cout, hid, nullptr, nullptr, w.w3t_bf, stream));
+    } else {
+        CK(v100_weight_prep(w1, hid, cin, nullptr, w.w1t, nullptr, stream));
+        CK(v100_weight_prep(w3, cout, hid, nullptr, w.w3t, nullptr, stream));
+    }
+    // BN3 backward
+    const int Gr = v100_dw_num_groups(B, cout);
+    CK(v100_chan_reduce2(dy, a3, w.part, Gr, B, cout, T2, stream));
+    CK(v100_bn_bwd_finalize(w.part, Gr, (long long)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], cout, stream));
+    CK(v100_chan_affine2(dy, a3, pp, qq, rr, w.da3, B, cout, T2, stream));
+    // pw-linear: weight grad, then data grad through ReLU6 with BN2-backward sums
+    CK(v100_pw_wgrad(w.da3, nullptr, nullptr, nullptr, nullptr, 0, a2, s2, t2, 1, w.slab, (float*)P[19], v100_pw_wgrad_splits(B, cout, hid),
+                     B, cout, hid, T2, bf, stream));
+    const int parts = v100_pw_num_parts(B, T2);
+    CK(v100_pw_gemm(w.w3t, w.w3t_bf, w.da3, nullptr, nullptr, nullptr, nullptr, 0, w.dz2, nullptr, s2, t2, a2, 4, w.part, B, hid, cout, T2, bf, stream));
+    CK(v100_bn_bwd_finalize(w.part, parts, (long long)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], hid, stream));
+    // depthwise: weight grad, then data grad through ReLU6 with BN1-backward sums
+    const int G = v100_dw_num_groups(B, hid);
+    CK(v100_dwconv_wgrad(w.dz2, a2, pp, qq, rr, 2, a1, s1, t1, 1, w.slab, (float*)P[16], G, B, hid, T, T2, K, S, pad, 0, stream));
+    CK(v100_dwconv(w.dz2, a2, wd, pp, qq, rr, 2, w.dz1, a1, s1, t1, 2, w.part, G, B, hid, T2, T, K, 1, K - 1 - pad, 1, S, 0, stream));
+    CK(v100_bn_bwd_finalize(w.part, G, (long long)B * T, g1, m1, r1, pp, qq, rr, (float*)P[14], (float*)P[15], hid, stream));
+    // pw: weight grad, data grad (+ residual)
+    CK(v100_pw_wgrad(w.dz1, a1, pp, qq, rr, 2, x, nullptr, nullptr, 0, w.slab, (float*)P[13], v100_pw_wgrad_splits(B, hid, cin),
+                     B, hid, cin, T, bf, stream));
+    if (dx)
+        CK(v100_pw_gemm(w.w1t, w.w1t_bf, w.dz1, a1, pp, qq, rr, 2, dx, nullptr, nullptr, nullptr, res ? dy : nullptr, res ? 5 : 0, nullptr,
+                        B, cin, hid, T, bf, stream));
+#undef CK
+    return V100_OK;
+}

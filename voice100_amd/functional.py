@@ -13,6 +13,7 @@ BatchNorm + ReLU6 are applied by the *consumer* while it loads its input:
     x --pw GEMM--> a1 (+stats) --dw (BN1+ReLU6 on load)--> a2 (+stats)
       --pw GEMM (BN2+ReLU6 on load)--> a3 (+stats) --affine(+x)--> y
 """
+import ctypes
 from typing import Optional
 
 import torch
@@ -90,8 +91,17 @@ def _bn_bwd(partial, parts, count, gamma, mean, rstd, c, like):
     return p, q, r, dg, db
 
 
+def _ptr_table(items):
+    arr = (ctypes.c_void_p * len(items))()
+    for i, t in enumerate(items):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
 class InvertedResidualTrainFn(torch.autograd.Function):
-    """Training-mode InvertedResidual (asr.py:40-59): batch statistics, running-stat update, autograd."""
+    """Training-mode InvertedResidual (asr.py:40-59): batch statistics, running-stat update, autograd.
+    Forward and backward are ONE call each into the library's block executor (csrc/block.hip), which
+    sequences the GEMM / depthwise / BatchNorm kernels on the current stream."""
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, wd, g2, b2, w3, g3, b3, rm1, rv1, nbt1, rm2, rv2, nbt2, rm3, rv3, nbt3,
@@ -101,101 +111,42 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         B, cin, T = x.shape
         hid, cout = w1.shape[0], w3.shape[0]
         k = int(kernel_size)
-        pad = (k - 1) // 2
         T2 = conv_out_len(T, k, stride)
         bf16 = precision == "bf16"
-        W1 = _Weights(w1.detach().reshape(hid, cin), bf16, False)
-        W3 = _Weights(w3.detach().reshape(cout, hid), bf16, False)
-        wd2 = wd.detach().reshape(hid, k).contiguous()
-
-        # pw: a1 = W1 x, with the partial sums for BN1
-        parts1 = N.helper("v100_pw_num_parts", B, T)
+        shape = (ctypes.c_int * 9)(B, cin, hid, cout, T, k, int(stride), int(bool(use_residual)), int(bf16))
         a1 = _f32(B, hid, T, like=x)
-        st = _f32(parts1, hid, 2, like=x)
-        _pw_gemm(W1.w, W1.w_bf, x, a1, hid, cin, T, B, bf16, epi=1, stats=st)
-        s1, t1, mean1, rstd1 = _bn_train(st, parts1, B * T, g1.detach(), b1.detach(), rm1, rv1, nbt1, hid, x)
-
-        # dw: a2 = dwconv(relu6(s1*a1+t1)), with the partial sums for BN2
-        G = N.helper("v100_dw_num_groups", B, hid)
         a2 = _f32(B, hid, T2, like=x)
-        st = _f32(G, hid, 2, like=x)
-        N.call("v100_dwconv", a1, None, wd2, s1, t1, None, 1, a2, None, None, None, 0, st, G, B, hid, T, T2, k, stride, pad, 0, 1, 0)
-        s2, t2, mean2, rstd2 = _bn_train(st, G, B * T2, g2.detach(), b2.detach(), rm2, rv2, nbt2, hid, x)
-
-        # pw-linear: a3 = W3 relu6(s2*a2+t2), with the partial sums for BN3
-        parts3 = N.helper("v100_pw_num_parts", B, T2)
         a3 = _f32(B, cout, T2, like=x)
-        st = _f32(parts3, cout, 2, like=x)
-        _pw_gemm(W3.w, W3.w_bf, a2, a3, cout, hid, T2, B, bf16, xa=s2, xb=t2, x_mode=1, epi=1, stats=st)
-        s3, t3, mean3, rstd3 = _bn_train(st, parts3, B * T2, g3.detach(), b3.detach(), rm3, rv3, nbt3, cout, x)
-
-        # y = BN3(a3) (+ x)
         y = _f32(B, cout, T2, like=x)
-        N.call("v100_chan_affine2", a3, x if use_residual else None, s3, None, t3, y, B, cout, T2)
-
-        ctx.save_for_backward(x, a1, a2, a3, w1, wd, w3, g1, g2, g3, s1, t1, mean1, rstd1, s2, t2, mean2, rstd2, mean3, rstd3)
-        ctx.cfg = (k, int(stride), bool(use_residual), bf16)
+        coef = _f32(12, max(hid, cout), like=x)
+        ws = torch.empty(N.helper("v100_ir_fwd_workspace_bytes", shape), dtype=torch.uint8, device=x.device)
+        tensors = (x, w1, g1, b1, rm1, rv1, nbt1, wd, g2, b2, rm2, rv2, nbt2, w3, g3, b3, rm3, rv3, nbt3, a1, a2, a3, y, coef, ws)
+        for t in tensors[:19]:
+            if not t.is_contiguous() or not t.is_cuda:
+                raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors")
+        N.call("v100_ir_fwd_train", shape, _ptr_table(tensors))
+        ctx.save_for_backward(x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef)
+        ctx.shape = shape
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x, a1, a2, a3, w1, wd, w3, g1, g2, g3, s1, t1, mean1, rstd1, s2, t2, mean2, rstd2, mean3, rstd3) = ctx.saved_tensors
-        k, stride, use_residual, bf16 = ctx.cfg
+        x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef = ctx.saved_tensors
+        shape = ctx.shape
         dy = dy.contiguous()
-        B, cin, T = x.shape
-        hid, cout = a1.shape[1], a3.shape[1]
-        T2 = a2.shape[2]
-        pad = (k - 1) // 2
-        W1 = _Weights(w1.detach().reshape(hid, cin), bf16, True)
-        W3 = _Weights(w3.detach().reshape(cout, hid), bf16, True)
-        wd2 = wd.detach().reshape(hid, k).contiguous()
-
-        # BN3 backward: reductions over (dy, a3), then da3 = p*dy + q*a3 + r
-        Gr = N.helper("v100_dw_num_groups", B, cout)
-        part = _f32(Gr, cout, 2, like=x)
-        N.call("v100_chan_reduce2", dy, a3, part, Gr, B, cout, T2)
-        p3, q3, r3, dg3, db3 = _bn_bwd(part, Gr, B * T2, g3.detach(), mean3, rstd3, cout, x)
-        da3 = _f32(B, cout, T2, like=x)
-        N.call("v100_chan_affine2", dy, a3, p3, q3, r3, da3, B, cout, T2)
-
-        # pw-linear weight grad: dW3 = da3 . relu6(s2*a2+t2)^T
-        S = N.helper("v100_pw_wgrad_splits", B, cout, hid)
-        partial = _f32(S, cout, hid, like=x)
-        dW3 = _f32(cout, hid, like=x)
-        N.call("v100_pw_wgrad", da3, None, None, None, None, 0, a2, s2, t2, 1, partial, dW3, S, B, cout, hid, T2, int(bf16))
-
-        # pw-linear data grad through ReLU6: dz2 = (W3^T da3) * [0 < s2*a2+t2 < 6], with BN2-backward sums
-        parts = N.helper("v100_pw_num_parts", B, T2)
-        dz2 = _f32(B, hid, T2, like=x)
-        st = _f32(parts, hid, 2, like=x)
-        _pw_gemm(W3.wt, W3.wt_bf, da3, dz2, hid, cout, T2, B, bf16, ea=s2, eb=t2, r=a2, epi=4, stats=st)
-        p2, q2, r2, dg2, db2 = _bn_bwd(st, parts, B * T2, g2.detach(), mean2, rstd2, hid, x)
-
-        # depthwise weight grad: dWd = corr(da2, relu6(s1*a1+t1)),  da2 = p2*dz2 + q2*a2 + r2
-        G = N.helper("v100_dw_num_groups", B, hid)
-        partial = _f32(G, hid, k, like=x)
-        dWd = _f32(hid, k, like=x)
-        N.call("v100_dwconv_wgrad", dz2, a2, p2, q2, r2, 2, a1, s1, t1, 1, partial, dWd, G, B, hid, T, T2, k, stride, pad, 0)
-
-        # depthwise data grad through ReLU6: dz1 = convT(da2) * [0 < s1*a1+t1 < 6], with BN1-backward sums
-        dz1 = _f32(B, hid, T, like=x)
-        st = _f32(G, hid, 2, like=x)
-        N.call("v100_dwconv", dz2, a2, wd2, p2, q2, r2, 2, dz1, a1, s1, t1, 2, st, G, B, hid, T2, T, k, 1, k - 1 - pad, 1, stride, 0)
-        p1, q1, r1, dg1, db1 = _bn_bwd(st, G, B * T, g1.detach(), mean1, rstd1, hid, x)
-
-        # pw weight grad: dW1 = da1 . x^T,  da1 = p1*dz1 + q1*a1 + r1
-        S = N.helper("v100_pw_wgrad_splits", B, hid, cin)
-        partial = _f32(S, hid, cin, like=x)
-        dW1 = _f32(hid, cin, like=x)
-        N.call("v100_pw_wgrad", dz1, a1, p1, q1, r1, 2, x, None, None, 0, partial, dW1, S, B, hid, cin, T, int(bf16))
-
-        # pw data grad: dx = W1^T da1 (+ dy through the residual)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = _f32(B, cin, T, like=x)
-            _pw_gemm(W1.wt, W1.wt_bf, dz1, dx, cin, hid, T, B, bf16, x2=a1, xa=p1, xb=q1, xc=r1, x_mode=2,
-                     r=dy if use_residual else None, epi=5 if use_residual else 0)
-
+        hid, cin = w1.shape[0], w1.shape[1]
+        cout, k = w3.shape[0], wd.shape[2]
+        # parameter gradients in one allocation: dW1 dg1 db1 dWd dg2 db2 dW3 dg3 db3
+        sizes = (hid * cin, hid, hid, hid * k, hid, hid, cout * hid, cout, cout)
+        flat = _f32(sum(sizes), like=x)
+        parts, off = [], 0
+        for n in sizes:
+            parts.append(flat[off:off + n])
+            off += n
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(N.helper("v100_ir_bwd_workspace_bytes", shape), dtype=torch.uint8, device=x.device)
+        N.call("v100_ir_bwd", shape, _ptr_table((x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, dy, dx) + tuple(parts) + (ws,)))
+        dW1, dg1, db1, dWd, dg2, db2, dW3, dg3, db3 = parts
         return (dx, dW1.view_as(w1), dg1, db1, dWd.view_as(wd), dg2, db2, dW3.view_as(w3), dg3, db3) + (None,) * 13
 
 
