@@ -57,32 +57,40 @@ def synth_batch(device, B, seed):
 
 
 def cpu_baseline(sample_b=8, iters=2):
-    """Oracle (CPU port of the reference path, stock PyTorch CPU ops, fp32, all host cores): train-mode
-    forward + log_softmax + CTC + backward on a B=sample_b slice of the workload."""
+    """Oracle (CPU port of the reference path, stock PyTorch CPU ops, fp32): train-mode forward +
+    log_softmax + CTC + backward on a B=sample_b slice of the workload.  The box's containers see more
+    logical CPUs than they can use at once (oversubscription makes torch's conv slower), so a few thread
+    counts are tried and the best is reported together with the count that produced it."""
     from oracle import cnn
     from voice100_amd.asr import AudioToTextCTC
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.manual_seed(1234)
     m = AudioToTextCTC(N_MEL, 512, VOCAB, 512)
     state = {k: v.detach().clone() for k, v in m.state_dict().items()}
     params = {k: v.requires_grad_(True) for k, v in state.items() if v.dtype.is_floating_point and "running" not in k}
     state.update(params)
     (audio, audio_len), (text, text_len) = synth_batch("cpu", sample_b, 1234)
-    times = []
-    for i in range(iters + 1):
-        for p in params.values():
-            p.grad = None
-        t0 = time.perf_counter()
-        loss = cnn.audio_to_text_ctc_loss(((audio, audio_len), (text, text_len)), state, training=True)
-        loss.backward()
-        dt = time.perf_counter() - t0
-        if i > 0:
-            times.append(dt)
-    best = sum(times) / len(times)
-    return {"value": round(sample_b * T_FRAMES / best, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+    best_t, best_n, tried = None, None, []
+    for n in sorted({min(avail, c) for c in (8, 16, 32)}):
+        torch.set_num_threads(n)
+        times = []
+        for i in range(iters + 1):
+            for p in params.values():
+                p.grad = None
+            t0 = time.perf_counter()
+            loss = cnn.audio_to_text_ctc_loss(((audio, audio_len), (text, text_len)), state, training=True)
+            loss.backward()
+            dt = time.perf_counter() - t0
+            if i > 0:
+                times.append(dt)
+        t = sum(times) / len(times)
+        tried.append((n, round(sample_b * T_FRAMES / t, 1)))
+        if best_t is None or t < best_t:
+            best_t, best_n = t, n
+    return {"value": round(sample_b * T_FRAMES / best_t, 1), "unit": "frames/s", "cores": best_n, "kind": "port",
             "sample": f"oracle.cnn train fwd+CTC+bwd, B={sample_b} x T={T_FRAMES} slice of the B=32 workload, fp32, "
-                      f"{iters} timed iters after 1 warm-up, torch.set_num_threads({cores})"}
+                      f"{iters} timed iters after 1 warm-up per thread count; tried (threads, frames/s) = {tried}; "
+                      f"{avail} logical CPUs visible"}
 
 
 def main():
