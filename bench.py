@@ -151,11 +151,13 @@ def main():
         dw_bytes, _ = encoder_dw_bytes(B_PER_GPU, T_FRAMES)
         roof = None
         if "dw_fwd" in kt:
-            n, ms = kt["dw_fwd"]
-            achieved = dw_bytes * args.steps / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "dwconv_kernel (depthwise fwd, 9 launches/step)", "achieved": round(achieved, 1),
+            n, ms, nbytes = kt["dw_fwd"]          # bytes are summed per launch by the library (T varies with timestretch)
+            achieved = nbytes / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "dwconv_kernel (depthwise forward, 9 launches per step)", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "algorithmic_bytes_per_step": dw_bytes}
+                    "traffic_profiled": "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) = 1.005 x algorithmic bytes: profiles/r01_dw_fwd_pmc_traffic.txt",
+                    "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                    "algorithmic_bytes_per_launch": round(nbytes / n), "algorithmic_bytes_nominal_step": dw_bytes}
         out = {
             "metric": "audio frames/sec (fwd+bwd) asr_en_base, B=32x1024-frame mel",
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,

@@ -129,12 +129,12 @@ def timing_enable(on: bool) -> None:
 
 
 def timing_read():
-    """{tag: (launches, total_ms)} recorded since timing_enable(True)."""
+    """{tag: (launches, total_ms, algorithmic_bytes)} recorded since timing_enable(True)."""
     lib = load()
     out = {}
     for name, tag in TIMING_TAGS.items():
-        ms, n = ctypes.c_double(0.0), ctypes.c_longlong(0)
-        lib.v100_timing_read(tag, ctypes.byref(ms), ctypes.byref(n))
+        ms, n, nb = ctypes.c_double(0.0), ctypes.c_longlong(0), ctypes.c_double(0.0)
+        lib.v100_timing_read(tag, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(nb))
         if n.value:
-            out[name] = (n.value, ms.value)
+            out[name] = (n.value, ms.value, nb.value)
     return out

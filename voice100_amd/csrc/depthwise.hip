@@ -244,7 +244,9 @@ extern "C" int v100_dwconv(const float* x, const float* x2, const float* w, cons
     DwParams p{x, x2, w, in_a, in_b, in_c, y, aux, out_a, out_b, stats,
                B, C, Tin, Tout, K, stride, pad, flip, upsample, G, in_mode, out_mode};
     hipStream_t st = (hipStream_t)stream;
-    V100TimedRegion timed(out_mode == DW_OUT_MASK_STATS ? V100_T_DW_BWD_DATA : V100_T_DW_FWD, st);
+    // algorithmic bytes of this launch: fp32 input(s) + output (+ aux) + taps + per-channel coefficients
+    const double nin = (in_mode == DW_IN_AFFINE2 ? 2.0 : 1.0) * B * C * (double)Tin, nout = (out_mode == DW_OUT_MASK_STATS ? 2.0 : 1.0) * B * C * (double)Tout;
+    V100TimedRegion timed(out_mode == DW_OUT_MASK_STATS ? V100_T_DW_BWD_DATA : V100_T_DW_FWD, st, 4.0 * (nin + nout) + 4.0 * C * K + 8.0 * C);
     bool done = false;
     const bool fits = (size_t)B * C * Tin * 4 < 0x7fffff00ull;
     if (!force_generic && upsample == 1 && fits) {
@@ -268,7 +270,7 @@ extern "C" int v100_dwconv_wgrad(const float* g, const float* g2, const float* g
     if (x_mode != DW_IN_NONE && (!xa || !xb)) return V100_ERR_NULL;
     DwWgradParams p{g, g2, ga, gb, gc, x, xa, xb, partial, B, C, Tin, Tout, K, stride, pad, G, g_mode, x_mode};
     hipStream_t st = (hipStream_t)stream;
-    V100TimedRegion timed(V100_T_DW_WGRAD, st);
+    V100TimedRegion timed(V100_T_DW_WGRAD, st, 4.0 * B * C * ((g_mode == DW_IN_AFFINE2 ? 2.0 : 1.0) * Tout + (double)Tin) + 4.0 * C * K);
     bool done = false;
     if (!force_generic && g_mode == DW_IN_AFFINE2 && x_mode == DW_IN_AFFINE_RELU6 && (size_t)B * C * Tin * 4 < 0x7fffff00ull) {
 #define X(KK) if (!done && K == KK && stride == 1) { launch_dw_wgrad<KK, 1>(p, st); done = true; }

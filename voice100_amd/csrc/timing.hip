@@ -7,7 +7,7 @@
 #include <mutex>
 
 namespace {
-struct Pair { hipEvent_t a, b; int tag; };
+struct Pair { hipEvent_t a, b; int tag; double bytes; };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Pair> g_pairs;
@@ -15,7 +15,7 @@ size_t g_used = 0;
 const size_t kMaxPairs = 16384;
 }
 
-void v100_timing_begin(int tag, hipStream_t st, int* slot) {
+void v100_timing_begin(int tag, hipStream_t st, int* slot, double bytes) {
     *slot = -1;
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
@@ -26,6 +26,7 @@ void v100_timing_begin(int tag, hipStream_t st, int* slot) {
         g_pairs.push_back(p);
     }
     g_pairs[g_used].tag = tag;
+    g_pairs[g_used].bytes = bytes;
     (void)hipEventRecord(g_pairs[g_used].a, st);
     *slot = (int)g_used++;
 }
@@ -43,19 +44,21 @@ extern "C" int v100_timing_enable(int on) {
     return V100_OK;
 }
 
-// Sum of elapsed ms and number of launches recorded under `tag` since the last enable(1). Synchronises the device.
-extern "C" int v100_timing_read(int tag, double* ms, long long* count) {
-    if (!ms || !count) return V100_ERR_NULL;
+// Sum of elapsed ms, number of launches and algorithmic bytes recorded under `tag` since the last enable(1).
+// Synchronises the device.
+extern "C" int v100_timing_read(int tag, double* ms, long long* count, double* bytes) {
+    if (!ms || !count || !bytes) return V100_ERR_NULL;
     if (hipDeviceSynchronize() != hipSuccess) return V100_ERR_LAUNCH;
     std::lock_guard<std::mutex> lk(g_mu);
-    double total = 0.0;
+    double total = 0.0, nbytes = 0.0;
     long long n = 0;
     for (size_t i = 0; i < g_used; ++i) {
         if (g_pairs[i].tag != tag) continue;
         float t = 0.f;
-        if (hipEventElapsedTime(&t, g_pairs[i].a, g_pairs[i].b) == hipSuccess) { total += t; ++n; }
+        if (hipEventElapsedTime(&t, g_pairs[i].a, g_pairs[i].b) == hipSuccess) { total += t; ++n; nbytes += g_pairs[i].bytes; }
     }
     *ms = total;
     *count = n;
+    *bytes = nbytes;
     return V100_OK;
 }
