@@ -41,7 +41,10 @@ __device__ __forceinline__ u16 f2bf(float f) {
     return __builtin_bit_cast(u16, h);
 }
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    // one v_cvt_pk_bf16_f32 (RNE, NaN-preserving) instead of two conversions + shift + or
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(PwParams p) {
         }
         // ... and first USED after it: without this fence hipcc hoists the staging arithmetic (and the
         // vmcnt wait it needs) above the MFMAs, which exposes the whole memory latency every k-step.
-        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));   // accumulators stay in AGPRs
         asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]));
         if (x_mode == PW_X_AFFINE2)
             asm volatile("" : "+v"(rb2[0]), "+v"(rb2[1]), "+v"(rb2[2]), "+v"(rb2[3]), "+v"(rb2[4]), "+v"(rb2[5]), "+v"(rb2[6]), "+v"(rb2[7]));
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
         // ... and first USED after it (see pw_gemm_bf16_kernel)
-        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));   // accumulators stay in AGPRs
         asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]));
         if constexpr (XM == PW_X_AFFINE2)
             asm volatile("" : "+v"(rb2[0]), "+v"(rb2[1]), "+v"(rb2[2]), "+v"(rb2[3]), "+v"(rb2[4]), "+v"(rb2[5]), "+v"(rb2[6]), "+v"(rb2[7]));
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgParams p) {
         }
         // ... and first USED after it: without this fence hipcc hoists the staging arithmetic (and the
         // vmcnt wait it needs) above the MFMAs, which exposes the whole memory latency every k-step.
-        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));   // accumulators stay in AGPRs
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             asm volatile("" : "+v"(ra[i][0]), "+v"(ra[i][1]), "+v"(rb[i][0]), "+v"(rb[i][1]));
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));   // accumulators stay in AGPRs
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             asm volatile("" : "+v"(ra[i][0]), "+v"(ra[i][1]), "+v"(rb[i][0]), "+v"(rb[i][1]));

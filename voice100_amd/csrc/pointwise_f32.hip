@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(PwParams p) {
         }
         // ... and first USED after it: without this fence hipcc hoists the staging arithmetic (and the
         // vmcnt wait it needs) above the MFMAs, which exposes the whole memory latency every k-step.
-        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));   // accumulators stay in AGPRs
         asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]));
         if (x_mode == PW_X_AFFINE2) asm volatile("" : "+v"(rb2[0]), "+v"(rb2[1]));
         __builtin_amdgcn_sched_barrier(0);
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32_kernel(WgParams p) {
         }
         // ... and first USED after it: without this fence hipcc hoists the staging arithmetic (and the
         // vmcnt wait it needs) above the MFMAs, which exposes the whole memory latency every k-step.
-        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));   // accumulators stay in AGPRs
         asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]));
         if (g_mode == PW_X_AFFINE2) asm volatile("" : "+v"(ra2[0]), "+v"(ra2[1]));
         __builtin_amdgcn_sched_barrier(0);
