@@ -164,6 +164,19 @@ int v100_ir_fwd_train(const int* shape, const void* const* ptrs, void* stream);
 long long v100_ir_bwd_workspace_bytes(const int* shape);
 int v100_ir_bwd(const int* shape, const void* const* ptrs, void* stream);
 
+/* ---- SURVEY 8(f) "next" rows: integer decode / alignment steps on the device (csrc/decode.hip), bit-exact ----
+ * greedy CTC decode: argmax per frame (first maximum), collapse repeats, drop blanks (voice100/text.py:99-104);
+ * out [B][T] int64 (zero padded), out_len [B]. */
+int v100_ctc_greedy_decode(const float* logits, const int* lens, long long* out, int* out_len, int B, int T, int V, int blank, void* stream);
+/* ctc_best_path (voice100/models/align.py:18-66) batched: logp [B][T][V] log-probabilities, labels [B][Lmax] int64;
+ * back_ws: B*T*(2*Lmax+1) int16; path [B][T] int32 = index into the blank-expanded labels; score [B]. */
+int v100_ctc_best_path(const float* logp, const long long* labels, const int* in_len, const int* lab_len, void* back_ws, int* path,
+                       float* score, int B, int T, int V, int Lmax, int max_move, void* stream);
+/* TextToAlignTextModel.align (voice100/models/tts.py:89-110) batched: text [B][Lmax] int64, align [B][Lmax][2] float64
+ * (gap, length), out [B][Tmax] int64, out_len [B]. */
+int v100_align_expand(const long long* text, const double* align, const int* text_len, long long* out, int* out_len, int B, int Lmax,
+                      int Tmax, int head, int tail, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
