@@ -174,3 +174,28 @@ def test_augment_golden(cuda):
     d = AugmentDecisions(); d.mix = True
     assert rel_err(run(d)[0], g["mixaudio/audio"]) < 1e-5
     assert rel_err(run(AugmentDecisions())[0], g["maskaudio/audio"]) < 1e-5
+
+
+def test_streaming_pipeline_config5(cuda):
+    """BASELINE configs[4] shape: 1-second 16 kHz chunks -> log-mel [B,101,64] -> ConvVoiceEncoder -> logits -> greedy CTC
+    tokens, all on the GPU, against the CPU oracle chain (oracle.mel -> oracle.cnn -> merge_repeated).  Each chunk is an
+    independent zero-padded utterance, as the reference's forward() would treat a 101-frame input."""
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd.mel import MelSpectrogramAudioTransform
+    from voice100_amd.decode import ctc_greedy_decode
+    from oracle import cnn, mel as omel, intops
+    g = load_golden("asr_tiny.npz")
+    m = _asr_from_golden(g, cuda, embed_size=32, hidden_size=32).eval()
+    state = sub(g, "state/")
+    gen = torch.Generator().manual_seed(21)
+    wav = torch.rand(4, 16000, generator=gen) * 2 - 1
+    feats = MelSpectrogramAudioTransform().to(cuda)(wav.to(cuda))
+    assert feats.shape == (4, 101, 64)
+    logits = m(feats)
+    assert logits.shape == (4, 51, 29)
+    ids, n = ctc_greedy_decode(logits)
+    ref_feats = torch.stack([torch.from_numpy(omel.log_mel(w.numpy())) for w in wav])
+    ref_logits = cnn.audio_to_text_ctc_forward(ref_feats, state, training=False)
+    assert rel_err(feats, ref_feats) < 1e-4 and rel_err(logits, ref_logits) < 2e-4
+    for b in range(4):
+        assert ids[b, :int(n[b])].cpu().tolist() == intops.merge_repeated_ids(ref_logits[b].argmax(-1).tolist())
