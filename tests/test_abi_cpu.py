@@ -37,6 +37,7 @@ def test_host_helpers_need_no_gpu(lib):
     assert lib.v100_dw_num_groups(32, 2048) == 1 and lib.v100_dw_num_groups(32, 256) == 8 and lib.v100_dw_num_groups(2, 4) == 2
     assert 1 <= lib.v100_pw_wgrad_splits(32, 2048, 512) <= 32
     shape = (ctypes.c_int * 9)(32, 512, 2048, 512, 512, 83, 1, 1, 1)
+    assert lib.v100_ir_prep_bytes(shape) >= 4 * 2048 * 512 * 2
     assert lib.v100_ir_fwd_workspace_bytes(shape) > 0 and lib.v100_ir_bwd_workspace_bytes(shape) > 2 * 32 * 2048 * 512 * 4
     # NULL pointers are reported, not dereferenced
     assert lib.v100_dwconv(None, None, None, None, None, None, 0, None, None, None, None, 3, None, 1, 1, 1, 8, 8, 3, 1, 1, 0, 1, 0, None) == 3

@@ -25,12 +25,31 @@ const float kMom = 0.1f, kEps = 1e-5f;
 // coef  = 12 vectors of `hid` floats: s1 t1 mean1 rstd1 s2 t2 mean2 rstd2 s3 t3 mean3 rstd3
 enum { IR_B, IR_CIN, IR_HID, IR_COUT, IR_T, IR_K, IR_STRIDE, IR_RES, IR_BF16, IR_NSHAPE };
 
-static size_t ir_fwd_carve(const int* sh, void* base, void** w1bf, void** w3bf, float** stats) {
-    const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T];
+// Prepared weights, written once by forward and reused by backward (caller-owned, saved with the block):
+// bf16 mode: w1_bf [hid][cin], w1t_bf [cin][hid], w3_bf [cout][hid], w3t_bf [hid][cout];  fp32 mode: w1t, w3t (fp32).
+struct IrPrep { void *w1bf, *w1tbf, *w3bf, *w3tbf; float *w1t, *w3t; };
+static size_t ir_prep_carve(const int* sh, void* base, IrPrep& w) {
+    const int cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT];
+    Carver c(base);
+    if (sh[IR_BF16]) {
+        w.w1bf = c.take<u16>((size_t)hid * cin); w.w1tbf = c.take<u16>((size_t)hid * cin);
+        w.w3bf = c.take<u16>((size_t)cout * hid); w.w3tbf = c.take<u16>((size_t)cout * hid);
+        w.w1t = nullptr; w.w3t = nullptr;
+    } else {
+        w.w1bf = w.w1tbf = w.w3bf = w.w3tbf = nullptr;
+        w.w1t = c.take<float>((size_t)hid * cin); w.w3t = c.take<float>((size_t)cout * hid);
+    }
+    return c.used + 256;
+}
+extern "C" long long v100_ir_prep_bytes(const int* shape) {
+    IrPrep w;
+    return (long long)ir_prep_carve(shape, nullptr, w);
+}
+
+static size_t ir_fwd_carve(const int* sh, void* base, float** stats) {
+    const int B = sh[IR_B], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T];
     const int T2 = conv_out(T, sh[IR_K], sh[IR_STRIDE]);
     Carver c(base);
-    *w1bf = c.take<u16>((size_t)hid * cin);
-    *w3bf = c.take<u16>((size_t)cout * hid);
     size_t n = (size_t)v100_pw_num_parts(B, T) * hid * 2;
     const size_t n2 = (size_t)v100_dw_num_groups(B, hid) * hid * 2;
     const size_t n3 = (size_t)v100_pw_num_parts(B, T2) * cout * 2;
@@ -41,12 +60,12 @@ static size_t ir_fwd_carve(const int* sh, void* base, void** w1bf, void** w3bf, 
 }
 
 extern "C" long long v100_ir_fwd_workspace_bytes(const int* shape) {
-    void *a, *b; float* s;
-    return (long long)ir_fwd_carve(shape, nullptr, &a, &b, &s);
+    float* s;
+    return (long long)ir_fwd_carve(shape, nullptr, &s);
 }
 
 // ptrs: 0 x | 1 w1 2 g1 3 b1 4 rm1 5 rv1 6 nbt1 | 7 wd 8 g2 9 b2 10 rm2 11 rv2 12 nbt2 | 13 w3 14 g3 15 b3 16 rm3 17 rv3 18 nbt3 |
-//       19 a1 20 a2 21 a3 22 y 23 coef 24 workspace
+//       19 a1 20 a2 21 a3 22 y 23 coef 24 workspace 25 prepared-weights buffer (v100_ir_prep_bytes)
 extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stream) {
     if (!sh || !P) return V100_ERR_NULL;
     const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T], K = sh[IR_K], S = sh[IR_STRIDE];
@@ -59,14 +78,16 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
     const int mc = hid > cout ? hid : cout;          // coef vector stride
     float *s1 = coef, *t1 = coef + mc, *m1 = coef + 2 * mc, *r1 = coef + 3 * mc, *s2 = coef + 4 * mc, *t2 = coef + 5 * mc,
           *m2 = coef + 6 * mc, *r2 = coef + 7 * mc, *s3 = coef + 8 * mc, *t3 = coef + 9 * mc, *m3 = coef + 10 * mc, *r3 = coef + 11 * mc;
-    void *w1bf, *w3bf; float* st;
-    ir_fwd_carve(sh, const_cast<void*>(P[24]), &w1bf, &w3bf, &st);
+    float* st;
+    ir_fwd_carve(sh, const_cast<void*>(P[24]), &st);
+    IrPrep pw;
+    ir_prep_carve(sh, const_cast<void*>(P[25]), pw);
+    void *w1bf = pw.w1bf, *w3bf = pw.w3bf;
     int rc;
 #define CK(call) do { rc = (call); if (rc) return rc; } while (0)
-    if (bf) {
-        CK(v100_weight_prep(w1, hid, cin, w1bf, nullptr, nullptr, stream));
-        CK(v100_weight_prep(w3, cout, hid, w3bf, nullptr, nullptr, stream));
-    }
+    // both orientations in one pass per weight: forward uses w*_bf, backward the transposed copies
+    CK(v100_weight_prep(w1, hid, cin, pw.w1bf, pw.w1t, pw.w1tbf, stream));
+    CK(v100_weight_prep(w3, cout, hid, pw.w3bf, pw.w3t, pw.w3tbf, stream));
     const int parts1 = v100_pw_num_parts(B, T), parts3 = v100_pw_num_parts(B, T2), G = v100_dw_num_groups(B, hid);
     CK(v100_pw_gemm(w1, w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, bf, stream));
     CK(v100_bn_finalize_train(st, parts1, (long long)B * T, (const float*)P[2], (const float*)P[3], (float*)P[4], (float*)P[5], (long long*)P[6],
@@ -82,15 +103,12 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
 }
 
 struct IrBwdWs {
-    void *w1t_bf, *w3t_bf; float *w1t, *w3t;
     float *part, *da3, *dz2, *dz1, *slab, *pqr;
 };
 static size_t ir_bwd_carve(const int* sh, void* base, IrBwdWs& w) {
     const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T], K = sh[IR_K];
     const int T2 = conv_out(T, K, sh[IR_STRIDE]);
     Carver c(base);
-    w.w1t_bf = c.take<u16>((size_t)hid * cin); w.w3t_bf = c.take<u16>((size_t)cout * hid);
-    w.w1t = c.take<float>((size_t)hid * cin);  w.w3t = c.take<float>((size_t)cout * hid);
     size_t n = (size_t)v100_dw_num_groups(B, cout) * cout * 2;
     size_t m = (size_t)v100_pw_num_parts(B, T2) * hid * 2; if (m > n) n = m;
     m = (size_t)v100_dw_num_groups(B, hid) * hid * 2; if (m > n) n = m;
@@ -112,7 +130,7 @@ extern "C" long long v100_ir_bwd_workspace_bytes(const int* shape) {
 }
 
 // ptrs: 0 x 1 a1 2 a2 3 a3 | 4 w1 5 wd 6 w3 | 7 g1 8 g2 9 g3 | 10 coef | 11 dy | 12 dx (may be NULL) |
-//       13 dW1 14 dg1 15 db1 16 dWd 17 dg2 18 db2 19 dW3 20 dg3 21 db3 | 22 workspace
+//       13 dW1 14 dg1 15 db1 16 dWd 17 dg2 18 db2 19 dW3 20 dg3 21 db3 | 22 workspace | 23 prepared weights (from forward)
 extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     if (!sh || !P) return V100_ERR_NULL;
     const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T], K = sh[IR_K], S = sh[IR_STRIDE];
@@ -131,13 +149,9 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     ir_bwd_carve(sh, const_cast<void*>(P[22]), w);
     float *pp = w.pqr, *qq = w.pqr + mc, *rr = w.pqr + 2 * mc;
     int rc;
-    if (bf) {
-        CK(v100_weight_prep(w1, hid, cin, nullptr, nullptr, w.w1t_bf, stream));
-        CK(v100_weight_prep(w3, cout, hid, nullptr, nullptr, w.w3t_bf, stream));
-    } else {
-        CK(v100_weight_prep(w1, hid, cin, nullptr, w.w1t, nullptr, stream));
-        CK(v100_weight_prep(w3, cout, hid, nullptr, w.w3t, nullptr, stream));
-    }
+    IrPrep pw;
+    ir_prep_carve(sh, const_cast<void*>(P[23]), pw);
+    (void)w1; (void)w3;
     // BN3 backward
     const int Gr = v100_dw_num_groups(B, cout);
     CK(v100_chan_reduce2(dy, a3, w.part, Gr, B, cout, T2, stream));
@@ -147,7 +161,7 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     CK(v100_pw_wgrad(w.da3, nullptr, nullptr, nullptr, nullptr, 0, a2, s2, t2, 1, w.slab, (float*)P[19], v100_pw_wgrad_splits(B, cout, hid),
                      B, cout, hid, T2, bf, stream));
     const int parts = v100_pw_num_parts(B, T2);
-    CK(v100_pw_gemm(w.w3t, w.w3t_bf, w.da3, nullptr, nullptr, nullptr, nullptr, 0, w.dz2, nullptr, s2, t2, a2, 4, w.part, B, hid, cout, T2, bf, stream));
+    CK(v100_pw_gemm(pw.w3t, pw.w3tbf, w.da3, nullptr, nullptr, nullptr, nullptr, 0, w.dz2, nullptr, s2, t2, a2, 4, w.part, B, hid, cout, T2, bf, stream));
     CK(v100_bn_bwd_finalize(w.part, parts, (long long)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], hid, stream));
     // depthwise: weight grad, then data grad through ReLU6 with BN1-backward sums
     const int G = v100_dw_num_groups(B, hid);
@@ -158,7 +172,7 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     CK(v100_pw_wgrad(w.dz1, a1, pp, qq, rr, 2, x, nullptr, nullptr, 0, w.slab, (float*)P[13], v100_pw_wgrad_splits(B, hid, cin),
                      B, hid, cin, T, bf, stream));
     if (dx)
-        CK(v100_pw_gemm(w.w1t, w.w1t_bf, w.dz1, a1, pp, qq, rr, 2, dx, nullptr, nullptr, nullptr, res ? dy : nullptr, res ? 5 : 0, nullptr,
+        CK(v100_pw_gemm(pw.w1t, pw.w1tbf, w.dz1, a1, pp, qq, rr, 2, dx, nullptr, nullptr, nullptr, res ? dy : nullptr, res ? 5 : 0, nullptr,
                         B, cin, hid, T, bf, stream));
 #undef CK
     return V100_OK;

@@ -120,18 +120,19 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         y = _f32(B, cout, T2, like=x)
         coef = _f32(12, max(hid, cout), like=x)
         ws = torch.empty(N.helper("v100_ir_fwd_workspace_bytes", shape), dtype=torch.uint8, device=x.device)
-        tensors = (x, w1, g1, b1, rm1, rv1, nbt1, wd, g2, b2, rm2, rv2, nbt2, w3, g3, b3, rm3, rv3, nbt3, a1, a2, a3, y, coef, ws)
+        prep = torch.empty(N.helper("v100_ir_prep_bytes", shape), dtype=torch.uint8, device=x.device)
+        tensors = (x, w1, g1, b1, rm1, rv1, nbt1, wd, g2, b2, rm2, rv2, nbt2, w3, g3, b3, rm3, rv3, nbt3, a1, a2, a3, y, coef, ws, prep)
         for t in tensors[:19]:
             if not t.is_contiguous() or not t.is_cuda:
                 raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors")
         N.call("v100_ir_fwd_train", shape, _ptr_table(tensors))
-        ctx.save_for_backward(x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef)
+        ctx.save_for_backward(x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, prep)
         ctx.shape = shape
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef = ctx.saved_tensors
+        x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, prep = ctx.saved_tensors
         shape = ctx.shape
         dy = dy.contiguous()
         hid, cin = w1.shape[0], w1.shape[1]
@@ -145,7 +146,7 @@ class InvertedResidualTrainFn(torch.autograd.Function):
             off += n
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ws = torch.empty(N.helper("v100_ir_bwd_workspace_bytes", shape), dtype=torch.uint8, device=x.device)
-        N.call("v100_ir_bwd", shape, _ptr_table((x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, dy, dx) + tuple(parts) + (ws,)))
+        N.call("v100_ir_bwd", shape, _ptr_table((x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, dy, dx) + tuple(parts) + (ws, prep)))
         dW1, dg1, db1, dWd, dg2, db2, dW3, dg3, db3 = parts
         return (dx, dW1.view_as(w1), dg1, db1, dWd.view_as(wd), dg2, db2, dW3.view_as(w3), dg3, db3) + (None,) * 13
 
