@@ -1,5 +1,6 @@
 // bf16-operand instantiations of the pointwise GEMM kernels (see pointwise_common.h / pointwise.hip).
 #include "pointwise_common.h"
+#include <type_traits>
 
 // =============================================================================================
 // bf16 path: operands rounded to bf16 while staging, fp32 accumulate (v_mfma_f32_32x32x16_bf16).
@@ -201,16 +202,26 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) ldsB[q] = bf_off(b_tq + q, b_kc);
 
-    u32x4 ra[4], rb[8], rb2[8], rca[2], rcb[2], rcc[2];
-    auto load_tiles = [&](int k0) {
+    // NST register stages of global loads in flight: with two, the loads of tile k+2 are issued before the MFMA
+    // block of tile k and first used after the MFMA block of tile k+1, i.e. a full iteration of latency cover on
+    // top of the MFMA phase (the single-stage loop was bound by one HBM round trip per k-step).  The two-tensor
+    // prologue (XM == AFFINE2) keeps one stage: twice its staging registers would not fit two waves per SIMD.
+    constexpr int NST = (XM == PW_X_AFFINE2) ? 1 : 2;
+    u32x4 ra[NST][4], rb[NST][8], rb2[NST][XM == PW_X_AFFINE2 ? 8 : 1], rca[2], rcb[2], rcc[XM == PW_X_AFFINE2 ? 2 : 1];
+    auto load_tiles = [&](int k0, auto stg) {
+        constexpr int SG = decltype(stg)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA[i], k0 * 2, 0);
+        for (int i = 0; i < 4; ++i) ra[SG][i] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA[i], k0 * 2, 0);
         const int so = k0 * T * 4;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            rb[e] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX[e], so, 0);
-            if constexpr (XM == PW_X_AFFINE2) rb2[e] = __builtin_amdgcn_raw_buffer_load_b128(rX2, voX[e], so, 0);
+            rb[SG][e] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX[e], so, 0);
+            if constexpr (XM == PW_X_AFFINE2) rb2[SG][e] = __builtin_amdgcn_raw_buffer_load_b128(rX2, voX[e], so, 0);
         }
+    };
+    // BN coefficients of the tile that is about to be STORED: tiny, L2-resident, single register stage; issued one
+    // MFMA phase before their use
+    auto load_coefs = [&](int k0) {
         if constexpr (XM != PW_X_NONE) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -220,13 +231,14 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, auto stg) {
+        constexpr int SG = decltype(stg)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&As[buf][ldsA[i]]) = ra[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&As[buf][ldsA[i]]) = ra[SG][i];
         float v[8][4];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const f32x4 x = __builtin_bit_cast(f32x4, rb[e]);
+            const f32x4 x = __builtin_bit_cast(f32x4, rb[SG][e]);
             if constexpr (XM == PW_X_NONE) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[e][q] = x[q];
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
                     for (int q = 0; q < 4; ++q) v[e][q] = relu6f(fmaf(x[q], ca, cb));
                 } else {
                     const float cc = __builtin_bit_cast(f32x4, rcc[e >> 2])[e & 3];
-                    const f32x4 x2 = __builtin_bit_cast(f32x4, rb2[e]);
+                    const f32x4 x2 = __builtin_bit_cast(f32x4, rb2[SG][e]);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[e][q] = fmaf(x[q], ca, fmaf(x2[q], cb, cc));
                 }
@@ -253,6 +265,28 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
         }
     };
 
+    // one quarter of store_tiles: A piece `sl` and t-column `sl` of this thread's B patch (interleaved with the MFMAs)
+    auto store_slice = [&](int buf, auto stg, auto slc) {
+        constexpr int SG = decltype(stg)::value;
+        constexpr int q = decltype(slc)::value;
+        *reinterpret_cast<u32x4*>(&As[buf][ldsA[q]]) = ra[SG][q];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = __builtin_bit_cast(f32x4, rb[SG][e])[q];
+            if constexpr (XM == PW_X_NONE) v[e] = x;
+            else {
+                const float ca = __builtin_bit_cast(f32x4, rca[e >> 2])[e & 3];
+                const float cb = __builtin_bit_cast(f32x4, rcb[e >> 2])[e & 3];
+                if constexpr (XM == PW_X_AFFINE_RELU6) v[e] = relu6f(fmaf(x, ca, cb));
+                else v[e] = fmaf(x, ca, fmaf(__builtin_bit_cast(f32x4, rb2[SG][e])[q], cb, __builtin_bit_cast(f32x4, rcc[e >> 2])[e & 3]));
+            }
+        }
+        u32x4 o;
+        o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
+        *reinterpret_cast<u32x4*>(&Bs[buf][ldsB[q]]) = o;
+    };
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -262,18 +296,13 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (K + BF_BK - 1) / BF_BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, NST - 1>;
     const int lr = lane & 31, lh = lane >> 5;
     const int sw = (lr >> 1) & 7;                       // fragment rows are lr (+32, +64..): same swizzle key
     const int rdA0 = (wm * 64 + lr) * 128, rdB0 = (wn * 64 + lr) * 128;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BF_BK);
-        __builtin_amdgcn_sched_barrier(0);              // loads are issued before the MFMA block ...
-#pragma unroll
-        for (int ks = 0; ks < BF_BK / 16; ++ks) {
+    auto mfma_step = [&](int cur, int ks) {
+        {
             const int co = ((ks * 2 + lh) ^ sw) << 4;
             const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[cur][rdA0 + co]);
             const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[cur][rdA0 + 32 * 128 + co]);
@@ -284,16 +313,77 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        // ... and first USED after it (see pw_gemm_bf16_kernel)
-        asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));   // accumulators stay in AGPRs
-        asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]));
-        if constexpr (XM == PW_X_AFFINE2)
-            asm volatile("" : "+v"(rb2[0]), "+v"(rb2[1]), "+v"(rb2[2]), "+v"(rb2[3]), "+v"(rb2[4]), "+v"(rb2[5]), "+v"(rb2[6]), "+v"(rb2[7]));
-        asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]));
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
+    };
+    auto mfma_block = [&](int cur) {
+#pragma unroll
+        for (int ks = 0; ks < BF_BK / 16; ++ks) mfma_step(cur, ks);
+    };
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+    // pin: the registers of stage SG are first USED after this point (and the MFMAs issued before it).
+    // (a macro, not a lambda: clang rejects captured arrays as inline-asm operands inside a generic lambda)
+#define PW_PIN(SG)                                                                                                                  \
+    do {                                                                                                                            \
+        asm volatile("" : "+v"(rb[SG][0]), "+v"(rb[SG][1]), "+v"(rb[SG][2]), "+v"(rb[SG][3]), "+v"(rb[SG][4]), "+v"(rb[SG][5]),     \
+                          "+v"(rb[SG][6]), "+v"(rb[SG][7]));                                                                        \
+        if constexpr (XM == PW_X_AFFINE2)                                                                                           \
+            asm volatile("" : "+v"(rb2[SG][0]), "+v"(rb2[SG][1]), "+v"(rb2[SG][2]), "+v"(rb2[SG][3]), "+v"(rb2[SG][4]),             \
+                              "+v"(rb2[SG][5]), "+v"(rb2[SG][6]), "+v"(rb2[SG][7]));                                                \
+        asm volatile("" : "+v"(ra[SG][0]), "+v"(ra[SG][1]), "+v"(ra[SG][2]), "+v"(ra[SG][3]));                                      \
+    } while (0)
+    if constexpr (NST == 1) {
+        load_tiles(0, S0{});
+        load_coefs(0);
+        store_tiles(0, S0{});
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) { load_tiles((kt + 1) * BF_BK, S0{}); load_coefs((kt + 1) * BF_BK); }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(cur);
+            PW_PIN(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) store_tiles(cur ^ 1, S0{});
+            __syncthreads();
+        }
+    } else {
+        // tile t lives in register stage t&1 and LDS buffer t&1
+        load_tiles(0, S0{});
+        load_coefs(0);
+        if (nk > 1) load_tiles(BF_BK, S1{});
+        store_tiles(0, S0{});
+        __syncthreads();
+        // Steady state: the tile to be stored was loaded a whole iteration ago, so its transform + LDS writes are
+        // interleaved with the MFMAs of the current tile (matrix pipe and VALU/LDS overlap inside one wave).
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            // even tile kt: compute LDS 0; stage 1 holds tile kt+1; stage 0 is free -> tile kt+2
+            if (kt + 2 < nk) load_tiles((kt + 2) * BF_BK, S0{});
+            load_coefs((kt + 1) * BF_BK);
+            __builtin_amdgcn_sched_barrier(0);
+            PW_PIN(NST - 1);
+            mfma_step(0, 0); mfma_step(0, 1);
+            store_slice(1, S1{}, Q0{}); mfma_step(0, 2);
+            store_slice(1, S1{}, Q1{}); mfma_step(0, 3);
+            store_slice(1, S1{}, Q2{}); store_slice(1, S1{}, Q3{});
+            __syncthreads();
+            // odd tile kt+1: compute LDS 1; stage 0 holds tile kt+2; stage 1 is free -> tile kt+3
+            if (kt + 3 < nk) load_tiles((kt + 3) * BF_BK, S1{});
+            if (kt + 2 < nk) load_coefs((kt + 2) * BF_BK);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more = kt + 2 < nk;          // wave-uniform; MFMAs stay outside the branches (one accumulator chain)
+            if (more) PW_PIN(0);
+            mfma_step(1, 0); mfma_step(1, 1);
+            if (more) store_slice(0, S0{}, Q0{});
+            mfma_step(1, 2);
+            if (more) store_slice(0, S0{}, Q1{});
+            mfma_step(1, 3);
+            if (more) { store_slice(0, S0{}, Q2{}); store_slice(0, S0{}, Q3{}); }
+            __syncthreads();
+        }
+        if (kt < nk) mfma_block(0);            // odd tile count: the last tile already sits in LDS 0
     }
+#undef PW_PIN
     pw_epilogue_lds<EPI>(p, acc, reinterpret_cast<float*>(smem), b, m0, t0, tt, wm, wn, tid);
 }
 
