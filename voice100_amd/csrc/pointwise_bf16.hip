@@ -163,17 +163,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <int XM, int EPI>
-__global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 128 * 128];    // 64 KB: 2 x (A, B) stages; reused by the epilogue
-    unsigned char (*As)[128 * 128] = reinterpret_cast<unsigned char (*)[128 * 128]>(smem);               // [2][m][k] bf16
-    unsigned char (*Bs)[128 * 128] = reinterpret_cast<unsigned char (*)[128 * 128]>(smem + 2 * 128 * 128);  // [2][t][k] bf16
+template <int XM, int EPI, int BM>
+__global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
+    // BM x 128 block tile, BM/64 x 2 waves of 64x64.  BM = 256 (8 waves, one block per CU) halves the L2 traffic of
+    // the X operand, which is what bounds these GEMMs (each X tile is re-read by every M-tile); BM = 128 for M <= 128.
+    constexpr int NT = BM * 2;                      // threads
+    constexpr int KPT = 2048 / NT;                  // k rows per thread in the X patch: 8 (256 threads) or 4 (512)
+    constexpr int A_BYTES = BM * 128;               // one A stage: [BM][64] bf16
+    constexpr int SMEM = (BM * 128 * 4 > 2 * A_BYTES + 2 * 128 * 128) ? BM * 128 * 4 : 2 * A_BYTES + 2 * 128 * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];      // stages, reused by the epilogue as [BM][128] fp32
+    unsigned char* As = smem;                       // [2][BM][64] bf16
+    unsigned char* Bs = smem + 2 * A_BYTES;         // [2][128][64] bf16
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int b, tt, mt;
     pw_work(p, b, tt, mt);
-    const int m0 = mt * PW_BM, t0 = tt * PW_BN;
+    const int m0 = mt * BM, t0 = tt * PW_BN;
     const int M = p.M, K = p.K, T = p.T;
     const size_t xoff = (size_t)b * K * T;
 
@@ -184,95 +190,60 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
     const __amdgpu_buffer_rsrc_t rCb = make_rsrc(XM != PW_X_NONE ? p.xb : p.X, (unsigned)K * 4u);
     const __amdgpu_buffer_rsrc_t rCc = make_rsrc(XM == PW_X_AFFINE2 ? p.xc : p.X, (unsigned)K * 4u);
 
-    const int b_tq = (tid & 31) * 4;       // t offset in tile
-    const int b_kc = tid >> 5;             // k chunk 0..7
+    const int b_tq = (tid & 31) * 4;               // t offset in tile
+    const int b_kg = tid >> 5;                     // k group: rows KPT*b_kg .. +KPT-1
     int voA[4], ldsA[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int piece = tid + 256 * i;
+        const int piece = tid + NT * i;
         const int row = piece >> 3, ch = piece & 7;
         voA[i] = ((m0 + row) * K + ch * 8) * 2;
         ldsA[i] = bf_off(row, ch);
     }
-    int voX[8];
+    int voX[KPT];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) voX[e] = ((8 * b_kc + e) * T + t0 + b_tq) * 4;
-    const int voC = 8 * b_kc * 4;
+    for (int e = 0; e < KPT; ++e) voX[e] = ((KPT * b_kg + e) * T + t0 + b_tq) * 4;
+    const int voC = KPT * b_kg * 4;
     int ldsB[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ldsB[q] = bf_off(b_tq + q, b_kc);
+    for (int q = 0; q < 4; ++q) ldsB[q] = bf_off(b_tq + q, (KPT * b_kg) >> 3) + ((KPT * b_kg) & 7) * 2;
 
-    // NST register stages of global loads in flight: with two, the loads of tile k+2 are issued before the MFMA
-    // block of tile k and first used after the MFMA block of tile k+1, i.e. a full iteration of latency cover on
-    // top of the MFMA phase (the single-stage loop was bound by one HBM round trip per k-step).  The two-tensor
-    // prologue (XM == AFFINE2) keeps one stage: twice its staging registers would not fit two waves per SIMD.
-    constexpr int NST = (XM == PW_X_AFFINE2) ? 1 : 2;
-    u32x4 ra[NST][4], rb[NST][8], rb2[NST][XM == PW_X_AFFINE2 ? 8 : 1], rca[2], rcb[2], rcc[XM == PW_X_AFFINE2 ? 2 : 1];
+    // NST register stages of global loads in flight: with two, the loads of tile k+2 are issued
+    // before the MFMA block of tile k and first used during the MFMA block of tile k+1.  The two-tensor prologue
+    // (XM == AFFINE2) keeps one stage at BM = 128 (register budget); at BM = 256 its patch is half as large.
+    constexpr int NST = (XM == PW_X_AFFINE2 && KPT == 8) ? 1 : 2;
+    constexpr int NC = KPT / 4;                     // float4 coefficient loads per array
+    u32x4 ra[NST][4], rb[NST][KPT], rb2[NST][XM == PW_X_AFFINE2 ? KPT : 1], rca[NC], rcb[NC], rcc[XM == PW_X_AFFINE2 ? NC : 1];
     auto load_tiles = [&](int k0, auto stg) {
         constexpr int SG = decltype(stg)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[SG][i] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA[i], k0 * 2, 0);
         const int so = k0 * T * 4;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < KPT; ++e) {
             rb[SG][e] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX[e], so, 0);
             if constexpr (XM == PW_X_AFFINE2) rb2[SG][e] = __builtin_amdgcn_raw_buffer_load_b128(rX2, voX[e], so, 0);
         }
     };
-    // BN coefficients of the tile that is about to be STORED: tiny, L2-resident, single register stage; issued one
-    // MFMA phase before their use
+    // BN coefficients of the tile that is about to be STORED: tiny, L2-resident, single register stage
     auto load_coefs = [&](int k0) {
         if constexpr (XM != PW_X_NONE) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < NC; ++h) {
                 rca[h] = __builtin_amdgcn_raw_buffer_load_b128(rCa, voC + 16 * h, k0 * 4, 0);
                 rcb[h] = __builtin_amdgcn_raw_buffer_load_b128(rCb, voC + 16 * h, k0 * 4, 0);
                 if constexpr (XM == PW_X_AFFINE2) rcc[h] = __builtin_amdgcn_raw_buffer_load_b128(rCc, voC + 16 * h, k0 * 4, 0);
             }
         }
     };
-    auto store_tiles = [&](int buf, auto stg) {
-        constexpr int SG = decltype(stg)::value;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&As[buf][ldsA[i]]) = ra[SG][i];
-        float v[8][4];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const f32x4 x = __builtin_bit_cast(f32x4, rb[SG][e]);
-            if constexpr (XM == PW_X_NONE) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[e][q] = x[q];
-            } else {
-                const float ca = __builtin_bit_cast(f32x4, rca[e >> 2])[e & 3];
-                const float cb = __builtin_bit_cast(f32x4, rcb[e >> 2])[e & 3];
-                if constexpr (XM == PW_X_AFFINE_RELU6) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[e][q] = relu6f(fmaf(x[q], ca, cb));
-                } else {
-                    const float cc = __builtin_bit_cast(f32x4, rcc[e >> 2])[e & 3];
-                    const f32x4 x2 = __builtin_bit_cast(f32x4, rb2[SG][e]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[e][q] = fmaf(x[q], ca, fmaf(x2[q], cb, cc));
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            u32x4 o;
-            o[0] = pack_bf16(v[0][q], v[1][q]); o[1] = pack_bf16(v[2][q], v[3][q]);
-            o[2] = pack_bf16(v[4][q], v[5][q]); o[3] = pack_bf16(v[6][q], v[7][q]);
-            *reinterpret_cast<u32x4*>(&Bs[buf][ldsB[q]]) = o;
-        }
-    };
-
-    // one quarter of store_tiles: A piece `sl` and t-column `sl` of this thread's B patch (interleaved with the MFMAs)
+    // one quarter of a tile store: A piece `q` and t-column `q` of this thread's X patch
     auto store_slice = [&](int buf, auto stg, auto slc) {
         constexpr int SG = decltype(stg)::value;
         constexpr int q = decltype(slc)::value;
-        *reinterpret_cast<u32x4*>(&As[buf][ldsA[q]]) = ra[SG][q];
-        float v[8];
+        *reinterpret_cast<u32x4*>(As + buf * A_BYTES + ldsA[q]) = ra[SG][q];
+        float v[KPT];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < KPT; ++e) {
             const float x = __builtin_bit_cast(f32x4, rb[SG][e])[q];
             if constexpr (XM == PW_X_NONE) v[e] = x;
             else {
@@ -282,9 +253,23 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
                 else v[e] = fmaf(x, ca, fmaf(__builtin_bit_cast(f32x4, rb2[SG][e])[q], cb, __builtin_bit_cast(f32x4, rcc[e >> 2])[e & 3]));
             }
         }
-        u32x4 o;
-        o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
-        *reinterpret_cast<u32x4*>(&Bs[buf][ldsB[q]]) = o;
+        unsigned char* dst = Bs + buf * (128 * 128) + ldsB[q];
+        if constexpr (KPT == 8) {
+            u32x4 o;
+            o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
+            *reinterpret_cast<u32x4*>(dst) = o;
+        } else {
+            uint2 o;
+            o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]);
+            *reinterpret_cast<uint2*>(dst) = o;
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, NST - 1>;
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+    auto store_tiles = [&](int buf, auto stg) {
+        store_slice(buf, stg, Q0{}); store_slice(buf, stg, Q1{}); store_slice(buf, stg, Q2{}); store_slice(buf, stg, Q3{});
     };
 
     f32x16 acc[2][2];
@@ -296,40 +281,35 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (K + BF_BK - 1) / BF_BK;
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, NST - 1>;
     const int lr = lane & 31, lh = lane >> 5;
     const int sw = (lr >> 1) & 7;                       // fragment rows are lr (+32, +64..): same swizzle key
     const int rdA0 = (wm * 64 + lr) * 128, rdB0 = (wn * 64 + lr) * 128;
     auto mfma_step = [&](int cur, int ks) {
-        {
-            const int co = ((ks * 2 + lh) ^ sw) << 4;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[cur][rdA0 + co]);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[cur][rdA0 + 32 * 128 + co]);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[cur][rdB0 + co]);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[cur][rdB0 + 32 * 128 + co]);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        }
+        const int co = ((ks * 2 + lh) ^ sw) << 4;
+        const unsigned char* Ab = As + cur * A_BYTES;
+        const unsigned char* Bb = Bs + cur * (128 * 128);
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + co);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + 32 * 128 + co);
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + co);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + 32 * 128 + co);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
     };
     auto mfma_block = [&](int cur) {
 #pragma unroll
         for (int ks = 0; ks < BF_BK / 16; ++ks) mfma_step(cur, ks);
     };
-    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
-    using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
-    // pin: the registers of stage SG are first USED after this point (and the MFMAs issued before it).
+    // pin: the registers of stage SG are first USED after this point.
     // (a macro, not a lambda: clang rejects captured arrays as inline-asm operands inside a generic lambda)
-#define PW_PIN(SG)                                                                                                                  \
-    do {                                                                                                                            \
-        asm volatile("" : "+v"(rb[SG][0]), "+v"(rb[SG][1]), "+v"(rb[SG][2]), "+v"(rb[SG][3]), "+v"(rb[SG][4]), "+v"(rb[SG][5]),     \
-                          "+v"(rb[SG][6]), "+v"(rb[SG][7]));                                                                        \
-        if constexpr (XM == PW_X_AFFINE2)                                                                                           \
-            asm volatile("" : "+v"(rb2[SG][0]), "+v"(rb2[SG][1]), "+v"(rb2[SG][2]), "+v"(rb2[SG][3]), "+v"(rb2[SG][4]),             \
-                              "+v"(rb2[SG][5]), "+v"(rb2[SG][6]), "+v"(rb2[SG][7]));                                                \
-        asm volatile("" : "+v"(ra[SG][0]), "+v"(ra[SG][1]), "+v"(ra[SG][2]), "+v"(ra[SG][3]));                                      \
+#define PW_PIN(SG)                                                                                            \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int e_ = 0; e_ < KPT; ++e_) {                                                  \
+            asm volatile("" : "+v"(rb[SG][e_]));                                                              \
+            if constexpr (XM == PW_X_AFFINE2) asm volatile("" : "+v"(rb2[SG][e_]));                           \
+        }                                                                                                     \
+        asm volatile("" : "+v"(ra[SG][0]), "+v"(ra[SG][1]), "+v"(ra[SG][2]), "+v"(ra[SG][3]));                \
     } while (0)
     if constexpr (NST == 1) {
         load_tiles(0, S0{});
@@ -339,8 +319,11 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nk) { load_tiles((kt + 1) * BF_BK, S0{}); load_coefs((kt + 1) * BF_BK); }
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);      // loads are issued before the MFMA block ...
             mfma_block(cur);
+            // ... and first USED after it: without the fence hipcc hoists the staging arithmetic (and the vmcnt wait it
+            // needs) above the MFMAs, which exposes the whole memory latency every k-step
+            asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));
             PW_PIN(0);
             __builtin_amdgcn_sched_barrier(0);
             if (kt + 1 < nk) store_tiles(cur ^ 1, S0{});
@@ -356,10 +339,42 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
         // Steady state: the tile to be stored was loaded a whole iteration ago, so its transform + LDS writes are
         // interleaved with the MFMAs of the current tile (matrix pipe and VALU/LDS overlap inside one wave).
         int kt = 0;
-        for (; kt + 1 < nk; kt += 2) {
-            // even tile kt: compute LDS 0; stage 1 holds tile kt+1; stage 0 is free -> tile kt+2
-            if (kt + 2 < nk) load_tiles((kt + 2) * BF_BK, S0{});
+        // Main loop: both prefetches are unconditional.  (A conditional load makes hipcc's waitcnt insertion assume
+        // the not-taken count at the join, so the wait for the OLDER stage degenerates into a wait for the prefetch
+        // just issued -- the whole point of the second register stage.)
+        for (; kt + 3 < nk; kt += 2) {
+            // even tile kt: compute LDS 0; stage 1 holds tile kt+1; stage 0 is free -> tile kt+2.
+            // vmcnt retires in order: the coefficient loads needed first are issued BEFORE the tile prefetch
             load_coefs((kt + 1) * BF_BK);
+            __builtin_amdgcn_sched_barrier(0);
+            load_tiles((kt + 2) * BF_BK, S0{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(0, 0); mfma_step(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            PW_PIN(NST - 1);
+            store_slice(1, S1{}, Q0{}); mfma_step(0, 2);
+            store_slice(1, S1{}, Q1{}); mfma_step(0, 3);
+            store_slice(1, S1{}, Q2{}); store_slice(1, S1{}, Q3{});
+            __syncthreads();
+            // odd tile kt+1: compute LDS 1; stage 0 holds tile kt+2; stage 1 is free -> tile kt+3
+            load_coefs((kt + 2) * BF_BK);
+            __builtin_amdgcn_sched_barrier(0);
+            load_tiles((kt + 3) * BF_BK, S1{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(1, 0); mfma_step(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            PW_PIN(0);
+            store_slice(0, S0{}, Q0{}); mfma_step(1, 2);
+            store_slice(0, S0{}, Q1{}); mfma_step(1, 3);
+            store_slice(0, S0{}, Q2{}); store_slice(0, S0{}, Q3{});
+            __syncthreads();
+        }
+        // Tail: the last two or three tiles (at most one pass), prefetches guarded
+        for (; kt + 1 < nk; kt += 2) {
+            const bool more = kt + 2 < nk;          // wave-uniform; MFMAs stay outside the branches (one accumulator chain)
+            load_coefs((kt + 1) * BF_BK);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) load_tiles((kt + 2) * BF_BK, S0{});
             __builtin_amdgcn_sched_barrier(0);
             PW_PIN(NST - 1);
             mfma_step(0, 0); mfma_step(0, 1);
@@ -367,11 +382,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
             store_slice(1, S1{}, Q1{}); mfma_step(0, 3);
             store_slice(1, S1{}, Q2{}); store_slice(1, S1{}, Q3{});
             __syncthreads();
-            // odd tile kt+1: compute LDS 1; stage 0 holds tile kt+2; stage 1 is free -> tile kt+3
-            if (kt + 3 < nk) load_tiles((kt + 3) * BF_BK, S1{});
-            if (kt + 2 < nk) load_coefs((kt + 2) * BF_BK);
+            if (more) load_coefs((kt + 2) * BF_BK);
             __builtin_amdgcn_sched_barrier(0);
-            const bool more = kt + 2 < nk;          // wave-uniform; MFMAs stay outside the branches (one accumulator chain)
             if (more) PW_PIN(0);
             mfma_step(1, 0); mfma_step(1, 1);
             if (more) store_slice(0, S0{}, Q0{});
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_fast_kernel(PwParams p) {
         if (kt < nk) mfma_block(0);            // odd tile count: the last tile already sits in LDS 0
     }
 #undef PW_PIN
-    pw_epilogue_lds<EPI>(p, acc, reinterpret_cast<float*>(smem), b, m0, t0, tt, wm, wn, tid);
+    pw_epilogue_lds<EPI, BM>(p, acc, reinterpret_cast<float*>(smem), b, m0, t0, tt, wm, wn, tid);
 }
 
 // Backward-weight, bf16: contraction index is t; both operands are read as 8 consecutive t
@@ -666,17 +678,24 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
 #define PW_NN_COMBOS(X) X(0, 0) X(0, 1) X(1, 1) X(0, 2) X(0, 3) X(0, 4) X(2, 0) X(2, 5)
 #define PW_WG_COMBOS(X) X(0, 0) X(0, 1) X(2, 0)
 
-void pw_launch_gemm_bf16(const PwParams& p, dim3 grid, hipStream_t st) {
+void pw_launch_gemm_bf16(const PwParams& p_in, dim3 grid_in, hipStream_t st) {
+    const PwParams& p = p_in;
+    const dim3 grid = grid_in;
     const bool tv = (p.T & 3) == 0, kv = (p.K & 7) == 0;
     // Any M, K, T: rows / columns past the tensor fall outside the buffer descriptors and read as zero; columns
     // t >= T inside a row read the next row's (finite) values, which only reach output columns that are never
     // stored; k >= K rows of X are zero, so whatever A holds there is multiplied by zero.
     const bool full = (p.K & 1) == 0 && (long)(p.K + 64) * p.T * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL &&
                       (long)p.B * p.M * p.T * 4 < 0x7fffff00L;
+    const bool big = full && p.M >= 256;      // 256-row block tile: half the X re-reads through L2
     if (full) {
+        PwParams pb = p;                       // the 256-row tiling has its own m-tile count / grid
+        pb.n_mtiles = (p.M + 255) / 256;
+        const dim3 gridb((unsigned)((long)pb.n_mtiles * p.n_ttiles * p.B));
 #define X(XM, EP)                                                                                                   \
         if (p.x_mode == XM && p.epi_mode == EP) {                                                                   \
-            hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP>), grid, dim3(256), 0, st, p);                      \
+            if (big) hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP, 256>), gridb, dim3(512), 0, st, pb);     \
+            else hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP, 128>), grid, dim3(256), 0, st, p);            \
             return;                                                                                                 \
         }
         PW_NN_COMBOS(X)

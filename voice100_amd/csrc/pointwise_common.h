@@ -175,7 +175,7 @@ __device__ __forceinline__ float half_wave_sum_dpp(float v) {
 // Epilogue through LDS: the 128x128 fp32 accumulator tile is parked in the (now idle) 64 KB staging buffers,
 // then every half-wave streams one output row per pass as 16-byte accesses (R read, Y write: 512 B contiguous
 // per row) and reduces the row's BatchNorm partial sums with DPP.  `ct` = 128*128 floats of LDS.
-template <int EPI_>
+template <int EPI_, int BM>
 __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)[2][2], float* ct, int b, int m0, int t0, int tt,
                                                 int wm, int wn, int tid) {
     constexpr int epi = EPI_;
@@ -198,9 +198,10 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
     const int wave = tid >> 6;
     const int t = t0 + col * 4;
     const size_t part = (size_t)b * p.n_ttiles + tt;
+    constexpr int RPP = BM / 16;             // rows per pass: one row per half-wave, BM/64*2 waves
 #pragma unroll 4
     for (int pass = 0; pass < 16; ++pass) {
-        const int row = pass * 8 + wave * 2 + half;
+        const int row = pass * RPP + wave * 2 + half;
         const int m = m0 + row;
         const bool mv = m < p.M;
         const f32x4 a = *reinterpret_cast<const f32x4*>(ct + row * 128 + col * 4);
