@@ -8,7 +8,8 @@ OBJD  := build/obj
 SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJD)/%.o,$(SRCS))
 LIB   := voice100_amd/libvoice100_hip.so
-HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wno-unused-result
+# the depthwise window walk is one fully unrolled body of up to 8*83 FMAs: lift clang's cap on '#pragma unroll'
+HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wno-unused-result -mllvm -pragma-unroll-threshold=1000000 $(EXTRA)
 
 all: $(LIB) oracle
 

@@ -139,9 +139,11 @@ int v100_exp_clip(const float* x, float* y, float offset, long long n, void* str
 
 /* ---- opt-in kernel timing (bench.py roofline): HIP events on the launch stream around the hot kernels.
  * tags: 0 depthwise fwd, 1 depthwise bwd-data, 2 depthwise bwd-weight, 3 pointwise GEMM, 4 pointwise bwd-weight.
- * enable(1) clears the counters; read() synchronises the device and returns the summed ms, launch count and (for the
- * depthwise tags) the algorithmic bytes of those launches: fp32 in + out + taps + BN coefficients. */
-int v100_timing_enable(int on);
+ * enable(mask): bit t of mask switches tag t on (0 = all off; an event pair costs ~3 us of queue time per launch, so
+ * time only what is read); a non-zero mask clears the counters.  read() synchronises the device and returns the summed
+ * ms, launch count and (for the depthwise tags) the algorithmic bytes of those launches: fp32 in + out + taps + BN
+ * coefficients. */
+int v100_timing_enable(int tag_mask);
 int v100_timing_read(int tag, double* ms, long long* count, double* bytes);
 
 /* ---- K10 log_softmax + CTC (asr.py:148-152: F.log_softmax(-1) then nn.CTCLoss(blank, 'mean', zero_infinity=True)) --

@@ -15,7 +15,7 @@ SPECS = [(64, 256, 256, 11, 2), (256, 1024, 256, 19, 1), (256, 1024, 256, 27, 1)
 
 
 def timeit(fn, iters):
-    for _ in range(3):
+    for _ in range(max(3, iters // 4)):
         fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,11 +29,14 @@ def timeit(fn, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--what", default="dw,pw")
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--T", type=int, default=1024)
+    ap.add_argument("--lib", default=None, help="alternative libvoice100_hip.so (A/B builds of one kernel in one run)")
     args = ap.parse_args()
+    if args.lib:
+        N.LIB_PATH = os.path.abspath(args.lib)
     dev = torch.device("cuda:0")
     B, T = args.B, args.T
     tot = {"dw_fwd": [0, 0.0], "dw_bwd": [0, 0.0], "dw_wgrad": [0, 0.0]}

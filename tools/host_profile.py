@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Host-side cost of one training step: enqueue time (no sync) vs GPU time, and a cProfile of the Python side."""
+import cProfile, pstats, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from voice100_amd import functional as F_, _native as N
+from voice100_amd.asr import AudioToTextCTC
+from voice100_amd.trainer import TrainStep
+
+dev = torch.device("cuda:0")
+N.load(); F_.set_matmul_precision("bf16")
+torch.manual_seed(1234)
+model = AudioToTextCTC(64, 512, 29, 512, learning_rate=1e-3, weight_decay=4e-5).to(dev)
+step = TrainStep(model)
+batch = bench.synth_batch(dev, 32, 1234)
+for _ in range(5): step(batch)
+torch.cuda.synchronize()
+for trial in range(2):
+    t0 = time.perf_counter()
+    for _ in range(20): step(batch)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"enqueue {1e3*(t1-t0)/20:.3f} ms/step, total {1e3*(t2-t0)/20:.3f} ms/step")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(20): step(batch)
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(45)

@@ -123,9 +123,18 @@ def helper(name, *args):
 TIMING_TAGS = {"dw_fwd": 0, "dw_bwd_data": 1, "dw_wgrad": 2, "pw_gemm": 3, "pw_wgrad": 4}
 
 
-def timing_enable(on: bool) -> None:
-    """Opt-in HIP-event timing inside the library (see include/voice100_hip.h); bench.py only."""
-    load().v100_timing_enable(int(on))
+def timing_enable(tags=True) -> None:
+    """Opt-in HIP-event timing inside the library (see include/voice100_hip.h); bench.py only.
+    tags: True = every tag, False/None = off, or an iterable of TIMING_TAGS names (each timed launch costs ~3 us)."""
+    if tags is True:
+        mask = (1 << len(TIMING_TAGS)) - 1
+    elif not tags:
+        mask = 0
+    else:
+        mask = 0
+        for t in tags:
+            mask |= 1 << TIMING_TAGS[t]
+    load().v100_timing_enable(mask)
 
 
 def timing_read():
