@@ -137,6 +137,21 @@ int v100_world_unnormalize(const float* x, float* f0, float* logspc, float* code
 /* y = max(exp(x) - offset, 0)   (WORLDVocoder.decode, voice100/vocoder.py:99) */
 int v100_exp_clip(const float* x, float* y, float offset, long long n, void* stream);
 
+/* ---- K11 dense k-tap conv blocks of the v2 models (csrc/layernorm.hip) -------------------
+ * ConvLayerBlock / ConvTransposeLayerBlock, voice100/models/_layers_v2.py:29-89: conv -> LayerNorm over channels
+ * -> exact GELU.  The dense convolution runs on the K1 GEMM over an im2col copy (rows tap-major: j*Cin + c);
+ * col2im is its adjoint (backward-data), a gather.  ln_gelu_fwd: out = gelu(layer_norm_C(y) * gamma + beta) on
+ * [B][C][T] (C <= 1024), saving mean / rstd [B][T]; ln_gelu_bwd: dy plus per-tile partial sums
+ * partial[v100_ln_num_parts(B,T)][C][2] = (dgamma, dbeta), summed over parts by v100_slab_sum2. */
+int v100_im2col(const float* x, float* cols, int B, int Cin, int Tin, int Tout, int k, int stride, int pad, void* stream);
+int v100_col2im(const float* dcols, float* dx, int B, int Cin, int Tin, int Tout, int k, int stride, int pad, void* stream);
+int v100_ln_num_parts(int B, int T);
+int v100_slab_sum2(const float* partial, int parts, float* out0, float* out1, int C, void* stream);
+int v100_ln_gelu_fwd(const float* y, const float* gamma, const float* beta, float eps, float* out, float* mean,
+                     float* rstd, int B, int C, int T, void* stream);
+int v100_ln_gelu_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* mean,
+                     const float* rstd, float* dy, float* partial, int B, int C, int T, void* stream);
+
 /* ---- opt-in kernel timing (bench.py roofline): HIP events on the launch stream around the hot kernels.
  * tags: 0 depthwise fwd, 1 depthwise bwd-data, 2 depthwise bwd-weight, 3 pointwise GEMM, 4 pointwise bwd-weight.
  * enable(mask): bit t of mask switches tag t on (0 = all off; an event pair costs ~3 us of queue time per launch, so

@@ -17,6 +17,7 @@ Reference anchors (relative to /root/reference):
   TextToAlignTextModel    voice100/models/tts.py:67-130
   AlignTextToAudioModel   voice100/models/tts.py:152-213
   WORLDLoss / WORLDNorm   voice100/models/_layers_v1.py:37-138
+  ConvLayerBlock / ConvTransposeLayerBlock / get_conv_layers   voice100/models/_layers_v2.py:29-106
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -282,3 +283,29 @@ def text_to_align_text_loss(batch, state: State, training: bool = True,
     loss = torch.mean(torch.abs(logalign - pred), dim=2)
     mask = padding_mask(text.shape[1], text_len, pred.dtype)
     return torch.sum(loss * mask) / torch.sum(mask)
+
+
+# --- v2 conv blocks ---------------------------------------------------
+LN_EPS = 1e-5          # nn.LayerNorm default, _layers_v2.py:40
+
+
+def conv_layer_block(x: torch.Tensor, state: State, prefix: str, transpose: bool, stride: int, padding: int) -> torch.Tensor:
+    """ConvLayerBlock / ConvTransposeLayerBlock.forward (_layers_v2.py:50-56, 83-89): conv -> LayerNorm over the
+    channel axis (via the two transposes) -> exact GELU.  x [B, Cin, T]."""
+    w = state[f"{prefix}conv.weight"]
+    b = state.get(f"{prefix}conv.bias")
+    if transpose:
+        y = F.conv_transpose1d(x, w, b, stride=stride, padding=padding)
+    else:
+        y = F.conv1d(x, w, b, stride=stride, padding=padding)
+    c = y.shape[1]
+    y = F.layer_norm(y.transpose(-2, -1), (c,), state[f"{prefix}layer_norm.weight"], state[f"{prefix}layer_norm.bias"], LN_EPS)
+    return F.gelu(y.transpose(-2, -1))
+
+
+def conv_layers(x: torch.Tensor, state: State, settings: Sequence[Sequence], prefix: str = "") -> torch.Tensor:
+    """get_conv_layers(...) as an nn.Sequential (_layers_v2.py:92-106); settings rows are
+    (out_channels, transpose, kernel_size, stride, padding, bias)."""
+    for i, (_out, transpose, _k, stride, padding, _bias) in enumerate(settings):
+        x = conv_layer_block(x, state, f"{prefix}{i}.", bool(transpose), int(stride), int(padding))
+    return x

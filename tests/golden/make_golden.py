@@ -337,6 +337,46 @@ def gen_mcep_and_int():
     np.savez_compressed(os.path.join(OUT, "int_tables.npz"), **out)
 
 
+def gen_v2_blocks():
+    """v2 conv stacks: get_conv_layers with the channel counts scaled down, the (k, stride,
+    padding, transpose, bias) pattern of config/asr_en_base.yaml:16-18 and config/tts_en_base.yaml:20-23."""
+    from voice100.models._layers_v2 import get_conv_layers
+    out = {}
+    gen = torch.Generator().manual_seed(4321)
+    # (in_channels, settings, B, T)
+    cfgs = [
+        (24, [[40, False, 5, 2, 2, False], [40, False, 5, 1, 2, False]], 2, 51),        # ASR encoder pattern
+        (48, [[40, False, 5, 1, 2, False], [40, True, 5, 2, 2, False], [40, False, 5, 1, 2, False]], 2, 23),   # TTS decoder
+        (16, [[72, False, 5, 2, 2, True], [72, True, 5, 2, 2, True]], 3, 34),           # biases on, C not a multiple of 32
+    ]
+    for n, (cin, settings, B, T) in enumerate(cfgs):
+        torch.manual_seed(4321 + n)
+        m = get_conv_layers(cin, settings)
+        from torch import nn
+        for mod in m.modules():
+            if isinstance(mod, nn.LayerNorm):
+                with torch.no_grad():
+                    mod.weight.copy_(torch.rand(mod.weight.shape, generator=gen) + 0.5)
+                    mod.bias.copy_(torch.randn(mod.bias.shape, generator=gen) * 0.3)
+        x = torch.randn(B, cin, T, generator=gen)
+        pre = f"s{n}/"
+        out[pre + "cin"] = np.array(cin, dtype=np.int64)
+        out[pre + "settings"] = np.array([[int(v) for v in row] for row in settings], dtype=np.int64)
+        out[pre + "x"] = x.numpy()
+        for key, v in m.state_dict().items():
+            out[pre + "state/" + key] = v.numpy().copy()
+        xg = x.clone().requires_grad_(True)
+        y = m(xg)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        out[pre + "y"] = y.detach().numpy()
+        out[pre + "gy"] = gy.numpy()
+        out[pre + "gx"] = xg.grad.numpy()
+        for key, p in m.named_parameters():
+            out[pre + "grad/" + key] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "v2_blocks.npz"), **out)
+
+
 def main():
     sys.path.insert(0, REF)
     sys.dont_write_bytecode = True
@@ -348,6 +388,7 @@ def main():
     gen_tts_tiny()
     gen_augment()
     gen_mcep_and_int()
+    gen_v2_blocks()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

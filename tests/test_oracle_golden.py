@@ -193,3 +193,18 @@ def test_augment_ops():
     assert rel_err(got, g["mixnoise/audio"]) < 1e-6
     assert rel_err(augment.mixaudio(audio, alen), g["mixaudio/audio"]) < 1e-6
     assert rel_err(augment.maskaudio(audio, alen), g["maskaudio/audio"]) < 1e-6
+
+
+@pytest.mark.parametrize("sid", ["s0", "s1", "s2"])
+def test_v2_conv_blocks_golden(sid):
+    """get_conv_layers stacks (ConvLayerBlock / ConvTransposeLayerBlock), output and all gradients."""
+    g = load_golden("v2_blocks.npz")
+    settings = [[int(v) for v in row] for row in g[sid + "/settings"]]
+    state = sub(g, sid + "/state/")
+    params = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    x = torch.from_numpy(g[sid + "/x"]).requires_grad_(True)
+    y = cnn.conv_layers(x, params, settings)
+    assert rel_err(y, g[sid + "/y"]) < TOL
+    (y * torch.from_numpy(g[sid + "/gy"])).sum().backward()
+    assert rel_err(x.grad, g[sid + "/gx"]) < 1e-4
+    assert_grads_close({k: p.grad for k, p in params.items()}, {k: g[sid + "/grad/" + k] for k in params}, 2e-4)

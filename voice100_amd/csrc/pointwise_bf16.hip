@@ -393,7 +393,10 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
             if (more) { store_slice(0, S0{}, Q2{}); store_slice(0, S0{}, Q3{}); }
             __syncthreads();
         }
-        if (kt < nk) mfma_block(0);            // odd tile count: the last tile already sits in LDS 0
+        if (kt < nk) {                         // odd tile count: the last tile already sits in LDS 0
+            mfma_block(0);
+            __syncthreads();                   // the epilogue reuses the stage buffers: every wave must be done reading
+        }
     }
 #undef PW_PIN
     pw_epilogue_lds<EPI, BM>(p, acc, reinterpret_cast<float*>(smem), b, m0, t0, tt, wm, wn, tid);

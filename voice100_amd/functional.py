@@ -413,6 +413,108 @@ def conv_transpose1d_k5s2(x, w, bias=None, precision: Optional[str] = None):
     return ConvTranspose1dK5S2Fn.apply(x, w, bias, precision or _PRECISION)
 
 
+class Conv1dDenseFn(torch.autograd.Function):
+    """nn.Conv1d(Cin, Cout, k, stride, padding, bias) with groups=1 -- the dense k=5 convolutions of the v2 conv
+    blocks (voice100/models/_layers_v2.py:41-48; config/asr_en_base.yaml:16-18).
+
+    One GEMM on the pointwise MFMA kernel with K = k*Cin over an im2col copy of x (rows tap-major), so every
+    prologue / precision mode of K1 applies; backward-weight is the K1 NT kernel against the same copy and
+    backward-data is the transposed GEMM followed by col2im (a gather, no atomics).
+    """
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding, precision):
+        _check(x, "conv1d_dense")
+        x = x.contiguous()
+        B, cin, T = x.shape
+        cout, cin_w, k = w.shape
+        if cin_w != cin:
+            raise RuntimeError(f"conv1d_dense: weight expects {cin_w} input channels, got {cin}")
+        tout = (T + 2 * padding - k) // stride + 1
+        if tout <= 0:
+            raise RuntimeError("conv1d_dense: input shorter than the kernel")
+        bf16 = precision == "bf16"
+        cols = _f32(B, k * cin, tout, like=x)
+        N.call("v100_im2col", x, cols, B, cin, T, tout, k, stride, padding)
+        w2d = w.detach().permute(0, 2, 1).reshape(cout, k * cin).contiguous()       # [Cout][j*Cin + c]
+        W = _Weights(w2d, bf16, False)
+        y = _f32(B, cout, tout, like=x)
+        _pw_gemm(W.w, W.w_bf, cols, y, cout, k * cin, tout, B, bf16, bias=bias.detach() if bias is not None else None, epi=0)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, bias is not None, bf16, tout)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding, has_bias, bf16, tout = ctx.cfg
+        dy = dy.contiguous()
+        B, cin, T = x.shape
+        cout, _, k = w.shape
+        kk = k * cin
+        cols = _f32(B, kk, tout, like=x)
+        N.call("v100_im2col", x, cols, B, cin, T, tout, k, stride, padding)
+        S = N.helper("v100_pw_wgrad_splits", B, cout, kk)
+        partial = _f32(S, cout, kk, like=x)
+        dW = _f32(cout, kk, like=x)
+        N.call("v100_pw_wgrad", dy, None, None, None, None, 0, cols, None, None, 0, partial, dW, S, B, cout, kk, tout, int(bf16))
+        dw = dW.view(cout, k, cin).permute(0, 2, 1).contiguous()
+        db = None
+        if has_bias:
+            G = N.helper("v100_dw_num_groups", B, cout)
+            part = _f32(G, cout, 2, like=x)
+            N.call("v100_chan_reduce2", dy, None, part, G, B, cout, tout)
+            db = _f32(cout, like=x)
+            N.call("v100_slab_sum0", part, G, db, cout)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w2d = w.detach().permute(0, 2, 1).reshape(cout, kk).contiguous()
+            W = _Weights(w2d, bf16, True)
+            dcols = cols                                   # the im2col copy is dead after the wgrad: reuse its storage
+            _pw_gemm(W.wt, W.wt_bf, dy, dcols, kk, cout, tout, B, bf16, epi=0)
+            dx = _f32(B, cin, T, like=x)
+            N.call("v100_col2im", dcols, dx, B, cin, T, tout, k, stride, padding)
+        return dx, dw, db, None, None, None
+
+
+def conv1d_dense(x, w, bias=None, stride: int = 1, padding: int = 0, precision: Optional[str] = None):
+    return Conv1dDenseFn.apply(x, w, bias, int(stride), int(padding), precision or _PRECISION)
+
+
+class LayerNormGeluFn(torch.autograd.Function):
+    """gelu(layer_norm over the channel axis) of a [B, C, T] tensor: the `transpose -> nn.LayerNorm(C) -> transpose
+    -> F.gelu` tail of the v2 conv blocks (_layers_v2.py:50-56, 83-89) without the transposes."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, eps):
+        _check(y, "layer_norm_gelu")
+        y = y.contiguous()
+        B, C, T = y.shape
+        out = _f32(B, C, T, like=y)
+        mean, rstd = _f32(B, T, like=y), _f32(B, T, like=y)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        N.call("v100_ln_gelu_fwd", y, g, b, float(eps), out, mean, rstd, B, C, T)
+        ctx.save_for_backward(y, g, b, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, g, b, mean, rstd = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, C, T = y.shape
+        parts = N.helper("v100_ln_num_parts", B, T)
+        partial = _f32(parts, C, 2, like=y)
+        dy = _f32(B, C, T, like=y)
+        N.call("v100_ln_gelu_bwd", dout, y, g, b, mean, rstd, dy, partial, B, C, T)
+        dg, db = _f32(C, like=y), _f32(C, like=y)
+        N.call("v100_slab_sum2", partial, parts, dg, db, C)
+        return dy, dg, db, None
+
+
+def layer_norm_gelu(y, gamma, beta, eps: float = 1e-5):
+    return LayerNormGeluFn.apply(y, gamma, beta, eps)
+
+
 def world_unnormalize_gate(x_bta, f0_mean, f0_std, ls_mean, ls_std, ca_mean, ca_std):
     """x [B,T,2+S+Cap] -> (f0 [B,T], logspc [B,T,S], codeap [B,T,Cap]); tts.py:192-201."""
     _check(x_bta, "world_unnormalize")
