@@ -9,7 +9,9 @@ SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJD)/%.o,$(SRCS))
 LIB   := voice100_amd/libvoice100_hip.so
 # the depthwise window walk is one fully unrolled body of up to 8*83 FMAs: lift clang's cap on '#pragma unroll'
-HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wno-unused-result -mllvm -pragma-unroll-threshold=1000000 $(EXTRA)
+# -fno-slp-vectorize: hipcc otherwise pairs adjacent fp32 FMAs into v_pk_fma_f32, which is no faster on gfx950 and costs
+# aligned register pairs + moves (the fused depthwise backward went from 215 to 207 VGPRs and lost 330 packed ops)
+HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wno-unused-result -mllvm -pragma-unroll-threshold=1000000 -fno-slp-vectorize $(EXTRA)
 
 all: $(LIB) oracle
 

@@ -50,6 +50,19 @@ int v100_dwconv_wgrad(const float* g, const float* g2, const float* ga, const fl
                       float* partial, float* dw, int G, int B, int C, int Tin, int Tout, int K, int stride,
                       int pad, int force_generic, void* stream);
 
+/* Backward of the training-mode depthwise stage of an InvertedResidual in ONE call (autograd of asr.py:49 with the
+ * BatchNorm backward of the stage after it applied on load and the ReLU6 / BatchNorm backward sums of the stage
+ * before it on the way out):   g' = ga*g + gb*g2 + gc,   xin = relu6(xa*xpre + xb),
+ *   dxin[b,c,u] = [0 < xa*xpre+xb < 6] * sum_j w[c][j] * g'[b,c,(u + pad - j)/stride]   -> dxin, stats (sum, sum*xpre)
+ *   dw[c][j]    = sum_{b,t} g'[b,c,t] * xin[b,c,t*stride - pad + j]                      -> dw (wpartial: [G][C][K])
+ * Tin / Tout are the forward conv's input / output lengths.  Stride 1 with a specialised K runs as one fused kernel
+ * (the window walk of the data gradient also accumulates the weight gradient); other shapes, or force_split != 0,
+ * run v100_dwconv_wgrad + v100_dwconv. */
+int v100_dwconv_bwd(const float* g, const float* g2, const float* w, const float* ga, const float* gb,
+                    const float* gc, const float* xpre, const float* xa, const float* xb, float* dxin,
+                    float* stats, float* wpartial, float* dw, int G, int B, int C, int Tin, int Tout, int K,
+                    int stride, int pad, int force_split, void* stream);
+
 /* ---- K1 pointwise (1x1 conv as GEMM on MFMA) ----------------------------------------------
  * Y[b][m][t] = epilogue( sum_k A[m][k] * x'[b][k][t] (+ bias[m]) )
  * Replaces nn.Conv1d(kernel_size=1): asr.py:47 (pw), :51 (pw-linear), :91 (LinearCharDecoder),

@@ -39,7 +39,7 @@ def main():
         N.LIB_PATH = os.path.abspath(args.lib)
     dev = torch.device("cuda:0")
     B, T = args.B, args.T
-    tot = {"dw_fwd": [0, 0.0], "dw_bwd": [0, 0.0], "dw_wgrad": [0, 0.0]}
+    tot = {"dw_fwd": [0, 0.0], "dw_bwd": [0, 0.0], "dw_wgrad": [0, 0.0], "dw_bwd_fused": [0, 0.0]}
     t = T
     for (cin, hid, cout, k, s) in SPECS:
         tout = (t - 1) // s + 1
@@ -58,14 +58,15 @@ def main():
             f = lambda: N.call("v100_dwconv", x, None, w, a, b, None, 1, y, None, None, None, 0, st, G, B, hid, t, tout, k, s, pad, 0, 1, 0)
             bd = lambda: N.call("v100_dwconv", y, y2, w, a, b, c, 2, dz1, x, a, b, 2, st, G, B, hid, tout, t, k, 1, k - 1 - pad, 1, s, 0)
             wg = lambda: N.call("v100_dwconv_wgrad", y, y2, a, b, c, 2, x, a, b, 1, part, dw, G, B, hid, t, tout, k, s, pad, 0)
+            bf_ = lambda: N.call("v100_dwconv_bwd", y, y2, w, a, b, c, x, a, b, dz1, st, part, dw, G, B, hid, t, tout, k, s, pad, 0)
             bytes_f = 4 * B * hid * (t + tout)
             bytes_b = 4 * B * hid * (2 * tout + 2 * t)
             bytes_w = 4 * B * hid * (2 * tout + t)
-            for name, fn, nb in (("dw_fwd", f, bytes_f), ("dw_bwd", bd, bytes_b), ("dw_wgrad", wg, bytes_w)):
+            for name, fn, nb in (("dw_fwd", f, bytes_f), ("dw_bwd", bd, bytes_b), ("dw_wgrad", wg, bytes_w), ("dw_bwd_fused", bf_, bytes_b)):
                 dt = timeit(fn, args.iters)
                 tot[name][0] += nb; tot[name][1] += dt
                 fl = 2 * B * hid * k * tout
-                print(f"{name:9s} C={hid:5d} k={k:3d} s={s} T={t:5d}: {dt*1e6:8.1f} us  {nb/dt/1e9:7.0f} GB/s ({nb/dt/8e12*100:5.1f}% of 8TB/s)  {fl/dt/1e12:6.1f} TFLOP/s")
+                print(f"{name:12s} C={hid:5d} k={k:3d} s={s} T={t:5d}: {dt*1e6:8.1f} us  {nb/dt/1e9:7.0f} GB/s ({nb/dt/8e12*100:5.1f}% of 8TB/s)  {fl/dt/1e12:6.1f} TFLOP/s")
         if "pw" in args.what:
             for bf in (0, 1):
                 for (M, K, TT, tag) in ((hid, cin, t, "pw1"), (cout, hid, tout, "pw2")):

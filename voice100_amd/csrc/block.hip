@@ -165,8 +165,7 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     CK(v100_bn_bwd_finalize(w.part, parts, (long long)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], hid, stream));
     // depthwise: weight grad, then data grad through ReLU6 with BN1-backward sums
     const int G = v100_dw_num_groups(B, hid);
-    CK(v100_dwconv_wgrad(w.dz2, a2, pp, qq, rr, 2, a1, s1, t1, 1, w.slab, (float*)P[16], G, B, hid, T, T2, K, S, pad, 0, stream));
-    CK(v100_dwconv(w.dz2, a2, wd, pp, qq, rr, 2, w.dz1, a1, s1, t1, 2, w.part, G, B, hid, T2, T, K, 1, K - 1 - pad, 1, S, 0, stream));
+    CK(v100_dwconv_bwd(w.dz2, a2, wd, pp, qq, rr, a1, s1, t1, w.dz1, w.part, w.slab, (float*)P[16], G, B, hid, T, T2, K, S, pad, 0, stream));
     CK(v100_bn_bwd_finalize(w.part, G, (long long)B * T, g1, m1, r1, pp, qq, rr, (float*)P[14], (float*)P[15], hid, stream));
     // pw: weight grad, data grad (+ residual)
     CK(v100_pw_wgrad(w.dz1, a1, pp, qq, rr, 2, x, nullptr, nullptr, 0, w.slab, (float*)P[13], v100_pw_wgrad_splits(B, hid, cin),

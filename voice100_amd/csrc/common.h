@@ -35,6 +35,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Full-wave sum on the DPP path: 6 VALU adds, no LDS crossbar (a __shfl_xor is a ds_bpermute: an LDS-pipe round trip
+// per step).  The total is valid in lanes 48-63 only.
+__device__ __forceinline__ float wave_sum_dpp_hi(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));  // row_bcast:15 into rows 1,3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, true));  // row_bcast:31 into rows 2,3
+    return v;
+}
+
 // fp32 -> bf16 round-to-nearest-even; plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ u16 f2bf(float f) {
     __bf16 h = (__bf16)f;

@@ -44,10 +44,13 @@ __global__ __launch_bounds__(256) void dwconv_generic_kernel(DwParams p) {
         const int b = b0 + (int)(idx / p.Tout), t = (int)(idx % p.Tout);
         const size_t ro = ((size_t)b * p.C + c) * p.Tin;
         float acc = 0.f;
-        for (int j = 0; j < K; ++j) {
-            const int u = t * S - p.pad + j;
-            if (u < 0 || u >= TinUp || (u % U) != 0) continue;
-            const int ti = u / U;
+        // taps that land on a real (non-inserted) input sample: j = j0, j0+U, ... with u = t*S - pad + j a multiple of U;
+        // consecutive ones read consecutive inputs, so no division or modulo inside the loop
+        const int base = t * S - p.pad;
+        int j0 = ((-base) % U + U) % U;                       // smallest j >= 0 with (base + j) % U == 0
+        if (base + j0 < 0) j0 += ((-(base + j0)) + U - 1) / U * U;
+        int ti = (base + j0) / U;
+        for (int j = j0; j < K && ti < p.Tin; j += U, ++ti) {
             const float v = dw_in_transform(in_mode, p.x[ro + ti], in_mode == DW_IN_AFFINE2 ? p.x2[ro + ti] : 0.f, ca, cb, cc);
             acc = fmaf(gw[j], v, acc);
         }
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradParams p) {
     }   // tile
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const float s = wave_sum(accw[j]);
-        if (lane == 0) lds_red[wave][j] = s;
+        const float s = wave_sum_dpp_hi(accw[j]);
+        if (lane == 63) lds_red[wave][j] = s;
     }
     __syncthreads();
     for (int j = threadIdx.x; j < K; j += 256)
@@ -242,7 +245,7 @@ extern "C" int v100_dwconv(const float* x, const float* x2, const float* w, cons
     if (out_mode == DW_OUT_MASK_STATS && !aux) return V100_ERR_NULL;
     if ((out_mode == DW_OUT_RAW_STATS || out_mode == DW_OUT_MASK_STATS) && !stats) return V100_ERR_NULL;
     DwParams p{x, x2, w, in_a, in_b, in_c, y, aux, out_a, out_b, stats,
-               B, C, Tin, Tout, K, stride, pad, flip, upsample, G, in_mode, out_mode};
+               B, C, Tin, Tout, K, stride, pad, flip, upsample, G, in_mode, out_mode, nullptr};
     hipStream_t st = (hipStream_t)stream;
     // algorithmic bytes of this launch: fp32 input(s) + output (+ aux) + taps + per-channel coefficients
     const double nin = (in_mode == DW_IN_AFFINE2 ? 2.0 : 1.0) * B * C * (double)Tin, nout = (out_mode == DW_OUT_MASK_STATS ? 2.0 : 1.0) * B * C * (double)Tout;
@@ -282,4 +285,37 @@ extern "C" int v100_dwconv_wgrad(const float* g, const float* g2, const float* g
     const int n = C * K;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, partial, dw, G, n, 0);
     return v100_launch_status();
+}
+
+// Backward of the training-mode depthwise stage in one call: dxin (through the ReLU6 mask of a1, with the BN1-backward
+// partial sums) and dW.  Stride 1 with a specialised K: ONE fused kernel (see dwconv_kernel, WG); anything else: the
+// two stand-alone passes above.  Same results either way up to fp32 summation order.
+extern "C" int v100_dwconv_bwd(const float* g, const float* g2, const float* w, const float* ga, const float* gb,
+                               const float* gc, const float* xpre, const float* xa, const float* xb, float* dxin,
+                               float* stats, float* wpartial, float* dw, int G, int B, int C, int Tin, int Tout, int K,
+                               int stride, int pad, int force_split, void* stream) {
+    if (!g || !g2 || !w || !ga || !gb || !gc || !xpre || !xa || !xb || !dxin || !stats || !wpartial || !dw) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || Tin <= 0 || Tout <= 0 || K <= 0 || stride <= 0 || G <= 0 || G > B) return V100_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fits = (size_t)B * C * (Tin > Tout ? Tin : Tout) * 4 < 0x7fffff00ull;
+    if (!force_split && stride == 1 && fits) {
+        // backward-data geometry: the conv runs over g (length Tout) and produces Tin outputs, taps flipped
+        DwParams p{g, g2, w, ga, gb, gc, dxin, xpre, xa, xb, stats,
+                   B, C, Tout, Tin, K, 1, K - 1 - pad, 1, 1, G, DW_IN_AFFINE2, DW_OUT_MASK_STATS, wpartial};
+        bool done;
+        {
+            V100TimedRegion timed(V100_T_DW_BWD_DATA, st, 4.0 * B * C * (2.0 * Tout + 2.0 * Tin) + 8.0 * C * K + 8.0 * C);
+            done = dw_launch_bwd_fused(p, st);
+        }
+        if (done) {
+            const int n = C * K;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, wpartial, dw, G, n, 0);
+            return v100_launch_status();
+        }
+    }
+    int rc = v100_dwconv_wgrad(g, g2, ga, gb, gc, DW_IN_AFFINE2, xpre, xa, xb, DW_IN_AFFINE_RELU6, wpartial, dw, G, B, C, Tin, Tout, K,
+                               stride, pad, 0, stream);
+    if (rc != V100_OK) return rc;
+    return v100_dwconv(g, g2, w, ga, gb, gc, DW_IN_AFFINE2, dxin, xpre, xa, xb, DW_OUT_MASK_STATS, stats, G, B, C, Tout, Tin, K, 1,
+                       K - 1 - pad, 1, stride, 0, stream);
 }

@@ -34,6 +34,7 @@ struct DwParams {
     const float* out_b;  // [C]
     float* stats;        // [G][C][2]
     int B, C, Tin, Tout, K, stride, pad, flip, upsample, G, in_mode, out_mode;
+    float* wpartial;     // [G][C][K]  backward-weight partial sums of the fused backward kernel (else null)
 };
 
 struct DwWgradParams {
@@ -150,8 +151,17 @@ struct DwGeom {
 // Forward / backward-data kernel.  K, stride S, outputs-per-lane R, the input/output modes and the
 // alignment class (AL: Tin and Tout multiples of 4 -> float4 global accesses) are compile time, so
 // the window walk is fully unrolled with static register indices and the staging is branch-free.
-template <int K, int S, int R, int IM, int OM, bool AL>
+//
+// WG (fused backward, stride 1): the same pass also accumulates the backward-weight of the forward conv.  In the
+// backward-data call the window holds the upstream gradient g' and each lane already loads the forward conv's
+// pre-activation input a1 at its R positions (for the ReLU6 mask); with xin = relu6(bn1(a1)),
+//     dxin[u] += wf[j'] * g'[u - pad' + j']      and      dWf[j'] += xin[u] * g'[u - pad' + j']
+// run over the SAME (position, tap, window element) triples (wf = taps flipped, dW[j] = dWf[K-1-j]), so the second
+// product costs one more v_fmac per triple and no memory traffic at all -- the stand-alone backward-weight kernel
+// re-reads all three tensors.  K more accumulators per lane, reduced once per workgroup.
+template <int K, int S, int R, int IM, int OM, bool AL, bool WG = false>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
+    static_assert(!WG || (S == 1 && OM == DW_OUT_MASK_STATS), "fused backward-weight rides on the stride-1 backward-data pass");
     using G_ = DwGeom<K, S, R>;
     constexpr int TILE = G_::TILE, WIN = G_::WIN, SPAN = G_::SPAN, NV = G_::NV, NCH = G_::NCH, NTC = G_::NTC, PD = G_::PD;
     constexpr bool TWO = IM == DW_IN_AFFINE2;
@@ -160,6 +170,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
     __shared__ __attribute__((aligned(16))) float lds_all[4][G_::SPAN4 + 8];
     __shared__ __attribute__((aligned(16))) float lds_w[NTC * 4];
     __shared__ float lds_red[4][2];
+    __shared__ float lds_wred[WG ? 4 : 1][WG ? K : 1];
 
     const int c = blockIdx.x;
     const int g = blockIdx.y;
@@ -184,6 +195,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
     const int ntiles = (Tout + TILE - 1) / TILE;
 
     float s0 = 0.f, s1 = 0.f;
+    float accw[WG ? K : 1];
+#pragma unroll
+    for (int j = 0; j < (WG ? K : 1); ++j) accw[j] = 0.f;
     DwRaw<NV, TWO> raw;
     const unsigned xbytes = (unsigned)((size_t)p.B * p.C * Tin * 4);
     const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, xbytes);
@@ -218,6 +232,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        float xin[WG ? R : 1];
+        if constexpr (WG) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) xin[r] = (t0 + r < Tout) ? relu6f(fmaf(auxv[r], oa, ob)) : 0.f;
+        }
         const float* win = lds + lane * (R * S);
         // The tap reads are loop-invariant; hide that from LICM (an opaque zero offset per item) or
         // hipcc hoists all K taps into registers for the whole kernel.
@@ -245,13 +264,23 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int j = i - r * S;
-                        if (j >= 0 && j < K) acc[r] = fmaf(tapc[j >> 2][j & 3], inc[ch][e], acc[r]);
+                        if (j >= 0 && j < K) {
+                            acc[r] = fmaf(tapc[j >> 2][j & 3], inc[ch][e], acc[r]);
+                            if constexpr (WG) accw[j] = fmaf(xin[r], inc[ch][e], accw[j]);
+                        }
                     }
                 }
             }
             // pin this chunk's FMAs in front of the barrier (pure ops otherwise sink below it)
 #pragma unroll
             for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acc[r]));
+            if constexpr (WG) {
+#pragma unroll
+                for (int d = 0; d < (R - 1) * S + 4; ++d) {
+                    const int j = 4 * ch + 3 - d;
+                    if (j >= 0 && j < K) asm volatile("" :: "v"(accw[j]));
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -292,6 +321,17 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
     }
     }   // tile
 
+    if constexpr (WG) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float s = wave_sum_dpp_hi(accw[j]);
+            if (lane == 63) lds_wred[wave][j] = s;
+        }
+        __syncthreads();
+        // flipped taps here = forward taps K-1-j
+        for (int j = threadIdx.x; j < K; j += 256)
+            p.wpartial[((size_t)g * p.C + c) * K + (K - 1 - j)] = (lds_wred[0][j] + lds_wred[1][j]) + (lds_wred[2][j] + lds_wred[3][j]);
+    }
     if constexpr (STATS) {
         s0 = wave_sum(s0);
         s1 = wave_sum(s1);
@@ -311,21 +351,26 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
 
 // One launcher per (input mode, output mode) pair, each in its own translation unit (they compile
 // in parallel).  Returns false when (K, stride) has no specialisation.
-template <int IM, int OM>
+#ifndef DW_FUSED_R
+#define DW_FUSED_R 4
+#endif
+template <int IM, int OM, bool WG = false>
 static bool dw_launch_specialised(const DwParams& p, hipStream_t st) {
     dim3 grid(p.C, p.G);
-    const bool big = p.Tout > 256;
+    const bool big = p.Tout > 256 && !(WG && DW_FUSED_R == 4);
     // rows of any length take the 16-byte (dword-aligned) global path; tails are masked per element
 #define DW_GO(KK, SS)                                                                                             \
     do {                                                                                                          \
-        if (big) hipLaunchKernelGGL((dwconv_kernel<KK, SS, 8, IM, OM, true>), grid, dim3(256), 0, st, p);         \
-        else hipLaunchKernelGGL((dwconv_kernel<KK, SS, 4, IM, OM, true>), grid, dim3(256), 0, st, p);             \
+        if (big) hipLaunchKernelGGL((dwconv_kernel<KK, SS, 8, IM, OM, true, WG>), grid, dim3(256), 0, st, p);     \
+        else hipLaunchKernelGGL((dwconv_kernel<KK, SS, 4, IM, OM, true, WG>), grid, dim3(256), 0, st, p);         \
         return true;                                                                                              \
     } while (0)
 #define X(KK) if (p.K == KK && p.stride == 1) DW_GO(KK, 1);
     V100_DW_SPECIALISED(X)
 #undef X
-    if (p.K == 11 && p.stride == 2) DW_GO(11, 2);
+    if constexpr (!WG) {
+        if (p.K == 11 && p.stride == 2) DW_GO(11, 2);
+    }
 #undef DW_GO
     return false;
 }
@@ -333,3 +378,4 @@ static bool dw_launch_specialised(const DwParams& p, hipStream_t st) {
 bool dw_launch_fwd_train(const DwParams& p, hipStream_t st);   // in AFFINE_RELU6, out RAW_STATS
 bool dw_launch_fwd_eval(const DwParams& p, hipStream_t st);    // in NONE,         out AFFINE_RELU6
 bool dw_launch_bwd_data(const DwParams& p, hipStream_t st);    // in AFFINE2,      out MASK_STATS
+bool dw_launch_bwd_fused(const DwParams& p, hipStream_t st);   // the same + backward-weight partial sums (stride 1)

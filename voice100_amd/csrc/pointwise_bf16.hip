@@ -6,7 +6,9 @@
 // bf16 path: operands rounded to bf16 while staging, fp32 accumulate (v_mfma_f32_32x32x16_bf16).
 // LDS images are [row][k] with k contiguous (64 bf16 = 128 B per row) and a 16-byte-chunk XOR
 // swizzle chunk ^= (row >> 1) & 7 so the fragment ds_read_b128 of 32 consecutive rows is
-// conflict-free (bank rule (a/4) % 64, 16-lane groups).
+// conflict-free (bank rule (a/4) % 64; the hardware's four 16-lane groups each see every slot of both row
+// parities once).  (Also spreading the X-patch STORES, whose lanes hold rows 4 apart, with an extra
+// ^ ((row >> 4) & 1) and a lane remap was measured: no gain, so the simpler form stays.)
 // =============================================================================================
 #define BF_BK 64
 
@@ -183,9 +185,9 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     const int M = p.M, K = p.K, T = p.T;
     const size_t xoff = (size_t)b * K * T;
 
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.Abf, (unsigned)M * K * 2u);
-    const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.X + xoff, (unsigned)K * T * 4u);
-    const __amdgpu_buffer_rsrc_t rX2 = make_rsrc((XM == PW_X_AFFINE2 ? p.X2 : p.X) + xoff, (unsigned)K * T * 4u);
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.Abf, (PW_ABLATE & 2) ? 0u : (unsigned)M * K * 2u);
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.X + xoff, (PW_ABLATE & 1) ? 0u : (unsigned)K * T * 4u);
+    const __amdgpu_buffer_rsrc_t rX2 = make_rsrc((XM == PW_X_AFFINE2 ? p.X2 : p.X) + xoff, (PW_ABLATE & 1) ? 0u : (unsigned)K * T * 4u);
     const __amdgpu_buffer_rsrc_t rCa = make_rsrc(XM != PW_X_NONE ? p.xa : p.X, (unsigned)K * 4u);
     const __amdgpu_buffer_rsrc_t rCb = make_rsrc(XM != PW_X_NONE ? p.xb : p.X, (unsigned)K * 4u);
     const __amdgpu_buffer_rsrc_t rCc = make_rsrc(XM == PW_X_AFFINE2 ? p.xc : p.X, (unsigned)K * 4u);
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     auto store_slice = [&](int buf, auto stg, auto slc) {
         constexpr int SG = decltype(stg)::value;
         constexpr int q = decltype(slc)::value;
+        if constexpr (PW_ABLATE & 32) return;          // timing-only: no transform / LDS stores
         *reinterpret_cast<u32x4*>(As + buf * A_BYTES + ldsA[q]) = ra[SG][q];
         float v[KPT];
 #pragma unroll
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (K + BF_BK - 1) / BF_BK;
+    const int nk = (PW_ABLATE & 16) ? 0 : (K + BF_BK - 1) / BF_BK;      // bit 4 (timing-only): no main loop
     const int lr = lane & 31, lh = lane >> 5;
     const int sw = (lr >> 1) & 7;                       // fragment rows are lr (+32, +64..): same swizzle key
     const int rdA0 = (wm * 64 + lr) * 128, rdB0 = (wn * 64 + lr) * 128;
@@ -288,10 +291,16 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         const int co = ((ks * 2 + lh) ^ sw) << 4;
         const unsigned char* Ab = As + cur * A_BYTES;
         const unsigned char* Bb = Bs + cur * (128 * 128);
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + co);
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + 32 * 128 + co);
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + co);
-        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + 32 * 128 + co);
+        bf16x8 a0, a1, b0, b1;
+        if constexpr (PW_ABLATE & 64) {                  // timing-only: fragments without LDS reads
+            a0 = a1 = b0 = b1 = (bf16x8){(short)(cur + 1), (short)ks, 3, 4, 5, 6, 7, 8};
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+        } else {
+            a0 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + co);
+            a1 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + 32 * 128 + co);
+            b0 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + co);
+            b1 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + 32 * 128 + co);
+        }
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     };
     // pin: the registers of stage SG are first USED after this point.
     // (a macro, not a lambda: clang rejects captured arrays as inline-asm operands inside a generic lambda)
+#define PW_LOOP_SYNC() do { if constexpr (!(PW_ABLATE & 128)) __syncthreads(); } while (0)   /* bit 7: timing-only */
 #define PW_PIN(SG)                                                                                            \
     do {                                                                                                      \
         _Pragma("unroll") for (int e_ = 0; e_ < KPT; ++e_) {                                                  \
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
             store_slice(1, S1{}, Q0{}); mfma_step(0, 2);
             store_slice(1, S1{}, Q1{}); mfma_step(0, 3);
             store_slice(1, S1{}, Q2{}); store_slice(1, S1{}, Q3{});
-            __syncthreads();
+            PW_LOOP_SYNC();
             // odd tile kt+1: compute LDS 1; stage 0 holds tile kt+2; stage 1 is free -> tile kt+3
             load_coefs((kt + 2) * BF_BK);
             __builtin_amdgcn_sched_barrier(0);
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
             store_slice(0, S0{}, Q0{}); mfma_step(1, 2);
             store_slice(0, S0{}, Q1{}); mfma_step(1, 3);
             store_slice(0, S0{}, Q2{}); store_slice(0, S0{}, Q3{});
-            __syncthreads();
+            PW_LOOP_SYNC();
         }
         // Tail: the last two or three tiles (at most one pass), prefetches guarded
         for (; kt + 1 < nk; kt += 2) {
@@ -399,6 +409,18 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         }
     }
 #undef PW_PIN
+#undef PW_LOOP_SYNC
+    if constexpr (PW_ABLATE & 8) {            // timing-only: no epilogue (keep the accumulators alive)
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 12345.678f) p.Y[0] = s;
+        return;
+    }
     pw_epilogue_lds<EPI, BM>(p, acc, reinterpret_cast<float*>(smem), b, m0, t0, tt, wm, wn, tid);
 }
 

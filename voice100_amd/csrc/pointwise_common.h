@@ -25,6 +25,12 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #define PW_BM 128
 #define PW_BN 128
 
+// Timing-only ablation builds (tools/ab_variants.sh PW_ABLATE ...): bit 0 drops the X loads, bit 1 the A loads (zero-record
+// buffer descriptors: same instruction stream, no traffic), bit 2 the epilogue's global stores.  0 in the product.
+#ifndef PW_ABLATE
+#define PW_ABLATE 0
+#endif
+
 struct PwParams {
     const float* A;       // [M][K] fp32 weights
     const u16* Abf;       // [M][K] bf16 weights (bf16 path)
@@ -233,7 +239,7 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
             }
             v[e] = x;
         }
-        if (mv) {
+        if (mv && !(PW_ABLATE & 4)) {
             if (t + 3 < p.T) *reinterpret_cast<f32x4u*>(p.Y + o) = v;
             else {
 #pragma unroll
