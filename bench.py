@@ -18,6 +18,7 @@ box's host cores on a bounded sample of the same workload.
 import argparse
 import json
 import os
+import random
 import sys
 import time
 
@@ -25,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -117,7 +119,11 @@ def main():
     N.load()
     F_.set_matmul_precision(args.precision)
 
-    torch.manual_seed(1234)                                  # reference: pl.seed_everything(1234), train_asr.py:13
+    # reference: pl.seed_everything(1234), train_asr.py:13 -- seeds python, numpy and torch; the augmentation draws its
+    # decisions from python's `random` (audio.py:35-49), so an unseeded run changes which steps are time-stretched
+    random.seed(1234 + rank)
+    np.random.seed(1234 + rank)
+    torch.manual_seed(1234)
     model = AudioToTextCTC(N_MEL, 512, VOCAB, 512, learning_rate=1e-3, weight_decay=4e-5).to(device)
     step = TrainStep(model)
     batch = synth_batch(device, B_PER_GPU, 1234 + rank)

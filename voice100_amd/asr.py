@@ -103,8 +103,11 @@ class AudioToTextCTC(nn.Module):
         return {"test_loss": self._calc_batch_loss(batch)}
 
     def configure_optimizers(self):
-        optimizer = torch.optim.Adam(self.parameters(), lr=self.hparams.learning_rate,
-                                     weight_decay=self.hparams.weight_decay)
+        # same update rule as the reference's torch.optim.Adam (asr.py:169-176); on the GPU PyTorch's single fused
+        # multi-tensor kernel replaces the ~12 foreach launches per step
+        params = list(self.parameters())
+        optimizer = torch.optim.Adam(params, lr=self.hparams.learning_rate, weight_decay=self.hparams.weight_decay,
+                                     fused=all(p.is_cuda for p in params))
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=1, gamma=0.98)
         return {"optimizer": optimizer, "lr_scheduler": scheduler}
 

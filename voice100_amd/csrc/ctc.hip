@@ -15,15 +15,17 @@
 #define CTC_MAXV 128
 #define NEG_INF (-INFINITY)
 
+// The recursion is a 512-step serial chain, so the two helpers use the hardware exp2 / log2 (v_exp_f32 / v_log_f32,
+// ~1 ulp): an absolute error of ~1e-7 per step in the log domain, against per-utterance losses of O(100).
 __device__ __forceinline__ float lse2(float a, float b) {
     const float m = fmaxf(a, b);
     if (m == NEG_INF) return NEG_INF;
-    return m + logf(expf(a - m) + expf(b - m));
+    return m + __logf(__expf(a - m) + __expf(b - m));
 }
 __device__ __forceinline__ float lse3(float a, float b, float c) {
     const float m = fmaxf(fmaxf(a, b), c);
     if (m == NEG_INF) return NEG_INF;
-    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
 }
 
 // lse[b][t] = logsumexp_c logits[b][t][c]

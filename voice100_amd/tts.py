@@ -179,7 +179,8 @@ class TextToAlignTextModel(nn.Module):
         return {"val_loss": self._calc_batch_loss(batch)}
 
     def configure_optimizers(self):
-        return torch.optim.Adam(self.parameters(), lr=self.hparams.learning_rate)
+        params = list(self.parameters())
+        return torch.optim.Adam(params, lr=self.hparams.learning_rate, fused=all(p.is_cuda for p in params))
 
     @staticmethod
     def add_model_specific_args(parent_parser):
@@ -247,7 +248,8 @@ class AlignTextToAudioModel(nn.Module):
         return {"test_loss": sum(self._calc_batch_loss(batch))}
 
     def configure_optimizers(self):
-        return torch.optim.Adam(self.parameters(), lr=self.hparams.learning_rate)
+        params = list(self.parameters())
+        return torch.optim.Adam(params, lr=self.hparams.learning_rate, fused=all(p.is_cuda for p in params))
 
     @staticmethod
     def add_model_specific_args(parent_parser):
