@@ -184,14 +184,16 @@ int v100_ctc_loss(const float* logits, const long long* targets, const int* in_l
                   float* nll, float* grad, int B, int T, int V, int Lmax, int blank, void* stream);
 
 /* ---- block executor (csrc/block.hip): the whole kernel chain of one InvertedResidual block (asr.py:40-59) per call.
- * shape = {B, Cin, hid, Cout, T, K, stride, residual, bf16}; coef = 12 vectors of `hid` floats (BN scale/shift/mean/rstd
+ * shape = {B, Cin, hid, Cout, T, K, stride, residual, bf16, prepped}; coef = 12 vectors of `hid` floats (BN scale/shift/mean/rstd
  * of the three BatchNorms) written by forward and read by backward.  Pointer tables (device pointers unless noted):
  *  fwd: x | w1 g1 b1 rm1 rv1 nbt1 | wd g2 b2 rm2 rv2 nbt2 | w3 g3 b3 rm3 rv3 nbt3 | a1 a2 a3 y coef workspace prep   (26)
  *  bwd: x a1 a2 a3 | w1 wd w3 | g1 g2 g3 | coef | dy | dx (NULL = skip) | dW1 dg1 db1 dWd dg2 db2 dW3 dg3 db3 | workspace prep (24)
- * prep = v100_ir_prep_bytes(shape) bytes: bf16 / transposed weight copies written by forward, reused by backward.
- * `shape` and the tables are HOST arrays. */
+ * prep = v100_ir_prep_bytes(shape) bytes: bf16 / transposed weight copies written by forward (unless shape.prepped: the
+ * caller has filled it, e.g. with v100_ir_prep_batched for the n <= 32 blocks of a stack in one launch; shapes = n x 10
+ * ints) and reused by backward.  `shape(s)` and the tables are HOST arrays. */
 long long v100_ir_prep_bytes(const int* shape);
 long long v100_ir_fwd_workspace_bytes(const int* shape);
+int v100_ir_prep_batched(const int* shapes, const void* const* w1s, const void* const* w3s, void* const* preps, int n, void* stream);
 int v100_ir_fwd_train(const int* shape, const void* const* ptrs, void* stream);
 long long v100_ir_bwd_workspace_bytes(const int* shape);
 int v100_ir_bwd(const int* shape, const void* const* ptrs, void* stream);

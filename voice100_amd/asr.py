@@ -37,6 +37,8 @@ class ConvVoiceEncoder(nn.Module):
             InvertedResidual(ci, co, kernel_size=k, stride=s, use_residual=r) for ci, co, k, s, r in spec])
 
     def forward(self, embed: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            F_.prepare_block_weights(self.layers)       # bf16 / transposed weight copies of all 9 blocks in one launch
         return self.layers(embed)
 
     def output_length(self, embed_len: torch.Tensor) -> torch.Tensor:

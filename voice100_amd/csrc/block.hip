@@ -21,9 +21,9 @@ inline int conv_out(int t, int k, int s) { return (t + 2 * ((k - 1) / 2) - k) / 
 const float kMom = 0.1f, kEps = 1e-5f;
 }
 
-// shape = {B, Cin, hid, Cout, T, K, stride, residual, bf16}
+// shape = {B, Cin, hid, Cout, T, K, stride, residual, bf16, prepped}
 // coef  = 12 vectors of `hid` floats: s1 t1 mean1 rstd1 s2 t2 mean2 rstd2 s3 t3 mean3 rstd3
-enum { IR_B, IR_CIN, IR_HID, IR_COUT, IR_T, IR_K, IR_STRIDE, IR_RES, IR_BF16, IR_NSHAPE };
+enum { IR_B, IR_CIN, IR_HID, IR_COUT, IR_T, IR_K, IR_STRIDE, IR_RES, IR_BF16, IR_PREPPED, IR_NSHAPE };
 
 // Prepared weights, written once by forward and reused by backward (caller-owned, saved with the block):
 // bf16 mode: w1_bf [hid][cin], w1t_bf [cin][hid], w3_bf [cout][hid], w3t_bf [hid][cout];  fp32 mode: w1t, w3t (fp32).
@@ -86,8 +86,12 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
     int rc;
 #define CK(call) do { rc = (call); if (rc) return rc; } while (0)
     // both orientations in one pass per weight: forward uses w*_bf, backward the transposed copies
-    CK(v100_weight_prep(w1, hid, cin, pw.w1bf, pw.w1t, pw.w1tbf, stream));
-    CK(v100_weight_prep(w3, cout, hid, pw.w3bf, pw.w3t, pw.w3tbf, stream));
+    // (skipped when the caller has already filled `prep` for these weights, e.g. for every block of a stack in one
+    // v100_ir_prep_batched launch)
+    if (!sh[IR_PREPPED]) {
+        CK(v100_weight_prep(w1, hid, cin, pw.w1bf, pw.w1t, pw.w1tbf, stream));
+        CK(v100_weight_prep(w3, cout, hid, pw.w3bf, pw.w3t, pw.w3tbf, stream));
+    }
     const int parts1 = v100_pw_num_parts(B, T), parts3 = v100_pw_num_parts(B, T2), G = v100_dw_num_groups(B, hid);
     CK(v100_pw_gemm(w1, w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, bf, stream));
     CK(v100_bn_finalize_train(st, parts1, (long long)B * T, (const float*)P[2], (const float*)P[3], (float*)P[4], (float*)P[5], (long long*)P[6],
@@ -175,4 +179,50 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
                         B, cin, hid, T, bf, stream));
 #undef CK
     return V100_OK;
+}
+
+// Prepared weights of n blocks in ONE launch (the per-block pair of weight_prep launches costs ~13 us a block, mostly
+// launch latency).  shapes: n x IR_NSHAPE ints; w1s / w3s: the fp32 weights; preps: each block's prep buffer.  HOST arrays.
+struct PrepBatch {
+    enum { MAXN = 32 };
+    const float* w[2 * MAXN]; u16* wbf[2 * MAXN]; float* wt[2 * MAXN]; u16* wtbf[2 * MAXN];
+    int rows[2 * MAXN], cols[2 * MAXN];
+};
+__global__ __launch_bounds__(256) void weight_prep_batched_kernel(PrepBatch t) {
+    const int e = blockIdx.y;
+    const float* __restrict__ w = t.w[e];
+    const int rows = t.rows[e], cols = t.cols[e];
+    const long n = (long)rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        const float v = w[i];
+        if (t.wbf[e]) t.wbf[e][i] = f2bf(v);
+        if (t.wt[e]) t.wt[e][(size_t)c * rows + r] = v;
+        if (t.wtbf[e]) t.wtbf[e][(size_t)c * rows + r] = f2bf(v);
+    }
+}
+extern "C" int v100_ir_prep_batched(const int* shapes, const void* const* w1s, const void* const* w3s, void* const* preps, int n,
+                                    void* stream) {
+    if (!shapes || !w1s || !w3s || !preps) return V100_ERR_NULL;
+    if (n <= 0 || n > PrepBatch::MAXN) return V100_ERR_SHAPE;
+    PrepBatch t;
+    long maxn = 0;
+    for (int i = 0; i < n; ++i) {
+        const int* sh = shapes + (size_t)i * IR_NSHAPE;
+        if (!w1s[i] || !w3s[i] || !preps[i]) return V100_ERR_NULL;
+        IrPrep pw;
+        ir_prep_carve(sh, preps[i], pw);
+        t.w[2 * i] = (const float*)w1s[i]; t.rows[2 * i] = sh[IR_HID]; t.cols[2 * i] = sh[IR_CIN];
+        t.wbf[2 * i] = (u16*)pw.w1bf; t.wt[2 * i] = pw.w1t; t.wtbf[2 * i] = (u16*)pw.w1tbf;
+        t.w[2 * i + 1] = (const float*)w3s[i]; t.rows[2 * i + 1] = sh[IR_COUT]; t.cols[2 * i + 1] = sh[IR_HID];
+        t.wbf[2 * i + 1] = (u16*)pw.w3bf; t.wt[2 * i + 1] = pw.w3t; t.wtbf[2 * i + 1] = (u16*)pw.w3tbf;
+        const long a = (long)sh[IR_HID] * sh[IR_CIN], b = (long)sh[IR_COUT] * sh[IR_HID];
+        if (a > maxn) maxn = a;
+        if (b > maxn) maxn = b;
+        if (a <= 0 || b <= 0) return V100_ERR_SHAPE;
+    }
+    long gx = (maxn + 255) / 256;
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(weight_prep_batched_kernel, dim3((unsigned)gx, 2 * n), dim3(256), 0, (hipStream_t)stream, t);
+    return v100_launch_status();
 }

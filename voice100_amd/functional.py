@@ -105,7 +105,7 @@ class InvertedResidualTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, wd, g2, b2, w3, g3, b3, rm1, rv1, nbt1, rm2, rv2, nbt2, rm3, rv3, nbt3,
-                kernel_size, stride, use_residual, precision):
+                kernel_size, stride, use_residual, precision, prep=None):
         _check(x, "InvertedResidual")
         x = x.contiguous()
         B, cin, T = x.shape
@@ -113,14 +113,15 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         k = int(kernel_size)
         T2 = conv_out_len(T, k, stride)
         bf16 = precision == "bf16"
-        shape = (ctypes.c_int * 9)(B, cin, hid, cout, T, k, int(stride), int(bool(use_residual)), int(bf16))
+        shape = (ctypes.c_int * 10)(B, cin, hid, cout, T, k, int(stride), int(bool(use_residual)), int(bf16), int(prep is not None))
         a1 = _f32(B, hid, T, like=x)
         a2 = _f32(B, hid, T2, like=x)
         a3 = _f32(B, cout, T2, like=x)
         y = _f32(B, cout, T2, like=x)
         coef = _f32(12, max(hid, cout), like=x)
         ws = torch.empty(N.helper("v100_ir_fwd_workspace_bytes", shape), dtype=torch.uint8, device=x.device)
-        prep = torch.empty(N.helper("v100_ir_prep_bytes", shape), dtype=torch.uint8, device=x.device)
+        if prep is None:
+            prep = torch.empty(N.helper("v100_ir_prep_bytes", shape), dtype=torch.uint8, device=x.device)
         tensors = (x, w1, g1, b1, rm1, rv1, nbt1, wd, g2, b2, rm2, rv2, nbt2, w3, g3, b3, rm3, rv3, nbt3, a1, a2, a3, y, coef, ws, prep)
         for t in tensors[:19]:
             if not t.is_contiguous() or not t.is_cuda:
@@ -148,7 +149,49 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         ws = torch.empty(N.helper("v100_ir_bwd_workspace_bytes", shape), dtype=torch.uint8, device=x.device)
         N.call("v100_ir_bwd", shape, _ptr_table((x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, dy, dx) + tuple(parts) + (ws, prep)))
         dW1, dg1, db1, dWd, dg2, db2, dW3, dg3, db3 = parts
-        return (dx, dW1.view_as(w1), dg1, db1, dWd.view_as(wd), dg2, db2, dW3.view_as(w3), dg3, db3) + (None,) * 13
+        return (dx, dW1.view_as(w1), dg1, db1, dWd.view_as(wd), dg2, db2, dW3.view_as(w3), dg3, db3) + (None,) * 14
+
+
+def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
+    """bf16 / transposed copies of the two 1x1 weights of every InvertedResidual in `blocks`, in ONE launch
+    (v100_ir_prep_batched), into per-module buffers that the blocks' forward then hands to the executor.  Called by the
+    stacks (ConvVoiceEncoder, VoiceDecoder, ...) at the top of a training-mode forward; a block whose weights changed
+    since (or that was never prepared) simply prepares its own copies as before."""
+    precision = precision or _PRECISION
+    bf16 = precision == "bf16"
+    todo = []
+    for blk in blocks:
+        w1, w3 = blk.conv[0][0].weight, blk.conv[2].weight
+        if not w1.is_cuda:
+            raise RuntimeError("InvertedResidual: parameters must be CUDA tensors (no CPU fallback)")
+        key = (w1.data_ptr(), w3.data_ptr(), w1._version, w3._version, bf16)
+        if getattr(blk, "_prep_key", None) == key:
+            continue
+        hid, cin = w1.shape[0], w1.shape[1]
+        cout = w3.shape[0]
+        shape = (0, cin, hid, cout, 0, 0, 1, 0, int(bf16), 1)
+        buf = getattr(blk, "_prep_buf", None)
+        nbytes = N.helper("v100_ir_prep_bytes", (ctypes.c_int * 10)(*shape))
+        if buf is None or buf.numel() != nbytes or buf.device != w1.device:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+            blk._prep_buf = buf
+        todo.append((blk, shape, w1, w3, buf, key))
+    for i in range(0, len(todo), 32):
+        chunk = todo[i:i + 32]
+        shapes = (ctypes.c_int * (10 * len(chunk)))(*[v for c in chunk for v in c[1]])
+        N.call("v100_ir_prep_batched", shapes, _ptr_table([c[2] for c in chunk]), _ptr_table([c[3] for c in chunk]),
+               _ptr_table([c[4] for c in chunk]), len(chunk))
+        for blk, _, _, _, _, key in chunk:
+            blk._prep_key = key
+
+
+def prepared_weights_of(blk, precision: Optional[str] = None):
+    """The block's prepared-weights buffer if it matches the current weights (see prepare_block_weights), else None."""
+    bf16 = (precision or _PRECISION) == "bf16"
+    w1, w3 = blk.conv[0][0].weight, blk.conv[2].weight
+    if getattr(blk, "_prep_key", None) == (w1.data_ptr(), w3.data_ptr(), w1._version, w3._version, bf16):
+        return blk._prep_buf
+    return None
 
 
 def inverted_residual_eval(x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3,

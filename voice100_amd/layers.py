@@ -65,7 +65,7 @@ class InvertedResidual(nn.Module):
                 bn1.running_mean, bn1.running_var, bn1.num_batches_tracked,
                 bn2.running_mean, bn2.running_var, bn2.num_batches_tracked,
                 bn3.running_mean, bn3.running_var, bn3.num_batches_tracked,
-                self.kernel_size, self.stride, self.use_residual, prec)
+                self.kernel_size, self.stride, self.use_residual, prec, F_.prepared_weights_of(self, prec))
         # eval mode: frozen statistics, inference only (autograd through eval-mode BN is not on the
         # reference's training path and is not built)
         with torch.no_grad():

@@ -58,6 +58,8 @@ class VoiceDecoder(nn.Module):
             PointwiseConv1d(half, out_channels, bias=True))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            F_.prepare_block_weights([m for m in self.layers if isinstance(m, InvertedResidual)])
         return self.layers(x)
 
 
@@ -143,6 +145,8 @@ class TextToAlignTextModel(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = F_.embedding_bct(x, self.embedding.weight)          # [B, H, L]
+        if self.training:
+            F_.prepare_block_weights([m for m in self.layers if isinstance(m, InvertedResidual)])
         x = self.layers(x)
         return F_.transpose_last2(x)                             # [B, L, 2]
 
