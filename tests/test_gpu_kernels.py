@@ -273,3 +273,39 @@ def test_ctc_loss_fused(cuda, B, T, V, L):
     loss.backward()
     assert abs(float(loss.detach()) - float(ref.detach())) < 1e-4 * max(1.0, abs(float(ref.detach())))
     assert rel_err(x.grad, ref_in.grad) < 2e-4
+
+
+@pytest.mark.parametrize("B,C,T,K,S", [(5, 12, 130, 19, 1), (3, 8, 77, 83, 1), (2, 6, 40, 9, 1), (4, 10, 61, 11, 2), (2, 4, 600, 51, 1)])
+def test_dwconv_bwd_fused_matches_split_and_torch(cuda, B, C, T, K, S):
+    """v100_dwconv_bwd: the fused kernel (stride 1, specialised K), the two-pass fallback (other K / stride) and
+    autograd of conv1d(relu6(bn(a1))) agree: dxin (through the ReLU6 mask), its BN-backward sums and dW."""
+    N = _native()
+    g = torch.Generator().manual_seed(K * 31 + T)
+    pad = (K - 1) // 2
+    Tout = (T + 2 * pad - K) // S + 1
+    a1 = torch.randn(B, C, T, generator=g) * 2
+    w = torch.randn(C, K, generator=g) * 0.2
+    xa, xb = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    dz2, a2 = torch.randn(B, C, Tout, generator=g), torch.randn(B, C, Tout, generator=g)
+    ga, gb, gc = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+    # reference: g' = BN-backward affine; xin = relu6(bn(a1)); y = dwconv(xin); loss = sum(y * g')
+    gp = ga[None, :, None] * dz2 + gb[None, :, None] * a2 + gc[None, :, None]
+    a1r, wr = a1.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    pre = a1r * xa[None, :, None] + xb[None, :, None]
+    y = torch.nn.functional.conv1d(torch.clamp(pre, 0, 6), wr[:, None, :], stride=S, padding=pad, groups=C)
+    (y * gp).sum().backward()
+    dpre = a1r.grad / xa[None, :, None]                      # gradient w.r.t. the pre-activation = what the kernel stores
+    dev = lambda t: t.to(cuda).contiguous()
+    G = N.helper("v100_dw_num_groups", B, C)
+    outs = []
+    for force_split in (0, 1):
+        dxin = torch.full((B, C, T), float("nan"), device=cuda)
+        st, part, dw = torch.zeros(G, C, 2, device=cuda), torch.zeros(G, C, K, device=cuda), torch.zeros(C, K, device=cuda)
+        N.call("v100_dwconv_bwd", dev(dz2), dev(a2), dev(w), dev(ga), dev(gb), dev(gc), dev(a1), dev(xa), dev(xb), dxin, st, part, dw,
+               G, B, C, T, Tout, K, S, pad, force_split)
+        outs.append((dxin.cpu(), st.sum(0).cpu(), dw.cpu()))
+        assert rel_err(dxin, dpre.detach()) < TOL
+        assert rel_err(dw, wr.grad) < TOL
+        assert rel_err(st.sum(0)[:, 0], dpre.detach().sum((0, 2)), floor=1e-2) < 10 * TOL
+        assert rel_err(st.sum(0)[:, 1], (dpre.detach() * a1).sum((0, 2)), floor=1e-2) < 10 * TOL
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-5 and rel_err(outs[0][2], outs[1][2]) < 1e-5
