@@ -137,8 +137,9 @@ def main():
         step(batch)
     sync()
     if not args.no_kernel_timing:
-        # HIP events inside the library, on the launch stream, around the roofline kernel only: an event pair costs
-        # ~3 us of queue time per launch (timing all ~130 hot launches of a step costs ~0.8 ms of it)
+        # HIP events inside the library, on the launch stream, for the roofline kernel only.  Its launches carry the
+        # events in the dispatch packet (hipExtLaunchKernelGGL: the pair reads the kernel's own start/stop timestamps);
+        # bracketing all ~130 hot launches of a step with hipEventRecord costs ~0.8 ms of it, hence the separate pass below
         N.timing_enable(["dw_fwd"])
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -165,12 +165,14 @@ int v100_ln_gelu_fwd(const float* y, const float* gamma, const float* beta, floa
 int v100_ln_gelu_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* mean,
                      const float* rstd, float* dy, float* partial, int B, int C, int T, void* stream);
 
-/* ---- opt-in kernel timing (bench.py roofline): HIP events on the launch stream around the hot kernels.
- * tags: 0 depthwise fwd, 1 depthwise bwd-data, 2 depthwise bwd-weight, 3 pointwise GEMM, 4 pointwise bwd-weight.
- * enable(mask): bit t of mask switches tag t on (0 = all off; an event pair costs ~3 us of queue time per launch, so
- * time only what is read); a non-zero mask clears the counters.  read() synchronises the device and returns the summed
- * ms, launch count and (for the depthwise tags) the algorithmic bytes of those launches: fp32 in + out + taps + BN
- * coefficients. */
+/* ---- opt-in kernel timing (bench.py roofline): HIP events on the launch stream for the hot kernels.
+ * tags: 0 depthwise fwd, 1 depthwise bwd, 2 depthwise bwd-weight (stand-alone), 3 pointwise GEMM, 4 pointwise bwd-weight.
+ * The depthwise launches are timed with the dispatch packet's own start/stop timestamps (hipExtLaunchKernelGGL: no
+ * marker packets, the pair reads what rocprofv3 reports as the kernel's duration); the GEMM tags bracket their launches
+ * with hipEventRecord (~3 us of queue time per launch, so time only what is read).
+ * enable(mask): bit t of mask switches tag t on (0 = all off); a non-zero mask clears the counters.  read()
+ * synchronises the device and returns the summed ms, launch count and (for the depthwise tags) the algorithmic bytes
+ * of those launches: fp32 in + out + taps + BN coefficients. */
 int v100_timing_enable(int tag_mask);
 int v100_timing_read(int tag, double* ms, long long* count, double* bytes);
 

@@ -249,15 +249,15 @@ extern "C" int v100_dwconv(const float* x, const float* x2, const float* w, cons
     hipStream_t st = (hipStream_t)stream;
     // algorithmic bytes of this launch: fp32 input(s) + output (+ aux) + taps + per-channel coefficients
     const double nin = (in_mode == DW_IN_AFFINE2 ? 2.0 : 1.0) * B * C * (double)Tin, nout = (out_mode == DW_OUT_MASK_STATS ? 2.0 : 1.0) * B * C * (double)Tout;
-    V100TimedRegion timed(out_mode == DW_OUT_MASK_STATS ? V100_T_DW_BWD_DATA : V100_T_DW_FWD, st, 4.0 * (nin + nout) + 4.0 * C * K + 8.0 * C);
+    V100TimedLaunch timed(out_mode == DW_OUT_MASK_STATS ? V100_T_DW_BWD_DATA : V100_T_DW_FWD, 4.0 * (nin + nout) + 4.0 * C * K + 8.0 * C);
     bool done = false;
     const bool fits = (size_t)B * C * Tin * 4 < 0x7fffff00ull;
     if (!force_generic && upsample == 1 && fits) {
-        if (in_mode == DW_IN_AFFINE_RELU6 && out_mode == DW_OUT_RAW_STATS) done = dw_launch_fwd_train(p, st);
-        else if (in_mode == DW_IN_NONE && out_mode == DW_OUT_AFFINE_RELU6) done = dw_launch_fwd_eval(p, st);
-        else if (in_mode == DW_IN_AFFINE2 && out_mode == DW_OUT_MASK_STATS) done = dw_launch_bwd_data(p, st);
+        if (in_mode == DW_IN_AFFINE_RELU6 && out_mode == DW_OUT_RAW_STATS) done = dw_launch_fwd_train(p, st, timed);
+        else if (in_mode == DW_IN_NONE && out_mode == DW_OUT_AFFINE_RELU6) done = dw_launch_fwd_eval(p, st, timed);
+        else if (in_mode == DW_IN_AFFINE2 && out_mode == DW_OUT_MASK_STATS) done = dw_launch_bwd_data(p, st, timed);
     }
-    if (!done) hipLaunchKernelGGL(dwconv_generic_kernel, dim3(C, G), dim3(256), K * sizeof(float), st, p);
+    if (!done) V100_LAUNCH(timed, dwconv_generic_kernel, dim3(C, G), dim3(256), K * sizeof(float), st, p);
     return v100_launch_status();
 }
 
@@ -302,11 +302,8 @@ extern "C" int v100_dwconv_bwd(const float* g, const float* g2, const float* w, 
         // backward-data geometry: the conv runs over g (length Tout) and produces Tin outputs, taps flipped
         DwParams p{g, g2, w, ga, gb, gc, dxin, xpre, xa, xb, stats,
                    B, C, Tout, Tin, K, 1, K - 1 - pad, 1, 1, G, DW_IN_AFFINE2, DW_OUT_MASK_STATS, wpartial};
-        bool done;
-        {
-            V100TimedRegion timed(V100_T_DW_BWD_DATA, st, 4.0 * B * C * (2.0 * Tout + 2.0 * Tin) + 8.0 * C * K + 8.0 * C);
-            done = dw_launch_bwd_fused(p, st);
-        }
+        V100TimedLaunch timed(V100_T_DW_BWD_DATA, 4.0 * B * C * (2.0 * Tout + 2.0 * Tin) + 8.0 * C * K + 8.0 * C);
+        const bool done = dw_launch_bwd_fused(p, st, timed);
         if (done) {
             const int n = C * K;
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, wpartial, dw, G, n, 0);

@@ -17,6 +17,7 @@
 // [G][C][2] slab -- deterministic, no atomics.
 #pragma once
 #include "common.h"
+#include "timing.h"
 
 enum { DW_IN_NONE = 0, DW_IN_AFFINE_RELU6 = 1, DW_IN_AFFINE2 = 2 };
 enum { DW_OUT_RAW_STATS = 0, DW_OUT_AFFINE_RELU6 = 1, DW_OUT_MASK_STATS = 2, DW_OUT_RAW = 3 };
@@ -355,14 +356,14 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
 #define DW_FUSED_R 4
 #endif
 template <int IM, int OM, bool WG = false>
-static bool dw_launch_specialised(const DwParams& p, hipStream_t st) {
+static bool dw_launch_specialised(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl) {
     dim3 grid(p.C, p.G);
     const bool big = p.Tout > 256 && !(WG && DW_FUSED_R == 4);
     // rows of any length take the 16-byte (dword-aligned) global path; tails are masked per element
 #define DW_GO(KK, SS)                                                                                             \
     do {                                                                                                          \
-        if (big) hipLaunchKernelGGL((dwconv_kernel<KK, SS, 8, IM, OM, true, WG>), grid, dim3(256), 0, st, p);     \
-        else hipLaunchKernelGGL((dwconv_kernel<KK, SS, 4, IM, OM, true, WG>), grid, dim3(256), 0, st, p);         \
+        if (big) V100_LAUNCH(tl, (dwconv_kernel<KK, SS, 8, IM, OM, true, WG>), grid, dim3(256), 0, st, p);        \
+        else V100_LAUNCH(tl, (dwconv_kernel<KK, SS, 4, IM, OM, true, WG>), grid, dim3(256), 0, st, p);            \
         return true;                                                                                              \
     } while (0)
 #define X(KK) if (p.K == KK && p.stride == 1) DW_GO(KK, 1);
@@ -375,7 +376,7 @@ static bool dw_launch_specialised(const DwParams& p, hipStream_t st) {
     return false;
 }
 
-bool dw_launch_fwd_train(const DwParams& p, hipStream_t st);   // in AFFINE_RELU6, out RAW_STATS
-bool dw_launch_fwd_eval(const DwParams& p, hipStream_t st);    // in NONE,         out AFFINE_RELU6
-bool dw_launch_bwd_data(const DwParams& p, hipStream_t st);    // in AFFINE2,      out MASK_STATS
-bool dw_launch_bwd_fused(const DwParams& p, hipStream_t st);   // the same + backward-weight partial sums (stride 1)
+bool dw_launch_fwd_train(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);   // in AFFINE_RELU6, out RAW_STATS
+bool dw_launch_fwd_eval(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);    // in NONE,         out AFFINE_RELU6
+bool dw_launch_bwd_data(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);    // in AFFINE2,      out MASK_STATS
+bool dw_launch_bwd_fused(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);   // the same + backward-weight partial sums (stride 1)

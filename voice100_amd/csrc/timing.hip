@@ -32,6 +32,22 @@ void v100_timing_begin(int tag, hipStream_t st, int* slot, double bytes) {
     *slot = (int)g_used++;
 }
 
+V100TimedLaunch::V100TimedLaunch(int tag, double bytes) {
+    if (!((g_mask >> tag) & 1u)) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_used >= kMaxPairs) return;
+    if (g_used >= g_pairs.size()) {
+        Pair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+        g_pairs.push_back(p);
+    }
+    g_pairs[g_used].tag = tag;
+    g_pairs[g_used].bytes = bytes;
+    a = g_pairs[g_used].a;
+    b = g_pairs[g_used].b;
+    ++g_used;
+}
+
 void v100_timing_end(int slot, hipStream_t st) {
     if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_mu);
