@@ -195,6 +195,13 @@ int v100_ctc_loss(const float* logits, const long long* targets, const int* in_l
  * ints) and reused by backward.  `shape(s)` and the tables are HOST arrays. */
 long long v100_ir_prep_bytes(const int* shape);
 long long v100_ir_fwd_workspace_bytes(const int* shape);
+/* eval mode (inference): folded BatchNorm coefficients + bf16 weight copies in a caller-owned cache (refill with
+ * v100_ir_eval_prep whenever a parameter or running statistic changes), then 3 launches per block and call.
+ *  prep ptrs: w1 | g1 b1 rm1 rv1 | g2 b2 rm2 rv2 | w3 | g3 b3 rm3 rv3 | cache   (15)
+ *  fwd  ptrs: x | w1 wd w3 | cache | h1 [B,hid,T] h2 [B,hid,T'] y [B,Cout,T']   (8) */
+long long v100_ir_eval_cache_bytes(const int* shape);
+int v100_ir_eval_prep(const int* shape, const void* const* ptrs, void* stream);
+int v100_ir_fwd_eval(const int* shape, const void* const* ptrs, void* stream);
 int v100_ir_prep_batched(const int* shapes, const void* const* w1s, const void* const* w3s, void* const* preps, int n, void* stream);
 int v100_ir_fwd_train(const int* shape, const void* const* ptrs, void* stream);
 long long v100_ir_bwd_workspace_bytes(const int* shape);

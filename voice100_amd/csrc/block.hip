@@ -20,6 +20,7 @@ struct Carver {
 inline int conv_out(int t, int k, int s) { return (t + 2 * ((k - 1) / 2) - k) / s + 1; }
 const float kMom = 0.1f, kEps = 1e-5f;
 }
+#define CK(call) do { rc = (call); if (rc) return rc; } while (0)
 
 // shape = {B, Cin, hid, Cout, T, K, stride, residual, bf16, prepped}
 // coef  = 12 vectors of `hid` floats: s1 t1 mean1 rstd1 s2 t2 mean2 rstd2 s3 t3 mean3 rstd3
@@ -84,7 +85,6 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
     ir_prep_carve(sh, const_cast<void*>(P[25]), pw);
     void *w1bf = pw.w1bf, *w3bf = pw.w3bf;
     int rc;
-#define CK(call) do { rc = (call); if (rc) return rc; } while (0)
     // both orientations in one pass per weight: forward uses w*_bf, backward the transposed copies
     // (skipped when the caller has already filled `prep` for these weights, e.g. for every block of a stack in one
     // v100_ir_prep_batched launch)
@@ -177,7 +177,57 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     if (dx)
         CK(v100_pw_gemm(pw.w1t, pw.w1tbf, w.dz1, a1, pp, qq, rr, 2, dx, nullptr, nullptr, nullptr, res ? dy : nullptr, res ? 5 : 0, nullptr,
                         B, cin, hid, T, bf, stream));
-#undef CK
+    return V100_OK;
+}
+
+// ---- eval mode: BatchNorm folded to per-channel scale/shift inside three kernels (pw+BN+ReLU6, dw+BN+ReLU6, pw+BN(+x)).
+// The folded coefficients and the bf16 weight copies only change when the parameters do, so they live in a caller-owned
+// cache filled by v100_ir_eval_prep; a forward is then 3 launches from one call.
+struct IrEvalCache { void *w1bf, *w3bf; float *s1, *t1, *s2, *t2, *s3, *t3; };
+static size_t ir_eval_carve(const int* sh, void* base, IrEvalCache& w) {
+    const int cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT];
+    Carver c(base);
+    w.w1bf = w.w3bf = nullptr;
+    if (sh[IR_BF16]) { w.w1bf = c.take<u16>((size_t)hid * cin); w.w3bf = c.take<u16>((size_t)cout * hid); }
+    w.s1 = c.take<float>(hid); w.t1 = c.take<float>(hid); w.s2 = c.take<float>(hid); w.t2 = c.take<float>(hid);
+    w.s3 = c.take<float>(cout); w.t3 = c.take<float>(cout);
+    return c.used + 256;
+}
+extern "C" long long v100_ir_eval_cache_bytes(const int* shape) {
+    IrEvalCache w;
+    return (long long)ir_eval_carve(shape, nullptr, w);
+}
+// ptrs: 0 w1 | 1 g1 2 b1 3 rm1 4 rv1 | 5 g2 6 b2 7 rm2 8 rv2 | 9 w3 | 10 g3 11 b3 12 rm3 13 rv3 | 14 cache
+extern "C" int v100_ir_eval_prep(const int* sh, const void* const* P, void* stream) {
+    if (!sh || !P) return V100_ERR_NULL;
+    const int cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT];
+    IrEvalCache c;
+    ir_eval_carve(sh, const_cast<void*>(P[14]), c);
+    int rc;
+    if (sh[IR_BF16]) {
+        CK(v100_weight_prep((const float*)P[0], hid, cin, c.w1bf, nullptr, nullptr, stream));
+        CK(v100_weight_prep((const float*)P[9], cout, hid, c.w3bf, nullptr, nullptr, stream));
+    }
+    CK(v100_bn_eval_coeffs((const float*)P[1], (const float*)P[2], (const float*)P[3], (const float*)P[4], kEps, c.s1, c.t1, hid, stream));
+    CK(v100_bn_eval_coeffs((const float*)P[5], (const float*)P[6], (const float*)P[7], (const float*)P[8], kEps, c.s2, c.t2, hid, stream));
+    CK(v100_bn_eval_coeffs((const float*)P[10], (const float*)P[11], (const float*)P[12], (const float*)P[13], kEps, c.s3, c.t3, cout, stream));
+    return V100_OK;
+}
+// ptrs: 0 x | 1 w1 2 wd 3 w3 | 4 cache | 5 h1 [B,hid,T] 6 h2 [B,hid,T2] 7 y [B,cout,T2]
+extern "C" int v100_ir_fwd_eval(const int* sh, const void* const* P, void* stream) {
+    if (!sh || !P) return V100_ERR_NULL;
+    const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T], K = sh[IR_K], S = sh[IR_STRIDE];
+    const int res = sh[IR_RES], bf = sh[IR_BF16];
+    const int pad = (K - 1) / 2, T2 = conv_out(T, K, S);
+    const float* x = (const float*)P[0];
+    IrEvalCache c;
+    ir_eval_carve(sh, const_cast<void*>(P[4]), c);
+    float *h1 = (float*)P[5], *h2 = (float*)P[6], *y = (float*)P[7];
+    int rc;
+    CK(v100_pw_gemm((const float*)P[1], c.w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, h1, nullptr, c.s1, c.t1, nullptr, 2, nullptr, B, hid, cin, T, bf, stream));
+    CK(v100_dwconv(h1, nullptr, (const float*)P[2], nullptr, nullptr, nullptr, 0, h2, nullptr, c.s2, c.t2, 1, nullptr, v100_dw_num_groups(B, hid),
+                   B, hid, T, T2, K, S, pad, 0, 1, 0, stream));
+    CK(v100_pw_gemm((const float*)P[3], c.w3bf, h2, nullptr, nullptr, nullptr, nullptr, 0, y, nullptr, c.s3, c.t3, res ? x : nullptr, 3, nullptr, B, cout, hid, T2, bf, stream));
     return V100_OK;
 }
 

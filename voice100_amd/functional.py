@@ -194,6 +194,35 @@ def prepared_weights_of(blk, precision: Optional[str] = None):
     return None
 
 
+def inverted_residual_eval_cached(blk, x, precision: Optional[str] = None):
+    """Eval-mode InvertedResidual through the block executor: the folded BatchNorm coefficients and bf16 weight copies
+    are cached on the module (refilled when any parameter / running statistic changes: tensor versions are the key),
+    so a forward is one host call = 3 kernel launches.  Inference only (no autograd)."""
+    _check(x, "InvertedResidual")
+    x = x.contiguous()
+    pw, dw, pl, bn3 = blk.conv[0], blk.conv[1], blk.conv[2], blk.conv[3]
+    bn1, bn2 = pw[1], dw[1]
+    w1, wd, w3 = pw[0].weight, dw[0].weight, pl.weight
+    bf16 = (precision or _PRECISION) == "bf16"
+    B, cin, T = x.shape
+    hid, cout, k = w1.shape[0], w3.shape[0], int(blk.kernel_size)
+    T2 = conv_out_len(T, k, blk.stride)
+    shape = (ctypes.c_int * 10)(B, cin, hid, cout, T, k, int(blk.stride), int(bool(blk.use_residual)), int(bf16), 0)
+    params = (w1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
+              w3, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var)
+    key = (bf16,) + tuple((t.data_ptr(), t._version) for t in params) + (wd.data_ptr(), wd._version)
+    if getattr(blk, "_eval_key", None) != key:
+        for t in params + (wd,):
+            if not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors (no CPU fallback)")
+        cache = torch.empty(N.helper("v100_ir_eval_cache_bytes", shape), dtype=torch.uint8, device=x.device)
+        N.call("v100_ir_eval_prep", shape, _ptr_table(tuple(t.detach() for t in params) + (cache,)))
+        blk._eval_cache, blk._eval_key = cache, key
+    h1, h2, y = _f32(B, hid, T, like=x), _f32(B, hid, T2, like=x), _f32(B, cout, T2, like=x)
+    N.call("v100_ir_fwd_eval", shape, _ptr_table((x, w1.detach(), wd.detach(), w3.detach(), blk._eval_cache, h1, h2, y)))
+    return y
+
+
 def inverted_residual_eval(x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3,
                            kernel_size, stride, use_residual, precision):
     """Eval-mode InvertedResidual: BatchNorm folded to per-channel scale/shift inside the three kernels."""

@@ -69,11 +69,7 @@ class InvertedResidual(nn.Module):
         # eval mode: frozen statistics, inference only (autograd through eval-mode BN is not on the
         # reference's training path and is not built)
         with torch.no_grad():
-            return F_.inverted_residual_eval(
-                x, pw[0].weight, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
-                dw[0].weight, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
-                pl.weight, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var,
-                self.kernel_size, self.stride, self.use_residual, prec)
+            return F_.inverted_residual_eval_cached(self, x, prec)
 
 
 class PointwiseConv1d(nn.Conv1d):
