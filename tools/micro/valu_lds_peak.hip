@@ -92,6 +92,58 @@ static void run_pipe(const char* name, int wgs_per_cu, float* out) {
     printf("pipelined %-34s wgs/cu=%d  %8.1f us  %7.1f TFLOP/s\n", name, wgs_per_cu, ms * 1e3, flop / (ms * 1e-3) / 1e12);
 }
 
+// bf16 dot2 variant of the same pipelined loop: one v_dot2c_f32_bf16 = two MACs per lane (bf16 pairs, fp32 accumulate).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+template <int R, int TAPS>
+__global__ __launch_bounds__(256) void probe_dot2(float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = 1e-9f * i;
+    __syncthreads();
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = threadIdx.x * 1e-3f + r;
+    const float* pw = lds + (threadIdx.x & 63) * 8;
+    const float* pb = lds + 2048;
+    f32x4 a = *reinterpret_cast<const f32x4*>(pw), w = *reinterpret_cast<const f32x4*>(pb);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 an = *reinterpret_cast<const f32x4*>(pw + 4 * ((it + u + 1) & 255));
+            f32x4 wn = w;
+            if (TAPS) wn = *reinterpret_cast<const f32x4*>(pb + 4 * ((it + u + 1) & 255));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    acc[r] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w[(e + r) & 3]), __builtin_bit_cast(bf16x2_t, a[e]), acc[r], false);
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acc[r]));
+            __builtin_amdgcn_sched_barrier(0);
+            a = an; w = wn;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) s += acc[r];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int R, int TAPS>
+static void run_dot2(const char* name, int wgs_per_cu, float* out) {
+    const int iters = 4000 * 8 / R, grid = 256 * wgs_per_cu;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((probe_dot2<R, TAPS>), dim3(grid), dim3(256), 0, 0, out, 100);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((probe_dot2<R, TAPS>), dim3(grid), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double macs = 2.0 * 256 * 8 * 4 * R * (double)iters * grid;     // 2 MACs per dot2
+    printf("dot2 bf16 %-34s wgs/cu=%d  %8.1f us  %7.1f TMAC-FLOP/s (2 flop per MAC)\n", name, wgs_per_cu, ms * 1e3, 2.0 * macs / (ms * 1e-3) / 1e12);
+}
+
 template <int NLDS, int PAD>
 static void run(const char* name, int wgs_per_cu, float* out, long long* cyc) {
     const int iters = 4000, grid = 256 * wgs_per_cu;
@@ -126,6 +178,11 @@ int main() {
         run_pipe<16, 1>("R=16 window+taps (2 reads/64 FMA)", w, out);
         run_pipe<16, 0>("R=16 window only (1 read/64 FMA)", w, out);
         run_pipe<32, 1>("R=32 window+taps (2 reads/128 FMA)", w, out);
+    }
+    for (int w : {3, 4, 8}) {
+        run_dot2<8, 1>("R=8  window+taps (2 reads/32 dot2)", w, out);
+        run_dot2<8, 0>("R=8  window only", w, out);
+        run_dot2<16, 1>("R=16 window+taps", w, out);
     }
     return 0;
 }
