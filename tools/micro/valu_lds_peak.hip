@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, long long* c
 
 // Software-pipelined like the depthwise kernel: chunk u+1's window (and tap) reads are issued before chunk u's FMAs.
 // R = outputs per lane: 4*R FMAs per chunk; TAPS = 1 streams a tap chunk next to every window chunk.
-template <int R, int TAPS>
+template <int R, int TAPS, int LSTRIDE = 8>
 __global__ __launch_bounds__(256) void probe_pipe(float* out, int iters) {
     __shared__ __attribute__((aligned(16))) float lds[4096];
     for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = 1e-9f * i;
@@ -51,13 +51,15 @@ __global__ __launch_bounds__(256) void probe_pipe(float* out, int iters) {
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = threadIdx.x * 1e-3f + r;
-    const float* pw = lds + (threadIdx.x & 63) * 8;
+    // lane stride of the window reads in floats: 8 = the depthwise kernel's R (2-way bank conflict inside the hardware's
+    // 16-lane ds_read_b128 groups), 12 = padded (conflict-free)
+    const float* pw = lds + (threadIdx.x & 63) * LSTRIDE;
     const float* pb = lds + 2048;
     f32x4 a = *reinterpret_cast<const f32x4*>(pw), w = *reinterpret_cast<const f32x4*>(pb);
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const f32x4 an = *reinterpret_cast<const f32x4*>(pw + 4 * ((it + u + 1) & 255));
+            const f32x4 an = *reinterpret_cast<const f32x4*>(pw + 4 * ((it + u + 1) & 127));
             f32x4 wn = w;
             if (TAPS) wn = *reinterpret_cast<const f32x4*>(pb + 4 * ((it + u + 1) & 255));
 #pragma unroll
@@ -76,15 +78,15 @@ __global__ __launch_bounds__(256) void probe_pipe(float* out, int iters) {
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int R, int TAPS>
+template <int R, int TAPS, int LSTRIDE = 8>
 static void run_pipe(const char* name, int wgs_per_cu, float* out) {
     const int iters = 4000 * 8 / R, grid = 256 * wgs_per_cu;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((probe_pipe<R, TAPS>), dim3(grid), dim3(256), 0, 0, out, 100);
+    hipLaunchKernelGGL((probe_pipe<R, TAPS, LSTRIDE>), dim3(grid), dim3(256), 0, 0, out, 100);
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((probe_pipe<R, TAPS>), dim3(grid), dim3(256), 0, 0, out, iters);
+    hipLaunchKernelGGL((probe_pipe<R, TAPS, LSTRIDE>), dim3(grid), dim3(256), 0, 0, out, iters);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -174,6 +176,8 @@ int main() {
     }
     for (int w : {3, 4, 6, 8}) {
         run_pipe<8, 1>("R=8  window+taps (2 reads/32 FMA)", w, out);
+        run_pipe<8, 1, 12>("R=8  window+taps, lane stride 12", w, out);
+        run_pipe<8, 0, 12>("R=8  window only, lane stride 12", w, out);
         run_pipe<8, 0>("R=8  window only (1 read/32 FMA)", w, out);
         run_pipe<16, 1>("R=16 window+taps (2 reads/64 FMA)", w, out);
         run_pipe<16, 0>("R=16 window only (1 read/64 FMA)", w, out);
