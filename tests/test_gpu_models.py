@@ -199,3 +199,48 @@ def test_streaming_pipeline_config5(cuda):
     assert rel_err(feats, ref_feats) < 1e-4 and rel_err(logits, ref_logits) < 2e-4
     for b in range(4):
         assert ids[b, :int(n[b])].cpu().tolist() == intops.merge_repeated_ids(ref_logits[b].argmax(-1).tolist())
+
+
+def test_rccl_gradient_exchange_single_rank(cuda):
+    """The bucketed all-reduce path (post-accumulate hooks -> flat buffer -> async RCCL all-reduce -> mean) on the
+    real backend: a one-rank "nccl" (= RCCL) group on this GPU.  Gradients and the parameter update must equal the
+    plain single-process step.  (The driver's multi-GPU bench is otherwise the first time this path meets a GPU.)"""
+    import os
+    import torch.distributed as dist
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd.dist import FlatGradBuckets
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        torch.manual_seed(3)
+        m1 = AudioToTextCTC(64, 32, 29, 32).to(cuda)
+        m2 = AudioToTextCTC(64, 32, 29, 32).to(cuda)
+        m2.load_state_dict(m1.state_dict())
+        for m in (m1, m2):
+            m.train()
+            m.batch_augment.do_timestretch = False
+        g = torch.Generator().manual_seed(5)
+        audio = torch.randn(4, 96, 64, generator=g).to(cuda)
+        batch = ((audio, torch.full((4,), 96, dtype=torch.int32, device=cuda)),
+                 (torch.randint(1, 29, (4, 10), generator=g).to(cuda), torch.full((4,), 10, dtype=torch.int32, device=cuda)))
+        import random
+        grads = []
+        for m, force in ((m1, False), (m2, True)):
+            random.seed(11); torch.manual_seed(11)
+            buckets = FlatGradBuckets(m.parameters(), bucket_bytes=1 << 16, force_exchange=force)
+            assert buckets.exchange == force
+            buckets.begin_step()
+            m.training_step(batch, 0).backward()
+            buckets.finish_step()
+            grads.append({k: p.grad.detach().clone() for k, p in m.named_parameters()})
+            buckets.remove_hooks()
+        assert len(grads[1]) == len(grads[0]) > 0
+        for k in grads[0]:
+            assert torch.equal(grads[0][k], grads[1][k]), k
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -30,7 +30,8 @@ class FlatGradBuckets:
     gradients stay where autograd put them (no extra kernels on the step).
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 16 << 20, process_group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 16 << 20, process_group=None,
+                 force_exchange: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -39,7 +40,9 @@ class FlatGradBuckets:
             raise ValueError("parameters must share one device and dtype")
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev) if self.world > 1 else None
+        # force_exchange: run the bucket / all-reduce machinery even in a group of one (tests of the RCCL path on one GPU)
+        self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev) if self.exchange else None
         order = list(reversed(self.params))
         self._bucket_of = {}
         self.buckets = []          # (start, end, [params])
@@ -60,7 +63,7 @@ class FlatGradBuckets:
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._hooks = []
-        if self.world > 1:
+        if self.exchange:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.begin_step()
@@ -91,7 +94,7 @@ class FlatGradBuckets:
 
     def finish_step(self):
         """Wait for the exchange and turn the sum into DDP's mean.  Call after backward."""
-        if self.world == 1:
+        if not self.exchange:
             return
         for b in range(len(self.buckets)):
             if self._pending[b] >= 0:          # some parameter of this bucket produced no gradient this step
