@@ -244,3 +244,51 @@ def test_rccl_gradient_exchange_single_rank(cuda):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_config4_phone_vocab(cuda):
+    """BASELINE configs[3]: asr_en_phone_base = the same network with the 71-symbol CMU vocabulary (text.py:19-31),
+    32 utterances per rank.  Reduced width against the CPU oracle (forward, CTC loss, gradients), then the full-size
+    per-rank step as a property check (shapes, finiteness, every parameter receives a gradient)."""
+    from oracle import cnn
+    from voice100_amd.asr import AudioToTextCTC
+    torch.manual_seed(71)
+    m = AudioToTextCTC(audio_size=64, embed_size=32, vocab_size=71, hidden_size=32)
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(71)
+    audio = torch.randn(3, 120, 64, generator=g) * 2 - 4
+    audio_len = torch.tensor([120, 97, 64], dtype=torch.int32)
+    text = torch.randint(1, 71, (3, 12), generator=g)
+    text_len = torch.tensor([12, 9, 5], dtype=torch.int32)
+    params = {k: v.clone().requires_grad_(True) for k, v in state.items() if v.dtype.is_floating_point and "running" not in k}
+    st = dict(state); st.update(params)
+    ref_logits = cnn.audio_to_text_ctc_forward(audio, st, training=True)
+    ref_loss = cnn.ctc_loss_from_logits(ref_logits, audio_len, text, text_len)
+    ref_loss.backward()
+
+    m = m.to(cuda).train()
+    m.decoder.layers[0].p = 0.0
+
+    class NoAug(torch.nn.Module):
+        def forward(self, a, l):
+            return a, l
+    m.batch_augment = NoAug()
+    batch = ((audio.to(cuda), audio_len.to(cuda)), (text.to(cuda), text_len.to(cuda)))
+    loss = m.training_step(batch, 0)
+    loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    assert_grads_close({k: p.grad for k, p in m.named_parameters()}, {k: params[k].grad for k, _ in m.named_parameters()}, 2e-3)
+
+    big = AudioToTextCTC(audio_size=64, embed_size=512, vocab_size=71, hidden_size=512).to(cuda).train()
+    assert big.decoder.layers[1].weight.shape == (71, 512, 1)
+    a = torch.randn(32, 1024, 64, device=cuda) * 2 - 4
+    lens = torch.full((32,), 1024, dtype=torch.int32, device=cuda)
+    tx = torch.randint(1, 71, (32, 100), device=cuda)
+    loss = big.training_step(((a, lens), (tx, torch.full((32,), 100, dtype=torch.int32, device=cuda))), 0)
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in big.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    with torch.no_grad():
+        big.eval()
+        assert big(a[:2]).shape == (2, 512, 71)
