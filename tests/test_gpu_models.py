@@ -292,3 +292,28 @@ def test_config4_phone_vocab(cuda):
     with torch.no_grad():
         big.eval()
         assert big(a[:2]).shape == (2, 512, 71)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_loop_reduces_loss(cuda, precision):
+    """End-to-end training on the HIP path (augmentation off, dropout on): forward, fused CTC, backward through the block
+    executors, gradient buckets, fused Adam.  Over-fitting one small batch must drive the loss down."""
+    import random
+    from voice100_amd import functional as F_
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd.trainer import TrainStep
+    random.seed(0); torch.manual_seed(0)
+    F_.set_matmul_precision(precision)
+    try:
+        m = AudioToTextCTC(64, 64, 29, 64, learning_rate=2e-3).to(cuda)
+        m.batch_augment.do_timestretch = False
+        step = TrainStep(m)
+        g = torch.Generator().manual_seed(1)
+        audio = (torch.randn(8, 128, 64, generator=g) * 2 - 4).to(cuda)
+        batch = ((audio, torch.full((8,), 128, dtype=torch.int32, device=cuda)),
+                 (torch.randint(1, 29, (8, 12), generator=g).to(cuda), torch.full((8,), 12, dtype=torch.int32, device=cuda)))
+        losses = [float(step(batch)) for _ in range(60)]
+    finally:
+        F_.set_matmul_precision("fp32")
+    assert all(l == l and l < 1e4 for l in losses)            # finite throughout
+    assert sum(losses[-5:]) / 5 < 0.6 * sum(losses[:5]) / 5, (losses[:5], losses[-5:])
