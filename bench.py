@@ -122,8 +122,11 @@ def main():
 
     # reference: pl.seed_everything(1234), train_asr.py:13 -- seeds python, numpy and torch; the augmentation draws its
     # decisions from python's `random` (audio.py:35-49), so an unseeded run changes which steps are time-stretched
-    random.seed(1234 + rank)
-    np.random.seed(1234 + rank)
+    # Every rank gets the SAME seed, as seed_everything does under Lightning's DDP: identical initial weights (no
+    # broadcast needed) and identical augmentation decisions per step on all ranks (so no rank is the straggler of a
+    # step because it alone drew a long time-stretch); only the synthetic data differs per rank.
+    random.seed(1234)
+    np.random.seed(1234)
     torch.manual_seed(1234)
     model = AudioToTextCTC(N_MEL, 512, VOCAB, 512, learning_rate=1e-3, weight_decay=4e-5).to(device)
     step = TrainStep(model)
