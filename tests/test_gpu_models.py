@@ -317,3 +317,39 @@ def test_training_loop_reduces_loss(cuda, precision):
         F_.set_matmul_precision("fp32")
     assert all(l == l and l < 1e4 for l in losses)            # finite throughout
     assert sum(losses[-5:]) / 5 < 0.6 * sum(losses[:5]) / 5, (losses[:5], losses[-5:])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_weight_caches_follow_the_optimizer(cuda, precision):
+    """Fused optimiser kernels update parameters without bumping tensor versions: the prepared-weight buffers (training)
+    and the eval-mode cache must still see every update.  One block, a large step: outputs must change after the step,
+    and an eval forward after training must match a fresh module loaded with the trained state."""
+    from voice100_amd import functional as F_
+    from voice100_amd.layers import InvertedResidual
+    F_.set_matmul_precision(precision)
+    try:
+        torch.manual_seed(0)
+        blk = InvertedResidual(16, 16, kernel_size=19).to(cuda)
+        stack = [blk]
+        opt = torch.optim.Adam(blk.parameters(), lr=0.05, fused=True)
+        x = torch.randn(2, 16, 64, device=cuda)
+        blk.eval()
+        y_eval0 = blk(x).clone()
+        blk.train()
+        outs = []
+        for _ in range(3):
+            F_.prepare_block_weights(stack)
+            y = blk(x)
+            outs.append(y.detach().clone())
+            opt.zero_grad()
+            y.square().mean().backward()
+            opt.step()
+        assert not torch.allclose(outs[0], outs[1]) and not torch.allclose(outs[1], outs[2])
+        blk.eval()
+        y_eval1 = blk(x)
+        assert not torch.allclose(y_eval0, y_eval1)
+        fresh = InvertedResidual(16, 16, kernel_size=19).to(cuda).eval()
+        fresh.load_state_dict(blk.state_dict())
+        assert rel_err(y_eval1, fresh(x)) < 1e-6
+    finally:
+        F_.set_matmul_precision("fp32")

@@ -154,9 +154,10 @@ class InvertedResidualTrainFn(torch.autograd.Function):
 
 def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
     """bf16 / transposed copies of the two 1x1 weights of every InvertedResidual in `blocks`, in ONE launch
-    (v100_ir_prep_batched), into per-module buffers that the blocks' forward then hands to the executor.  Called by the
-    stacks (ConvVoiceEncoder, VoiceDecoder, ...) at the top of a training-mode forward; a block whose weights changed
-    since (or that was never prepared) simply prepares its own copies as before."""
+    (v100_ir_prep_batched), into per-module buffers that the blocks' next forward hands to the executor.  Called by the
+    stacks (ConvVoiceEncoder, VoiceDecoder, ...) at the top of EVERY training-mode forward: nothing is cached across
+    forwards (weights change under the optimiser, and fused optimiser kernels do not bump tensor versions, so there is no
+    reliable staleness key).  A block that runs without this call prepares its own copies as before."""
     precision = precision or _PRECISION
     bf16 = precision == "bf16"
     todo = []
@@ -164,9 +165,6 @@ def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
         w1, w3 = blk.conv[0][0].weight, blk.conv[2].weight
         if not w1.is_cuda:
             raise RuntimeError("InvertedResidual: parameters must be CUDA tensors (no CPU fallback)")
-        key = (w1.data_ptr(), w3.data_ptr(), w1._version, w3._version, bf16)
-        if getattr(blk, "_prep_key", None) == key:
-            continue
         hid, cin = w1.shape[0], w1.shape[1]
         cout = w3.shape[0]
         shape = (0, cin, hid, cout, 0, 0, 1, 0, int(bf16), 1)
@@ -175,21 +173,21 @@ def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
         if buf is None or buf.numel() != nbytes or buf.device != w1.device:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
             blk._prep_buf = buf
-        todo.append((blk, shape, w1, w3, buf, key))
+        todo.append((blk, shape, w1, w3, buf))
     for i in range(0, len(todo), 32):
         chunk = todo[i:i + 32]
         shapes = (ctypes.c_int * (10 * len(chunk)))(*[v for c in chunk for v in c[1]])
         N.call("v100_ir_prep_batched", shapes, _ptr_table([c[2] for c in chunk]), _ptr_table([c[3] for c in chunk]),
                _ptr_table([c[4] for c in chunk]), len(chunk))
-        for blk, _, _, _, _, key in chunk:
-            blk._prep_key = key
+        for blk, _, _, _, _ in chunk:
+            blk._prep_fresh = bf16          # consumed (once) by the block's next training-mode forward at this precision
 
 
 def prepared_weights_of(blk, precision: Optional[str] = None):
-    """The block's prepared-weights buffer if it matches the current weights (see prepare_block_weights), else None."""
+    """The block's prepared-weights buffer if prepare_block_weights filled it for THIS forward, else None."""
     bf16 = (precision or _PRECISION) == "bf16"
-    w1, w3 = blk.conv[0][0].weight, blk.conv[2].weight
-    if getattr(blk, "_prep_key", None) == (w1.data_ptr(), w3.data_ptr(), w1._version, w3._version, bf16):
+    if getattr(blk, "_prep_fresh", None) is bf16:
+        blk._prep_fresh = None
         return blk._prep_buf
     return None
 

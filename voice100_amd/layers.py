@@ -55,6 +55,13 @@ class InvertedResidual(nn.Module):
         if use_residual and (in_channels != out_channels or stride != 1):
             raise ValueError("use_residual needs in_channels == out_channels and stride == 1")
 
+    def train(self, mode: bool = True):
+        # Any train()/eval() switch drops the eval-mode cache (folded BatchNorm coefficients, bf16 weights): training
+        # updates parameters and running statistics through raw pointers / fused optimiser kernels, which do not bump
+        # the tensor versions the cache is keyed on.
+        self._eval_key = None
+        return super().train(mode)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         pw, dw, pl, bn3 = self.conv[0], self.conv[1], self.conv[2], self.conv[3]
         bn1, bn2 = pw[1], dw[1]
