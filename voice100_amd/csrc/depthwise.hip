@@ -78,6 +78,114 @@ __global__ __launch_bounds__(256) void dwconv_generic_kernel(DwParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward-data of the stride-2 layer (L0 of the encoder, k = 11: asr.py:68): a stride-1 convolution with flipped
+// taps over the upstream gradient zero-stuffed by 2.  Output t only meets the taps j of one parity (those with
+// t - pad + j even), so a lane's 8 consecutive outputs need 12 consecutive upstream samples: three ds_read_b128 of
+// the per-wave staged row (BN-backward affine of (dz2, a2) applied on the way in) and ~5.5 FMAs per output, all with
+// compile-time tap / window indices.  Same epilogue as dwconv_kernel's DW_OUT_MASK_STATS (ReLU6 mask from a1,
+// BN1-backward partial sums).  Memory-bound; replaces the one-thread-per-output generic kernel on the training path.
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_up2_bwd_kernel(DwParams p) {
+    constexpr int R = 8, TILE = 64 * R;              // outputs per wave pass
+    constexpr int PADB = (K - 1) / 2;                // pad of the equivalent stride-1 conv (odd K, symmetric padding)
+    constexpr int WOFF = 4;                          // the lane window starts WOFF samples before t0/2 (16-byte aligned)
+    constexpr int SPAN = TILE / 2 + 12;              // staged samples per tile: [tile*256 - 4, tile*256 + 256 + 8)
+    __shared__ __attribute__((aligned(16))) float lds_all[4][SPAN + 4];
+    __shared__ float lds_w[K];
+    __shared__ float lds_red[4][2];
+    const int c = blockIdx.x, g = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* lds = lds_all[wave];
+    for (int j = threadIdx.x; j < K; j += 256) lds_w[j] = p.w[(size_t)c * K + (K - 1 - j)];     // flipped taps
+    __syncthreads();
+    float wf[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) wf[j] = lds_w[j];
+    const float ca = p.in_a[c], cb = p.in_b[c], cc = p.in_c[c], oa = p.out_a[c], ob = p.out_b[c];
+    const int Tin = p.Tin, Tout = p.Tout;            // Tin: upstream length (forward output), Tout: forward input length
+    const int bper = (p.B + p.G - 1) / p.G;
+    const int b0 = g * bper;
+    const int nb = min(p.B, b0 + bper) - b0;
+    const int ntiles = (Tout + TILE - 1) / TILE;
+    float s0 = 0.f, s1 = 0.f;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int in0 = tile * (TILE / 2) - WOFF;    // upstream index of LDS slot 0
+        for (int bi = wave; bi < nb; bi += 4) {
+            const int b = b0 + bi;
+            const size_t ro = ((size_t)b * p.C + c) * Tin;
+            // stage: SPAN samples, 4 per lane and pass (in0 is a multiple of 4: aligned float4 when Tin % 4 == 0)
+#pragma unroll
+            for (int v = 0; v < (SPAN + 255) / 256; ++v) {
+                const int i = 4 * (lane + 64 * v);
+                if (i < SPAN) {
+                    const int ti0 = in0 + i;
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+                    if (ti0 >= 0 && ti0 + 3 < Tin) {               // whole quad in range: 16-byte (dword-aligned) loads
+                        a = *reinterpret_cast<const f32x4u*>(p.x + ro + ti0);
+                        a2 = *reinterpret_cast<const f32x4u*>(p.x2 + ro + ti0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (ti0 + e >= 0 && ti0 + e < Tin) { a[e] = p.x[ro + ti0 + e]; a2[e] = p.x2[ro + ti0 + e]; }
+                    }
+                    f32x4 val;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = (ti0 + e >= 0 && ti0 + e < Tin) ? fmaf(a[e], ca, fmaf(a2[e], cb, cc)) : 0.f;
+                    *reinterpret_cast<f32x4*>(lds + i) = val;
+                }
+            }
+            // other lanes' LDS stores must precede this lane's window reads: the hardware runs a wave's LDS operations
+            // in order, the compiler (single-thread view: no alias between the two) must not swap them
+            asm volatile("" ::: "memory");
+            const int t0 = tile * TILE + lane * R;
+            const size_t oo = ((size_t)b * p.C + c) * Tout + t0;
+            float auxv[R];
+            dw_load_run<R, true>(auxv, p.aux + oo, t0, Tout);
+            const float* win = lds + lane * (R / 2);                 // = slot of upstream index t0/2 - WOFF
+            f32x4 wv[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) wv[q] = *reinterpret_cast<const f32x4*>(win + 4 * q);
+            float outv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    if (((r - PADB + j) & 1) == 0) {                  // t0 is even: parity of t - pad + j = parity of r - pad + j
+                        const int wi = (r - PADB + j) / 2 + WOFF;      // (negative numerators are even here: exact)
+                        if (wi >= 0 && wi < 12) acc = fmaf(wf[j], wv[wi >> 2][wi & 3], acc);
+                    }
+                }
+                const float pre = fmaf(auxv[r], oa, ob);
+                acc = (pre > 0.f && pre < 6.f) ? acc : 0.f;
+                if (t0 + r < Tout) { s0 += acc; s1 = fmaf(acc, auxv[r], s1); }
+                outv[r] = acc;
+            }
+#pragma unroll
+            for (int q = 0; q < R / 4; ++q) {
+                if (t0 + 4 * q + 3 < Tout) {
+                    f32x4 o = {outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]};
+                    *reinterpret_cast<f32x4u*>(p.y + oo + 4 * q) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (t0 + 4 * q + e < Tout) p.y[oo + 4 * q + e] = outv[4 * q + e];
+                }
+            }
+            asm volatile("" ::: "memory");     // ... and the next row's stores must stay behind this row's reads
+        }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) { lds_red[wave][0] = s0; lds_red[wave][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p.stats[((size_t)g * p.C + c) * 2 + 0] = (lds_red[0][0] + lds_red[1][0]) + (lds_red[2][0] + lds_red[3][0]);
+        p.stats[((size_t)g * p.C + c) * 2 + 1] = (lds_red[0][1] + lds_red[1][1]) + (lds_red[2][1] + lds_red[3][1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward-weight: dW[c][j] = sum_{b,t} g[b,c,t] * xin[b,c,t*S - pad + j].
 // Same staging of xin (with its BN affine + ReLU6 recomputed on the way in); each lane keeps K
 // partial sums in registers across all its tiles and the wave reduces them once at the end.
@@ -119,6 +227,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradParams p) {
     for (; bi < nb; bi += 4) {
         const int b = b0 + bi;
         dw_stage_to_lds<NV, SPAN, DW_IN_AFFINE_RELU6, false>(raw, lds, in0, Tin, xa, xb, 0.f, lane);
+        asm volatile("" ::: "memory");     // cross-lane LDS hand-off: keep stores before the window reads (see dwconv_kernel)
         if (bi + 4 < nb) {
             const unsigned rb = (unsigned)(((size_t)(b + 4) * p.C + c) * Tin * 4);
             dw_issue_loads<NV, SPAN, false, AL>(raw, rx, rx, rb, in0, Tin, lane);
@@ -159,6 +268,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradParams p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        asm volatile("" ::: "memory");
     }
     }   // tile
 #pragma unroll
@@ -256,6 +366,12 @@ extern "C" int v100_dwconv(const float* x, const float* x2, const float* w, cons
         if (in_mode == DW_IN_AFFINE_RELU6 && out_mode == DW_OUT_RAW_STATS) done = dw_launch_fwd_train(p, st, timed);
         else if (in_mode == DW_IN_NONE && out_mode == DW_OUT_AFFINE_RELU6) done = dw_launch_fwd_eval(p, st, timed);
         else if (in_mode == DW_IN_AFFINE2 && out_mode == DW_OUT_MASK_STATS) done = dw_launch_bwd_data(p, st, timed);
+    }
+    // backward-data of the stride-2 first layer: zero-stuffed by 2, flipped taps, symmetric padding
+    if (!done && !force_generic && upsample == 2 && stride == 1 && flip && K == 11 && pad == (K - 1) / 2 && in_mode == DW_IN_AFFINE2 &&
+        out_mode == DW_OUT_MASK_STATS) {
+        V100_LAUNCH(timed, (dwconv_up2_bwd_kernel<11>), dim3(C, G), dim3(256), 0, st, p);
+        done = true;
     }
     if (!done) V100_LAUNCH(timed, dwconv_generic_kernel, dim3(C, G), dim3(256), K * sizeof(float), st, p);
     return v100_launch_status();

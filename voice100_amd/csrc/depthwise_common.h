@@ -218,6 +218,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
     for (; bi < nb; bi += 4) {
         const int b = b0 + bi;
         dw_stage_to_lds<NV, SPAN, IM, TWO>(raw, lds, in0, Tin, ca, cb, cc, lane);
+        // Cross-lane hand-off through LDS inside one wave: the hardware runs a wave's LDS operations in order, but the
+        // compiler sees one thread, finds no alias between this lane's stores and its window reads, and may swap
+        // them (it did in dwconv_up2_bwd_kernel).  A compiler-only barrier keeps program order; it emits nothing.
+        asm volatile("" ::: "memory");
 
         // prefetch the next row's input while this one computes
         if (bi + 4 < nb) {
@@ -319,6 +323,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
             for (int r = 0; r < R; ++r)
                 if (t0 + r < Tout) p.y[oo + r] = outv[r];
         }
+        asm volatile("" ::: "memory");     // the next row's LDS stores stay behind this row's window reads
     }
     }   // tile
 
