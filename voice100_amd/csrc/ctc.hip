@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");       // wave-local LDS hand-off between lanes: keep program order for the compiler too
     if (m > NEG_INF) {
         for (int s = lane; s < S; s += 64) {
             int c = (s & 1) ? (int)tg[s >> 1] : blank;
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         }
     }
     __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");       // wave-local LDS hand-off between lanes: keep program order for the compiler too
     const float z = lse[(size_t)b * T + t];
     const float* lg = logits + ((size_t)b * T + t) * V;
     for (int c = lane; c < V; c += 64) {
