@@ -69,8 +69,9 @@ int v100_dwconv_bwd(const float* g, const float* g2, const float* w, const float
  * tts.py:26,77 (heads); with A = W^T it is their backward-data.
  * epi_mode: 0 store   1 store + stats(sum, sum^2)   2 clamp(y*ea+eb,0,6)   3 y*ea+eb (+R)
  *           4 y *= [0 < R*ea+eb < 6] + stats(sum y, sum y*R)   5 y + R
- * stats: [v100_pw_num_parts(B,T)][M][2].  use_bf16: operands rounded to bf16 (A_bf16 = bf16 copy of A),
- * fp32 accumulate; 0 = exact fp32 MFMA. */
+ * stats: [v100_pw_num_parts(B,T)][M][2].  use_bf16: 1 = operands rounded to bf16 (A_bf16 = bf16 copy of A), fp32
+ * accumulate; 2 = IEEE fp16 operands (A_bf16 = fp16 copy, v100_weight_prep_f16), inference combinations only
+ * (x_mode 0 with epi_mode 0 / 2 / 3, anything else returns the shape status); 0 = exact fp32 MFMA. */
 int v100_pw_num_parts(int B, int T);
 int v100_pw_gemm(const float* A, const void* A_bf16, const float* X, const float* X2, const float* xa,
                  const float* xb, const float* xc, int x_mode, float* Y, const float* bias, const float* ea,
@@ -86,6 +87,8 @@ int v100_pw_wgrad(const float* G, const float* G2, const float* ga, const float*
 
 /* fp32 [rows][cols] weight -> optional bf16 copy, transposed fp32 copy, transposed bf16 copy. */
 int v100_weight_prep(const float* w, int rows, int cols, void* w_bf16, float* wt, void* wt_bf16, void* stream);
+/* w16[i] = IEEE half(w[i]): the weight copy of the fp16 inference precision (use_bf16 = 2 below) */
+int v100_weight_prep_f16(const float* w, int rows, int cols, void* w16, void* stream);
 
 /* ---- K3 BatchNorm1d (asr.py:36,52; eps 1e-5, momentum 0.1) ----------------------------------
  * finalize_train: slab of (sum x, sum x^2) -> scale = gamma*rstd, shift = beta - mean*scale, saved

@@ -353,3 +353,39 @@ def test_weight_caches_follow_the_optimizer(cuda, precision):
         assert rel_err(y_eval1, fresh(x)) < 1e-6
     finally:
         F_.set_matmul_precision("fp32")
+
+
+def test_fp16_inference_precision(cuda):
+    """'fp16' = IEEE half MFMA operands for inference (BASELINE config 5 names fp16).  Eval forward of the ASR model and
+    the TTS audio model against the fp32 path (fp16 has 3 more mantissa bits than bf16: tighter than the bf16 bar);
+    training under it is refused."""
+    from voice100_amd import functional as F_
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd.tts import AlignTextToAudioModel
+    torch.manual_seed(5)
+    asr = AudioToTextCTC(64, 64, 29, 64).to(cuda).eval()
+    tts = AlignTextToAudioModel(vocab_size=29, hidden_size=64, use_mcep=False).to(cuda).eval()
+    audio = torch.randn(3, 101, 64, device=cuda) * 2 - 4
+    at = torch.randint(0, 29, (2, 40), device=cuda)
+    with torch.no_grad():
+        ref_a = asr(audio)
+        ref_t = tts(at)
+        errs = {}
+        for prec in ("fp16", "bf16"):
+            F_.set_matmul_precision(prec)
+            try:
+                ya = asr(audio)
+                yt = tts(at)
+            finally:
+                F_.set_matmul_precision("fp32")
+            errs[prec] = (rel_err(ya, ref_a), max(rel_err(a, b) for a, b in zip(yt, ref_t)))
+    assert errs["fp16"][0] < 5e-3 and errs["fp16"][1] < 5e-3, errs
+    assert errs["fp16"][0] < errs["bf16"][0] and errs["fp16"][1] < errs["bf16"][1], errs     # and better than bf16
+    F_.set_matmul_precision("fp16")
+    try:
+        asr.train()
+        with pytest.raises(RuntimeError):
+            asr(audio)
+    finally:
+        F_.set_matmul_precision("fp32")
+        asr.eval()

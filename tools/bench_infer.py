@@ -32,7 +32,7 @@ def timeit(fn, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--iters", type=int, default=50)
     args = ap.parse_args()
     dev = torch.device("cuda:0")

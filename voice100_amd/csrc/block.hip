@@ -71,6 +71,7 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
     if (!sh || !P) return V100_ERR_NULL;
     const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T], K = sh[IR_K], S = sh[IR_STRIDE];
     const int res = sh[IR_RES], bf = sh[IR_BF16];
+    if (bf != 0 && bf != 1) return V100_ERR_SHAPE;            // training: fp32 or bf16 operands (fp16 = inference only)
     const int pad = (K - 1) / 2, T2 = conv_out(T, K, S);
     const float* x = (const float*)P[0];
     const float* w1 = (const float*)P[1]; const float* wd = (const float*)P[7]; const float* w3 = (const float*)P[13];
@@ -204,7 +205,10 @@ extern "C" int v100_ir_eval_prep(const int* sh, const void* const* P, void* stre
     IrEvalCache c;
     ir_eval_carve(sh, const_cast<void*>(P[14]), c);
     int rc;
-    if (sh[IR_BF16]) {
+    if (sh[IR_BF16] == 2) {                                   // fp16 operands
+        CK(v100_weight_prep_f16((const float*)P[0], hid, cin, c.w1bf, stream));
+        CK(v100_weight_prep_f16((const float*)P[9], cout, hid, c.w3bf, stream));
+    } else if (sh[IR_BF16]) {
         CK(v100_weight_prep((const float*)P[0], hid, cin, c.w1bf, nullptr, nullptr, stream));
         CK(v100_weight_prep((const float*)P[9], cout, hid, c.w3bf, nullptr, nullptr, stream));
     }

@@ -59,4 +59,26 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return r;
 }
 
+// 16-bit operand formats of the MFMA GEMMs: bf16 (training + inference) or IEEE fp16 (inference), fp32 accumulate
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <bool F16>
+__device__ __forceinline__ unsigned pack16(float lo, float hi) {
+    if constexpr (F16) {
+        const f16x2 h = {(_Float16)lo, (_Float16)hi};            // round to nearest even (v_cvt_f16_f32 x2 + v_pack_b32_f16)
+        return __builtin_bit_cast(unsigned, h);
+    } else {
+        return pack_bf16(lo, hi);
+    }
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ u16 f2h(float f) {
+    const _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(u16, h);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -21,6 +21,7 @@
 
 void pw_launch_gemm_f32(const PwParams& p, dim3 grid, hipStream_t st);
 void pw_launch_gemm_bf16(const PwParams& p, dim3 grid, hipStream_t st);
+bool pw_launch_gemm_f16(const PwParams& p, dim3 grid, hipStream_t st);
 void pw_launch_wgrad_f32(const WgParams& p, dim3 grid, hipStream_t st);
 void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st);
 
@@ -35,14 +36,14 @@ __global__ void pw_slab_reduce_kernel(const float* __restrict__ partial, float* 
 
 // fp32 [rows][cols] -> bf16 [rows][cols] and/or transposed copies (weights are tiny: <= 1M elements)
 __global__ void weight_prep_kernel(const float* __restrict__ w, int rows, int cols, u16* __restrict__ w_bf,
-                                   float* __restrict__ wt, u16* __restrict__ wt_bf) {
+                                   float* __restrict__ wt, u16* __restrict__ wt_bf, int f16) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)rows * cols) return;
     const int r = (int)(i / cols), c = (int)(i % cols);
     const float v = w[i];
-    if (w_bf) w_bf[i] = f2bf(v);
+    if (w_bf) w_bf[i] = f16 ? f2h(v) : f2bf(v);
     if (wt) wt[(size_t)c * rows + r] = v;
-    if (wt_bf) wt_bf[(size_t)c * rows + r] = f2bf(v);
+    if (wt_bf) wt_bf[(size_t)c * rows + r] = f16 ? f2h(v) : f2bf(v);
 }
 
 extern "C" int v100_pw_num_parts(int B, int T) { return B * ceil_div(T, PW_BN); }
@@ -61,7 +62,17 @@ extern "C" int v100_weight_prep(const float* w, int rows, int cols, void* w_bf, 
     if (rows <= 0 || cols <= 0) return V100_ERR_SHAPE;
     const long n = (long)rows * cols;
     hipLaunchKernelGGL(weight_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, rows, cols,
-                       (u16*)w_bf, wt, (u16*)wt_bf);
+                       (u16*)w_bf, wt, (u16*)wt_bf, 0);
+    return v100_launch_status();
+}
+
+// fp16 copy of a weight (inference precision "fp16"): w16[i] = half(w[i])
+extern "C" int v100_weight_prep_f16(const float* w, int rows, int cols, void* w16, void* stream) {
+    if (!w || !w16) return V100_ERR_NULL;
+    if (rows <= 0 || cols <= 0) return V100_ERR_SHAPE;
+    const long n = (long)rows * cols;
+    hipLaunchKernelGGL(weight_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, rows, cols,
+                       (u16*)w16, (float*)nullptr, (u16*)nullptr, 1);
     return v100_launch_status();
 }
 
@@ -79,13 +90,15 @@ extern "C" int v100_pw_gemm(const float* A, const void* A_bf16, const float* X, 
     if ((epi_mode == PW_EPI_MASK_STATS || epi_mode == PW_EPI_ADD) && !R) return V100_ERR_NULL;
     if ((epi_mode == PW_EPI_STATS || epi_mode == PW_EPI_MASK_STATS) && !stats) return V100_ERR_NULL;
     const int nmt = ceil_div(M, PW_BM), ntt = ceil_div(T, PW_BN);
-    PwParams p{A, (const u16*)A_bf16, X, X2, xa, xb, xc, Y, bias, ea, eb, R, stats, B, M, K, T, x_mode, epi_mode, nmt, ntt};
+    if (use_bf16 < 0 || use_bf16 > 2) return V100_ERR_SHAPE;
+    PwParams p{A, (const u16*)A_bf16, X, X2, xa, xb, xc, Y, bias, ea, eb, R, stats, B, M, K, T, x_mode, epi_mode, nmt, ntt, use_bf16};
     const long nwg = (long)nmt * ntt * B;
     if (nwg > 0x7fffffffL) return V100_ERR_SHAPE;
     dim3 grid((unsigned)nwg);
     hipStream_t st = (hipStream_t)stream;
     V100TimedRegion timed(V100_T_PW_GEMM, st);
-    if (use_bf16) pw_launch_gemm_bf16(p, grid, st);
+    if (use_bf16 == 2) { if (!pw_launch_gemm_f16(p, grid, st)) return V100_ERR_SHAPE; }     // fp16: inference combinations only
+    else if (use_bf16) pw_launch_gemm_bf16(p, grid, st);
     else pw_launch_gemm_f32(p, grid, st);
     return v100_launch_status();
 }

@@ -46,7 +46,7 @@ __device__ __forceinline__ uint4 mask8bf(uint4 v, int k, int K, bool row_ok) {
     return uint4{w[0], w[1], w[2], w[3]};
 }
 
-template <int XM_, int EPI_, bool TV, bool KV>
+template <int XM_, int EPI_, bool TV, bool KV, bool F16 = false>
 __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(PwParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char As[2][128 * 128];   // [m][k] bf16, 16 KB per buffer
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][128 * 128];   // [t][k] bf16
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(PwParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint4 o;
-            o.x = pack_bf16(v[0][q], v[1][q]); o.y = pack_bf16(v[2][q], v[3][q]);
-            o.z = pack_bf16(v[4][q], v[5][q]); o.w = pack_bf16(v[6][q], v[7][q]);
+            o.x = pack16<F16>(v[0][q], v[1][q]); o.y = pack16<F16>(v[2][q], v[3][q]);
+            o.z = pack16<F16>(v[4][q], v[5][q]); o.w = pack16<F16>(v[6][q], v[7][q]);
             *reinterpret_cast<uint4*>(&Bs[buf][bf_off(b_tq + q, b_kc)]) = o;
         }
     };
@@ -135,10 +135,10 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(PwParams p) {
             const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[cur][bf_off(wm * 64 + 32 + lr, ch)]);
             const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[cur][bf_off(wn * 64 + lr, ch)]);
             const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[cur][bf_off(wn * 64 + 32 + lr, ch)]);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            acc[0][0] = mfma16<F16>(a0, b0, acc[0][0]);
+            acc[0][1] = mfma16<F16>(a0, b1, acc[0][1]);
+            acc[1][0] = mfma16<F16>(a1, b0, acc[1][0]);
+            acc[1][1] = mfma16<F16>(a1, b1, acc[1][1]);
         }
         // ... and first USED after it: without this fence hipcc hoists the staging arithmetic (and the
         // vmcnt wait it needs) above the MFMAs, which exposes the whole memory latency every k-step.
@@ -165,7 +165,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <int XM, int EPI, int BM>
+template <int XM, int EPI, int BM, bool F16 = false>
 __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     // BM x 128 block tile, BM/64 x 2 waves of 64x64.  BM = 256 (8 waves, one block per CU) halves the L2 traffic of
     // the X operand, which is what bounds these GEMMs (each X tile is re-read by every M-tile); BM = 128 for M <= 128.
@@ -259,11 +259,11 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         unsigned char* dst = Bs + buf * (128 * 128) + ldsB[q];
         if constexpr (KPT == 8) {
             u32x4 o;
-            o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
+            o[0] = pack16<F16>(v[0], v[1]); o[1] = pack16<F16>(v[2], v[3]); o[2] = pack16<F16>(v[4], v[5]); o[3] = pack16<F16>(v[6], v[7]);
             *reinterpret_cast<u32x4*>(dst) = o;
         } else {
             uint2 o;
-            o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]);
+            o.x = pack16<F16>(v[0], v[1]); o.y = pack16<F16>(v[2], v[3]);
             *reinterpret_cast<uint2*>(dst) = o;
         }
     };
@@ -301,10 +301,10 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
             b0 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + co);
             b1 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + 32 * 128 + co);
         }
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        acc[0][0] = mfma16<F16>(a0, b0, acc[0][0]);
+        acc[0][1] = mfma16<F16>(a0, b1, acc[0][1]);
+        acc[1][0] = mfma16<F16>(a1, b0, acc[1][0]);
+        acc[1][1] = mfma16<F16>(a1, b1, acc[1][1]);
     };
     auto mfma_block = [&](int cur) {
 #pragma unroll
@@ -702,6 +702,30 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
 // use; everything else goes to the generic instantiation (run-time modes, scalar-safe loads).
 #define PW_NN_COMBOS(X) X(0, 0) X(0, 1) X(1, 1) X(0, 2) X(0, 3) X(0, 4) X(2, 0) X(2, 5)
 #define PW_WG_COMBOS(X) X(0, 0) X(0, 1) X(2, 0)
+
+// fp16 operands (inference): the forward combinations only -- plain / bias (heads, ConvTranspose, dense conv), folded
+// BN+ReLU6, folded BN(+residual).  false = this combination has no fp16 instantiation.
+bool pw_launch_gemm_f16(const PwParams& p, dim3 grid, hipStream_t st) {
+    if (p.x_mode != PW_X_NONE) return false;
+    const bool tv = (p.T & 3) == 0, kv = (p.K & 7) == 0;
+    const bool full = (p.K & 1) == 0 && (long)(p.K + 64) * p.T * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL &&
+                      (long)p.B * p.M * p.T * 4 < 0x7fffff00L;
+    const bool big = full && p.M >= 256;
+    PwParams pb = p;
+    pb.n_mtiles = (p.M + 255) / 256;
+    const dim3 gridb((unsigned)((long)pb.n_mtiles * p.n_ttiles * p.B));
+#define X(EP)                                                                                                           \
+    if (p.epi_mode == EP) {                                                                                             \
+        if (big) hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<0, EP, 256, true>), gridb, dim3(512), 0, st, pb);        \
+        else if (full) hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<0, EP, 128, true>), grid, dim3(256), 0, st, p);     \
+        else if (tv && kv) hipLaunchKernelGGL((pw_gemm_bf16_kernel<0, EP, true, true, true>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((pw_gemm_bf16_kernel<0, EP, false, false, true>), grid, dim3(256), 0, st, p);           \
+        return true;                                                                                                    \
+    }
+    X(0) X(2) X(3)
+#undef X
+    return false;
+}
 
 void pw_launch_gemm_bf16(const PwParams& p_in, dim3 grid_in, hipStream_t st) {
     const PwParams& p = p_in;

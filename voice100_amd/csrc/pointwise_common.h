@@ -43,6 +43,7 @@ struct PwParams {
     const float* R;       // [B][M][T] residual / pre-activation tensor
     float* stats;         // [B * n_ttiles][M][2]
     int B, M, K, T, x_mode, epi_mode, n_mtiles, n_ttiles;
+    int fmt;              // 16-bit operand format of the bf16-path kernels: 1 bf16, 2 fp16 (inference combinations only)
 };
 
 __device__ __forceinline__ float pw_x_transform(int mode, float v, float v2, float a, float b, float c) {

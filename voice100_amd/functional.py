@@ -27,11 +27,26 @@ _PRECISION = "fp32"
 
 
 def set_matmul_precision(p: str) -> None:
-    """"fp32" (default, parity path) or "bf16" (throughput path) for the 1x1 GEMMs."""
+    """Operand format of the MFMA GEMMs: "fp32" (default, exact fp32, the parity path), "bf16" (throughput path,
+    training and inference) or "fp16" (IEEE half operands, inference only: BASELINE config 5)."""
     global _PRECISION
-    if p not in ("fp32", "bf16"):
-        raise ValueError("precision must be 'fp32' or 'bf16'")
+    if p not in ("fp32", "bf16", "fp16"):
+        raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
     _PRECISION = p
+
+
+def _fmt(precision: Optional[str]) -> int:
+    """0 fp32, 1 bf16, 2 fp16 -- the `use_bf16` value of the C ABI (truthy for both 16-bit formats)."""
+    precision = precision or _PRECISION
+    try:
+        return {"fp32": 0, "bf16": 1, "fp16": 2}[precision]
+    except KeyError:
+        raise ValueError(f"unknown precision {precision!r}") from None
+
+
+def _no_fp16_training(fmt: int, what: str):
+    if fmt == 2:
+        raise RuntimeError(f"{what}: 'fp16' is an inference precision (no gradient kernels); train with 'bf16' or 'fp32'")
 
 
 def get_matmul_precision() -> str:
@@ -56,14 +71,25 @@ def conv_out_len(t: int, k: int, stride: int) -> int:
 
 
 class _Weights:
-    """fp32 [M, K] weight plus the copies a step needs (bf16 and/or transposed)."""
+    """fp32 [M, K] weight plus the copies a step needs (16-bit and/or transposed).  fmt: 0 fp32, 1 bf16, 2 fp16."""
 
-    def __init__(self, w2d: torch.Tensor, bf16: bool, transposed: bool):
+    def __init__(self, w2d: torch.Tensor, fmt, transposed: bool):
+        fmt = int(fmt)
         self.w = w2d
         m, k = w2d.shape
-        self.w_bf = torch.empty((m, k), dtype=torch.bfloat16, device=w2d.device) if bf16 else None
-        self.wt = _f32(k, m, like=w2d) if (transposed and not bf16) else None
-        self.wt_bf = torch.empty((k, m), dtype=torch.bfloat16, device=w2d.device) if (transposed and bf16) else None
+        self.w_bf = self.wt = self.wt_bf = None
+        if fmt == 2:
+            _no_fp16_training(2 if transposed else 0, "backward GEMM")
+            self.w_bf = torch.empty((m, k), dtype=torch.float16, device=w2d.device)
+            N.call("v100_weight_prep_f16", w2d, m, k, self.w_bf)
+            return
+        if fmt:
+            self.w_bf = torch.empty((m, k), dtype=torch.bfloat16, device=w2d.device)
+        if transposed:
+            if fmt:
+                self.wt_bf = torch.empty((k, m), dtype=torch.bfloat16, device=w2d.device)
+            else:
+                self.wt = _f32(k, m, like=w2d)
         if self.w_bf is not None or self.wt is not None or self.wt_bf is not None:
             N.call("v100_weight_prep", w2d, m, k, self.w_bf, self.wt, self.wt_bf)
 
@@ -112,7 +138,8 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         hid, cout = w1.shape[0], w3.shape[0]
         k = int(kernel_size)
         T2 = conv_out_len(T, k, stride)
-        bf16 = precision == "bf16"
+        bf16 = _fmt(precision)
+        _no_fp16_training(bf16, "InvertedResidual (training mode)")
         shape = (ctypes.c_int * 10)(B, cin, hid, cout, T, k, int(stride), int(bool(use_residual)), int(bf16), int(prep is not None))
         a1 = _f32(B, hid, T, like=x)
         a2 = _f32(B, hid, T2, like=x)
@@ -158,8 +185,8 @@ def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
     stacks (ConvVoiceEncoder, VoiceDecoder, ...) at the top of EVERY training-mode forward: nothing is cached across
     forwards (weights change under the optimiser, and fused optimiser kernels do not bump tensor versions, so there is no
     reliable staleness key).  A block that runs without this call prepares its own copies as before."""
-    precision = precision or _PRECISION
-    bf16 = precision == "bf16"
+    bf16 = _fmt(precision)
+    _no_fp16_training(bf16, "InvertedResidual (training mode)")
     todo = []
     for blk in blocks:
         w1, w3 = blk.conv[0][0].weight, blk.conv[2].weight
@@ -185,8 +212,9 @@ def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
 
 def prepared_weights_of(blk, precision: Optional[str] = None):
     """The block's prepared-weights buffer if prepare_block_weights filled it for THIS forward, else None."""
-    bf16 = (precision or _PRECISION) == "bf16"
-    if getattr(blk, "_prep_fresh", None) is bf16:
+    bf16 = _fmt(precision)
+    fresh = getattr(blk, "_prep_fresh", None)
+    if fresh is not None and fresh == bf16:
         blk._prep_fresh = None
         return blk._prep_buf
     return None
@@ -201,7 +229,7 @@ def inverted_residual_eval_cached(blk, x, precision: Optional[str] = None):
     pw, dw, pl, bn3 = blk.conv[0], blk.conv[1], blk.conv[2], blk.conv[3]
     bn1, bn2 = pw[1], dw[1]
     w1, wd, w3 = pw[0].weight, dw[0].weight, pl.weight
-    bf16 = (precision or _PRECISION) == "bf16"
+    bf16 = _fmt(precision)
     B, cin, T = x.shape
     hid, cout, k = w1.shape[0], w3.shape[0], int(blk.kernel_size)
     T2 = conv_out_len(T, k, blk.stride)
@@ -231,7 +259,7 @@ def inverted_residual_eval(x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3
     k = int(kernel_size)
     pad = (k - 1) // 2
     T2 = conv_out_len(T, k, stride)
-    bf16 = precision == "bf16"
+    bf16 = _fmt(precision)
     W1 = _Weights(w1.detach().reshape(hid, cin), bf16, False)
     W3 = _Weights(w3.detach().reshape(cout, hid), bf16, False)
     s1, t1 = _bn_eval(g1, b1, rm1, rv1, hid, x)
@@ -257,7 +285,7 @@ class PointwiseConvFn(torch.autograd.Function):
         x = x.contiguous()
         B, cin, T = x.shape
         cout = w.shape[0]
-        bf16 = precision == "bf16"
+        bf16 = _fmt(precision)
         W = _Weights(w.detach().reshape(cout, cin), bf16, False)
         y = _f32(B, cout, T, like=x)
         _pw_gemm(W.w, W.w_bf, x, y, cout, cin, T, B, bf16, bias=bias.detach() if bias is not None else None, epi=0)
@@ -273,6 +301,7 @@ class PointwiseConvFn(torch.autograd.Function):
         B, cin, T = x.shape
         cout = w.shape[0]
         bf16 = ctx.bf16
+        _no_fp16_training(bf16, "backward")
         W = _Weights(w.detach().reshape(cout, cin), bf16, True)
         S = N.helper("v100_pw_wgrad_splits", B, cout, cin)
         partial = _f32(S, cout, cin, like=x)
@@ -417,7 +446,7 @@ class ConvTranspose1dK5S2Fn(torch.autograd.Function):
         x = x.contiguous()
         B, cin, L = x.shape
         cout = w.shape[1]
-        bf16 = precision == "bf16"
+        bf16 = _fmt(precision)
         xe, xo = ConvTranspose1dK5S2Fn._stack(x)
         ae, ao = ConvTranspose1dK5S2Fn._mats(w)
         We, Wo = _Weights(ae, bf16, False), _Weights(ao, bf16, False)
@@ -443,6 +472,7 @@ class ConvTranspose1dK5S2Fn(torch.autograd.Function):
         cout = w.shape[1]
         T = 2 * L - 1
         bf16 = ctx.bf16
+        _no_fp16_training(bf16, "backward")
         dye, dyo = _f32(B, cout, L, like=x), torch.zeros((B, cout, L), dtype=torch.float32, device=x.device)
         N.call("v100_shift_copy", dy, dye, None, B, cout, T, L, cout, 0, cout, 0, 2, 0, 1, 0, L, 0)
         if L > 1:
@@ -503,7 +533,7 @@ class Conv1dDenseFn(torch.autograd.Function):
         tout = (T + 2 * padding - k) // stride + 1
         if tout <= 0:
             raise RuntimeError("conv1d_dense: input shorter than the kernel")
-        bf16 = precision == "bf16"
+        bf16 = _fmt(precision)
         cols = _f32(B, k * cin, tout, like=x)
         N.call("v100_im2col", x, cols, B, cin, T, tout, k, stride, padding)
         w2d = w.detach().permute(0, 2, 1).reshape(cout, k * cin).contiguous()       # [Cout][j*Cin + c]
@@ -518,6 +548,7 @@ class Conv1dDenseFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         stride, padding, has_bias, bf16, tout = ctx.cfg
+        _no_fp16_training(bf16, "backward")
         dy = dy.contiguous()
         B, cin, T = x.shape
         cout, _, k = w.shape
