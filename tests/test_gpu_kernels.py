@@ -309,3 +309,51 @@ def test_dwconv_bwd_fused_matches_split_and_torch(cuda, B, C, T, K, S):
         assert rel_err(st.sum(0)[:, 0], dpre.detach().sum((0, 2)), floor=1e-2) < 10 * TOL
         assert rel_err(st.sum(0)[:, 1], (dpre.detach() * a1).sum((0, 2)), floor=1e-2) < 10 * TOL
     assert rel_err(outs[0][0], outs[1][0]) < 1e-5 and rel_err(outs[0][2], outs[1][2]) < 1e-5
+
+
+def test_tensors_past_the_2gib_descriptor_limit(cuda):
+    """Maximum sizes: activations above 2 GiB do not fit one buffer descriptor, so the depthwise and GEMM launchers
+    leave their buffer-addressed kernels for the 64-bit-indexed ones.  The big call must agree with the same entry point
+    run on single utterances of it (which take the specialised kernels) and, on sampled rows, with torch fp32."""
+    N = _native()
+    g = torch.Generator().manual_seed(99)
+    # depthwise forward (BN+ReLU6 prologue, raw + statistics): 9 x 2048 x 32768 fp32 = 2.25 GiB in, the same out
+    B, C, T, K = 9, 2048, 32768, 19
+    pad = (K - 1) // 2
+    x = torch.randn(B, C, T, device=cuda)
+    w = (torch.randn(C, K, generator=g) * 0.2).to(cuda)
+    s, sh = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
+    G = N.helper("v100_dw_num_groups", B, C)
+    y = torch.empty(B, C, T, device=cuda)
+    st = torch.zeros(G, C, 2, device=cuda)
+    N.call("v100_dwconv", x, None, w, s, sh, None, 1, y, None, None, None, 0, st, G, B, C, T, T, K, 1, pad, 0, 1, 0)
+    for b in (0, B - 1):
+        y1 = torch.empty(1, C, T, device=cuda)
+        st1 = torch.zeros(1, C, 2, device=cuda)
+        N.call("v100_dwconv", x[b:b + 1], None, w, s, sh, None, 1, y1, None, None, None, 0, st1, 1, 1, C, T, T, K, 1, pad, 0, 1, 0)
+        assert rel_err(y[b:b + 1], y1) < 1e-6
+    rows = [(0, 0), (4, 1000), (B - 1, C - 1)]
+    for b, c in rows:
+        h = torch.clamp(x[b, c] * s[c] + sh[c], 0, 6).cpu()
+        ref = F.conv1d(h[None, None], w[c].cpu()[None, None], padding=pad)[0, 0]
+        assert rel_err(y[b, c], ref) < TOL
+    assert rel_err(st.sum(0)[:, 0], y.sum((0, 2)), floor=1.0) < 1e-3
+    del x, y, st, y1
+    torch.cuda.empty_cache()
+    # pointwise GEMM, bf16 operands, statistics epilogue: output 9 x 2048 x 32768 fp32 = 2.25 GiB
+    B, M, Kc, T = 9, 2048, 64, 32768
+    A = (torch.randn(M, Kc, generator=g) / Kc ** 0.5).to(cuda)
+    Abf = A.to(torch.bfloat16)
+    X = torch.randn(B, Kc, T, device=cuda)
+    parts = N.helper("v100_pw_num_parts", B, T)
+    Y = torch.empty(B, M, T, device=cuda)
+    stp = torch.zeros(parts, M, 2, device=cuda)
+    N.call("v100_pw_gemm", A, Abf, X, None, None, None, None, 0, Y, None, None, None, None, 1, stp, B, M, Kc, T, 1)
+    for b in (0, B - 1):
+        Y1 = torch.empty(1, M, T, device=cuda)
+        st1 = torch.zeros(N.helper("v100_pw_num_parts", 1, T), M, 2, device=cuda)
+        N.call("v100_pw_gemm", A, Abf, X[b:b + 1], None, None, None, None, 0, Y1, None, None, None, None, 1, st1, 1, M, Kc, T, 1)
+        assert rel_err(Y[b:b + 1], Y1) < 1e-6
+    ref = torch.einsum("mk,kt->mt", Abf.float().cpu(), X[B - 1].to(torch.bfloat16).float().cpu())
+    assert rel_err(Y[B - 1], ref) < 1e-4
+    assert rel_err(stp.sum(0)[:, 1], (Y * Y).sum((0, 2))) < 1e-3
