@@ -179,6 +179,17 @@ def main():
         elapsed = float(t)
 
     if rank == 0:
+        # the fraction is reported against the nominal HBM rate AND a device-copy rate measured on this box
+        src = torch.empty(1 << 28, device=device, dtype=torch.float32).normal_()      # 1 GiB read + 1 GiB write per copy
+        dst = torch.empty_like(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dst.copy_(src); sync()
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record(); sync()
+        copy_gbs = 10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
         frames = B_PER_GPU * T_FRAMES * world * args.steps
         dw_bytes, _ = encoder_dw_bytes(B_PER_GPU, T_FRAMES)
         roof = None
@@ -193,7 +204,8 @@ def main():
                     "traffic": round(PMC_TRAFFIC_RATIO * nbytes / n),
                     "traffic_source": f"{PMC_TRAFFIC_RATIO} x algorithmic bytes (rocprofv3 PMC, profiles/r01k_pmc_counters.txt)",
                     "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
-                    "algorithmic_bytes_per_launch": round(nbytes / n), "algorithmic_bytes_nominal_step": dw_bytes}
+                    "algorithmic_bytes_per_launch": round(nbytes / n), "algorithmic_bytes_nominal_step": dw_bytes,
+                    "measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
         out = {
             "metric": "audio frames/sec (fwd+bwd) asr_en_base, B=32x1024-frame mel",
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,

@@ -161,6 +161,22 @@ int v100_exp_clip(const float* x, float* y, float offset, long long n, void* str
  * partial[v100_ln_num_parts(B,T)][C][2] = (dgamma, dbeta), summed over parts by v100_slab_sum2. */
 int v100_im2col(const float* x, float* cols, int B, int Cin, int Tin, int Tout, int k, int stride, int pad, void* stream);
 int v100_col2im(const float* dcols, float* dx, int B, int Cin, int Tin, int Tout, int k, int stride, int pad, void* stream);
+/* Stride-1 dense convolutions and the two output phases of ConvTranspose1d(k5,s2,p2) WITHOUT the im2col copy
+ * (csrc/pointwise*.hip, "tap-addressed X"): the GEMM's contraction index is k = tap*cx + c and row k is row c of a
+ * zero-padded copy Xp [B][cx][Tx] of the input, read from column t + shifts[tap] (0 <= shift <= 15, T + shift <= Tx):
+ *   Y[b][m][t]        = sum_{tap,c} A[m][tap*cx + c] * Xp[b][c][t + shifts[tap]]  (+ bias[m]) (+ R[b][m][t], bf16/fp32 only)
+ *   dW[m][tap*cx + c] = sum_{b,t<T} G[b][m*Tg + g_off + t] * Xp[b][c][t + shifts[tap]]      (G rows of pitch Tg)
+ * nn.Conv1d(Cin,Cout,k,padding=(k-1)/2) forward: Xp = pad(x, (k-1)/2), shifts = 0..k-1, A[m][j*Cin+c] = W[m][c][j];
+ * its backward-data is the same GEMM on pad(dy) with the taps reversed.  `shifts` is a HOST array of ntap (<= 8) ints.
+ * v100_pad_copy: dst[b][c][lpad + i] = src[b][c][src_off + i*src_step], i < n, zero elsewhere in the Tx-long row
+ * (src_step 2 splits a ConvTranspose gradient into its even / odd phases).  v100_pw_taps_supported = 1 when the two
+ * GEMM entry points accept the shape at that precision (bf16/fp16 need cx % 64 == 0); otherwise use im2col. */
+int v100_pad_copy(const float* src, float* dst, int B, int C, int Tsrc, int src_step, int src_off, int n, int Tx, int lpad, void* stream);
+int v100_pw_taps_supported(int B, int M, int cx, int ntap, int T, int Tx, int use_bf16);
+int v100_pw_gemm_taps(const float* A, const void* A_bf16, const float* Xp, float* Y, const float* bias, const float* R,
+                      int B, int M, int cx, int T, int Tx, int ntap, const int* shifts, int use_bf16, void* stream);
+int v100_pw_wgrad_taps(const float* G, int Tg, int g_off, const float* Xp, float* partial, float* dW, int S, int B, int M,
+                       int cx, int T, int Tx, int ntap, const int* shifts, int use_bf16, void* stream);
 int v100_ln_num_parts(int B, int T);
 int v100_slab_sum2(const float* partial, int parts, float* out0, float* out1, int C, void* stream);
 int v100_ln_gelu_fwd(const float* y, const float* gamma, const float* beta, float eps, float* out, float* mean,

@@ -100,3 +100,37 @@ def test_conv1d_dense_shapes_and_errors(cuda):
         F_.conv1d_dense(torch.randn(1, 4, 8), torch.randn(4, 4, 5))                       # CPU tensor: no fallback
     with pytest.raises(RuntimeError):
         F_.conv1d_dense(torch.randn(1, 4, 3, device=cuda), torch.randn(4, 4, 5, device=cuda))   # shorter than the kernel
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin,settings,B,T", [(64, [[128, False, 5, 1, 2, True]], 3, 77), (1024, TTS_DECODER, 2, 64),
+                                              (128, [[64, True, 5, 2, 2, True], [192, False, 3, 1, 1, False]], 2, 1),
+                                              (64, [[64, False, 7, 1, 3, False]], 2, 300)])
+def test_tap_addressed_gemm_equals_the_im2col_path(cuda, cin, settings, B, T, precision):
+    """The tap-addressed GEMMs (no im2col / tap-stacked copies) contract the same operands in the same order as the
+    explicit-copy path: in fp32 outputs and all gradients agree to round-off."""
+    from voice100_amd.layers_v2 import get_conv_layers
+    from voice100_amd import functional as F_
+    torch.manual_seed(11)
+    m = get_conv_layers(cin, settings).to(cuda)
+    x = torch.randn(B, cin, T, device=cuda)
+    F_.set_matmul_precision(precision)
+    res = []
+    try:
+        for taps in (True, False):
+            F_.USE_TAP_GEMM = taps
+            m.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_(True)
+            y = m(xg)
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(cuda)
+            y.backward(gy)
+            res.append((y.detach(), xg.grad, {k: p.grad.cpu() for k, p in m.named_parameters()}))
+    finally:
+        F_.USE_TAP_GEMM = True
+        F_.set_matmul_precision("fp32")
+    (y1, gx1, gp1), (y0, gx0, gp0) = res
+    # bf16: a round-off-level difference in one layer's gradient flips the bf16 rounding of a few operands of the next GEMM
+    ytol, gtol = (1e-6, 1e-5) if precision == "fp32" else (1e-3, 3e-3)
+    assert rel_err(y1, y0) < ytol
+    assert rel_err(gx1, gx0) < gtol
+    assert_grads_close(gp1, gp0, gtol)

@@ -24,6 +24,11 @@ void pw_launch_gemm_bf16(const PwParams& p, dim3 grid, hipStream_t st);
 bool pw_launch_gemm_f16(const PwParams& p, dim3 grid, hipStream_t st);
 void pw_launch_wgrad_f32(const WgParams& p, dim3 grid, hipStream_t st);
 void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st);
+bool pw_taps_fit_bf16(int B, int M, int cx, int ntap, int T, int Tx);
+bool pw_launch_gemm_taps_bf16(const PwParams& p, dim3 grid, hipStream_t st);
+bool pw_launch_wgrad_taps_bf16(const WgParams& p, dim3 grid, hipStream_t st);
+void pw_launch_gemm_taps_f32(const PwParams& p, dim3 grid, hipStream_t st);
+void pw_launch_wgrad_taps_f32(const WgParams& p, dim3 grid, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 __global__ void pw_slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int S, long n) {
@@ -119,6 +124,103 @@ extern "C" int v100_pw_wgrad(const float* G, const float* G2, const float* ga, c
     V100TimedRegion timed(V100_T_PW_WGRAD, st);
     if (use_bf16) pw_launch_wgrad_bf16(p, grid, st);
     else pw_launch_wgrad_f32(p, grid, st);
+    const long n = (long)M * K;
+    hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, dW, S, n);
+    return v100_launch_status();
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Dense k-tap Conv1d / ConvTranspose1d phases as ONE GEMM over a zero-padded copy of the input (no im2col):
+//   Y[b][m][t] = sum_{tap, c} A[m][tap * cx + c] * Xp[b][c][t + shift[tap]]            (+ bias[m])  (+ R[b][m][t])
+//   dA[m][tap * cx + c] = sum_{b, t < T} G[b][m][g_off + t] * Xp[b][c][t + shift[tap]]
+// Xp [B][cx][Tx] is written by v100_pad_copy; every t + shift[tap] (t < T) must lie inside a row (Tx >= T + max shift).
+
+// dst[b][c][lpad + i] = src[b][c][src_off + i * src_step] for i < n, zero elsewhere in the Tx-long row: zero padding,
+// optional de-interleave (src_step 2) of a ConvTranspose gradient into its even / odd output phases
+__global__ void pad_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int Tsrc, int src_step, int src_off,
+                                int n, int Tx, int lpad, long rows) {
+    const long row = (long)blockIdx.y * gridDim.z + blockIdx.z;
+    if (row >= rows) return;
+    const float* s = src + row * Tsrc;
+    float* d = dst + row * Tx;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < Tx; j += gridDim.x * blockDim.x) {
+        const int i = j - lpad;
+        d[j] = (i >= 0 && i < n) ? s[src_off + (long)i * src_step] : 0.f;
+    }
+}
+
+extern "C" int v100_pad_copy(const float* src, float* dst, int B, int C, int Tsrc, int src_step, int src_off, int n, int Tx,
+                             int lpad, void* stream) {
+    if (!src || !dst) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || Tsrc <= 0 || src_step <= 0 || src_off < 0 || n < 0 || lpad < 0 || Tx < lpad + n) return V100_ERR_SHAPE;
+    if (n > 0 && src_off + (long)(n - 1) * src_step >= Tsrc) return V100_ERR_SHAPE;
+    const long rows = (long)B * C;
+    const unsigned gz = (unsigned)(rows < 32768 ? rows : 32768), gy = (unsigned)((rows + gz - 1) / gz);
+    if (gy > 65535u) return V100_ERR_SHAPE;
+    const unsigned gx = (unsigned)(ceil_div(Tx, 256) < 4 ? ceil_div(Tx, 256) : 4);
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(gx, gy, gz), dim3(256), 0, (hipStream_t)stream, src, dst, Tsrc, src_step, src_off, n, Tx,
+                       lpad, rows);
+    return v100_launch_status();
+}
+
+static unsigned pw_pack_shifts(const int* shifts, int ntap, int T, int Tx, bool& ok) {
+    unsigned packed = 0;
+    ok = shifts && ntap >= 1 && ntap <= 8;
+    for (int i = 0; ok && i < ntap; ++i) {
+        if (shifts[i] < 0 || shifts[i] > 15 || (long)T + shifts[i] > Tx) ok = false;
+        else packed |= (unsigned)shifts[i] << (4 * i);
+    }
+    return packed;
+}
+
+// 1 when v100_pw_gemm_taps / v100_pw_wgrad_taps run this shape at the given precision (0 fp32, 1 bf16, 2 fp16)
+extern "C" int v100_pw_taps_supported(int B, int M, int cx, int ntap, int T, int Tx, int use_bf16) {
+    if (B <= 0 || M <= 0 || cx <= 0 || T <= 0 || Tx < T || ntap < 1 || ntap > 8) return 0;
+    if ((long)ntap * cx > 0x7fffffffL / 4) return 0;
+    return use_bf16 ? (pw_taps_fit_bf16(B, M, cx, ntap, T, Tx) ? 1 : 0) : 1;
+}
+
+extern "C" int v100_pw_gemm_taps(const float* A, const void* A_bf16, const float* Xp, float* Y, const float* bias, const float* R,
+                                 int B, int M, int cx, int T, int Tx, int ntap, const int* shifts, int use_bf16, void* stream) {
+    if (!Xp || !Y) return V100_ERR_NULL;
+    if (use_bf16 ? !A_bf16 : !A) return V100_ERR_NULL;
+    if (use_bf16 < 0 || use_bf16 > 2) return V100_ERR_SHAPE;
+    if (!v100_pw_taps_supported(B, M, cx, ntap, T, Tx, use_bf16)) return V100_ERR_SHAPE;
+    if (use_bf16 == 2 && R) return V100_ERR_SHAPE;                 // fp16 = inference: store(+bias) only
+    bool ok;
+    const unsigned packed = pw_pack_shifts(shifts, ntap, T, Tx, ok);
+    if (!ok) return V100_ERR_SHAPE;
+    const int nmt = ceil_div(M, PW_BM), ntt = ceil_div(T, PW_BN);
+    PwParams p{A, (const u16*)A_bf16, Xp, nullptr, nullptr, nullptr, nullptr, Y, bias, nullptr, nullptr, R, nullptr,
+               B, M, ntap * cx, T, PW_X_NONE, R ? PW_EPI_ADD : PW_EPI_STORE, nmt, ntt, use_bf16, ntap, cx, Tx, packed};
+    const long nwg = (long)nmt * ntt * B;
+    if (nwg > 0x7fffffffL) return V100_ERR_SHAPE;
+    dim3 grid((unsigned)nwg);
+    hipStream_t st = (hipStream_t)stream;
+    V100TimedRegion timed(V100_T_PW_GEMM, st);
+    if (use_bf16) { if (!pw_launch_gemm_taps_bf16(p, grid, st)) return V100_ERR_SHAPE; }
+    else pw_launch_gemm_taps_f32(p, grid, st);
+    return v100_launch_status();
+}
+
+extern "C" int v100_pw_wgrad_taps(const float* G, int Tg, int g_off, const float* Xp, float* partial, float* dW, int S, int B, int M,
+                                  int cx, int T, int Tx, int ntap, const int* shifts, int use_bf16, void* stream) {
+    if (!G || !Xp || !partial || !dW) return V100_ERR_NULL;
+    if (S <= 0 || S > B || g_off < 0 || Tg < g_off + T || use_bf16 < 0 || use_bf16 > 1) return V100_ERR_SHAPE;
+    if (!v100_pw_taps_supported(B, M, cx, ntap, T, Tx, use_bf16)) return V100_ERR_SHAPE;
+    bool ok;
+    const unsigned packed = pw_pack_shifts(shifts, ntap, T, Tx, ok);
+    if (!ok) return V100_ERR_SHAPE;
+    const int K = ntap * cx;
+    const int nmt = ceil_div(M, PW_BM), nkt = ceil_div(K, PW_BN);
+    WgParams p{G, nullptr, nullptr, nullptr, nullptr, Xp, nullptr, nullptr, partial, B, M, K, T, S, PW_X_NONE, PW_X_NONE, nmt, nkt,
+               ntap, cx, Tx, Tg, g_off, packed};
+    dim3 grid((unsigned)(nmt * nkt * S));
+    hipStream_t st = (hipStream_t)stream;
+    V100TimedRegion timed(V100_T_PW_WGRAD, st);
+    if (use_bf16) { if (!pw_launch_wgrad_taps_bf16(p, grid, st)) return V100_ERR_SHAPE; }
+    else pw_launch_wgrad_taps_f32(p, grid, st);
     const long n = (long)M * K;
     hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, dW, S, n);
     return v100_launch_status();

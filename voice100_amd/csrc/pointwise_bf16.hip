@@ -165,8 +165,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <int XM, int EPI, int BM, bool F16 = false>
+template <int XM, int EPI, int BM, bool F16 = false, bool TAPS = false>
 __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
+    static_assert(!TAPS || XM == PW_X_NONE, "tap-addressed X has no prologue");
     // BM x 128 block tile, BM/64 x 2 waves of 64x64.  BM = 256 (8 waves, one block per CU) halves the L2 traffic of
     // the X operand, which is what bounds these GEMMs (each X tile is re-read by every M-tile); BM = 128 for M <= 128.
     constexpr int NT = BM * 2;                      // threads
@@ -183,11 +184,14 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     pw_work(p, b, tt, mt);
     const int m0 = mt * BM, t0 = tt * PW_BN;
     const int M = p.M, K = p.K, T = p.T;
-    const size_t xoff = (size_t)b * K * T;
+    // tap-addressed X: physical rows are the cx channels of the padded tensor, row pitch Tx (see PwParams)
+    const int Tx = TAPS ? p.Tx : T;
+    const int Kx = TAPS ? p.cx : K;
+    const size_t xoff = (size_t)b * Kx * Tx;
 
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.Abf, (PW_ABLATE & 2) ? 0u : (unsigned)M * K * 2u);
-    const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.X + xoff, (PW_ABLATE & 1) ? 0u : (unsigned)K * T * 4u);
-    const __amdgpu_buffer_rsrc_t rX2 = make_rsrc((XM == PW_X_AFFINE2 ? p.X2 : p.X) + xoff, (PW_ABLATE & 1) ? 0u : (unsigned)K * T * 4u);
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.X + xoff, (PW_ABLATE & 1) ? 0u : (unsigned)Kx * Tx * 4u);
+    const __amdgpu_buffer_rsrc_t rX2 = make_rsrc((XM == PW_X_AFFINE2 ? p.X2 : p.X) + xoff, (PW_ABLATE & 1) ? 0u : (unsigned)Kx * Tx * 4u);
     const __amdgpu_buffer_rsrc_t rCa = make_rsrc(XM != PW_X_NONE ? p.xa : p.X, (unsigned)K * 4u);
     const __amdgpu_buffer_rsrc_t rCb = make_rsrc(XM != PW_X_NONE ? p.xb : p.X, (unsigned)K * 4u);
     const __amdgpu_buffer_rsrc_t rCc = make_rsrc(XM == PW_X_AFFINE2 ? p.xc : p.X, (unsigned)K * 4u);
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     }
     int voX[KPT];
 #pragma unroll
-    for (int e = 0; e < KPT; ++e) voX[e] = ((KPT * b_kg + e) * T + t0 + b_tq) * 4;
+    for (int e = 0; e < KPT; ++e) voX[e] = ((KPT * b_kg + e) * Tx + t0 + b_tq) * 4;
     const int voC = KPT * b_kg * 4;
     int ldsB[4];
 #pragma unroll
@@ -220,7 +224,11 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         constexpr int SG = decltype(stg)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[SG][i] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA[i], k0 * 2, 0);
-        const int so = k0 * T * 4;
+        int so = k0 * T * 4;
+        if constexpr (TAPS) {                  // a k-tile never straddles two taps (cx % 64 == 0, checked by the launcher)
+            const int tap = k0 / p.cx;
+            so = ((k0 - tap * p.cx) * Tx + pw_tap_shift(p.shifts, tap)) * 4;
+        }
 #pragma unroll
         for (int e = 0; e < KPT; ++e) {
             rb[SG][e] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX[e], so, 0);
@@ -553,8 +561,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgParams p) {
 
 // Fast path of the backward-weight kernel for T % 64 == 0: buffer loads with per-batch descriptors
 // (rows past M / K read as zero in hardware), per-lane offsets computed once.
-template <int GM, int XM, bool TAIL>
+template <int GM, int XM, bool TAIL, bool TAPS = false>
 __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
+    static_assert(!TAPS || (GM == PW_X_NONE && XM == PW_X_NONE), "tap-addressed X has no prologues");
     __shared__ __attribute__((aligned(16))) unsigned char As[2][128 * 128];   // [m][t] bf16
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][128 * 128];   // [k][t] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -581,14 +590,20 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
         xb[i] = (XM != PW_X_NONE) ? p.xb[kv ? k : 0] : 0.f;
         voG[i] = (m * T + ch * 8) * 4;
         voX[i] = (k * T + ch * 8) * 4;
+        if constexpr (TAPS) {                  // column k of dW = tap * cx + c: row c of the padded X, shifted (see WgParams)
+            const int tap = kv ? k / p.cx : 0;
+            voG[i] = (m * p.Tg + p.g_off + ch * 8) * 4;
+            voX[i] = kv ? ((k - tap * p.cx) * p.Tx + pw_tap_shift(p.shifts, tap) + ch * 8) * 4 : 0x7fffff00;   // past the descriptor: zero
+        }
         ldsO[i] = bf_off(row, ch);
     }
+    const int Tg = TAPS ? p.Tg : T, Kx = TAPS ? p.cx : K, Tx = TAPS ? p.Tx : T;
 
     u32x4 ra[4][2], ra2[4][2], rb[4][2];
     auto load_tiles = [&](int b, int t0) {
-        const __amdgpu_buffer_rsrc_t rG = make_rsrc(p.G + (size_t)b * M * T, (unsigned)M * T * 4u);
-        const __amdgpu_buffer_rsrc_t rG2 = make_rsrc((GM == PW_X_AFFINE2 ? p.G2 : p.G) + (size_t)b * M * T, (unsigned)M * T * 4u);
-        const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.X + (size_t)b * K * T, (unsigned)K * T * 4u);
+        const __amdgpu_buffer_rsrc_t rG = make_rsrc(p.G + (size_t)b * M * Tg, (unsigned)M * Tg * 4u);
+        const __amdgpu_buffer_rsrc_t rG2 = make_rsrc((GM == PW_X_AFFINE2 ? p.G2 : p.G) + (size_t)b * M * Tg, (unsigned)M * Tg * 4u);
+        const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.X + (size_t)b * Kx * Tx, (unsigned)Kx * Tx * 4u);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -787,4 +802,37 @@ void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
 #undef X
     if (tv) hipLaunchKernelGGL((pw_wgrad_bf16_kernel<-1, -1, true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((pw_wgrad_bf16_kernel<-1, -1, false>), grid, dim3(256), 0, st, p);
+}
+
+
+// Tap-addressed X operand (PwParams / WgParams): plain store (+bias) or +R epilogue, no prologues.  false = the shape
+// does not fit the buffer-addressed kernels (the caller falls back to an explicit im2col copy).
+bool pw_taps_fit_bf16(int B, int M, int cx, int ntap, int T, int Tx) {
+    const long K = (long)ntap * cx;
+    return cx % BF_BK == 0 && ntap >= 1 && ntap <= 8 && (long)(cx + 64) * Tx * 4 < 0x7fffff00L && (M + 128L) * K * 2 < 0x7fffffffL &&
+           (long)B * M * T * 4 < 0x7fffff00L && (M + 128L) * Tx * 4 < 0x7fffff00L;
+}
+
+bool pw_launch_gemm_taps_bf16(const PwParams& p, dim3 grid, hipStream_t st) {
+    if (!pw_taps_fit_bf16(p.B, p.M, p.cx, p.ntap, p.T, p.Tx)) return false;
+    const bool big = p.M >= 256;
+    PwParams pb = p;
+    pb.n_mtiles = (p.M + 255) / 256;
+    const dim3 gridb((unsigned)((long)pb.n_mtiles * p.n_ttiles * p.B));
+#define X(EP, F16)                                                                                                      \
+    if (p.epi_mode == EP && (p.fmt == 2) == F16) {                                                                      \
+        if (big) hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<0, EP, 256, F16, true>), gridb, dim3(512), 0, st, pb);   \
+        else hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<0, EP, 128, F16, true>), grid, dim3(256), 0, st, p);          \
+        return true;                                                                                                    \
+    }
+    X(0, false) X(5, false) X(0, true)
+#undef X
+    return false;
+}
+
+bool pw_launch_wgrad_taps_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
+    if (!((p.M + 128L) * p.Tg * 4 < 0x7fffff00L && (p.cx + 128L) * p.Tx * 4 < 0x7fffff00L && p.ntap >= 1 && p.ntap <= 8)) return false;
+    if (p.T % BF_BK == 0) hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<0, 0, false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<0, 0, true, true>), grid, dim3(256), 0, st, p);
+    return true;
 }

@@ -44,7 +44,14 @@ struct PwParams {
     float* stats;         // [B * n_ttiles][M][2]
     int B, M, K, T, x_mode, epi_mode, n_mtiles, n_ttiles;
     int fmt;              // 16-bit operand format of the bf16-path kernels: 1 bf16, 2 fp16 (inference combinations only)
+    // Tap-addressed X operand (dense k-tap convolutions as ONE GEMM, no im2col copy): when ntap > 0 the contraction
+    // index is k = tap * cx + c and row k is row c of a zero-padded tensor X [B][cx][Tx] read from column
+    // t + shift(tap); shifts are >= 0 (the padding absorbs the negative taps), 4 bits each in `shifts`.  K = ntap * cx.
+    int ntap, cx, Tx;
+    unsigned shifts;
 };
+
+__device__ __forceinline__ int pw_tap_shift(unsigned shifts, int tap) { return (int)((shifts >> (4 * tap)) & 15u); }
 
 __device__ __forceinline__ float pw_x_transform(int mode, float v, float v2, float a, float b, float c) {
     if (mode == PW_X_AFFINE_RELU6) return relu6f(fmaf(v, a, b));
@@ -273,6 +280,10 @@ struct WgParams {
     const float* X;  const float* xa; const float* xb;                                        // B operand [B][K][T], coeffs [K]
     float* partial;  // [S][M][K]
     int B, M, K, T, S, g_mode, x_mode, n_mtiles, n_ktiles;
+    // tap-addressed X rows (see PwParams): column k = tap * cx + c of dW is contracted against row c of the padded
+    // X [B][cx][Tx] shifted by shift(tap); G may itself sit in a padded buffer: row pitch Tg, first column g_off.
+    int ntap, cx, Tx, Tg, g_off;
+    unsigned shifts;
 };
 
 

@@ -7,7 +7,7 @@
 #define F32_BK 16
 #define F32_LD (128 + 4)
 
-template <int XM_, int EPI_, bool TV, bool KV>
+template <int XM_, int EPI_, bool TV, bool KV, bool TAPS = false>
 __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(PwParams p) {
     __shared__ __attribute__((aligned(16))) float As[2][F32_BK][F32_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][F32_BK][F32_LD];
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(PwParams p) {
     const int m0 = mt * PW_BM, t0 = tt * PW_BN;
     const int M = p.M, K = p.K, T = p.T;
     const int x_mode = PW_MODE(XM_, p.x_mode);
-    const size_t xoff = (size_t)b * K * T;
+    const size_t xoff = TAPS ? (size_t)b * p.cx * p.Tx : (size_t)b * K * T;
 
     const int a_k = (tid & 3) * 4;          // + k0, 4 consecutive k
     const int a_m = tid >> 2;               // + 64*i
@@ -36,6 +36,10 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(PwParams p) {
             ra[i] = ld4<KV>(p.A, (size_t)m * K, k0 + a_k, K, m < M);
             const int k = k0 + b_k + 8 * i;
             const bool kv = k < K;
+            if constexpr (TAPS) {              // row k = tap * cx + c: row c of the padded X, read from column t + shift(tap)
+                const int tap = kv ? k / p.cx : 0;
+                rb[i] = ld4<true>(p.X, xoff + (size_t)(k - tap * p.cx) * p.Tx + pw_tap_shift(p.shifts, tap), t0 + b_t, T, kv);
+            } else
             rb[i] = ld4<TV>(p.X, xoff + (size_t)k * T, t0 + b_t, T, kv);
             if (x_mode == PW_X_AFFINE2) rb2[i] = ld4<TV>(p.X2, xoff + (size_t)k * T, t0 + b_t, T, kv);
             if (x_mode != PW_X_NONE) { ca[i] = ldc(p.xa, k, kv, 1.f); cb[i] = ldc(p.xb, k, kv, 0.f); }
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(PwParams p) {
 // ---------------------------------------------------------------------------------------------
 // Backward-weight, fp32.  Both operands are contraction(t)-contiguous in HBM; the tile loader
 // transposes them into LDS as [t][row] so a lane's MFMA operand is a conflict-free ds_read_b32.
-template <int GM_, int XM_, bool TV>
+template <int GM_, int XM_, bool TV, bool TAPS = false>
 __global__ __launch_bounds__(256) void pw_wgrad_f32_kernel(WgParams p) {
     __shared__ __attribute__((aligned(16))) float As[2][F32_BK][F32_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][F32_BK][F32_LD];
@@ -131,11 +135,24 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32_kernel(WgParams p) {
         xb[i] = (x_mode != PW_X_NONE) ? ldc(p.xb, k, kv[i], 0.f) : 0.f;
     }
 
+    size_t xrow[2] = {0, 0};                // tap-addressed X: in-utterance offset of this thread's two rows (see WgParams)
+    if constexpr (TAPS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = n0 + l_r + 64 * i, tap = kv[i] ? k / p.cx : 0;
+            xrow[i] = (size_t)(k - tap * p.cx) * p.Tx + pw_tap_shift(p.shifts, tap);
+        }
+    }
     f32x4 ra[2], ra2[2], rb[2];
     auto load_tiles = [&](int b, int t0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + l_r + 64 * i, k = n0 + l_r + 64 * i;
+            if constexpr (TAPS) {
+                ra[i] = ld4<true>(p.G, ((size_t)b * M + m) * p.Tg + p.g_off, t0 + l_t, T, mv[i]);
+                rb[i] = ld4<true>(p.X, (size_t)b * p.cx * p.Tx + xrow[i], t0 + l_t, T, kv[i]);
+                continue;
+            }
             ra[i] = ld4<TV>(p.G, ((size_t)b * M + m) * T, t0 + l_t, T, mv[i]);
             if (g_mode == PW_X_AFFINE2) ra2[i] = ld4<TV>(p.G2, ((size_t)b * M + m) * T, t0 + l_t, T, mv[i]);
             rb[i] = ld4<TV>(p.X, ((size_t)b * K + k) * T, t0 + l_t, T, kv[i]);
@@ -243,4 +260,14 @@ void pw_launch_wgrad_f32(const WgParams& p, dim3 grid, hipStream_t st) {
 #undef X
     if (tv) hipLaunchKernelGGL((pw_wgrad_f32_kernel<-1, -1, true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((pw_wgrad_f32_kernel<-1, -1, false>), grid, dim3(256), 0, st, p);
+}
+
+
+// Tap-addressed X operand (PwParams / WgParams): plain store (+bias) or +R epilogue, no prologues.
+void pw_launch_gemm_taps_f32(const PwParams& p, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((pw_gemm_f32_kernel<0, -1, true, true, true>), grid, dim3(256), 0, st, p);
+}
+
+void pw_launch_wgrad_taps_f32(const WgParams& p, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((pw_wgrad_f32_kernel<0, 0, true, true>), grid, dim3(256), 0, st, p);
 }

@@ -411,6 +411,38 @@ def embedding_bct(idx, table):
     return EmbeddingBCTFn.apply(idx, table)
 
 
+def _pad_rows(x, lpad: int, tx: int, step: int = 1, off: int = 0, n: Optional[int] = None):
+    """Zero-padded copy [B, C, tx] of x[..., off::step][:n] starting at column lpad (v100_pad_copy): the X operand of
+    the tap-addressed GEMMs.  64 floats of slack behind it: their 16-byte loads may run a few elements past the last row."""
+    B, C, T = x.shape
+    n = T if n is None else n
+    flat = torch.empty(B * C * tx + 64, dtype=torch.float32, device=x.device)
+    xp = flat[:B * C * tx].view(B, C, tx)
+    N.call("v100_pad_copy", x, xp, B, C, T, step, off, n, tx, lpad)
+    return xp
+
+
+USE_TAP_GEMM = True      # False forces the explicit im2col / tap-stacking copies (A/B measurements and the equivalence test)
+
+
+def _taps_ok(b, m, cx, ntap, t, tx, fmt) -> bool:
+    return USE_TAP_GEMM and bool(N.helper("v100_pw_taps_supported", b, m, cx, ntap, t, tx, int(fmt)))
+
+
+def _gemm_taps(W, xp, y, bias, r, m, cx, t, shifts, fmt):
+    B, _, tx = xp.shape
+    N.call("v100_pw_gemm_taps", W.w, W.w_bf, xp, y, bias, r, B, m, cx, t, tx, len(shifts), (ctypes.c_int * len(shifts))(*shifts), int(fmt))
+
+
+def _wgrad_taps(g, tg, g_off, xp, m, cx, t, shifts, fmt):
+    B, _, tx = xp.shape
+    kk = len(shifts) * cx
+    S = N.helper("v100_pw_wgrad_splits", B, m, kk)
+    partial, dW = _f32(S, m, kk, like=xp), _f32(m, kk, like=xp)
+    N.call("v100_pw_wgrad_taps", g, tg, g_off, xp, partial, dW, S, B, m, cx, t, tx, len(shifts), (ctypes.c_int * len(shifts))(*shifts), int(fmt))
+    return dW
+
+
 class ConvTranspose1dK5S2Fn(torch.autograd.Function):
     """nn.ConvTranspose1d(Cin, Cout, kernel_size=5, stride=2, padding=2, bias) -- tts.py:22.
 
@@ -447,12 +479,21 @@ class ConvTranspose1dK5S2Fn(torch.autograd.Function):
         B, cin, L = x.shape
         cout = w.shape[1]
         bf16 = _fmt(precision)
-        xe, xo = ConvTranspose1dK5S2Fn._stack(x)
         ae, ao = ConvTranspose1dK5S2Fn._mats(w)
         We, Wo = _Weights(ae, bf16, False), _Weights(ao, bf16, False)
         ye, yo = _f32(B, cout, L, like=x), _f32(B, cout, L, like=x)
-        _pw_gemm(We.w, We.w_bf, xe, ye, cout, 3 * cin, L, B, bf16)
-        _pw_gemm(Wo.w, Wo.w_bf, xo, yo, cout, 2 * cin, L, B, bf16)
+        tx = (L + 2 + 3) // 4 * 4
+        # no tap-stacked copies: both phases read one zero-padded copy of x through the tap-addressed GEMM
+        # (x[u+1], x[u], x[u-1] = xp[u+2], xp[u+1], xp[u]); forward and backward-data shapes must both fit
+        ctx.taps = _taps_ok(B, cout, cin, 3, L, tx, bf16) and (bf16 == 2 or _taps_ok(B, cin, cout, 3, L, tx, bf16))
+        if ctx.taps:
+            xp = _pad_rows(x, 1, tx)
+            _gemm_taps(We, xp, ye, None, None, cout, cin, L, (2, 1, 0), bf16)
+            _gemm_taps(Wo, xp, yo, None, None, cout, cin, L, (2, 1), bf16)
+        else:
+            xe, xo = ConvTranspose1dK5S2Fn._stack(x)
+            _pw_gemm(We.w, We.w_bf, xe, ye, cout, 3 * cin, L, B, bf16)
+            _pw_gemm(Wo.w, Wo.w_bf, xo, yo, cout, 2 * cin, L, B, bf16)
         T = 2 * L - 1
         y = _f32(B, cout, T, like=x)
         b = bias.detach() if bias is not None else None
@@ -473,6 +514,8 @@ class ConvTranspose1dK5S2Fn(torch.autograd.Function):
         T = 2 * L - 1
         bf16 = ctx.bf16
         _no_fp16_training(bf16, "backward")
+        if ctx.taps:
+            return ConvTranspose1dK5S2Fn._backward_taps(ctx, x, w, dy)
         dye, dyo = _f32(B, cout, L, like=x), torch.zeros((B, cout, L), dtype=torch.float32, device=x.device)
         N.call("v100_shift_copy", dy, dye, None, B, cout, T, L, cout, 0, cout, 0, 2, 0, 1, 0, L, 0)
         if L > 1:
@@ -509,6 +552,46 @@ class ConvTranspose1dK5S2Fn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def _convt_backward_taps(ctx, x, w, dy):
+    """Backward of ConvTranspose1dK5S2Fn on the tap-addressed GEMMs: dy is split into its even / odd phases straight into
+    zero-padded rows (one pass each), which serve as the G operand of the two weight-gradient GEMMs and as the X
+    operand of the two data-gradient GEMMs (the second accumulates onto the first: R epilogue)."""
+    B, cin, L = x.shape
+    cout = w.shape[1]
+    T = 2 * L - 1
+    bf16 = ctx.bf16
+    tx = (L + 2 + 3) // 4 * 4
+    xp = _pad_rows(x, 1, tx)
+    dyep = _pad_rows(dy, 1, tx, step=2, off=0, n=L)
+    dyop = _pad_rows(dy, 1, tx, step=2, off=1 if L > 1 else 0, n=L - 1)
+    dae = _wgrad_taps(dyep, tx, 1, xp, cout, cin, L, (2, 1, 0), bf16)
+    dao = _wgrad_taps(dyop, tx, 1, xp, cout, cin, L, (2, 1), bf16)
+    dw = torch.empty_like(w)
+    dw[:, :, [0, 2, 4]] = dae.view(cout, 3, cin).permute(2, 0, 1)
+    dw[:, :, [1, 3]] = dao.view(cout, 2, cin).permute(2, 0, 1)
+    db = None
+    if ctx.has_bias:
+        G = N.helper("v100_dw_num_groups", B, cout)
+        part = _f32(G, cout, 2, like=x)
+        N.call("v100_chan_reduce2", dy, None, part, G, B, cout, T)
+        db = _f32(cout, like=x)
+        N.call("v100_slab_sum0", part, G, db, cout)
+    dx = None
+    if ctx.needs_input_grad[0]:
+        wd = w.detach()
+        # dx[u] = w0 dye[u-1] + w2 dye[u] + w4 dye[u+1]  +  w1 dyo[u-1] + w3 dyo[u];  rows [c][tap*Cout + m]
+        a1 = wd[:, :, [0, 2, 4]].permute(0, 2, 1).reshape(cin, 3 * cout).contiguous()
+        a2 = wd[:, :, [1, 3]].permute(0, 2, 1).reshape(cin, 2 * cout).contiguous()
+        W1, W2 = _Weights(a1, bf16, False), _Weights(a2, bf16, False)
+        dx1, dx = _f32(B, cin, L, like=x), _f32(B, cin, L, like=x)
+        _gemm_taps(W1, dyep, dx1, None, None, cin, cout, L, (0, 1, 2), bf16)
+        _gemm_taps(W2, dyop, dx, None, dx1, cin, cout, L, (0, 1), bf16)
+    return dx, dw, db, None
+
+
+ConvTranspose1dK5S2Fn._backward_taps = staticmethod(_convt_backward_taps)
+
+
 def conv_transpose1d_k5s2(x, w, bias=None, precision: Optional[str] = None):
     return ConvTranspose1dK5S2Fn.apply(x, w, bias, precision or _PRECISION)
 
@@ -534,31 +617,44 @@ class Conv1dDenseFn(torch.autograd.Function):
         if tout <= 0:
             raise RuntimeError("conv1d_dense: input shorter than the kernel")
         bf16 = _fmt(precision)
-        cols = _f32(B, k * cin, tout, like=x)
-        N.call("v100_im2col", x, cols, B, cin, T, tout, k, stride, padding)
         w2d = w.detach().permute(0, 2, 1).reshape(cout, k * cin).contiguous()       # [Cout][j*Cin + c]
         W = _Weights(w2d, bf16, False)
         y = _f32(B, cout, tout, like=x)
-        _pw_gemm(W.w, W.w_bf, cols, y, cout, k * cin, tout, B, bf16, bias=bias.detach() if bias is not None else None, epi=0)
+        bias_d = bias.detach() if bias is not None else None
+        # "same" stride-1 convolutions skip the im2col copy: the GEMM reads a zero-padded copy of x once per tap
+        # (tap-addressed X operand, include/voice100_hip.h); forward and backward-data shapes must both fit
+        tx = (T + k - 1 + 3) // 4 * 4
+        taps = (stride == 1 and 2 * padding == k - 1 and k <= 8 and _taps_ok(B, cout, cin, k, T, tx, bf16)
+                and (bf16 == 2 or _taps_ok(B, cin, cout, k, T, tx, bf16)))
+        if taps:
+            _gemm_taps(W, _pad_rows(x, padding, tx), y, bias_d, None, cout, cin, T, tuple(range(k)), bf16)
+        else:
+            cols = _f32(B, k * cin, tout, like=x)
+            N.call("v100_im2col", x, cols, B, cin, T, tout, k, stride, padding)
+            _pw_gemm(W.w, W.w_bf, cols, y, cout, k * cin, tout, B, bf16, bias=bias_d, epi=0)
         ctx.save_for_backward(x, w)
-        ctx.cfg = (stride, padding, bias is not None, bf16, tout)
+        ctx.cfg = (stride, padding, bias is not None, bf16, tout, taps)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        stride, padding, has_bias, bf16, tout = ctx.cfg
+        stride, padding, has_bias, bf16, tout, taps = ctx.cfg
         _no_fp16_training(bf16, "backward")
         dy = dy.contiguous()
         B, cin, T = x.shape
         cout, _, k = w.shape
         kk = k * cin
-        cols = _f32(B, kk, tout, like=x)
-        N.call("v100_im2col", x, cols, B, cin, T, tout, k, stride, padding)
-        S = N.helper("v100_pw_wgrad_splits", B, cout, kk)
-        partial = _f32(S, cout, kk, like=x)
-        dW = _f32(cout, kk, like=x)
-        N.call("v100_pw_wgrad", dy, None, None, None, None, 0, cols, None, None, 0, partial, dW, S, B, cout, kk, tout, int(bf16))
+        tx = (T + k - 1 + 3) // 4 * 4
+        if taps:
+            dW = _wgrad_taps(dy, T, 0, _pad_rows(x, padding, tx), cout, cin, T, tuple(range(k)), bf16)
+        else:
+            cols = _f32(B, kk, tout, like=x)
+            N.call("v100_im2col", x, cols, B, cin, T, tout, k, stride, padding)
+            S = N.helper("v100_pw_wgrad_splits", B, cout, kk)
+            partial = _f32(S, cout, kk, like=x)
+            dW = _f32(cout, kk, like=x)
+            N.call("v100_pw_wgrad", dy, None, None, None, None, 0, cols, None, None, 0, partial, dW, S, B, cout, kk, tout, int(bf16))
         dw = dW.view(cout, k, cin).permute(0, 2, 1).contiguous()
         db = None
         if has_bias:
@@ -568,7 +664,12 @@ class Conv1dDenseFn(torch.autograd.Function):
             db = _f32(cout, like=x)
             N.call("v100_slab_sum0", part, G, db, cout)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and taps:
+            # dx[c][u] = sum_{j,m} W[m][c][j] dy[m][u + pad - j]: the same GEMM on pad(dy) with the taps reversed
+            a = w.detach().flip(2).permute(1, 2, 0).reshape(cin, k * cout).contiguous()       # [Cin][i*Cout + m] = W[m][c][k-1-i]
+            dx = _f32(B, cin, T, like=x)
+            _gemm_taps(_Weights(a, bf16, False), _pad_rows(dy, padding, tx), dx, None, None, cin, cout, T, tuple(range(k)), bf16)
+        elif ctx.needs_input_grad[0]:
             w2d = w.detach().permute(0, 2, 1).reshape(cout, kk).contiguous()
             W = _Weights(w2d, bf16, True)
             dcols = cols                                   # the im2col copy is dead after the wgrad: reuse its storage
