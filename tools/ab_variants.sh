@@ -9,7 +9,7 @@ for v in "$@"; do
   d=build/variants/obj_$v; mkdir -p $d
   for f in ${FILES:-depthwise depthwise_fwd_train depthwise_fwd_eval depthwise_bwd_data}; do
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Iinclude -Ivoice100_amd/csrc -Wno-unused-result \
-      -mllvm -pragma-unroll-threshold=1000000 -D$name=$v -c voice100_amd/csrc/$f.hip -o $d/$f.o &
+      -mllvm -pragma-unroll-threshold=1000000 -fno-slp-vectorize -D$name=$v -c voice100_amd/csrc/$f.hip -o $d/$f.o &
   done
   wait
   pat=$(echo ${FILES:-depthwise depthwise_fwd_train depthwise_fwd_eval depthwise_bwd_data} | sed 's/ /|/g')

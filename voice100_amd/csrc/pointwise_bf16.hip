@@ -751,7 +751,10 @@ void pw_launch_gemm_bf16(const PwParams& p_in, dim3 grid_in, hipStream_t st) {
     // stored; k >= K rows of X are zero, so whatever A holds there is multiplied by zero.
     const bool full = (p.K & 1) == 0 && (long)(p.K + 64) * p.T * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL &&
                       (long)p.B * p.M * p.T * 4 < 0x7fffff00L;
-    const bool big = full && p.M >= 256;      // 256-row block tile: half the X re-reads through L2
+    // 256-row block tile: half the X staging per flop.  (A/B in one process, tools/step_time.py: 128-row tiles everywhere cost
+    // +0.2 ms of GEMM time per step; 128-row tiles only for the K <= 512 GEMMs -- two workgroups per CU, epilogue of one
+    // over the main loop of the other -- measured equal, so one rule.)
+    const bool big = full && p.M >= 256;
     if (full) {
         PwParams pb = p;                       // the 256-row tiling has its own m-tile count / grid
         pb.n_mtiles = (p.M + 255) / 256;
