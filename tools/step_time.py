@@ -23,7 +23,7 @@ model = AudioToTextCTC(64, 512, 29, 512, learning_rate=1e-3, weight_decay=4e-5).
 model.batch_augment.forward = lambda a, l: (a, l)
 step = TrainStep(model)
 (audio, audio_len), tgt = bench.synth_batch(dev, 32, 1234)
-audio = audio[:, :args.T].contiguous()
+audio = (audio[:, :args.T] if args.T <= audio.shape[1] else torch.cat([audio, audio[:, :args.T - audio.shape[1]]], 1)).contiguous()
 batch = ((audio, torch.full_like(audio_len, args.T)), tgt)
 for _ in range(5): step(batch)
 torch.cuda.synchronize()
