@@ -117,7 +117,7 @@ def test_asr_c1_full_size(cuda):
 
 
 def test_asr_metric_shape_properties(cuda):
-    """BASELINE metric size (B=32, T=1024), where the oracle is too slow to run in a test: size-independent
+    """BASELINE metric size (B=32, T=1024): size-independent
     properties -- batch independence in eval mode (an utterance's logits do not depend on its batch-mates),
     shape/length arithmetic, finiteness; train-mode step produces finite grads for every parameter."""
     from voice100_amd.asr import AudioToTextCTC
@@ -389,3 +389,56 @@ def test_fp16_inference_precision(cuda):
     finally:
         F_.set_matmul_precision("fp32")
         asr.eval()
+
+
+def test_asr_metric_shape_ragged_lengths_vs_oracle(cuda):
+    """BASELINE metric shape (asr_en_base, B=32 x 1024 frames) with ragged utterance lengths ~U{512..1024}:
+    one fp32 training step (augmentation and dropout off) against the CPU oracle -- loss, the updated BatchNorm running
+    statistics and the gradient of every parameter.  The padding frames take part in the convolutions and the batch
+    statistics exactly as in the reference; only the CTC lattice sees the lengths."""
+    from oracle import cnn
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd import functional as F_
+    torch.manual_seed(77)
+    m = AudioToTextCTC(audio_size=64, embed_size=512, vocab_size=29, hidden_size=512)
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(78)
+    audio = torch.randn(32, 1024, 64, generator=gen) * 2 - 4
+    audio_len = torch.randint(512, 1025, (32,), generator=gen, dtype=torch.int32)
+    audio_len[0] = 1024
+    for b in range(32):
+        audio[b, int(audio_len[b]):] = float(np.log(1e-6))
+    text = torch.randint(1, 29, (32, 100), generator=gen)
+    text_len = torch.randint(20, 101, (32,), generator=gen, dtype=torch.int32)
+    # oracle
+    params = {k: v.clone().requires_grad_(True) for k, v in state.items() if v.dtype.is_floating_point and "running" not in k}
+    st = dict(state); st.update(params)
+    updates = cnn.BNUpdates()
+    torch.set_num_threads(min(32, max(8, torch.get_num_threads())))
+    ref_loss = cnn.audio_to_text_ctc_loss(((audio, audio_len), (text, text_len)), st, training=True, updates=updates)
+    ref_grads = dict(zip(params, torch.autograd.grad(ref_loss, list(params.values()))))
+    # HIP path
+    F_.set_matmul_precision("fp32")
+    m = m.to(cuda).train()
+    m.decoder.layers[0].p = 0.0
+    m.batch_augment.forward = lambda a, l: (a, l)
+    loss = m.training_step(((audio.to(cuda), audio_len.to(cuda)), (text.to(cuda), text_len.to(cuda))), 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-4 * abs(float(ref_loss.detach()))
+    got = {k: p.grad.cpu() for k, p in m.named_parameters()}
+    num = sum(float((got[k].double() - ref_grads[k].double()).pow(2).sum()) for k in ref_grads)
+    den = sum(float(ref_grads[k].double().pow(2).sum()) for k in ref_grads)
+    assert (num / den) ** 0.5 < 5e-3                      # all gradients, relative L2: the bar of test_gpu_fuzz (ReLU6 kinks)
+    # per parameter too, but against a floor: BatchNorm biases in front of another training-mode BatchNorm have an
+    # analytically zero gradient (a constant shift is normalised away) -- both sides hold round-off noise there
+    floor = 1e-3 * den ** 0.5
+    for k in ref_grads:
+        err = float((got[k].double() - ref_grads[k].double()).norm())
+        assert err < 3e-2 * max(float(ref_grads[k].double().norm()), floor), k
+    sd = m.state_dict()
+    for k, v in updates.items():
+        if "running" in k:
+            # zero-mean channels (a bias-free conv of a normalised input) hold round-off noise: floor the scale
+            assert float((sd[k].cpu() - v).abs().max()) < 1e-4 * max(float(v.abs().max()), 1e-2), k
+        else:
+            assert int(sd[k]) == int(v), k
