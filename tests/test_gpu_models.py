@@ -442,3 +442,49 @@ def test_asr_metric_shape_ragged_lengths_vs_oracle(cuda):
             assert float((sd[k].cpu() - v).abs().max()) < 1e-4 * max(float(v.abs().max()), 1e-2), k
         else:
             assert int(sd[k]) == int(v), k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_streaming_config5_full_size_vs_oracle(cuda, precision):
+    """BASELINE configs[4] at full size: 32 one-second 16 kHz chunks -> log-mel -> asr_en_base encoder -> logits -> greedy
+    CTC tokens, against the CPU oracle chain on the same seeded weights.  fp32: features / logits to 1e-4 and the token
+    ids bit-exact for every chunk whose frame-wise argmax margins exceed the logit tolerance; fp16 (the precision the
+    config names): logits at the fp16 bar, tokens equal on the chunks with margins above that bar."""
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd.mel import MelSpectrogramAudioTransform
+    from voice100_amd.decode import ctc_greedy_decode
+    from voice100_amd import functional as F_
+    from oracle import cnn, mel as omel, intops
+    torch.manual_seed(99)
+    m = AudioToTextCTC(audio_size=64, embed_size=512, vocab_size=29, hidden_size=512)
+    gen = torch.Generator().manual_seed(100)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=gen) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gen) + 0.5)
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    wav = torch.rand(32, 16000, generator=gen) * 2 - 1
+    ref_feats = torch.stack([torch.from_numpy(omel.log_mel(w.numpy())) for w in wav])
+    torch.set_num_threads(min(32, max(8, torch.get_num_threads())))
+    with torch.no_grad():
+        ref_logits = cnn.audio_to_text_ctc_forward(ref_feats, state, training=False)
+    F_.set_matmul_precision(precision)
+    try:
+        m = m.to(cuda).eval()
+        with torch.no_grad():
+            feats = MelSpectrogramAudioTransform().to(cuda)(wav.to(cuda))
+            logits = m(feats)
+            ids, n = ctc_greedy_decode(logits)
+    finally:
+        F_.set_matmul_precision("fp32")
+    tol = 2e-4 if precision == "fp32" else 1e-2
+    assert feats.shape == (32, 101, 64) and logits.shape == (32, 51, 29)
+    assert rel_err(feats, ref_feats) < 1e-4 and rel_err(logits, ref_logits) < tol
+    top2 = ref_logits.topk(2, dim=-1).values
+    margin = (top2[..., 0] - top2[..., 1]).min(dim=1).values
+    clear = margin > 4 * tol * float(ref_logits.abs().max())
+    assert int(clear.sum()) >= 8
+    for b in range(32):
+        if clear[b]:
+            assert ids[b, :int(n[b])].cpu().tolist() == intops.merge_repeated_ids(ref_logits[b].argmax(-1).tolist())

@@ -141,3 +141,69 @@ def test_world_glue(cuda):
     assert rel_err(spc, np.maximum(np.exp(logspc.astype(np.float64)) - 1e-15, 0)) < 1e-5
     with pytest.raises(RuntimeError):
         v.encode(torch.zeros(1600))          # pyworld is not part of this path
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+def test_tts_config3_full_size_vs_oracle(cuda, precision):
+    """BASELINE configs[2] at full size (tts_en_base audio model, B=16 aligned-text frames of 512 -> 1023 WORLD frames)
+    against the CPU oracle on the same seeded weights: predict() in eval mode (fp32 1e-4; bf16 / fp16 operands at their
+    stated bars), the F0 gate bit-exact where the logit is not within rounding of zero; fp32 also one training step
+    (five losses, all gradients)."""
+    from oracle import cnn
+    from voice100_amd.tts import AlignTextToAudioModel
+    from voice100_amd import functional as F_
+    torch.manual_seed(4321)
+    m = AlignTextToAudioModel(vocab_size=29, hidden_size=512)
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=gen) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gen) + 0.5)
+        m.norm.f0_mean.fill_(120.0); m.norm.f0_std.fill_(40.0)
+        m.norm.logspc_mean.copy_(torch.randn(257, generator=gen) - 6.0); m.norm.logspc_std.copy_(torch.rand(257, generator=gen) + 0.5)
+        m.norm.codeap_mean.fill_(-1.0); m.norm.codeap_std.fill_(0.7)
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    at = torch.randint(0, 29, (16, 512), generator=gen)
+    torch.set_num_threads(min(32, max(8, torch.get_num_threads())))
+    with torch.no_grad():
+        hasf0_ref = cnn.align_text_to_audio_forward(at, state, False)[0]
+        f0_ref, logspc_ref, codeap_ref = cnn.align_text_to_audio_predict(at, state)
+    F_.set_matmul_precision(precision)
+    try:
+        m = m.to(cuda).eval()
+        with torch.no_grad():
+            f0, logspc, codeap = m.predict(at.to(cuda))
+        tol = {"fp32": 1e-4, "bf16": 3e-2, "fp16": 1e-2}[precision]
+        assert f0.shape == (16, 1023) and logspc.shape == (16, 1023, 257) and codeap.shape == (16, 1023, 1)
+        assert rel_err(logspc, logspc_ref) < tol and rel_err(codeap, codeap_ref) < tol
+        sure = hasf0_ref.abs() > (1e-3 if precision == "fp32" else 0.2)
+        assert torch.equal((f0.cpu() == 0)[sure], (f0_ref == 0)[sure])                   # the gate
+        assert rel_err(f0.cpu() * sure, f0_ref * sure) < tol
+        if precision != "fp32":
+            return
+        # one training step at this size: targets of the collate shape (data_modules.py:458-474), ragged lengths
+        Tw = 1023
+        f0_t = torch.rand(16, Tw, generator=gen) * 250.0
+        f0_len = torch.randint(600, Tw + 1, (16,), generator=gen, dtype=torch.int32)
+        logspc_t = torch.randn(16, Tw, 257, generator=gen) - 6.0
+        codeap_t = torch.randn(16, Tw, 1, generator=gen) * 0.5 - 1.0
+        at_len = (f0_len + 1) // 2
+        params = {k: v.clone().requires_grad_(True) for k, v in state.items()
+                  if v.dtype.is_floating_point and "running" not in k and not k.startswith("norm.")}
+        st = dict(state); st.update(params)
+        batch = ((f0_t, f0_len, logspc_t, codeap_t), (at, at_len))
+        ref_losses = cnn.align_text_to_audio_loss(batch, st, use_mcep=False, training=True, updates=cnn.BNUpdates())
+        ref_total = sum(ref_losses)
+        ref_grads = dict(zip(params, torch.autograd.grad(ref_total, list(params.values()))))
+        m.train()
+        dev = lambda t: t.to(cuda)
+        loss = m.training_step(((dev(f0_t), dev(f0_len), dev(logspc_t), dev(codeap_t)), (dev(at), dev(at_len))), 0)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(ref_total.detach())) < 1e-4 * abs(float(ref_total.detach()))
+        got = {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}
+        num = sum(float((got[k].double() - ref_grads[k].double()).pow(2).sum()) for k in ref_grads)
+        den = sum(float(ref_grads[k].double().pow(2).sum()) for k in ref_grads)
+        assert (num / den) ** 0.5 < 5e-3
+    finally:
+        F_.set_matmul_precision("fp32")
