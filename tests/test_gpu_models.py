@@ -391,11 +391,13 @@ def test_fp16_inference_precision(cuda):
         asr.eval()
 
 
-def test_asr_metric_shape_ragged_lengths_vs_oracle(cuda):
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_asr_metric_shape_ragged_lengths_vs_oracle(cuda, precision):
     """BASELINE metric shape (asr_en_base, B=32 x 1024 frames) with ragged utterance lengths ~U{512..1024}:
     one fp32 training step (augmentation and dropout off) against the CPU oracle -- loss, the updated BatchNorm running
     statistics and the gradient of every parameter.  The padding frames take part in the convolutions and the batch
-    statistics exactly as in the reference; only the CTC lattice sees the lengths."""
+    statistics exactly as in the reference; only the CTC lattice sees the lengths.  bf16 = the precision bench.py runs
+    (GEMM operands rounded to bf16): the same step at the relaxed bars of the bf16 path."""
     from oracle import cnn
     from voice100_amd.asr import AudioToTextCTC
     from voice100_amd import functional as F_
@@ -418,12 +420,26 @@ def test_asr_metric_shape_ragged_lengths_vs_oracle(cuda):
     ref_loss = cnn.audio_to_text_ctc_loss(((audio, audio_len), (text, text_len)), st, training=True, updates=updates)
     ref_grads = dict(zip(params, torch.autograd.grad(ref_loss, list(params.values()))))
     # HIP path
-    F_.set_matmul_precision("fp32")
-    m = m.to(cuda).train()
-    m.decoder.layers[0].p = 0.0
-    m.batch_augment.forward = lambda a, l: (a, l)
-    loss = m.training_step(((audio.to(cuda), audio_len.to(cuda)), (text.to(cuda), text_len.to(cuda))), 0)
-    loss.backward()
+    F_.set_matmul_precision(precision)
+    try:
+        m = m.to(cuda).train()
+        m.decoder.layers[0].p = 0.0
+        m.batch_augment.forward = lambda a, l: (a, l)
+        loss = m.training_step(((audio.to(cuda), audio_len.to(cuda)), (text.to(cuda), text_len.to(cuda))), 0)
+        loss.backward()
+    finally:
+        F_.set_matmul_precision("fp32")
+    if precision == "bf16":
+        assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-2 * abs(float(ref_loss.detach()))
+        got = {k: p.grad.cpu() for k, p in m.named_parameters()}
+        # The gradient of the untrained 9-block net is ill-conditioned: fp32 round-off (1e-7) already shows as 2e-3 below,
+        # so bf16 operand rounding (4e-3) cannot be held to a small relative error.  What the throughput path must keep
+        # is the direction: cosine similarity with the fp32 oracle gradient over all parameters.
+        dot = sum(float((got[k].double() * ref_grads[k].double()).sum()) for k in ref_grads)
+        n1 = sum(float(got[k].double().pow(2).sum()) for k in ref_grads) ** 0.5
+        n2 = sum(float(ref_grads[k].double().pow(2).sum()) for k in ref_grads) ** 0.5
+        assert dot / (n1 * n2) > 0.9 and 0.8 < n1 / n2 < 1.25
+        return
     assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-4 * abs(float(ref_loss.detach()))
     got = {k: p.grad.cpu() for k, p in m.named_parameters()}
     num = sum(float((got[k].double() - ref_grads[k].double()).pow(2).sum()) for k in ref_grads)
