@@ -357,3 +357,53 @@ def test_tensors_past_the_2gib_descriptor_limit(cuda):
     ref = torch.einsum("mk,kt->mt", Abf.float().cpu(), X[B - 1].to(torch.bfloat16).float().cpu())
     assert rel_err(Y[B - 1], ref) < 1e-4
     assert rel_err(stp.sum(0)[:, 1], (Y * Y).sum((0, 2))) < 1e-3
+
+
+@pytest.mark.parametrize("B,M,cx,T,shifts,lpad", [(2, 40, 64, 77, (0, 1, 2, 3, 4), 2), (3, 256, 192, 130, (2, 0, 1), 1), (1, 300, 128, 513, (5, 0, 3, 1, 7, 2, 6, 4), 4),
+                                                   (2, 64, 24, 50, (1, 0), 1), (2, 129, 64, 1, (0, 1, 2), 1)])
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_tap_addressed_gemm_and_wgrad(cuda, B, M, cx, T, shifts, lpad, bf16):
+    """v100_pad_copy / v100_pw_gemm_taps / v100_pw_wgrad_taps against the explicit sum over taps in torch fp32: arbitrary
+    (unsorted) shifts, channel counts that are odd multiples of 64 (bf16) or no multiple at all (fp32), M and T off the
+    tile sizes, the +R epilogue, bias, and a padded, offset G operand."""
+    import ctypes
+    N = _native()
+    ntap = len(shifts)
+    g = torch.Generator().manual_seed(M * 3 + T)
+    tx = (T + max(shifts) + 3) // 4 * 4 + 4
+    if bf16 and not N.helper("v100_pw_taps_supported", B, M, cx, ntap, T, tx, 1):
+        # bf16 operands need cx % 64 == 0; the entry point refuses loudly (callers then take the im2col path)
+        assert cx % 64 != 0
+        d = torch.zeros(1 << 16, device=cuda)
+        with pytest.raises(RuntimeError):
+            N.call("v100_pw_gemm_taps", d, d.to(torch.bfloat16), d, d, None, None, B, M, cx, T, tx, ntap, (ctypes.c_int * ntap)(*shifts), 1)
+        return
+    tol = 2e-2 if bf16 else TOL
+    x = torch.randn(B, cx, T + 3, generator=g)                 # source rows longer than what is copied
+    xp = torch.full((B * cx * tx + 64,), float("nan"), device=cuda)[:B * cx * tx].view(B, cx, tx)
+    N.call("v100_pad_copy", x.to(cuda), xp, B, cx, T + 3, 1, 1, T, tx, lpad)
+    ref_xp = torch.zeros(B, cx, tx)
+    ref_xp[:, :, lpad:lpad + T] = x[:, :, 1:1 + T]
+    assert torch.equal(xp.cpu(), ref_xp)
+    A = torch.randn(M, ntap * cx, generator=g) / (ntap * cx) ** 0.5
+    bias, R = torch.randn(M, generator=g), torch.randn(B, M, T, generator=g)
+    Ad = A.to(cuda)
+    Abf = Ad.to(torch.bfloat16) if bf16 else None
+    sh = (ctypes.c_int * ntap)(*shifts)
+    xv = torch.cat([ref_xp[:, :, s:s + T] for s in shifts], dim=1)           # the virtual [B, ntap*cx, T] operand
+    ref = torch.einsum("mk,bkt->bmt", A, xv)
+    Y = torch.full((B, M, T), float("nan"), device=cuda)
+    N.call("v100_pw_gemm_taps", Ad, Abf, xp, Y, bias.to(cuda), None, B, M, cx, T, tx, ntap, sh, bf16)
+    assert rel_err(Y, ref + bias[None, :, None]) < tol
+    N.call("v100_pw_gemm_taps", Ad, Abf, xp, Y, None, R.to(cuda), B, M, cx, T, tx, ntap, sh, bf16)
+    assert rel_err(Y, ref + R) < tol
+    # backward-weight with G inside a padded buffer (pitch tg, first column g_off)
+    G = torch.randn(B, M, T, generator=g)
+    tg, g_off = T + 9, 5
+    Gp = torch.full((B, M, tg), 7.0)
+    Gp[:, :, g_off:g_off + T] = G
+    S = N.helper("v100_pw_wgrad_splits", B, M, ntap * cx)
+    partial = torch.empty(S, M, ntap * cx, device=cuda)
+    dW = torch.empty(M, ntap * cx, device=cuda)
+    N.call("v100_pw_wgrad_taps", Gp.to(cuda), tg, g_off, xp, partial, dW, S, B, M, cx, T, tx, ntap, sh, bf16)
+    assert rel_err(dW, torch.einsum("bmt,bkt->mk", G, xv)) < tol
