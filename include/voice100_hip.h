@@ -199,7 +199,9 @@ int v100_timing_read(int tag, double* ms, long long* count, double* bytes);
  * logits [B][T][V] fp32, targets [B][Lmax] int64, in_len / tgt_len [B] int32 (device).  Writes nll[b] =
  * -log p(target_b | logits_b) (inf when infeasible) and grad[b][t][c] = d nll_b / d logits[b][t][c] (zero for
  * padded frames and infeasible utterances); the caller forms mean_b(nll_b / tgt_len_b) and scales grad.
- * workspace: v100_ctc_workspace_floats(B, T, Lmax) floats.  Limits: V <= 128, Lmax <= 255. */
+ * workspace: v100_ctc_workspace_floats(B, T, Lmax) floats.  Limits: V <= 128, Lmax <= 2047
+ * (256 threads x up to 16 lattice states each).  Labels outside [0, V) are treated as blank (the host wrapper can validate
+ * them first: VOICE100_CHECK_IDS=1). */
 int v100_ctc_workspace_floats(int B, int T, int Lmax);
 int v100_ctc_loss(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace,
                   float* nll, float* grad, int B, int T, int V, int Lmax, int blank, void* stream);

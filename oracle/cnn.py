@@ -309,85 +309,3 @@ def conv_layers(x: torch.Tensor, state: State, settings: Sequence[Sequence], pre
     for i, (_out, transpose, _k, stride, padding, _bias) in enumerate(settings):
         x = conv_layer_block(x, state, f"{prefix}{i}.", bool(transpose), int(stride), int(padding))
     return x
-
-
-# --- v2 models around the conv stacks (_asr_v2.py, _tts_v2.py) --------------------------------
-def _bilstm(x_btc: torch.Tensor, lengths: torch.Tensor, state: State, prefix: str, num_layers: int, hidden: int,
-            batch_first_out: bool) -> Tuple[torch.Tensor, torch.Tensor]:
-    """nn.LSTM(bidirectional) over packed sequences, eval mode (the inter-layer dropout of 0.2 is a training-only draw)."""
-    lstm = torch.nn.LSTM(input_size=x_btc.shape[2], hidden_size=hidden, num_layers=num_layers, bidirectional=True)
-    weights = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)}
-    assert set(weights) == set(dict(lstm.named_parameters()))
-    packed = torch.nn.utils.rnn.pack_padded_sequence(x_btc, lengths.cpu(), batch_first=True, enforce_sorted=False)
-    out, _ = torch.func.functional_call(lstm, weights, (packed,))      # keeps the autograd graph to `state`
-    return torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=batch_first_out)
-
-
-def audio_to_align_text_forward(audio: torch.Tensor, audio_len: torch.Tensor, state: State, settings, num_layers: int,
-                                hidden: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """AudioToAlignText.forward (_asr_v2.py:38-52): audio [B, T, F] -> (logits [T', B, V], lengths [B])."""
-    x = conv_layers(audio.transpose(-2, -1), state, settings, "encoder.")
-    x_len = torch.divide(audio_len + 1, 2, rounding_mode="trunc")
-    out, out_len = _bilstm(x.transpose(-2, -1), x_len, state, "lstm.", num_layers, hidden, batch_first_out=False)
-    return F.linear(out, state["dense.weight"], state["dense.bias"]), out_len
-
-
-def audio_to_align_text_loss(audio, audio_len, text, text_len, state: State, settings, num_layers: int, hidden: int) -> torch.Tensor:
-    """_asr_v2.py:54-61 without the augmentation draw: log_softmax -> CTCLoss(zero_infinity=True), mean reduction."""
-    logits, logits_len = audio_to_align_text_forward(audio, audio_len, state, settings, num_layers, hidden)
-    return F.ctc_loss(F.log_softmax(logits, dim=-1), text, logits_len, text_len, blank=0, zero_infinity=True)
-
-
-def align_text_to_audio_v2_forward(aligntext: torch.Tensor, aligntext_len: torch.Tensor, state: State, settings, num_layers: int,
-                                   hidden: int, f0_size: int, logspc_size: int, codeap_size: int):
-    """AlignTextToAudio.forward (_tts_v2.py:52-80)."""
-    x = F.embedding(aligntext, state["embedding.weight"])
-    out, _ = _bilstm(x, aligntext_len, state, "lstm.", num_layers, hidden, batch_first_out=True)
-    x = conv_layers(out.transpose(-2, -1), state, settings, "decoder.").transpose(-2, -1)
-    x = F.linear(x, state["projection.weight"], state["projection.bias"])
-    hasf0, f0, logspc, hascodeap, codeap = torch.split(x, [f0_size, f0_size, logspc_size, codeap_size, codeap_size], dim=2)
-    return hasf0[:, :, 0], f0[:, :, 0], logspc, hascodeap, codeap
-
-
-def align_text_to_audio_v2_predict(aligntext, aligntext_len, state: State, settings, num_layers: int, hidden: int,
-                                   f0_size: int, logspc_size: int, codeap_size: int):
-    """AlignTextToAudio.predict (_tts_v2.py:82-101): un-normalise, zero f0 / codeap where their gates are negative."""
-    hasf0, f0, logspc, hascodeap, codeap = align_text_to_audio_v2_forward(
-        aligntext, aligntext_len, state, settings, num_layers, hidden, f0_size, logspc_size, codeap_size)
-    f0 = state["norm.f0_std"] * f0 + state["norm.f0_mean"]
-    logspc = state["norm.logspc_std"] * logspc + state["norm.logspc_mean"]
-    codeap = state["norm.codeap_std"] * codeap + state["norm.codeap_mean"]
-    return torch.where(hasf0 < 0, torch.zeros(1), f0), logspc, torch.where(hascodeap < 0, torch.zeros(1, 1), codeap)
-
-
-def world_loss_v2(length, hasf0_logits, f0_hat, logspc_hat, hascodeap_logits, codeap_hat, hasf0, f0, logspc, hascodeap, codeap):
-    """WORLDLoss.forward of _layers_v2.py:139-161 (mse variant): five masked means, each sum / sum(mask)."""
-    def cut(a, b):
-        n = min(a.shape[1], b.shape[1])
-        return a[:, :n], b[:, :n]
-    hasf0_logits, hasf0 = cut(hasf0_logits, hasf0)
-    f0_hat, f0 = cut(f0_hat, f0)
-    logspc_hat, logspc = cut(logspc_hat, logspc)
-    hascodeap_logits, hascodeap = cut(hascodeap_logits, hascodeap)
-    codeap_hat, codeap = cut(codeap_hat, codeap)
-    mask = padding_mask(f0.shape[1], length, f0.dtype)
-    bce = F.binary_cross_entropy_with_logits
-    terms = (bce(hasf0_logits, hasf0, reduction="none") * mask,
-             (f0_hat - f0) ** 2 * hasf0 * mask,
-             ((logspc_hat - logspc) ** 2).mean(dim=2) * mask,
-             bce(hascodeap_logits, hascodeap, reduction="none").mean(dim=2) * mask,
-             ((codeap_hat - codeap) ** 2 * hascodeap).mean(dim=2) * mask)
-    return tuple(t.sum() / mask.sum() for t in terms)
-
-
-def align_text_to_audio_v2_loss(batch, state: State, settings, num_layers: int, hidden: int, f0_size: int, logspc_size: int,
-                                codeap_size: int):
-    """_tts_v2.py:103-121: targets thresholded (f0 >= 30, codeap < -0.2), normalised, then world_loss_v2."""
-    (f0, f0_len, logspc, codeap), (aligntext, aligntext_len) = batch
-    hasf0 = (f0 >= 30.0).to(torch.float32)
-    hascodeap = (codeap < -0.2).to(torch.float32)
-    f0 = (f0 - state["norm.f0_mean"]) / state["norm.f0_std"]
-    logspc = (logspc - state["norm.logspc_mean"]) / state["norm.logspc_std"]
-    codeap = (codeap - state["norm.codeap_mean"]) / state["norm.codeap_std"]
-    pred = align_text_to_audio_v2_forward(aligntext, aligntext_len, state, settings, num_layers, hidden, f0_size, logspc_size, codeap_size)
-    return world_loss_v2(f0_len, *pred, hasf0, f0, logspc, hascodeap, codeap)

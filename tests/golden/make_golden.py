@@ -377,100 +377,6 @@ def gen_v2_blocks():
     np.savez_compressed(os.path.join(OUT, "v2_blocks.npz"), **out)
 
 
-def gen_v2_models():
-    """v2 models (_asr_v2.py AudioToAlignText, _tts_v2.py AlignTextToAudio), channel counts scaled down from
-    config/asr_en_base.yaml / config/tts_en_base.yaml.  Two LSTM depths: 2 layers for eval-mode forward / predict / loss,
-    1 layer (no inter-layer dropout draw) for a training-mode loss + gradients with the augmentation stubbed to identity."""
-    from voice100.models._asr_v2 import AudioToAlignText
-    from voice100.models._tts_v2 import AlignTextToAudio
-    from torch import nn
-    out = {}
-    gen = torch.Generator().manual_seed(977)
-
-    def randomize_ln(m):
-        for mod in m.modules():
-            if isinstance(mod, nn.LayerNorm):
-                with torch.no_grad():
-                    mod.weight.copy_(torch.rand(mod.weight.shape, generator=gen) + 0.5)
-                    mod.bias.copy_(torch.randn(mod.bias.shape, generator=gen) * 0.3)
-
-    enc = [[40, False, 5, 2, 2, False], [40, False, 5, 1, 2, False]]
-    for layers in (2, 1):
-        pre = f"asr{layers}/"
-        torch.manual_seed(500 + layers)
-        m = AudioToAlignText(audio_size=24, encoder_settings=enc, decoder_num_layers=layers, decoder_hidden_size=40, vocab_size=13)
-        randomize_ln(m)
-        B, T = 3, 61
-        audio = torch.randn(B, T, 24, generator=gen)
-        audio_len = torch.tensor([61, 40, 53])
-        text = torch.randint(1, 13, (B, 9), generator=gen)
-        text_len = torch.tensor([9, 5, 7])
-        out[pre + "settings"] = np.array([[int(v) for v in r] for r in enc], dtype=np.int64)
-        out[pre + "hp"] = np.array([24, layers, 40, 13], dtype=np.int64)
-        out.update(_np({pre + "audio": audio, pre + "audio_len": audio_len, pre + "text": text, pre + "text_len": text_len}))
-        out.update(_np(_state(m, pre + "state/")))
-        m.eval()
-        with torch.no_grad():
-            logits, logits_len = m(audio, audio_len)
-            loss = m._calc_batch_loss(((audio, audio_len), (text, text_len)))
-        out.update(_np({pre + "logits": logits, pre + "logits_len": logits_len, pre + "eval_loss": loss}))
-        if layers == 1:
-            m.train()
-            del m.batch_augment
-            object.__setattr__(m, "batch_augment", lambda a, l: (a, l))
-            loss = m._calc_batch_loss(((audio, audio_len), (text, text_len)))
-            loss.backward()
-            out[pre + "train_loss"] = loss.detach().numpy()
-            for k, p_ in m.named_parameters():
-                out[pre + "grad/" + k] = p_.grad.numpy().copy()
-
-    dec = [[40, False, 5, 1, 2, False], [40, True, 5, 2, 2, False], [40, False, 5, 1, 2, False]]
-    for layers in (2, 1):
-        pre = f"tts{layers}/"
-        torch.manual_seed(600 + layers)
-        S, CA = 11, 2
-        m = AlignTextToAudio(vocab_size=13, logspc_size=S, codeap_size=CA, encoder_num_layers=layers, encoder_hidden_size=24,
-                             decoder_settings=dec)
-        randomize_ln(m)
-        with torch.no_grad():
-            m.norm.f0_mean.fill_(120.0); m.norm.f0_std.fill_(35.0)
-            m.norm.logspc_mean.copy_(torch.randn(S, generator=gen) - 6.0); m.norm.logspc_std.copy_(torch.rand(S, generator=gen) + 0.5)
-            m.norm.codeap_mean.copy_(torch.randn(CA, generator=gen) - 1.0); m.norm.codeap_std.copy_(torch.rand(CA, generator=gen) + 0.5)
-        B, L = 3, 19
-        aligntext = torch.randint(0, 13, (B, L), generator=gen)
-        aligntext_len = torch.tensor([19, 12, 16])
-        Tt = 2 * L + 1                      # one frame longer than the model's 2L-1 (+2 here): adjust_size truncates
-        f0 = torch.rand(B, Tt, generator=gen) * 200.0
-        f0_len = torch.tensor([37, 23, 31])
-        logspc = torch.randn(B, Tt, S, generator=gen) - 6.0
-        codeap = torch.randn(B, Tt, CA, generator=gen) * 0.5 - 0.3
-        out[pre + "settings"] = np.array([[int(v) for v in r] for r in dec], dtype=np.int64)
-        out[pre + "hp"] = np.array([13, S, CA, layers, 24], dtype=np.int64)
-        out.update(_np({pre + "aligntext": aligntext, pre + "aligntext_len": aligntext_len, pre + "f0": f0, pre + "f0_len": f0_len,
-                        pre + "logspc": logspc, pre + "codeap": codeap}))
-        out.update(_np(_state(m, pre + "state/")))
-        batch = ((f0, f0_len, logspc, codeap), (aligntext, aligntext_len))
-        m.eval()
-        with torch.no_grad():
-            fw = m(aligntext, aligntext_len)
-            pr = m.predict(aligntext, aligntext_len)
-            ls = m._calc_batch_loss(batch)
-        for n, v in enumerate(fw):
-            out[pre + f"fwd{n}"] = v.numpy().copy()
-        for n, v in enumerate(pr):
-            out[pre + f"pred{n}"] = v.numpy().copy()
-        out[pre + "eval_losses"] = np.array([float(v) for v in ls], dtype=np.float32)
-        if layers == 1:
-            m.train()
-            loss = m.training_step(batch, 0)
-            loss.backward()
-            out[pre + "train_loss"] = loss.detach().numpy()
-            for k, p_ in m.named_parameters():
-                if p_.grad is not None:
-                    out[pre + "grad/" + k] = p_.grad.numpy().copy()
-    np.savez_compressed(os.path.join(OUT, "v2_models.npz"), **out)
-
-
 def main():
     sys.path.insert(0, REF)
     sys.dont_write_bytecode = True
@@ -483,7 +389,6 @@ def main():
     gen_augment()
     gen_mcep_and_int()
     gen_v2_blocks()
-    gen_v2_models()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

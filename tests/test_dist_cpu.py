@@ -66,6 +66,53 @@ def test_flat_bucket_allreduce_gloo_world2():
     assert ok and bn_local
 
 
+def test_trainstep_through_launcher_gloo_world2(tmp_path):
+    """The N > 1 launch path of `python bench.py --gpus N` (trainer.launch_ranks -> torch.distributed.run, rendezvous on
+    127.0.0.1) driving the real TrainStep: ranks seeded differently must hold identical weights after construction
+    (rank 0's) and after three optimiser steps, with several buckets in flight per step."""
+    import sys
+    from voice100_amd.trainer import launch_ranks
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_worker.py")
+    rc = launch_ranks(worker, [str(tmp_path)], 2, timeout=300)
+    assert rc == 0
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
+    assert r0["nbuckets"] > 1
+    assert not all(torch.equal(a, b) for a, b in zip(r0["before"], r1["before"]))       # seeds really differed
+    for a, b, c in zip(r0["after_init"], r1["after_init"], r0["before"]):
+        assert torch.equal(a, b) and torch.equal(a, c)                                  # broadcast of rank 0's weights
+    for a, b in zip(r0["final"], r1["final"]):
+        assert torch.equal(a, b)                                                        # same averaged gradients applied
+    assert not torch.allclose(r0["bn_mean"], r1["bn_mean"])                             # BatchNorm statistics stay per rank
+    assert r0["losses"] != r1["losses"] and abs(r0["lr"] - 0.98e-2) < 1e-9
+
+
+def test_second_backward_in_one_step_raises():
+    """Gradient accumulation is not supported by the bucket state machine: say so instead of racing the all-reduce."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_double_backward_worker, args=(_free_port(), out))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0
+    assert out.get(timeout=10) == "raised"
+
+
+def _double_backward_worker(port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from voice100_amd.dist import FlatGradBuckets
+    lin = torch.nn.Linear(4, 4)
+    buckets = FlatGradBuckets(lin.parameters(), bucket_bytes=16, force_exchange=True)
+    buckets.begin_step()
+    lin(torch.randn(2, 4)).sum().backward()
+    try:
+        lin(torch.randn(2, 4)).sum().backward()
+        out.put("silent")
+    except RuntimeError as e:
+        out.put("raised" if "one backward" in str(e) else str(e))
+    dist.destroy_process_group()
+
+
 def test_shard_batch_covers_everything():
     from voice100_amd.dist import shard_batch
     for n in (1, 7, 32, 256):

@@ -249,7 +249,8 @@ def test_errors_are_loud(cuda):
         InvertedResidual(4, 4, 5)(torch.zeros(1, 4, 16))                                     # no CPU fallback
 
 
-@pytest.mark.parametrize("B,T,V,L", [(3, 40, 29, 7), (4, 130, 71, 30), (2, 9, 5, 6), (5, 64, 29, 1)])
+@pytest.mark.parametrize("B,T,V,L", [(3, 40, 29, 7), (4, 130, 71, 30), (2, 9, 5, 6), (5, 64, 29, 1),
+                                     (3, 700, 29, 300), (2, 1300, 71, 600), (2, 2500, 29, 1200)])   # L > 255: 4 / 8 / 16 states per thread
 def test_ctc_loss_fused(cuda, B, T, V, L):
     """Fused log_softmax + CTC (value and gradient) vs torch's CPU F.ctc_loss, ragged lengths, repeated labels,
     an infeasible utterance (zero_infinity) and an empty target."""

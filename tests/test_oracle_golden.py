@@ -208,55 +208,3 @@ def test_v2_conv_blocks_golden(sid):
     (y * torch.from_numpy(g[sid + "/gy"])).sum().backward()
     assert rel_err(x.grad, g[sid + "/gx"]) < 1e-4
     assert_grads_close({k: p.grad for k, p in params.items()}, {k: g[sid + "/grad/" + k] for k in params}, 2e-4)
-
-
-@pytest.mark.parametrize("layers", [2, 1])
-def test_v2_asr_model_golden(layers):
-    """AudioToAlignText (_asr_v2.py): conv encoder -> BiLSTM -> Linear logits, lengths, CTC loss and (1 LSTM layer) gradients."""
-    g = load_golden("v2_models.npz")
-    pre = f"asr{layers}/"
-    settings = [[int(v) for v in row] for row in g[pre + "settings"]]
-    _, nl, hidden, _ = (int(v) for v in g[pre + "hp"])
-    state = sub(g, pre + "state/")
-    t = lambda k: torch.from_numpy(g[pre + k])
-    logits, lens = cnn.audio_to_align_text_forward(t("audio"), t("audio_len"), state, settings, nl, hidden)
-    assert torch.equal(lens, t("logits_len"))
-    assert rel_err(logits, g[pre + "logits"]) < TOL
-    loss = cnn.audio_to_align_text_loss(t("audio"), t("audio_len"), t("text"), t("text_len"), state, settings, nl, hidden)
-    assert abs(float(loss.detach()) - float(g[pre + "eval_loss"])) < 1e-4 * abs(float(loss.detach()))
-    if layers == 1:
-        params = {k: v.clone().requires_grad_(True) for k, v in state.items()}
-        loss = cnn.audio_to_align_text_loss(t("audio"), t("audio_len"), t("text"), t("text_len"), params, settings, nl, hidden)
-        assert abs(float(loss.detach()) - float(g[pre + "train_loss"])) < 1e-4 * abs(float(loss.detach()))
-        names = [k[len(pre + "grad/"):] for k in g if k.startswith(pre + "grad/")]
-        grads = torch.autograd.grad(loss, [params[k] for k in names])
-        assert_grads_close(dict(zip(names, grads)), {k: g[pre + "grad/" + k] for k in names}, 2e-4)
-
-
-@pytest.mark.parametrize("layers", [2, 1])
-def test_v2_tts_model_golden(layers):
-    """AlignTextToAudio (_tts_v2.py): forward split, predict gating, the five v2 WORLD losses and (1 LSTM layer) gradients."""
-    g = load_golden("v2_models.npz")
-    pre = f"tts{layers}/"
-    settings = [[int(v) for v in row] for row in g[pre + "settings"]]
-    _, S, CA, nl, hidden = (int(v) for v in g[pre + "hp"])
-    state = sub(g, pre + "state/")
-    t = lambda k: torch.from_numpy(g[pre + k])
-    args = (settings, nl, hidden, 1, S, CA)
-    fw = cnn.align_text_to_audio_v2_forward(t("aligntext"), t("aligntext_len"), state, *args)
-    for n, v in enumerate(fw):
-        assert rel_err(v, g[pre + f"fwd{n}"]) < TOL
-    pr = cnn.align_text_to_audio_v2_predict(t("aligntext"), t("aligntext_len"), state, *args)
-    for n, v in enumerate(pr):
-        assert rel_err(v, g[pre + f"pred{n}"]) < TOL
-    batch = ((t("f0"), t("f0_len"), t("logspc"), t("codeap")), (t("aligntext"), t("aligntext_len")))
-    losses = cnn.align_text_to_audio_v2_loss(batch, state, *args)
-    np.testing.assert_allclose([float(v) for v in losses], g[pre + "eval_losses"], rtol=1e-4)
-    if layers == 1:
-        params = {k: (v.clone().requires_grad_(True) if not k.startswith("norm.") else v) for k, v in state.items()}
-        l = cnn.align_text_to_audio_v2_loss(batch, params, *args)
-        loss = l[0] + l[1] + 5.0 * l[2] + l[3] + l[4]
-        assert abs(float(loss.detach()) - float(g[pre + "train_loss"])) < 1e-4 * abs(float(loss.detach()))
-        names = [k[len(pre + "grad/"):] for k in g if k.startswith(pre + "grad/")]
-        grads = torch.autograd.grad(loss, [params[k] for k in names])
-        assert_grads_close(dict(zip(names, grads)), {k: g[pre + "grad/" + k] for k in names}, 2e-4)

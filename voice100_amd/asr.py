@@ -2,17 +2,18 @@
 
 Drop-in for voice100/models/asr.py:62-196 -- same class names, constructor
 arguments, forward() layouts and state_dict keys -- with the convolution stacks
-running on the MI355X kernels.  pytorch_lightning is not required: the model is a
-plain nn.Module that also answers the LightningModule hooks the reference's
-trainers call (training_step / validation_step / test_step / configure_optimizers),
-see voice100_amd.trainer for the step loop that replaces `Trainer.fit`.
+running on the MI355X kernels.  The model derives from Voice100ModelBase
+(= pytorch_lightning.LightningModule when that is importable, else the shim in
+voice100_amd/_base.py with the same hooks), so `Trainer.fit`, `load_from_checkpoint`
+and the reference's ONNX exporter flow see a drop-in module; voice100_amd.trainer
+is the step loop used where Lightning is absent.
 """
-from argparse import Namespace
-
 import torch
 from torch import nn
 
+from . import _stock
 from . import functional as F_
+from ._base import Voice100ModelBase, tracing
 from .audio import BatchSpectrogramAugumentation
 from .layers import InvertedResidual, PointwiseConv1d
 
@@ -37,7 +38,7 @@ class ConvVoiceEncoder(nn.Module):
             InvertedResidual(ci, co, kernel_size=k, stride=s, use_residual=r) for ci, co, k, s, r in spec])
 
     def forward(self, embed: torch.Tensor) -> torch.Tensor:
-        if self.training:
+        if self.training and not tracing():
             F_.prepare_block_weights(self.layers)       # bf16 / transposed weight copies of all 9 blocks in one launch
         return self.layers(embed)
 
@@ -55,17 +56,18 @@ class LinearCharDecoder(nn.Module):
 
     def forward(self, enc_out: torch.Tensor) -> torch.Tensor:
         drop, conv = self.layers[0], self.layers[1]
+        if tracing():
+            return conv(drop(enc_out))
         x = F_.dropout(enc_out, drop.p, self.training, self._keep_mask)
         return conv(x)
 
 
-class AudioToTextCTC(nn.Module):
+class AudioToTextCTC(Voice100ModelBase):
     """audio [B, T, audio_size] fp32 -> logits [B, (T+1)//2, vocab_size] (asr.py:97-196)."""
 
     def __init__(self, audio_size, embed_size, vocab_size, hidden_size, learning_rate=0.001, weight_decay=0.00004):
         super().__init__()
-        self.hparams = Namespace(audio_size=audio_size, embed_size=embed_size, vocab_size=vocab_size,
-                                 hidden_size=hidden_size, learning_rate=learning_rate, weight_decay=weight_decay)
+        self.save_hyperparameters()
         self.embed_size = embed_size
         self.encoder = ConvVoiceEncoder(audio_size, embed_size, hidden_size)
         self.decoder = LinearCharDecoder(embed_size, vocab_size)
@@ -74,9 +76,8 @@ class AudioToTextCTC(nn.Module):
         self.do_normalize = False
 
     def forward(self, audio: torch.Tensor) -> torch.Tensor:
-        if torch.onnx.is_in_onnx_export():
-            raise RuntimeError("ONNX export needs a stock-op graph; export the reference module with this "
-                               "module's state_dict (identical keys) instead")
+        if tracing():                            # torch.jit.trace / torch.onnx.export: plain aten ops (_stock.py)
+            return torch.transpose(self.decoder(self.encoder(torch.transpose(audio, 1, 2))), 1, 2)
         x = F_.transpose_last2(audio)            # [B,T,C] -> [B,C,T]
         x = self.encoder(x)
         x = self.decoder(x)
@@ -85,10 +86,23 @@ class AudioToTextCTC(nn.Module):
     def output_length(self, audio_len: torch.Tensor) -> torch.Tensor:
         return self.encoder.output_length(audio_len)
 
+    def normalize(self, audio: torch.Tensor, audio_len: torch.Tensor) -> torch.Tensor:
+        """Masked per-utterance mean / std normalisation over time (asr.py:124-131).  Off by default in the reference
+        (`do_normalize = False`, asr.py:108): a handful of reductions on an 8 MB tensor, stock torch ops."""
+        from .tts import generate_padding_mask
+        mask = torch.unsqueeze(generate_padding_mask(audio[:, :, 0], audio_len), dim=2)
+        n = torch.sum(mask, dim=1, keepdim=True)
+        mean = torch.sum(audio * mask, dim=1, keepdim=True) / n
+        audio = (audio - mean) * mask
+        std = torch.sqrt(torch.sum(audio ** 2, dim=1, keepdim=True) / n)
+        return audio / (std + 1e-15) * mask
+
     def _calc_batch_loss(self, batch):
         (audio, audio_len), (text, text_len) = batch
         if self.training:
             audio, audio_len = self.batch_augment(audio, audio_len)
+        if self.do_normalize:
+            audio = self.normalize(audio, audio_len)
         logits = self.forward(audio)                         # [B, T', V]
         logits_len = self.output_length(audio_len)
         # log_softmax + CTCLoss(blank=0, mean, zero_infinity=True) fused in the HIP lattice kernels (K10)
@@ -96,13 +110,19 @@ class AudioToTextCTC(nn.Module):
 
     # LightningModule-style hooks the reference's trainers call (asr.py:154-178)
     def training_step(self, batch, batch_idx=0):
-        return self._calc_batch_loss(batch)
+        loss = self._calc_batch_loss(batch)
+        self.log_dict({"train_loss": loss})
+        return loss
 
     def validation_step(self, batch, batch_idx=0):
-        return {"val_loss": self._calc_batch_loss(batch)}
+        metrics = {"val_loss": self._calc_batch_loss(batch)}
+        self.log_dict(metrics)
+        return metrics
 
     def test_step(self, batch, batch_idx=0):
-        return {"test_loss": self._calc_batch_loss(batch)}
+        metrics = {"test_loss": self._calc_batch_loss(batch)}
+        self.log_dict(metrics)
+        return metrics
 
     def configure_optimizers(self):
         # same update rule as the reference's torch.optim.Adam (asr.py:169-176); on the GPU PyTorch's single fused

@@ -41,6 +41,9 @@ __global__ void ctc_lse_kernel(const float* __restrict__ logits, float* __restri
 }
 
 // grid (B, 2): y = 0 alpha, y = 1 beta.  lattice[b][t][s] written for t < in_len[b], s < 2*tgt_len[b]+1.
+// NS = lattice states per thread: 256 * NS >= 2 * Lmax + 1 (NS = 2 covers transcripts of up to 255 tokens, the
+// benchmark's; 4 / 8 / 16 cover up to 511 / 1023 / 2047 -- nn.CTCLoss itself has no limit, asr.py:105).
+template <int NS>
 __global__ __launch_bounds__(256) void ctc_lattice_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
                                                           const long long* __restrict__ targets, const int* __restrict__ in_len,
                                                           const int* __restrict__ tgt_len, float* __restrict__ alpha,
@@ -64,7 +67,6 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const float* __restric
     if (Tb <= 0) { if (dir == 0 && tid == 0) nll[b] = INFINITY; return; }
 
     // states handled by this thread: s = tid, tid + 256, ... ; class and skip permission per state
-    const int NS = 2;                                // up to 512 states per utterance
     int cls[NS]; bool skip[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -182,7 +184,7 @@ extern "C" int v100_ctc_workspace_floats(int B, int T, int Lmax) {      // alpha
 extern "C" int v100_ctc_loss(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace,
                              float* nll, float* grad, int B, int T, int V, int Lmax, int blank, void* stream) {
     if (!logits || !targets || !in_len || !tgt_len || !workspace || !nll || !grad) return V100_ERR_NULL;
-    if (B <= 0 || T <= 0 || V <= 0 || V > CTC_MAXV || Lmax < 0 || 2 * Lmax + 1 > 512 || blank < 0 || blank >= V) return V100_ERR_SHAPE;
+    if (B <= 0 || T <= 0 || V <= 0 || V > CTC_MAXV || Lmax < 0 || 2 * Lmax + 1 > 4096 || blank < 0 || blank >= V) return V100_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int Smax = 2 * Lmax + 1;
     float* alpha = workspace;
@@ -191,8 +193,16 @@ extern "C" int v100_ctc_loss(const float* logits, const long long* targets, cons
     const long rows = (long)B * T;
     hipLaunchKernelGGL(ctc_lse_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logits, lse, rows, V);
     const size_t shmem = (size_t)(CTC_CHUNK * V + 2 * (Smax + 4)) * sizeof(float);
-    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(B, 2), dim3(256), shmem, st, logits, lse, targets, in_len, tgt_len, alpha, beta, nll,
-                       T, V, Lmax, Smax, blank);
+#define CTC_LATTICE(NS_)                                                                                                          \
+    if (shmem > 65536)                                                                                                            \
+        (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);       \
+    hipLaunchKernelGGL(ctc_lattice_kernel<NS_>, dim3(B, 2), dim3(256), shmem, st, logits, lse, targets, in_len, tgt_len, alpha, beta, \
+                       nll, T, V, Lmax, Smax, blank)
+    if (Smax <= 512) { CTC_LATTICE(2); }
+    else if (Smax <= 1024) { CTC_LATTICE(4); }
+    else if (Smax <= 2048) { CTC_LATTICE(8); }
+    else { CTC_LATTICE(16); }
+#undef CTC_LATTICE
     hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len,
                        alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank);
     return v100_launch_status();

@@ -61,6 +61,7 @@ class FlatGradBuckets:
         if members:
             self.buckets.append((start, off, members))
         self._pending = [0] * len(self.buckets)
+        self._next = 0             # buckets are launched strictly in index order, so every rank issues the same collectives
         self._handles = []
         self._hooks = []
         if self.exchange:
@@ -74,6 +75,7 @@ class FlatGradBuckets:
             p.grad = None
         for i, (_, _, members) in enumerate(self.buckets):
             self._pending[i] = len(members)
+        self._next = 0
         self._handles = []
 
     def _launch(self, b):
@@ -88,17 +90,25 @@ class FlatGradBuckets:
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
+        if self._pending[b] <= 0:
+            # a second backward inside one begin_step()/finish_step() pair would accumulate into p.grad, which by now is a
+            # view of the flat buffer an all-reduce may still be reading
+            raise RuntimeError("FlatGradBuckets: a gradient arrived for a bucket that was already exchanged this step; "
+                               "exactly one backward per begin_step()/finish_step() (no gradient accumulation)")
         self._pending[b] -= 1
-        if self._pending[b] == 0:
-            self._launch(b)
+        # launch in index order only: a rank on which some parameter received no gradient must not issue its
+        # collectives in a different order (sizes differ per bucket) than the other ranks
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
 
     def finish_step(self):
         """Wait for the exchange and turn the sum into DDP's mean.  Call after backward."""
         if not self.exchange:
             return
-        for b in range(len(self.buckets)):
-            if self._pending[b] >= 0:          # some parameter of this bucket produced no gradient this step
-                self._launch(b)
+        while self._next < len(self.buckets):      # buckets with a parameter that produced no gradient this step
+            self._launch(self._next)
+            self._next += 1
         for h in self._handles:
             h.wait()
         self.flat.div_(self.world)
@@ -107,6 +117,27 @@ class FlatGradBuckets:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+def broadcast_module_state(module: torch.nn.Module, src: int = 0, process_group=None) -> None:
+    """Copy rank `src`'s parameters and buffers to every rank (what DistributedDataParallel does at construction):
+    afterwards all replicas start from identical weights, whatever each rank seeded or loaded.  One flat message per
+    dtype; a no-op without an initialised process group or in a group of one."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return
+    tensors = [t.detach() for t in list(module.parameters()) + list(module.buffers())]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    for (dt, dev), group in by_dtype.items():
+        flat = torch.cat([t.reshape(-1) for t in group]) if group else None
+        dist.broadcast(flat, src=src, group=process_group)
+        off = 0
+        with torch.no_grad():
+            for t in group:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
 
 
 def shard_batch(n_items: int, rank: int, world: int):

@@ -14,11 +14,24 @@ BatchNorm + ReLU6 are applied by the *consumer* while it loads its input:
       --pw GEMM (BN2+ReLU6 on load)--> a3 (+stats) --affine(+x)--> y
 """
 import ctypes
+import os
 from typing import Optional
 
 import torch
 
 from . import _native as N
+
+# The kernels clamp out-of-range ids instead of faulting (embedding rows: bn.hip; CTC labels -> blank: ctc.hip), where
+# the reference's nn.Embedding / nn.CTCLoss raise.  VOICE100_CHECK_IDS=1 validates them on the host first (one device
+# sync per call, so it is a debugging switch, off by default).
+CHECK_IDS = os.environ.get("VOICE100_CHECK_IDS", "0") not in ("", "0")
+
+
+def _check_ids(idx: torch.Tensor, n: int, what: str) -> None:
+    if CHECK_IDS and idx.numel():
+        lo, hi = int(idx.min()), int(idx.max())
+        if lo < 0 or hi >= n:
+            raise IndexError(f"{what}: index out of range [0, {n}) (min {lo}, max {hi})")
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -181,13 +194,14 @@ class InvertedResidualTrainFn(torch.autograd.Function):
 
 def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
     """bf16 / transposed copies of the two 1x1 weights of every InvertedResidual in `blocks`, in ONE launch
-    (v100_ir_prep_batched), into per-module buffers that the blocks' next forward hands to the executor.  Called by the
-    stacks (ConvVoiceEncoder, VoiceDecoder, ...) at the top of EVERY training-mode forward: nothing is cached across
-    forwards (weights change under the optimiser, and fused optimiser kernels do not bump tensor versions, so there is no
-    reliable staleness key).  A block that runs without this call prepares its own copies as before."""
+    (v100_ir_prep_batched), into slices of ONE freshly allocated buffer that the blocks' next forward hands to the
+    executor and saves for its backward.  Called by the stacks (ConvVoiceEncoder, VoiceDecoder, ...) at the top of EVERY
+    training-mode forward: nothing is cached or overwritten across forwards (weights change under the optimiser, fused
+    optimiser kernels do not bump tensor versions, and a backward that runs after a later forward must still see the
+    copies of ITS forward).  A block that runs without this call prepares its own copies as before."""
     bf16 = _fmt(precision)
     _no_fp16_training(bf16, "InvertedResidual (training mode)")
-    todo = []
+    todo, total = [], 0
     for blk in blocks:
         w1, w3 = blk.conv[0][0].weight, blk.conv[2].weight
         if not w1.is_cuda:
@@ -195,19 +209,21 @@ def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
         hid, cin = w1.shape[0], w1.shape[1]
         cout = w3.shape[0]
         shape = (0, cin, hid, cout, 0, 0, 1, 0, int(bf16), 1)
-        buf = getattr(blk, "_prep_buf", None)
         nbytes = N.helper("v100_ir_prep_bytes", (ctypes.c_int * 10)(*shape))
-        if buf is None or buf.numel() != nbytes or buf.device != w1.device:
-            buf = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
-            blk._prep_buf = buf
-        todo.append((blk, shape, w1, w3, buf))
+        todo.append((blk, shape, w1, w3, total, nbytes))
+        total += (nbytes + 255) // 256 * 256
+    if not todo:
+        return
+    pool = torch.empty(total, dtype=torch.uint8, device=todo[0][2].device)
+    bufs = [pool[off:off + nbytes] for _, _, _, _, off, nbytes in todo]
     for i in range(0, len(todo), 32):
         chunk = todo[i:i + 32]
         shapes = (ctypes.c_int * (10 * len(chunk)))(*[v for c in chunk for v in c[1]])
         N.call("v100_ir_prep_batched", shapes, _ptr_table([c[2] for c in chunk]), _ptr_table([c[3] for c in chunk]),
-               _ptr_table([c[4] for c in chunk]), len(chunk))
-        for blk, _, _, _, _ in chunk:
-            blk._prep_fresh = bf16          # consumed (once) by the block's next training-mode forward at this precision
+               _ptr_table(bufs[i:i + 32]), len(chunk))
+    for (blk, _, _, _, _, _), buf in zip(todo, bufs):
+        blk._prep_buf = buf
+        blk._prep_fresh = bf16          # consumed (once) by the block's next training-mode forward at this precision
 
 
 def prepared_weights_of(blk, precision: Optional[str] = None):
@@ -215,8 +231,8 @@ def prepared_weights_of(blk, precision: Optional[str] = None):
     bf16 = _fmt(precision)
     fresh = getattr(blk, "_prep_fresh", None)
     if fresh is not None and fresh == bf16:
-        blk._prep_fresh = None
-        return blk._prep_buf
+        buf, blk._prep_fresh, blk._prep_buf = blk._prep_buf, None, None     # the forward's ctx now owns it
+        return buf
     return None
 
 
@@ -390,6 +406,7 @@ class EmbeddingBCTFn(torch.autograd.Function):
         idx = idx.contiguous().to(torch.int64)
         B, T = idx.shape
         V, C = table.shape
+        _check_ids(idx, V, "embedding")
         out = _f32(B, C, T, like=table)
         N.call("v100_embedding_bct", idx, table.detach().contiguous(), out, B, V, C, T)
         ctx.save_for_backward(idx)
@@ -734,7 +751,9 @@ def world_unnormalize_gate(x_bta, f0_mean, f0_std, ls_mean, ls_std, ca_mean, ca_
 
 class CTCLossFn(torch.autograd.Function):
     """log_softmax(dim=-1) + CTCLoss(blank=0, reduction='mean', zero_infinity=True) on logits [B, T, V]
-    (asr.py:146-152), forward and gradient in one pass of the HIP lattice kernels."""
+    (asr.py:146-152), forward and gradient in one pass of the HIP lattice kernels.  Limits of the kernel: V <= 128 classes,
+    padded target width <= 2047 tokens (nn.CTCLoss has none; the reference's longest transcripts are a few hundred
+    characters).  Labels outside [0, V) count as blank unless VOICE100_CHECK_IDS=1 (then IndexError, like the reference)."""
 
     @staticmethod
     def forward(ctx, logits, targets, input_lengths, target_lengths, blank):
@@ -743,6 +762,9 @@ class CTCLossFn(torch.autograd.Function):
         B, T, V = logits.shape
         targets = targets.to(device=logits.device, dtype=torch.int64).contiguous()
         lmax = targets.shape[1]
+        if lmax > 2047:
+            raise RuntimeError(f"ctc_loss: padded target width {lmax} exceeds the kernel's 2047-token limit")
+        _check_ids(targets, V, "ctc_loss targets")
         il = input_lengths.to(device=logits.device, dtype=torch.int32).contiguous()
         tl = target_lengths.to(device=logits.device, dtype=torch.int32).contiguous()
         nws = N.helper("v100_ctc_workspace_floats", B, T, lmax)

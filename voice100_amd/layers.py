@@ -10,7 +10,9 @@ sub-modules' own forward().
 import torch
 from torch import nn
 
+from . import _stock
 from . import functional as F_
+from ._base import tracing
 
 
 class ConvBNActivate(nn.ModuleList):
@@ -63,6 +65,8 @@ class InvertedResidual(nn.Module):
         return super().train(mode)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if tracing():                 # graph recording (torch.jit.trace / ONNX export): plain aten ops, see _stock.py
+            return _stock.inverted_residual(self, x)
         pw, dw, pl, bn3 = self.conv[0], self.conv[1], self.conv[2], self.conv[3]
         bn1, bn2 = pw[1], dw[1]
         prec = F_.get_matmul_precision()
@@ -74,7 +78,10 @@ class InvertedResidual(nn.Module):
                 bn3.running_mean, bn3.running_var, bn3.num_batches_tracked,
                 self.kernel_size, self.stride, self.use_residual, prec, F_.prepared_weights_of(self, prec))
         # eval mode: frozen statistics, inference only (autograd through eval-mode BN is not on the
-        # reference's training path and is not built)
+        # reference's training path and is not built) -- say so instead of silently returning a constant
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise RuntimeError("InvertedResidual in eval mode is inference-only (frozen-BatchNorm fine-tuning is not "
+                               "built): call it under torch.no_grad(), or switch the block to train()")
         with torch.no_grad():
             return F_.inverted_residual_eval_cached(self, x, prec)
 
@@ -86,4 +93,6 @@ class PointwiseConv1d(nn.Conv1d):
         super().__init__(in_channels, out_channels, kernel_size=1, padding=0, bias=bias)
 
     def forward(self, x):
+        if tracing():
+            return _stock.pointwise_conv1d(self, x)
         return F_.pointwise_conv1d(x, self.weight, self.bias)

@@ -16,7 +16,9 @@ from typing import List, Tuple
 import torch
 from torch import nn
 
+from . import _stock
 from . import functional as F_
+from ._base import tracing
 
 __all__ = ["ConvLayerBlock", "ConvTransposeLayerBlock", "get_conv_layers"]
 
@@ -31,6 +33,8 @@ class ConvLayerBlock(nn.Module):
                               stride=stride, padding=padding, bias=bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if tracing():
+            return _stock.conv_layer_block(self, x, transpose=False)
         c = self.conv
         y = F_.conv1d_dense(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0])
         return F_.layer_norm_gelu(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
@@ -50,6 +54,8 @@ class ConvTransposeLayerBlock(nn.Module):
                                        stride=stride, padding=padding, bias=bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if tracing():
+            return _stock.conv_layer_block(self, x, transpose=True)
         y = F_.conv_transpose1d_k5s2(x, self.conv.weight, self.conv.bias)
         return F_.layer_norm_gelu(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
 

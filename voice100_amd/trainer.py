@@ -2,12 +2,15 @@
 (voice100/train_asr.py:12-38): Adam (L2-style weight_decay as torch.optim.Adam), StepLR(0.98) per
 epoch, one gradient all-reduce per step when launched with one process per GPU."""
 import os
-from typing import Optional
+import socket
+import subprocess
+import sys
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist
 
-from .dist import FlatGradBuckets
+from .dist import FlatGradBuckets, broadcast_module_state
 
 
 def init_distributed(backend: Optional[str] = None):
@@ -22,11 +25,30 @@ def init_distributed(backend: Optional[str] = None):
     return rank, local_rank, world
 
 
+def launch_ranks(script: str, argv: List[str], nproc: int, timeout: Optional[float] = None) -> int:
+    """Start `nproc` ranks of `script` on this node -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> script argv...` -- as a CHILD process and return its exit code.
+    Call it before anything in the calling process has touched the GPU (a process that has initialised HIP must not
+    fork GPU work; the children are fresh interpreters, nothing is re-exec'd)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env, timeout=timeout).returncode
+
+
 class TrainStep:
-    """One optimisation step of a module exposing training_step(batch, idx) and configure_optimizers()."""
+    """One optimisation step of a module exposing training_step(batch, idx) and configure_optimizers().
+    With more than one rank the constructor first copies rank 0's parameters and buffers to every rank (DDP's
+    construction-time broadcast), so replicas cannot start from different weights."""
 
     def __init__(self, model: torch.nn.Module, bucket_bytes: int = 16 << 20):
         self.model = model
+        broadcast_module_state(model)
         cfg = model.configure_optimizers()
         if isinstance(cfg, dict):
             self.optimizer, self.scheduler = cfg["optimizer"], cfg.get("lr_scheduler")

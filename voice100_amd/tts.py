@@ -4,13 +4,15 @@ voice100/models/_layers_v1.py:14-138 (same class names, constructor arguments, f
 state_dict keys); the convolution stacks, the transposed convolution and the predict epilogue run
 on the MI355X kernels.
 """
-from argparse import ArgumentParser, Namespace
+from argparse import ArgumentParser
 from typing import Tuple
 
 import torch
 from torch import nn
 
+from . import _stock
 from . import functional as F_
+from ._base import Voice100ModelBase, tracing
 from .layers import InvertedResidual, PointwiseConv1d
 
 __all__ = ["VoiceDecoder", "TextToAlignTextModel", "AlignTextToAudioModel", "WORLDNorm", "WORLDLoss",
@@ -36,6 +38,8 @@ class ConvTranspose1d(nn.ConvTranspose1d):
     def forward(self, x):
         if self.kernel_size != (5,) or self.stride != (2,) or self.padding != (2,) or self.output_padding != (0,):
             raise RuntimeError("only ConvTranspose1d(kernel_size=5, stride=2, padding=2) is built")
+        if tracing():
+            return _stock.conv_transpose1d(self, x)
         return F_.conv_transpose1d_k5s2(x, self.weight, self.bias)
 
 
@@ -58,7 +62,7 @@ class VoiceDecoder(nn.Module):
             PointwiseConv1d(half, out_channels, bias=True))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.training:
+        if self.training and not tracing():
             F_.prepare_block_weights([m for m in self.layers if isinstance(m, InvertedResidual)])
         return self.layers(x)
 
@@ -129,12 +133,12 @@ class WORLDNorm(nn.Module):
                 self.codeap_std * codeap + self.codeap_mean)
 
 
-class TextToAlignTextModel(nn.Module):
+class TextToAlignTextModel(Voice100ModelBase):
     """text [B, L] int64 -> [B, L, 2] log(gap+1), log(len+1) predictions (tts.py:67-149)."""
 
     def __init__(self, vocab_size, hidden_size, learning_rate=1e-3) -> None:
         super().__init__()
-        self.hparams = Namespace(vocab_size=vocab_size, hidden_size=hidden_size, learning_rate=learning_rate)
+        self.save_hyperparameters()
         self.embedding = nn.Embedding(vocab_size, hidden_size)
         self.layers = nn.Sequential(
             InvertedResidual(hidden_size, hidden_size, kernel_size=5),
@@ -144,6 +148,8 @@ class TextToAlignTextModel(nn.Module):
             PointwiseConv1d(hidden_size, 2, bias=True))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if tracing():
+            return torch.transpose(self.layers(_stock.embedding_bct(x, self.embedding.weight)), 1, 2)
         x = F_.embedding_bct(x, self.embedding.weight)          # [B, H, L]
         if self.training:
             F_.prepare_block_weights([m for m in self.layers if isinstance(m, InvertedResidual)])
@@ -177,10 +183,14 @@ class TextToAlignTextModel(nn.Module):
         return torch.sum(loss * mask) / torch.sum(mask)
 
     def training_step(self, batch, batch_idx=0):
-        return self._calc_batch_loss(batch)
+        loss = self._calc_batch_loss(batch)
+        self.log("train_loss", loss)
+        return loss
 
     def validation_step(self, batch, batch_idx=0):
-        return {"val_loss": self._calc_batch_loss(batch)}
+        loss = self._calc_batch_loss(batch)
+        self.log("val_loss", loss)
+        return {"val_loss": loss}
 
     def configure_optimizers(self):
         params = list(self.parameters())
@@ -198,12 +208,12 @@ class TextToAlignTextModel(nn.Module):
         return TextToAlignTextModel(hidden_size=args.hidden_size, learning_rate=args.learning_rate, **kwargs)
 
 
-class AlignTextToAudioModel(nn.Module):
+class AlignTextToAudioModel(Voice100ModelBase):
     """aligned text [B, L] int64 -> WORLD features at 2L-1 frames (tts.py:152-262)."""
 
     def __init__(self, vocab_size: int, hidden_size: int, learning_rate: float = 1e-3, use_mcep: bool = False) -> None:
         super().__init__()
-        self.hparams = Namespace(vocab_size=vocab_size, hidden_size=hidden_size, learning_rate=learning_rate, use_mcep=use_mcep)
+        self.save_hyperparameters()
         self.hidden_size = hidden_size
         self.vocab_size = vocab_size
         self.sample_rate = 16000
@@ -219,6 +229,8 @@ class AlignTextToAudioModel(nn.Module):
         self.criterion = WORLDLoss(use_mel_weights=not use_mcep, sample_rate=self.sample_rate, n_fft=self.n_fft)
 
     def _decode(self, aligntext: torch.Tensor) -> torch.Tensor:
+        if tracing():
+            return torch.transpose(self.decoder(_stock.embedding_bct(aligntext, self.embedding.weight)), 1, 2)
         x = F_.embedding_bct(aligntext, self.embedding.weight)   # [B, H, L]
         x = self.decoder(x)                                      # [B, A, 2L-1]
         return F_.transpose_last2(x)                             # [B, 2L-1, A]
@@ -233,6 +245,8 @@ class AlignTextToAudioModel(nn.Module):
     def predict(self, aligntext: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         x = self._decode(aligntext)
         n = self.norm
+        if tracing():
+            return _stock.world_unnormalize_gate(x, n, [self.hasf0_size, self.f0_size, self.logspc_size, self.codeap_size])
         return F_.world_unnormalize_gate(x, n.f0_mean, n.f0_std, n.logspc_mean, n.logspc_std, n.codeap_mean, n.codeap_std)
 
     def _calc_batch_loss(self, batch):
@@ -242,14 +256,24 @@ class AlignTextToAudioModel(nn.Module):
         hasf0_logits, f0_hat, logspc_hat, codeap_hat = self.forward(aligntext)
         return self.criterion(f0_len, hasf0_logits, f0_hat, logspc_hat, codeap_hat, hasf0, f0, logspc, codeap)
 
+    def _step(self, task: str, batch) -> torch.Tensor:
+        hasf0_loss, f0_loss, logspc_loss, codeap_loss = self._calc_batch_loss(batch)
+        loss = hasf0_loss + f0_loss + logspc_loss + codeap_loss
+        self.log(f"{task}_loss", loss)                           # tts.py:232-237
+        self.log(f"{task}_hasf0_loss", hasf0_loss)
+        self.log(f"{task}_f0_loss", f0_loss)
+        self.log(f"{task}_logspc_loss", logspc_loss)
+        self.log(f"{task}_codeap_loss", codeap_loss)
+        return loss
+
     def training_step(self, batch, batch_idx=0) -> torch.Tensor:
-        return sum(self._calc_batch_loss(batch))
+        return self._step("train", batch)
 
     def validation_step(self, batch, batch_idx=0):
-        return {"val_loss": sum(self._calc_batch_loss(batch))}
+        return {"val_loss": self._step("val", batch)}
 
     def test_step(self, batch, batch_idx=0):
-        return {"test_loss": sum(self._calc_batch_loss(batch))}
+        return {"test_loss": self._step("test", batch)}
 
     def configure_optimizers(self):
         params = list(self.parameters())
