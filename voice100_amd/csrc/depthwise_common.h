@@ -18,6 +18,7 @@
 #pragma once
 #include "common.h"
 #include "timing.h"
+#include <stdlib.h>
 
 enum { DW_IN_NONE = 0, DW_IN_AFFINE_RELU6 = 1, DW_IN_AFFINE2 = 2 };
 enum { DW_OUT_RAW_STATS = 0, DW_OUT_AFFINE_RELU6 = 1, DW_OUT_MASK_STATS = 2, DW_OUT_RAW = 3 };
@@ -352,6 +353,24 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
     }
 }
 
+#include "depthwise_mfma.h"
+
+// Which stride-1 path runs: the Toeplitz-MFMA kernel (default) or the register-window VALU kernel (V100_DW_PATH=valu, kept
+// for A/B measurements and as the path for shapes the MFMA kernel does not cover); V100_DW_DIGITS = 2 | 3 bf16 digits per
+// fp32 operand (default 3: fp32-exact products).  Read once.
+struct DwPathConfig { bool mfma; int digits; };
+static inline DwPathConfig dw_path_config() {
+    static const DwPathConfig cfg = [] {
+        DwPathConfig c{true, 3};
+        const char* e = getenv("V100_DW_PATH");
+        if (e && e[0] == 'v') c.mfma = false;
+        const char* d = getenv("V100_DW_DIGITS");
+        if (d && d[0] == '2') c.digits = 2;
+        return c;
+    }();
+    return cfg;
+}
+
 // kernel sizes used by the reference's networks: asr.py:68-76, tts.py:18-25, 73-76
 #define V100_DW_SPECIALISED(X) X(5) X(7) X(11) X(17) X(19) X(27) X(29) X(33) X(35) X(51) X(59) X(65) X(67) X(75) X(83)
 
@@ -363,6 +382,19 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
 template <int IM, int OM, bool WG = false>
 static bool dw_launch_specialised(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl) {
     dim3 grid(p.C, p.G);
+    {
+        const DwPathConfig cfg = dw_path_config();
+        if (cfg.mfma && p.stride == 1 && p.upsample == 1) {
+#define X(KK)                                                                                                           \
+    if (p.K == KK) {                                                                                                    \
+        if (cfg.digits == 2) V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 2, WG>), grid, dim3(256), 0, st, p);      \
+        else V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 3, WG>), grid, dim3(256), 0, st, p);                      \
+        return true;                                                                                                    \
+    }
+            V100_DW_SPECIALISED(X)
+#undef X
+        }
+    }
     const bool big = p.Tout > 256 && !(WG && DW_FUSED_R == 4);
     // rows of any length take the 16-byte (dword-aligned) global path; tails are masked per element
 #define DW_GO(KK, SS)                                                                                             \

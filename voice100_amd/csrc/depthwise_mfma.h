@@ -1,0 +1,335 @@
+// K2 on the matrix cores: stride-1 depthwise Conv1d as a banded-Toeplitz product, fp32 result.
+//
+// Why: the register-window kernel (dwconv_kernel) needs 2*K flop per output on the fp32 VALU; for K >= 51 that is
+// the same time as (or more than) streaming the row from HBM, so the layer cannot reach the memory roofline whatever
+// the schedule.  The matrix pipe has 16x the VALU's rate in bf16, and an fp32 value is
+// EXACTLY the sum of three bf16 values (8 + 8 + 8 mantissa bits, split by truncation), so
+//     x * w = sum_{i,j} x_i * w_j,   every bf16 x bf16 product exact in the fp32 accumulator,
+// and keeping the six terms with i + j <= 4 drops only terms below 2^-24 of the product: fp32 accuracy at 6 MFMAs per
+// 16x16x32 tile step.  For K = 83 that is 1.5 matrix-pipe cycles per output per SIMD against ~4 on the VALU, and the
+// VALU is left with the staging work only, so every layer of the encoder becomes HBM-bound.
+//
+// Formulation.  One wave owns a (batch row, 512-output tile) item of its channel.  The staged input span is kept in LDS as
+// NT bf16 "digit" images img_t[i] (i = input position - in0a, in0a = tile start - pad rounded down to a multiple of 4 so
+// that the global float4 loads and the 8-byte LDS stores stay aligned).  With off = (-pad) & 3,
+//     y[out0 + 256*sub + 16*n + m] = sum_kk A[m][kk] * B[kk][n],   A[m][kk] = w[kk - m - off],   B[kk][n] = img[256*sub + 16*n + kk]
+// for m, n in [0, 16), kk in [0, 32*STEPS): per (sub, step) one v_mfma_f32_16x16x32_bf16 per digit pair.  A (the channel's
+// taps) is built once per workgroup and lives in registers; B fragments are conflict-free ds_read_b128 of the images
+// (lane (n, q) reads 16 bytes at 32*n + 16*q + 64*step + 512*sub); the 16x16 result has 4 consecutive outputs per lane,
+// so a wave stores 1 KiB contiguous per instruction.  Same prologues / epilogues / per-channel partial sums as dwconv_kernel.
+//
+// WG (fused backward, stride 1): the backward-weight of the forward conv rides on the backward-data pass, also on the
+// matrix pipe.  In that pass the images hold the upstream gradient g' and every lane loads the forward conv's
+// pre-activation input a1 at its output positions (for the ReLU6 mask), so xin = relu6(bn1(a1)) is at hand.  With
+// e = 16*p + r the position inside the tile,
+//     dWf[jf] = sum_e xin[e] * g'img[off + e + jf] = sum_r E[r + jf + off][r],   E[i][r] = sum_p g'img[16*p + i] * ximg[16*p + r]:
+// E is a plain matrix product over the block index p of the two images viewed as [32 x 16] row-major tiles, i.e. both
+// MFMA operands are COLUMN reads of row-major bf16 tiles -- ds_read_b64_tr_b16 (address = image + 8 bytes * lane, the row
+// shift 16*ib of the g' operand is 32 bytes: aligned).  One contraction step covers the whole 512-position tile; E
+// ((K+18) x 16 fp32) stays in the accumulators for all rows of the workgroup and its diagonals are summed once at the end.
+// K+15 over K more work than the K*T products needed, no extra HBM traffic, no K accumulators per lane.
+#pragma once
+
+typedef float dwm_f32x4 __attribute__((ext_vector_type(4)));
+typedef short dwm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int dwm_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int dwm_u32x2 __attribute__((ext_vector_type(2)));
+typedef short dwm_s16x4 __attribute__((ext_vector_type(4)));
+
+// 8 bf16 of one MFMA operand fragment as two transposing LDS reads (rows 4G..4G+3 and 16+4G..16+4G+3 of a [32 x 16] tile,
+// G = lane >> 4, column lane & 15); `tile` points at element 0 of the tile, 8-byte aligned.  EXEC must be all ones.
+__device__ __forceinline__ dwm_bf16x8 dwm_tr_fragment(const unsigned short* tile, int lane) {
+    typedef __attribute__((address_space(3))) dwm_s16x4 lds_s16x4;
+    const dwm_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + 4 * lane));
+    const dwm_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + 256 + 4 * lane));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// acc += sum over the digit pairs (i, j) with i + j <= NT - 1 (0-based) of a[i] x b[j], smallest terms first
+template <int NT>
+__device__ __forceinline__ dwm_f32x4 dwm_mfma_digits(const dwm_bf16x8 (&a)[NT], const dwm_bf16x8 (&b)[NT], dwm_f32x4 acc) {
+    if constexpr (NT >= 3) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    }
+    if constexpr (NT >= 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+template <int K>
+struct DwMfmaGeom {
+    static constexpr int SUBS = 2;
+    static constexpr int TILE = 256 * SUBS;                       // outputs per wave item
+    static constexpr int STEPS = (K + 15 + 3 + 31) / 32;          // contraction steps of 32 (off <= 3)
+    static constexpr int IMG = 256 * (SUBS - 1) + 240 + 32 * STEPS;   // image elements the B reads touch
+    static constexpr int NV = (IMG + 255) / 256;                  // float4 loads per lane
+    static constexpr int IMGP = NV * 256;                         // image elements written (all finite: zero or real samples)
+    static constexpr int WPAD = 18;                               // zero taps in front of w[0] (m + off <= 18)
+    static constexpr int WLEN = WPAD + 32 * STEPS;
+    static constexpr int IB = (K + 15 + 3 + 15) / 16;             // 16-row blocks of E (fused backward-weight)
+};
+
+// bf16 digit t of an fp32 value by truncation: v = d0 + d1 + d2 exactly (24 mantissa bits), each digit's low 16 bits zero
+__device__ __forceinline__ void dwm_split(float v, unsigned (&d)[3]) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, v);
+    d[0] = u0 & 0xffff0000u;
+    const float r1 = v - __builtin_bit_cast(float, d[0]);
+    const unsigned u1 = __builtin_bit_cast(unsigned, r1);
+    d[1] = u1 & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, d[1]);
+    d[2] = __builtin_bit_cast(unsigned, r2) & 0xffff0000u;
+}
+// two digits (high halves of lo / hi) -> one dword of two bf16
+__device__ __forceinline__ unsigned dwm_pack(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+template <int K, int IM, int OM, int NT, bool WG = false>
+__global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p) {
+    using G_ = DwMfmaGeom<K>;
+    constexpr int SUBS = G_::SUBS, TILE = G_::TILE, STEPS = G_::STEPS, NV = G_::NV, IMGP = G_::IMGP, WPAD = G_::WPAD, WLEN = G_::WLEN;
+    constexpr int IB = G_::IB;
+    constexpr bool TWO = IM == DW_IN_AFFINE2;
+    constexpr bool STATS = (OM == DW_OUT_RAW_STATS || OM == DW_OUT_MASK_STATS);
+    static_assert(NT >= 1 && NT <= 3, "one to three bf16 digits per operand");
+    static_assert(!WG || OM == DW_OUT_MASK_STATS, "the fused backward-weight rides on the backward-data pass");
+
+    // per wave: NT digit images of the staged span (+ NT digit images of xin over the tile when WG); the E tiles of the
+    // fused backward-weight are spilled over the same bytes at the very end
+    constexpr int WAVE_U16 = NT * IMGP + (WG ? NT * TILE : 0);
+    constexpr int E_FLOATS = WG ? 16 * IB * 16 : 0;
+    constexpr int LDS_BYTES = (4 * WAVE_U16 * 2 > 4 * E_FLOATS * 4) ? 4 * WAVE_U16 * 2 : 4 * E_FLOATS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    __shared__ float lds_w[WLEN];
+    __shared__ float lds_red[4][2];
+
+    const int c = blockIdx.x;
+    const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n_ = lane & 15, q_ = lane >> 4;
+
+    for (int i = threadIdx.x; i < WLEN; i += 256) {
+        const int j = i - WPAD;
+        lds_w[i] = (j >= 0 && j < K) ? p.w[(size_t)c * K + (p.flip ? (K - 1 - j) : j)] : 0.f;
+    }
+    __syncthreads();
+
+    // A fragments: lane (m = n_, q_) holds A[m][32*s + 8*q + jj] = w[32*s + 8*q + jj - m - off], jj = 0..7, as NT digit packs
+    const int off = (-p.pad) & 3;
+    dwm_bf16x8 afr[STEPS][NT];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        unsigned pk[NT][4];
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+            unsigned d0[3], d1[3];
+            dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp - n_ - off], d0);
+            dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp + 1 - n_ - off], d1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) pk[t][jp] = dwm_pack(d0[t], d1[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const dwm_u32x4 v = {pk[t][0], pk[t][1], pk[t][2], pk[t][3]};
+            afr[s][t] = __builtin_bit_cast(dwm_bf16x8, v);
+        }
+    }
+
+    float ca = 1.f, cb = 0.f, cc = 0.f, oa = 1.f, ob = 0.f;
+    if constexpr (IM != DW_IN_NONE) { ca = p.in_a[c]; cb = p.in_b[c]; }
+    if constexpr (IM == DW_IN_AFFINE2) cc = p.in_c[c];
+    if constexpr (OM == DW_OUT_AFFINE_RELU6 || OM == DW_OUT_MASK_STATS) { oa = p.out_a[c]; ob = p.out_b[c]; }
+
+    const int Tin = p.Tin, Tout = p.Tout;
+    const int bper = (p.B + p.G - 1) / p.G;
+    const int b0 = g * bper;
+    const int nb = min(p.B, b0 + bper) - b0;
+    const int ntiles = (Tout + TILE - 1) / TILE;
+
+    float s0 = 0.f, s1 = 0.f;
+    DwRaw<NV, TWO> raw;
+    const unsigned xbytes = (unsigned)((size_t)p.B * p.C * Tin * 4);
+    const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, xbytes);
+    const __amdgpu_buffer_rsrc_t rx2 = dw_make_rsrc(TWO ? p.x2 : p.x, xbytes);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned short* img = reinterpret_cast<unsigned short*>(lds_raw) + wave_u * WAVE_U16;
+    unsigned short* ximg = img + NT * IMGP;                  // WG only
+    const unsigned short* bsrc = img + 16 * n_ + 8 * q_;
+    dwm_f32x4 eacc[WG ? IB : 1];
+#pragma unroll
+    for (int ib = 0; ib < (WG ? IB : 1); ++ib) eacc[ib] = dwm_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int out0 = tile * TILE;
+        const int in0a = (out0 - p.pad) & ~3;                 // input position of image element 0 (multiple of 4)
+        // per-lane load positions of this tile (row-invariant)
+        int vo[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int ia = in0a + 4 * (lane + 64 * v);
+            const bool ok = ia >= 0 && ia < Tin && 4 * (lane + 64 * v) < G_::IMG;
+            vo[v] = ok ? ia * 4 : 0x7ffffff0;
+        }
+        int bi = wave_u;
+        if (bi < nb) {
+            const unsigned rb = (unsigned)(((size_t)(b0 + bi) * p.C + c) * Tin * 4);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                raw.v[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo[v], (int)rb, 0));
+                if constexpr (TWO) raw.v2[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, vo[v], (int)rb, 0));
+            }
+        }
+        for (; bi < nb; bi += 4) {
+            const int b = b0 + bi;
+            float auxv[SUBS][4];
+            if constexpr (OM == DW_OUT_MASK_STATS) {
+#pragma unroll
+                for (int sub = 0; sub < SUBS; ++sub) {
+                    const int t0 = out0 + 256 * sub + 16 * n_ + 4 * q_;
+                    dw_load_run<4, true>(auxv[sub], p.aux + ((size_t)b * p.C + c) * Tout + t0, t0, Tout);
+                }
+            }
+            // ---- stage: transform, zero outside the row, split into bf16 digits, 8-byte LDS stores ----
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int ia = in0a + 4 * (lane + 64 * v);
+                unsigned dg[4][3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float val;
+                    if constexpr (IM == DW_IN_AFFINE_RELU6) val = relu6f(fmaf(raw.v[v][e], ca, cb));
+                    else if constexpr (IM == DW_IN_AFFINE2) val = fmaf(raw.v[v][e], ca, fmaf(raw.v2[v][e], cb, cc));
+                    else val = raw.v[v][e];
+                    // zero padding applies to the TRANSFORMED tensor; a float4 that straddles the row end (Tin % 4 != 0) holds the
+                    // next row's first samples, so the plain copy needs the mask too (ia is a multiple of 4: ia >= 0 covers e)
+                    val = (ia >= 0 && ia + e < Tin) ? val : 0.f;
+                    dwm_split(val, dg[e]);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const dwm_u32x2 w2 = {dwm_pack(dg[0][t], dg[1][t]), dwm_pack(dg[2][t], dg[3][t])};
+                    *reinterpret_cast<dwm_u32x2*>(img + t * IMGP + 4 * (lane + 64 * v)) = w2;
+                }
+            }
+            if constexpr (WG) {
+                // xin = relu6(bn1(a1)) at this lane's 2 x 4 output positions -> digit images of the tile
+#pragma unroll
+                for (int sub = 0; sub < SUBS; ++sub) {
+                    const int t0 = out0 + 256 * sub + 16 * n_ + 4 * q_;
+                    unsigned dg[4][3];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dwm_split((t0 + r < Tout) ? relu6f(fmaf(auxv[sub][r], oa, ob)) : 0.f, dg[r]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const dwm_u32x2 w2 = {dwm_pack(dg[0][t], dg[1][t]), dwm_pack(dg[2][t], dg[3][t])};
+                        *reinterpret_cast<dwm_u32x2*>(ximg + t * TILE + 256 * sub + 16 * n_ + 4 * q_) = w2;
+                    }
+                }
+            }
+            // cross-lane hand-off through LDS inside one wave (hardware keeps a wave's LDS operations in order; the
+            // compiler must too)
+            asm volatile("" ::: "memory");
+
+            // prefetch the next row of this tile while this one computes
+            if (bi + 4 < nb) {
+                const unsigned rb = (unsigned)(((size_t)(b + 4) * p.C + c) * Tin * 4);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    raw.v[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo[v], (int)rb, 0));
+                    if constexpr (TWO) raw.v2[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, vo[v], (int)rb, 0));
+                }
+            }
+
+            if constexpr (WG) {
+                // E[16*ib + m][r] += sum_p g'img[16*(p + ib) + m] * ximg[16*p + r]: one contraction step = the whole tile
+                dwm_bf16x8 xfr[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) xfr[t] = dwm_tr_fragment(ximg + t * TILE, lane);
+#pragma unroll
+                for (int ib = 0; ib < IB; ++ib) {
+                    dwm_bf16x8 gfr[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) gfr[t] = dwm_tr_fragment(img + t * IMGP + 16 * ib, lane);
+                    eacc[ib] = dwm_mfma_digits<NT>(gfr, xfr, eacc[ib]);
+                }
+            }
+
+#pragma unroll
+            for (int sub = 0; sub < SUBS; ++sub) {
+                const int t0 = out0 + 256 * sub + 16 * n_ + 4 * q_;
+                const size_t oo = ((size_t)b * p.C + c) * Tout + t0;
+                dwm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < STEPS; ++s) {
+                    dwm_bf16x8 bfr[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        bfr[t] = *reinterpret_cast<const dwm_bf16x8*>(bsrc + t * IMGP + 256 * sub + 32 * s);
+                    acc = dwm_mfma_digits<NT>(afr[s], bfr, acc);
+                }
+                // ---- epilogue: 4 consecutive outputs per lane ----
+                float outv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool valid = t0 + r < Tout;
+                    float yv = acc[r];
+                    if constexpr (OM == DW_OUT_RAW_STATS) {
+                        if (valid) { s0 += yv; s1 = fmaf(yv, yv, s1); }
+                    } else if constexpr (OM == DW_OUT_AFFINE_RELU6) {
+                        yv = relu6f(fmaf(yv, oa, ob));
+                    } else if constexpr (OM == DW_OUT_MASK_STATS) {
+                        const float pre = fmaf(auxv[sub][r], oa, ob);
+                        yv = (pre > 0.f && pre < 6.f) ? yv : 0.f;
+                        if (valid) { s0 += yv; s1 = fmaf(yv, auxv[sub][r], s1); }
+                    }
+                    outv[r] = yv;
+                }
+                if (t0 + 3 < Tout) {
+                    const f32x4 o = {outv[0], outv[1], outv[2], outv[3]};
+                    *reinterpret_cast<f32x4u*>(p.y + oo) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t0 + r < Tout) p.y[oo + r] = outv[r];
+                }
+            }
+            asm volatile("" ::: "memory");     // the next row's LDS stores stay behind this row's fragment reads
+        }
+    }
+
+    if constexpr (WG) {
+        // dWf[jf] = sum over waves and r of E[r + jf + off][r]; the E tiles go through LDS (over the dead images)
+        __syncthreads();
+        float* ebuf = reinterpret_cast<float*>(lds_raw);
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ebuf[(wave * 16 * IB + 16 * ib + 4 * q_ + r) * 16 + n_] = eacc[ib][r];
+        __syncthreads();
+        for (int jf = threadIdx.x; jf < K; jf += 256) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float sw = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sw += ebuf[(w * 16 * IB + r + jf + off) * 16 + r];
+                sum += sw;
+            }
+            p.wpartial[((size_t)g * p.C + c) * K + (K - 1 - jf)] = sum;      // flipped taps here = forward taps K-1-jf
+        }
+        __syncthreads();
+    }
+    if constexpr (STATS) {
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) { lds_red[wave][0] = s0; lds_red[wave][1] = s1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            p.stats[((size_t)g * p.C + c) * 2 + 0] = (lds_red[0][0] + lds_red[1][0]) + (lds_red[2][0] + lds_red[3][0]);
+            p.stats[((size_t)g * p.C + c) * 2 + 1] = (lds_red[0][1] + lds_red[1][1]) + (lds_red[2][1] + lds_red[3][1]);
+        }
+    }
+}
