@@ -31,7 +31,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate ~6300
-PMC_TRAFFIC_RATIO = 1.005      # measured HBM bytes / algorithmic bytes of the depthwise forward kernels (profiles/r01k_pmc_counters.txt)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_dw_fwd_pmc.json")   # HBM bytes / algorithmic bytes of the depthwise forward kernels (rocprofv3 PMC passes)
 B_PER_GPU, T_FRAMES, N_MEL, VOCAB, TEXT_LEN = 32, 1024, 64, 29, 100
 
 
@@ -59,41 +59,135 @@ def synth_batch(device, B, seed, frames=T_FRAMES):
     return ((audio.to(device), audio_len.to(device)), (text.to(device), text_len.to(device)))
 
 
-def cpu_baseline(sample_b=8, iters=2):
-    """Oracle (CPU port of the reference path, stock PyTorch CPU ops, fp32): train-mode forward +
-    log_softmax + CTC + backward on a B=sample_b slice of the workload.  The box's containers see more
-    logical CPUs than they can use at once (oversubscription makes torch's conv slower), so a few thread
-    counts are tried and the best is reported together with the count that produced it."""
+def usable_cpus():
+    """Logical CPUs this process may run on at once: the scheduler affinity, capped by the cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline():
+    """Oracle (CPU port of the reference path, stock PyTorch CPU ops, fp32) on this box's host cores, per BASELINE.md 3:
+    (ii) the metric -- train-mode forward + log_softmax + CTC + backward at B = 32 x T = 1024, 1 warm-up + 3 timed iterations per
+    thread count, thread counts swept upwards (8, 16, 32, ... up to the usable cores) until throughput stops improving;
+    (i) config 1 -- eval forward B = 2 x 256 frames, 3 warm-ups + 20 timed; (iii) config 3 -- AlignTextToAudioModel.predict
+    B = 16 x L = 512, 1 warm-up + 3 timed.  `value` is (ii), the bench's own workload."""
     from oracle import cnn
     from voice100_amd.asr import AudioToTextCTC
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    from voice100_amd.tts import AlignTextToAudioModel
+    usable = usable_cpus()
     torch.manual_seed(1234)
     m = AudioToTextCTC(N_MEL, 512, VOCAB, 512)
     state = {k: v.detach().clone() for k, v in m.state_dict().items()}
     params = {k: v.requires_grad_(True) for k, v in state.items() if v.dtype.is_floating_point and "running" not in k}
     state.update(params)
-    (audio, audio_len), (text, text_len) = synth_batch("cpu", sample_b, 1234)
+    batch = synth_batch("cpu", B_PER_GPU, 1234)
+    counts = sorted({c for c in (8, 16, 32, 64, 128) if c < usable} | {min(usable, 128)})
     best_t, best_n, tried = None, None, []
-    for n in sorted({min(avail, c) for c in (8, 16, 32)}):
+    for n in counts:
         torch.set_num_threads(n)
         times = []
-        for i in range(iters + 1):
+        for i in range(4):
             for p in params.values():
                 p.grad = None
             t0 = time.perf_counter()
-            loss = cnn.audio_to_text_ctc_loss(((audio, audio_len), (text, text_len)), state, training=True)
+            loss = cnn.audio_to_text_ctc_loss(batch, state, training=True)
             loss.backward()
-            dt = time.perf_counter() - t0
             if i > 0:
-                times.append(dt)
+                times.append(time.perf_counter() - t0)
         t = sum(times) / len(times)
-        tried.append((n, round(sample_b * T_FRAMES / t, 1)))
-        if best_t is None or t < best_t:
-            best_t, best_n = t, n
-    return {"value": round(sample_b * T_FRAMES / best_t, 1), "unit": "frames/s", "cores": best_n, "kind": "port",
-            "sample": f"oracle.cnn train fwd+CTC+bwd, B={sample_b} x T={T_FRAMES} slice of the B=32 workload, fp32, "
-                      f"{iters} timed iters after 1 warm-up per thread count; tried (threads, frames/s) = {tried}; "
-                      f"{avail} logical CPUs visible"}
+        tried.append((n, round(B_PER_GPU * T_FRAMES / t, 1)))
+        if best_t is not None and t > best_t:
+            break                                  # past the knee: more threads only oversubscribe the shared host
+        best_t, best_n = t, n
+    torch.set_num_threads(best_n)
+    with torch.no_grad():
+        ev = {k: v.detach() for k, v in state.items()}
+        x = torch.rand(2, 256, N_MEL)
+        for _ in range(3):
+            cnn.audio_to_text_ctc_forward(x, ev, training=False)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            cnn.audio_to_text_ctc_forward(x, ev, training=False)
+        c1 = (time.perf_counter() - t0) / 20
+        tts = AlignTextToAudioModel(vocab_size=VOCAB, hidden_size=512, use_mcep=False)
+        ts = {k: v.detach() for k, v in tts.state_dict().items()}
+        at = torch.randint(0, VOCAB, (16, 512))
+        cnn.align_text_to_audio_predict(at, ts)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            cnn.align_text_to_audio_predict(at, ts)
+        c3 = (time.perf_counter() - t0) / 3
+    return {"value": round(B_PER_GPU * T_FRAMES / best_t, 1), "unit": "frames/s", "cores": best_n, "kind": "port",
+            "sample": f"oracle.cnn train fwd + log_softmax + CTC + bwd at the bench workload (B={B_PER_GPU} x T={T_FRAMES}, fp32), 1 warm-up + "
+                      f"3 timed iterations per thread count; (threads, frames/s) tried = {tried}; {usable} usable logical CPUs "
+                      f"({os.cpu_count()} visible)",
+            "config1_eval_B2_T256": {"ms": round(c1 * 1e3, 2), "frames_per_s": round(2 * 256 / c1, 1), "cores": best_n},
+            "config3_tts_predict_B16_L512": {"ms": round(c3 * 1e3, 1), "aligntext_frames_per_s": round(16 * 512 / c3, 1),
+                                             "world_frames_per_s": round(16 * 1023 / c3, 1), "cores": best_n}}
+
+
+def other_configs(device, N, F_):
+    """BASELINE configs 1, 3 and 5 on the GPU, measured after the timed region of the same run (rank 0, N = 1): latency /
+    throughput of each, the depthwise forward kernels' HBM fraction inside config 3's VoiceDecoder, and the time of the
+    log-mel front-end inside config 5 (its algorithmic bytes: waveform in + log-mel out)."""
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd.tts import AlignTextToAudioModel
+    from voice100_amd.mel import MelSpectrogramAudioTransform
+    from voice100_amd.decode import ctc_greedy_decode
+
+    def timeit(fn, iters=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    out = {}
+    with torch.no_grad():
+        asr = AudioToTextCTC(N_MEL, 512, VOCAB, 512).to(device).eval()
+        x = torch.rand(2, 256, N_MEL, device=device)
+        dt = timeit(lambda: asr(x))
+        out["config1_asr_eval_B2_T256"] = {"ms": round(dt * 1e3, 3), "frames_per_s": round(2 * 256 / dt, 1)}
+        tts = AlignTextToAudioModel(vocab_size=VOCAB, hidden_size=512, use_mcep=False).to(device).eval()
+        at = torch.randint(0, VOCAB, (16, 512), device=device)
+        dt = timeit(lambda: tts.predict(at))
+        N.timing_enable(["dw_fwd"])
+        for _ in range(5):
+            tts.predict(at)
+        torch.cuda.synchronize()
+        n, ms, nbytes = N.timing_read().get("dw_fwd", (0, 0.0, 0.0))
+        N.timing_enable(False)
+        out["config3_tts_predict_B16_L512"] = {
+            "ms": round(dt * 1e3, 3), "aligntext_frames_per_s": round(16 * 512 / dt, 1), "world_frames_per_s": round(16 * 1023 / dt, 1),
+            "voice_decoder_dw_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1) if n else None,
+            "voice_decoder_dw_frac_of_8tbs": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if n else None,
+            "voice_decoder_dw_launches": n}
+        F_.set_matmul_precision("fp16")                 # config 5 names fp16
+        mel = MelSpectrogramAudioTransform().to(device)
+        B = 256
+        wav = torch.rand(B, 16000, device=device) * 2 - 1
+        dt_mel = timeit(lambda: mel(wav))
+        feats = mel(wav)
+
+        def stream():
+            ids, _ = ctc_greedy_decode(asr(mel(wav)))
+            return ids
+        dt = timeit(stream)
+        mel_bytes = 4.0 * B * (16000 + feats.shape[1] * feats.shape[2])
+        out["config5_stream_1s_chunks_fp16_B256"] = {
+            "ms": round(dt * 1e3, 3), "chunks_per_s": round(B / dt, 1), "mel_frontend_ms": round(dt_mel * 1e3, 3),
+            "mel_frontend_algorithmic_gbs": round(mel_bytes / dt_mel / 1e9, 1)}
+        F_.set_matmul_precision("bf16")
+    return out
 
 
 def main():
@@ -104,6 +198,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     from voice100_amd.trainer import TrainStep, init_distributed, launch_ranks
@@ -208,13 +303,14 @@ def main():
         if "dw_fwd" in kt:
             n, ms, nbytes = kt["dw_fwd"]          # bytes are summed per launch by the library (T varies with timestretch)
             achieved = nbytes / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "dwconv_kernel (depthwise forward, 9 launches per step)", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    # PMC counters cannot be read from inside this process: the per-launch HBM bytes are the algorithmic
-                    # bytes of THIS run's launches times the ratio rocprofv3 measured for these kernels (separate
-                    # --pmc passes, 2*FETCH_SIZE + WRITE_SIZE with the gfx950 correction): profiles/r01k_pmc_counters.txt
-                    "traffic": round(PMC_TRAFFIC_RATIO * nbytes / n),
-                    "traffic_source": f"{PMC_TRAFFIC_RATIO} x algorithmic bytes (rocprofv3 PMC, profiles/r01k_pmc_counters.txt)",
+            # PMC counters cannot be read from inside this process: the per-launch HBM bytes are the algorithmic bytes of THIS
+            # run's launches times the ratio rocprofv3 measured for these kernels (separate --pmc passes, 2*FETCH_SIZE +
+            # WRITE_SIZE with the gfx950 correction; tools/pmc_passes.sh), null when that file is absent
+            pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else None
+            roof = {"bound": "hbm", "kernel": "dwconv_mfma_kernel (depthwise forward: 8 Toeplitz-MFMA launches + the stride-2 first layer per step)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": round(pmc["ratio"] * nbytes / n) if pmc else None,
+                    "traffic_source": (f"{pmc['ratio']} x algorithmic bytes (rocprofv3 PMC, profiles/{os.path.basename(PMC_FILE)})" if pmc else None),
                     "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                     "algorithmic_bytes_per_launch": round(nbytes / n), "algorithmic_bytes_nominal_step": dw_bytes,
                     "measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
@@ -236,6 +332,8 @@ def main():
             "roofline": roof,
             "kernel_ms_per_step": kt_all,
         }
+        if world == 1 and not args.no_other_configs and args.precision == "bf16":
+            out["other_configs"] = other_configs(device, N, F_)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         else:

@@ -150,6 +150,22 @@ int v100_log_transpose(const float* in, float* out, int B, int C, int T, float o
 int v100_world_unnormalize(const float* x, float* f0, float* logspc, float* codeap, const float* f0_mean, const float* f0_std,
                            const float* ls_mean, const float* ls_std, const float* ca_mean, const float* ca_std,
                            int B, int T, int S, int Cap, void* stream);
+/* ---- K12 WORLDLoss, value + gradient in one pass (voice100/models/_layers_v1.py:37-93), with the target preparation of
+ * AlignTextToAudioModel._calc_batch_loss (voice100/models/tts.py:203-206: hasf0 = f0 >= 30, WORLDNorm.normalize) --------
+ * pred [B][Tp][A], A = 2 + S + Cap: the decoder output as is (hasf0 logit, f0_hat, logspc_hat[S], codeap_hat[Cap] per frame).
+ * Targets f0 [B][Tt], logspc [B][Tt][S], codeap [B][Tt][Cap], length [B] int32; frames t < min(Tp, Tt) count
+ * (adjust_size, _layers_v1.py:27-34) and of those t < length[b] (generate_padding_mask, :14-24).
+ * f0_mean .. ca_std: the six WORLDNorm vectors (then the targets are RAW and hasf0 may be NULL = raw f0 >= 30), or all NULL
+ * (targets already normalised; hasf0 [B][Tt] required).  w: [S] logspc weights (use_mel_weights) or NULL = mean over S.
+ * l1: 0 squared error, 1 absolute error.  Writes loss[4] = (hasf0, f0, logspc, codeap) terms, each sum / sum(mask), and
+ * unit [B][Tp][A] = d loss_term(a) / d pred for a unit upstream gradient.  partial: v100_world_loss_parts(B, Tp) x 4 floats. */
+int v100_world_loss_parts(int B, int Tp);
+int v100_world_loss(const float* pred, const float* f0, const float* hasf0, const float* logspc, const float* codeap,
+                    const int* length, const float* f0_mean, const float* f0_std, const float* ls_mean, const float* ls_std,
+                    const float* ca_mean, const float* ca_std, const float* w, float* partial, float* loss, float* unit,
+                    int B, int Tp, int Tt, int S, int Cap, int l1, void* stream);
+/* dpred[b][t][a] = unit[b][t][a] * gout[term(a)], gout [4] on the device */
+int v100_world_loss_bwd(const float* unit, const float* gout, float* dpred, int B, int Tp, int S, int Cap, void* stream);
 /* y = max(exp(x) - offset, 0)   (WORLDVocoder.decode, voice100/vocoder.py:99) */
 int v100_exp_clip(const float* x, float* y, float offset, long long n, void* stream);
 

@@ -207,3 +207,52 @@ def test_tts_config3_full_size_vs_oracle(cuda, precision):
         assert (num / den) ** 0.5 < 5e-3
     finally:
         F_.set_matmul_precision("fp32")
+
+
+@pytest.mark.parametrize("loss,use_w,S,cap,Tp,Tt", [("mse", True, 257, 1, 47, 49), ("mse", False, 25, 1, 40, 33), ("l1", True, 257, 2, 30, 30),
+                                                     ("l1", False, 9, 3, 5, 8)])
+def test_world_loss_fused_vs_oracle(cuda, loss, use_w, S, cap, Tp, Tt):
+    """WORLDLoss on the fused kernel -- both entry points (reference signature with normalised targets; decoder output + raw
+    targets + WORLDNorm) -- against the oracle's restatement of _layers_v1.py:60-93: four terms and d/d(predictions), ragged
+    lengths (one of them zero, one longer than the common length), prediction / target time axes of different length."""
+    from oracle import cnn
+    from voice100_amd.tts import WORLDLoss, WORLDNorm
+    g = torch.Generator().manual_seed(S * 7 + Tp)
+    B = 4
+    pred = torch.randn(B, Tp, 2 + S + cap, generator=g)
+    f0 = torch.rand(B, Tt, generator=g) * 200.0
+    f0[:, ::3] = 0.0                                                   # unvoiced frames
+    logspc = torch.randn(B, Tt, S, generator=g) - 6.0
+    codeap = torch.randn(B, Tt, cap, generator=g) * 0.5
+    length = torch.tensor([min(Tp, Tt), 0, 7 if min(Tp, Tt) > 7 else 2, max(Tp, Tt) + 5], dtype=torch.int32)
+    norm = WORLDNorm(S, cap)
+    with torch.no_grad():
+        norm.f0_mean.fill_(120.0); norm.f0_std.fill_(35.0)
+        norm.logspc_mean.copy_(torch.randn(S, generator=g) - 6.0); norm.logspc_std.copy_(torch.rand(S, generator=g) + 0.5)
+        norm.codeap_mean.copy_(torch.randn(cap, generator=g)); norm.codeap_std.copy_(torch.rand(cap, generator=g) + 0.5)
+    crit = WORLDLoss(loss=loss, use_mel_weights=use_w and S == 257)
+    state = {"norm." + k: v.detach() for k, v in norm.state_dict().items()}
+    hasf0 = (f0 >= 30.0).to(torch.float32)
+    f0n, lsn, can = cnn.world_normalize(f0, logspc, codeap, state)
+    pr = pred.clone().requires_grad_(True)
+    hl, fh, lh, ch = torch.split(pr, [1, 1, S, cap], dim=2)
+    ref = cnn.world_loss(length, hl[:, :, 0], fh[:, :, 0], lh, ch, hasf0, f0n, lsn, can,
+                         use_mel_weights=crit.logspc_weights is not None, loss=loss)
+    gout = torch.tensor([1.0, 0.5, 2.0, -1.5])
+    (torch.stack(ref) * gout).sum().backward()
+    crit, norm = crit.to(cuda), norm.to(cuda)
+    # (a) decoder output + raw targets
+    pa = pred.to(cuda).requires_grad_(True)
+    got = crit.fused(length.to(cuda), pa, f0.to(cuda), logspc.to(cuda), codeap.to(cuda), norm)
+    (torch.stack(got) * gout.to(cuda)).sum().backward()
+    for a, b in zip(got, ref):
+        assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(b)))
+    assert rel_err(pa.grad, pr.grad) < 1e-5
+    # (b) the reference's signature: eight tensors, targets normalised by the caller
+    pb = pred.to(cuda).requires_grad_(True)
+    hl, fh, lh, ch = torch.split(pb, [1, 1, S, cap], dim=2)
+    got = crit(length.to(cuda), hl[:, :, 0], fh[:, :, 0], lh, ch, hasf0.to(cuda), f0n.to(cuda), lsn.to(cuda), can.to(cuda))
+    (torch.stack(got) * gout.to(cuda)).sum().backward()
+    for a, b in zip(got, ref):
+        assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(b)))
+    assert rel_err(pb.grad, pr.grad) < 1e-5

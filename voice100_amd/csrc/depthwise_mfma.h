@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
 
 #pragma unroll
             for (int sub = 0; sub < SUBS; ++sub) {
+                if (out0 + 256 * sub >= Tout) break;      // wave-uniform: a time-stretched row that ends inside the first half
                 const int t0 = out0 + 256 * sub + 16 * n_ + 4 * q_;
                 const size_t oo = ((size_t)b * p.C + c) * Tout + t0;
                 dwm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};

@@ -749,6 +749,52 @@ def world_unnormalize_gate(x_bta, f0_mean, f0_std, ls_mean, ls_std, ca_mean, ca_
 
 
 
+class WorldLossFn(torch.autograd.Function):
+    """WORLDLoss (voice100/models/_layers_v1.py:60-93) on the decoder output pred [B, Tp, 2+S+Cap], one HIP pass for the
+    four loss terms AND their gradient (v100_world_loss); backward is one scaling kernel.  With `norm` (the six WORLDNorm
+    vectors) the targets are the RAW WORLD features and hasf0 = f0 >= 30 is formed in the kernel (tts.py:203-206)."""
+
+    @staticmethod
+    def forward(ctx, pred, length, hasf0, f0, logspc, codeap, norm, weights, l1):
+        _check(pred, "world_loss")
+        pred = pred.contiguous()
+        B, Tp, A = pred.shape
+        S, cap = logspc.shape[2], codeap.shape[2]
+        if A != 2 + S + cap:
+            raise RuntimeError(f"world_loss: pred has {A} features, targets imply {2 + S + cap}")
+        Tt = f0.shape[1]
+        dev = pred.device
+        f0, logspc, codeap = (t.to(device=dev, dtype=torch.float32).contiguous() for t in (f0, logspc, codeap))
+        if logspc.shape[1] != Tt or codeap.shape[1] != Tt:
+            raise RuntimeError("world_loss: targets must share one time axis")
+        hasf0 = None if hasf0 is None else hasf0.to(device=dev, dtype=torch.float32).contiguous()
+        length = length.to(device=dev, dtype=torch.int32).contiguous()
+        nrm = [None] * 6 if norm is None else [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in norm]
+        w = None if weights is None else weights.detach().to(device=dev, dtype=torch.float32).contiguous()
+        partial = _f32(N.helper("v100_world_loss_parts", B, Tp), 4, like=pred)
+        loss = _f32(4, like=pred)
+        unit = torch.empty_like(pred)
+        N.call("v100_world_loss", pred, f0, hasf0, logspc, codeap, length, *nrm, w, partial, loss, unit, B, Tp, Tt, S, cap, int(l1))
+        ctx.save_for_backward(unit)
+        ctx.dims = (B, Tp, S, cap)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (unit,) = ctx.saved_tensors
+        B, Tp, S, cap = ctx.dims
+        dpred = torch.empty_like(unit)
+        N.call("v100_world_loss_bwd", unit, gout.to(torch.float32).contiguous(), dpred, B, Tp, S, cap)
+        return (dpred,) + (None,) * 8
+
+
+def world_loss(pred_bta, length, hasf0, f0, logspc, codeap, norm=None, weights=None, loss: str = "mse"):
+    """The four WORLDLoss terms (hasf0, f0, logspc, codeap) as a [4] tensor."""
+    if loss not in ("l1", "mse"):
+        raise ValueError("Unknown loss type")
+    return WorldLossFn.apply(pred_bta, length, hasf0, f0, logspc, codeap, norm, weights, loss == "l1")
+
+
 class CTCLossFn(torch.autograd.Function):
     """log_softmax(dim=-1) + CTCLoss(blank=0, reduction='mean', zero_infinity=True) on logits [B, T, V]
     (asr.py:146-152), forward and gradient in one pass of the HIP lattice kernels.  Limits of the kernel: V <= 128 classes,

@@ -69,8 +69,9 @@ class VoiceDecoder(nn.Module):
 
 class WORLDLoss(nn.Module):
     """Masked BCE (has-f0) + MSE/L1 (f0, log-spectrum with optional mel-slope weights, coded aperiodicity),
-    each summed over valid frames / number of valid frames (_layers_v1.py:37-93).  Small reductions over
-    [B, T, <=260]: stock torch ops on the GPU."""
+    each summed over valid frames / number of valid frames (_layers_v1.py:37-93).  On the GPU the four terms and their
+    gradient come from ONE fused HIP pass (functional.world_loss, csrc/world_loss.hip); `forward` keeps the reference's
+    signature (eight separate tensors), `fused` takes the decoder output and the raw targets as the model has them."""
 
     def __init__(self, loss: str = "mse", use_mel_weights: bool = False, sample_rate: int = 16000, n_fft: int = 512,
                  device=None, dtype=None) -> None:
@@ -89,7 +90,20 @@ class WORLDLoss(nn.Module):
     def _el(self, a, b):
         return (a - b) ** 2 if self.loss == "mse" else (a - b).abs()
 
+    def fused(self, length, pred, f0, logspc, codeap, norm):
+        """pred [B, T', 2+S+Cap] (the decoder output), raw targets, WORLDNorm `norm`: hasf0 = f0 >= 30, normalisation,
+        adjust_size, masks, the four terms and d/dpred in one kernel (tts.py:203-211 + _layers_v1.py:68-93)."""
+        nv = (norm.f0_mean, norm.f0_std, norm.logspc_mean, norm.logspc_std, norm.codeap_mean, norm.codeap_std)
+        out = F_.world_loss(pred, length, None, f0, logspc, codeap, nv, self.logspc_weights, self.loss)
+        return out[0], out[1], out[2], out[3]
+
     def forward(self, length, hasf0_logits, f0_hat, logspc_hat, codeap_hat, hasf0, f0, logspc, codeap):
+        if hasf0_logits.is_cuda and not tracing():
+            # the reference's signature on the fused kernel: the four predictions are packed into one [B, T', A] tensor
+            # (one cat; autograd splits the gradient), targets are already normalised
+            pred = torch.cat([hasf0_logits[:, :, None], f0_hat[:, :, None], logspc_hat, codeap_hat], dim=2)
+            out = F_.world_loss(pred, length, hasf0, f0, logspc, codeap, None, self.logspc_weights, self.loss)
+            return out[0], out[1], out[2], out[3]
         hasf0_logits, hasf0 = adjust_size(hasf0_logits, hasf0)
         f0_hat, f0 = adjust_size(f0_hat, f0)
         logspc_hat, logspc = adjust_size(logspc_hat, logspc)
@@ -251,10 +265,9 @@ class AlignTextToAudioModel(Voice100ModelBase):
 
     def _calc_batch_loss(self, batch):
         (f0, f0_len, logspc, codeap), (aligntext, aligntext_len) = batch
-        hasf0 = (f0 >= 30.0).to(torch.float32)
-        f0, logspc, codeap = self.norm.normalize(f0, logspc, codeap)
-        hasf0_logits, f0_hat, logspc_hat, codeap_hat = self.forward(aligntext)
-        return self.criterion(f0_len, hasf0_logits, f0_hat, logspc_hat, codeap_hat, hasf0, f0, logspc, codeap)
+        # tts.py:203-211 -- hasf0 = f0 >= 30, WORLDNorm.normalize, forward, WORLDLoss -- with everything after the decoder
+        # in one fused kernel over the decoder output (no split / normalise / mask / reduce passes)
+        return self.criterion.fused(f0_len, self._decode(aligntext), f0, logspc, codeap, self.norm)
 
     def _step(self, task: str, batch) -> torch.Tensor:
         hasf0_loss, f0_loss, logspc_loss, codeap_loss = self._calc_batch_loss(batch)
