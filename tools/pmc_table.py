@@ -59,7 +59,7 @@ if tot_algo:
                              "tools/pmc_passes.sh + tools/pmc_table.py over tools/bench_kernels.py --what dw"}, open(jout, "w"), indent=1)
 print()
 print("SQ counters per kernel (fractions of SQ_WAVE_CYCLES; WAIT_ANY = parked on s_waitcnt / barrier, WAIT_INST_ANY = issue stall, ACTIVE = issuing;")
-print("mfma = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CYCLES): share of the matrix pipes' time)")
+print("mfma_busy/sq_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, the raw ratio of the two counters as in profiles/r01k_pmc_counters.txt: for comparing builds)")
 for n, c in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
     wc = c.get("SQ_WAVE_CYCLES", 0)
     if wc <= 0 or not any(s in n for s in ("dwconv", "pw_gemm", "pw_wgrad")):
@@ -67,4 +67,4 @@ for n, c in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
     busy = c.get("SQ_BUSY_CYCLES", 0)
     print(f"{n[:86]:86s} wait_any {100 * c.get('SQ_WAIT_ANY', 0) / wc:5.1f}%  wait_inst {100 * c.get('SQ_WAIT_INST_ANY', 0) / wc:5.1f}%  "
           f"active {100 * c.get('SQ_ACTIVE_INST_ANY', 0) / wc:5.1f}%  lds_conflict/wave_cycles {100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / wc:5.2f}%  "
-          f"mfma {100 * c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (4 * busy) if busy else 0:5.1f}%")
+          f"mfma_busy/sq_busy {c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / busy if busy else 0:5.2f}")
