@@ -211,6 +211,30 @@ int v100_ln_gelu_bwd(const float* dout, const float* y, const float* gamma, cons
 int v100_timing_enable(int tag_mask);
 int v100_timing_read(int tag, double* ms, long long* count, double* bytes);
 
+/* ---- "act16": bf16 STORAGE of the big hidden tensors in bf16-operand training (csrc/block.hip) ---------------
+ * In bf16 mode the reference under autocast keeps its conv activations in bf16; here the two tensors a block saves for
+ * backward (a1 = expand output, a2 = depthwise output, each 4x the block's width) and optionally the two hidden gradients
+ * are stored as bf16 [B][C][P], P = (T + 7) & ~7 (pitched rows: every 4- / 8-sample access stays 8 / 16-byte aligned for any
+ * T).  Accumulators, BatchNorm statistics and reductions stay fp32.  io16 masks select which operands are such tensors:
+ *   v100_pw_gemm_io:   1 X, 2 X2, 4 Y, 8 R        v100_pw_wgrad_io: 1 G, 2 G2, 4 X
+ *   v100_dwconv_*_io:  1 x (first stream), 2 x2, 4 aux (a1), 8 y
+ * Same arithmetic as v100_pw_gemm / v100_pw_wgrad / v100_dwconv / v100_dwconv_bwd (bf16 operands); only the combinations the
+ * block executor issues exist, anything else returns 1 (no fallback). */
+int v100_pw_gemm_io(const void* A_bf16, const void* X, const void* X2, const float* xa, const float* xb, const float* xc,
+                    int x_mode, void* Y, const float* ea, const float* eb, const void* R, int epi_mode, float* stats,
+                    int B, int M, int K, int T, int io16, void* stream);
+int v100_pw_wgrad_io(const void* G, const void* G2, const float* ga, const float* gb, const float* gc, int g_mode,
+                     const void* X, const float* xa, const float* xb, int x_mode, float* partial, float* dW, int S, int B,
+                     int M, int K, int T, int io16, void* stream);
+int v100_dw_mfma_supported(int K, int stride);
+int v100_dwconv_fwd_train_io(const void* a1, const float* w, const float* in_a, const float* in_b, void* a2, float* stats,
+                             int G, int B, int C, int T, int K, int io16, void* stream);
+int v100_dwconv_bwd_io(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc,
+                       const void* xpre, const float* xa, const float* xb, void* dxin, float* stats, float* wpartial,
+                       float* dw, int G, int B, int C, int T, int K, int io16, void* stream);
+/* 1 when v100_ir_fwd_train / v100_ir_bwd accept shape[10] (act16) != 0 for this block */
+int v100_ir_act16_supported(const int* shape);
+
 /* ---- K10 log_softmax + CTC (asr.py:148-152: F.log_softmax(-1) then nn.CTCLoss(blank, 'mean', zero_infinity=True)) --
  * logits [B][T][V] fp32, targets [B][Lmax] int64, in_len / tgt_len [B] int32 (device).  Writes nll[b] =
  * -log p(target_b | logits_b) (inf when infeasible) and grad[b][t][c] = d nll_b / d logits[b][t][c] (zero for
@@ -223,7 +247,8 @@ int v100_ctc_loss(const float* logits, const long long* targets, const int* in_l
                   float* nll, float* grad, int B, int T, int V, int Lmax, int blank, void* stream);
 
 /* ---- block executor (csrc/block.hip): the whole kernel chain of one InvertedResidual block (asr.py:40-59) per call.
- * shape = {B, Cin, hid, Cout, T, K, stride, residual, bf16, prepped}; coef = 12 vectors of `hid` floats (BN scale/shift/mean/rstd
+ * shape = {B, Cin, hid, Cout, T, K, stride, residual, bf16, prepped, act16} (11 ints; act16: see "act16" above -- then the
+ * caller passes a1 / a2 as bf16 [B][hid][(T+7)&~7]); coef = 12 vectors of `hid` floats (BN scale/shift/mean/rstd
  * of the three BatchNorms) written by forward and read by backward.  Pointer tables (device pointers unless noted):
  *  fwd: x | w1 g1 b1 rm1 rv1 nbt1 | wd g2 b2 rm2 rv2 nbt2 | w3 g3 b3 rm3 rv3 nbt3 | a1 a2 a3 y coef workspace prep   (26)
  *  bwd: x a1 a2 a3 | w1 wd w3 | g1 g2 g3 | coef | dy | dx (NULL = skip) | dW1 dg1 db1 dWd dg2 db2 dW3 dg3 db3 | workspace prep (24)

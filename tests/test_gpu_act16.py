@@ -1,0 +1,207 @@
+"""bf16 STORAGE of the hidden tensors ("act16", include/voice100_hip.h): every *_io kernel entry point against the fp32-storage
+entry point of the same arithmetic, fed the same (bf16-representable) values -- the two must agree to fp32 round-off, the only
+intended difference being the rounding of a STORED output.  Shapes include a row length that is not a multiple of 8 (pitched
+rows) and one that spans two 512-sample depthwise tiles."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+X, X2, Y, R = 1, 2, 4, 8            # PW_IO_*
+G_, G2_, WX = 1, 2, 4               # WG_IO_*
+DX, DX2, DAUX, DY = 1, 2, 4, 8      # DW_IO_*
+
+
+def _native():
+    from voice100_amd import _native as N
+    N.load()
+    return N
+
+
+def pitch(T):
+    return (T + 7) & ~7
+
+
+def to16(t):
+    """fp32 [B, C, T] -> bf16 [B, C, pitch(T)] (padding filled with NaN: nothing may read it) and the rounded values as fp32."""
+    B, C, T = t.shape
+    out = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=t.device)
+    out[:, :, :T] = t.to(torch.bfloat16)
+    return out, out[:, :, :T].to(torch.float32).contiguous()
+
+
+def from16(t16, T):
+    return t16[:, :, :T].to(torch.float32)
+
+
+SHAPES = [(2, 32, 8, 48), (3, 256, 64, 100), (2, 64, 256, 133), (1, 512, 128, 700)]
+
+
+@pytest.mark.parametrize("B,M,K,T", SHAPES)
+def test_gemm_io_variants(cuda, B, M, K, T):
+    N = _native()
+    g = torch.Generator().manual_seed(M + T)
+    A = (torch.randn(M, K, generator=g) / K ** 0.5).to(cuda)
+    Abf = A.to(torch.bfloat16)
+    x = torch.randn(B, K, T, generator=g).to(cuda)
+    x16, xr = to16(x)
+    x2 = torch.randn(B, K, T, generator=g).to(cuda)
+    x216, x2r = to16(x2)
+    xa, xb, xc = (torch.randn(K, generator=g).to(cuda) for _ in range(3))
+    ea, eb = torch.rand(M, generator=g).to(cuda) + 0.5, torch.randn(M, generator=g).to(cuda)
+    r = (torch.randn(B, M, T, generator=g) * 3).to(cuda)
+    r16, rr = to16(r)
+    parts = N.helper("v100_pw_num_parts", B, T)
+
+    def ref(xm, ep, xin, x2in, rin):
+        y = torch.empty(B, M, T, device=cuda)
+        st = torch.zeros(parts, M, 2, device=cuda)
+        N.call("v100_pw_gemm", A, Abf, xin, x2in, xa if xm else None, xb if xm else None, xc if xm == 2 else None, xm, y, None,
+               ea if ep == 4 else None, eb if ep == 4 else None, rin, ep, st if ep in (1, 4) else None, B, M, K, T, 1)
+        return y, st
+
+    def io(xm, ep, xin, x2in, rin, mask):
+        y = (torch.full((B, M, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda) if mask & Y else torch.empty(B, M, T, device=cuda))
+        st = torch.zeros(parts, M, 2, device=cuda)
+        N.call("v100_pw_gemm_io", Abf, xin, x2in, xa if xm else None, xb if xm else None, xc if xm == 2 else None, xm, y,
+               ea if ep == 4 else None, eb if ep == 4 else None, rin, ep, st if ep in (1, 4) else None, B, M, K, T, mask)
+        return y, st
+
+    # expand forward: stats epilogue, Y stored as bf16
+    y0, s0 = ref(0, 1, x, None, None)
+    y1, s1 = io(0, 1, x, None, None, Y)
+    assert torch.equal(from16(y1, T), y0.to(torch.bfloat16).to(torch.float32))
+    assert rel_err(s1, s0) < 1e-6
+    # project forward: BN + ReLU6 on load of a bf16 X
+    y0, s0 = ref(1, 1, xr, None, None)
+    y1, s1 = io(1, 1, x16, None, None, X)
+    assert rel_err(y1, y0) < 1e-6 and rel_err(s1, s0) < 1e-6
+    # project backward-data: ReLU6 mask + sums from a bf16 R; fp32 and bf16 output
+    y0, s0 = ref(0, 4, x, None, rr)
+    y1, s1 = io(0, 4, x, None, r16, R)
+    assert rel_err(y1, y0) < 1e-6 and rel_err(s1, s0) < 1e-6
+    y1, s1 = io(0, 4, x, None, r16, R | Y)
+    assert torch.equal(from16(y1, T), y0.to(torch.bfloat16).to(torch.float32)) and rel_err(s1, s0) < 1e-6
+    # expand backward-data: affine of (X fp32 | bf16, X2 bf16), + residual / plain
+    for ep in (5, 0):
+        res = r if ep == 5 else None
+        y0, _ = ref(2, ep, x, x2r, res)
+        y1, _ = io(2, ep, x, x216, res, X2)
+        assert rel_err(y1, y0) < 1e-6
+        y0, _ = ref(2, ep, xr, x2r, res)
+        y1, _ = io(2, ep, x16, x216, res, X | X2)
+        assert rel_err(y1, y0) < 1e-6
+
+
+@pytest.mark.parametrize("B,M,K,T", [(2, 32, 8, 48), (4, 256, 64, 100), (3, 64, 256, 133), (2, 512, 128, 704)])
+def test_wgrad_io_variants(cuda, B, M, K, T):
+    N = _native()
+    g = torch.Generator().manual_seed(M * 3 + T)
+    gm = torch.randn(B, M, T, generator=g).to(cuda)
+    g16, gr = to16(gm)
+    g2 = torch.randn(B, M, T, generator=g).to(cuda)
+    g216, g2r = to16(g2)
+    xm = torch.randn(B, K, T, generator=g).to(cuda)
+    x16, xr = to16(xm)
+    ga, gb, gc = (torch.randn(M, generator=g).to(cuda) for _ in range(3))
+    xa, xb = torch.rand(K, generator=g).to(cuda) + 0.5, torch.randn(K, generator=g).to(cuda)
+    S = N.helper("v100_pw_wgrad_splits", B, M, K)
+
+    def run(name, G, G2, gmode, Xt, xmode, mask=None):
+        partial = torch.empty(S, M, K, device=cuda)
+        dW = torch.empty(M, K, device=cuda)
+        args = (G, G2, ga if gmode else None, gb if gmode else None, gc if gmode == 2 else None, gmode, Xt, xa if xmode else None,
+                xb if xmode else None, xmode, partial, dW, S, B, M, K, T)
+        if mask is None:
+            N.call(name, *args, 1)
+        else:
+            N.call(name, *args, mask)
+        return dW
+
+    assert rel_err(run("v100_pw_wgrad_io", gm, g216, 2, xm, 0, G2_), run("v100_pw_wgrad", gm, g2r, 2, xm, 0)) < 1e-6
+    assert rel_err(run("v100_pw_wgrad_io", g16, g216, 2, xm, 0, G_ | G2_), run("v100_pw_wgrad", gr, g2r, 2, xm, 0)) < 1e-6
+    assert rel_err(run("v100_pw_wgrad_io", gm, None, 0, x16, 1, WX), run("v100_pw_wgrad", gm, None, 0, xr, 1)) < 1e-6
+
+
+@pytest.mark.parametrize("B,C,T,K", [(2, 8, 48, 19), (3, 6, 133, 83), (2, 4, 700, 51), (5, 12, 512, 5), (2, 4, 1100, 35)])
+def test_dwconv_io_variants(cuda, B, C, T, K):
+    N = _native()
+    g = torch.Generator().manual_seed(C * 7 + T + K)
+    pad = (K - 1) // 2
+    a1 = (torch.randn(B, C, T, generator=g) * 2).to(cuda)
+    a116, a1r = to16(a1)
+    w = (torch.randn(C, K, generator=g) * 0.2).to(cuda)
+    s1, t1 = torch.rand(C, generator=g).to(cuda) + 0.5, torch.randn(C, generator=g).to(cuda)
+    G = N.helper("v100_dw_num_groups", B, C)
+    # forward: bf16 in, bf16 out
+    y0 = torch.empty(B, C, T, device=cuda)
+    st0 = torch.zeros(G, C, 2, device=cuda)
+    N.call("v100_dwconv", a1r, None, w, s1, t1, None, 1, y0, None, None, None, 0, st0, G, B, C, T, T, K, 1, pad, 0, 1, 0)
+    y1 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    st1 = torch.zeros(G, C, 2, device=cuda)
+    N.call("v100_dwconv_fwd_train_io", a116, w, s1, t1, y1, st1, G, B, C, T, K, DX | DY)
+    assert torch.equal(from16(y1, T), y0.to(torch.bfloat16).to(torch.float32))
+    assert rel_err(st1, st0) < 1e-6
+    # fused backward: dz2 fp32 | bf16, a2 bf16, a1 bf16 -> dz1 fp32 | bf16, BN1-backward sums, dW
+    dz2 = torch.randn(B, C, T, generator=g).to(cuda)
+    dz216, dz2r = to16(dz2)
+    a2 = torch.randn(B, C, T, generator=g).to(cuda)
+    a216, a2r = to16(a2)
+    ga, gb, gc = torch.rand(C, generator=g).to(cuda) + 0.5, (torch.randn(C, generator=g) * 0.3).to(cuda), (torch.randn(C, generator=g) * 0.1).to(cuda)
+
+    def ref(dzin):
+        dz1 = torch.empty(B, C, T, device=cuda)
+        st = torch.zeros(G, C, 2, device=cuda)
+        part = torch.empty(G, C, K, device=cuda)
+        dw = torch.empty(C, K, device=cuda)
+        N.call("v100_dwconv_bwd", dzin, a2r, w, ga, gb, gc, a1r, s1, t1, dz1, st, part, dw, G, B, C, T, T, K, 1, pad, 0)
+        return dz1, st, dw
+
+    for mask, dzin16, dzref in ((DX2 | DAUX, dz2, dz2), (DX | DX2 | DAUX | DY, dz216, dz2r)):
+        dz1r, str_, dwr = ref(dzref)
+        dz1 = (torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda) if mask & DY else torch.empty(B, C, T, device=cuda))
+        st = torch.zeros(G, C, 2, device=cuda)
+        part = torch.empty(G, C, K, device=cuda)
+        dw = torch.empty(C, K, device=cuda)
+        N.call("v100_dwconv_bwd_io", dzin16, a216, w, ga, gb, gc, a116, s1, t1, dz1, st, part, dw, G, B, C, T, K, mask)
+        if mask & DY:
+            assert torch.equal(from16(dz1, T), dz1r.to(torch.bfloat16).to(torch.float32))
+        else:
+            assert rel_err(dz1, dz1r) < 1e-6
+        assert rel_err(st, str_) < 1e-5 and rel_err(dw, dwr) < 1e-5
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_block_act16_matches_fp32_storage(cuda, level):
+    """A training-mode block at bf16 precision with the hidden tensors stored as bf16 vs the same block with fp32 storage:
+    outputs, input gradient and parameter gradients within bf16 storage error of each other (and both within the bf16 bar
+    of the fp32 oracle, tests/test_gpu_models.py)."""
+    from voice100_amd import functional as F_
+    from voice100_amd.layers import InvertedResidual
+    torch.manual_seed(3)
+    F_.set_matmul_precision("bf16")
+    keep = F_.get_activation_storage()
+    try:
+        outs = []
+        for lv in (0, level):
+            F_.set_activation_storage(lv)
+            torch.manual_seed(3)
+            blk = InvertedResidual(64, 64, kernel_size=27).to(cuda).train()
+            x = torch.randn(3, 64, 203, generator=torch.Generator().manual_seed(5)).to(cuda).requires_grad_(True)
+            y = blk(x)
+            (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(6)).to(cuda)).sum().backward()
+            outs.append((y.detach(), x.grad, {k: p.grad for k, p in blk.named_parameters()},
+                         blk.conv[1][1].running_var.clone()))
+        (y0, gx0, gp0, rv0), (y1, gx1, gp1, rv1) = outs
+        assert rel_err(y1, y0) < 2e-2 and rel_err(rv1, rv0) < 2e-2
+        assert float((gx1 - gx0).norm() / gx0.norm()) < 5e-2
+        # floor: BN1's gamma has a mathematically (almost) zero gradient here -- a per-channel rescale before the depthwise
+        # conv is undone by the training-mode BN2 behind it -- so its two round-off-sized values cannot be compared relatively
+        scale = max(float(v.norm()) for v in gp0.values())
+        errs = {k: float((gp1[k] - gp0[k]).norm()) / max(float(gp0[k].norm()), 1e-2 * scale) for k in gp0}
+        assert max(errs.values()) < 8e-2, errs
+    finally:
+        F_.set_activation_storage(keep)
+        F_.set_matmul_precision("fp32")

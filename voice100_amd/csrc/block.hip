@@ -22,9 +22,26 @@ const float kMom = 0.1f, kEps = 1e-5f;
 }
 #define CK(call) do { rc = (call); if (rc) return rc; } while (0)
 
-// shape = {B, Cin, hid, Cout, T, K, stride, residual, bf16, prepped}
+// shape = {B, Cin, hid, Cout, T, K, stride, residual, bf16, prepped, act16}
 // coef  = 12 vectors of `hid` floats: s1 t1 mean1 rstd1 s2 t2 mean2 rstd2 s3 t3 mean3 rstd3
-enum { IR_B, IR_CIN, IR_HID, IR_COUT, IR_T, IR_K, IR_STRIDE, IR_RES, IR_BF16, IR_PREPPED, IR_NSHAPE };
+// act16 (bf16 operands only): 0 = every activation fp32; 1 = the two hidden tensors saved for backward, a1 and a2, are
+// stored as bf16 [B][hid][pitch16(T)] (the caller allocates them so); 2 = also the hidden gradients dz2 / dz1 inside the
+// backward workspace.  Statistics and every accumulation stay fp32; only the stored copies are rounded.
+enum { IR_B, IR_CIN, IR_HID, IR_COUT, IR_T, IR_K, IR_STRIDE, IR_RES, IR_BF16, IR_PREPPED, IR_ACT16, IR_NSHAPE };
+static inline int pitch16(int T) { return (T + 7) & ~7; }
+enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8, WG_IO_G = 1, WG_IO_G2 = 2, WG_IO_X = 4, DW_IO_X = 1, DW_IO_X2 = 2, DW_IO_AUX = 4,
+       DW_IO_Y = 8 };
+
+// 1 when a block of this shape can run with act16 != 0 (stride 1, a depthwise kernel size with an MFMA kernel, bf16 operands,
+// tensors addressable by the buffer-descriptor kernels)
+extern "C" int v100_ir_act16_supported(const int* sh) {
+    if (!sh || sh[IR_BF16] != 1 || sh[IR_STRIDE] != 1) return 0;
+    if (!v100_dw_mfma_supported(sh[IR_K], sh[IR_STRIDE])) return 0;
+    const long B = sh[IR_B], hid = sh[IR_HID], cin = sh[IR_CIN], cout = sh[IR_COUT], P = pitch16(sh[IR_T]);
+    if (hid % 2 || cin % 2 || cout % 2) return 0;
+    if (B * hid * P * 4 >= 0x7fffff00L || (hid + 128) * P * 4 >= 0x7fffff00L || (hid + 128) * (cin > cout ? cin : cout) * 2 >= 0x7fffff00L) return 0;
+    return 1;
+}
 
 // Prepared weights, written once by forward and reused by backward (caller-owned, saved with the block):
 // bf16 mode: w1_bf [hid][cin], w1t_bf [cin][hid], w3_bf [cout][hid], w3t_bf [hid][cout];  fp32 mode: w1t, w3t (fp32).
@@ -94,6 +111,20 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
         CK(v100_weight_prep(w3, cout, hid, pw.w3bf, pw.w3t, pw.w3tbf, stream));
     }
     const int parts1 = v100_pw_num_parts(B, T), parts3 = v100_pw_num_parts(B, T2), G = v100_dw_num_groups(B, hid);
+    if (sh[IR_ACT16]) {
+        if (!v100_ir_act16_supported(sh)) return V100_ERR_SHAPE;
+        CK(v100_pw_gemm_io(w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, PW_IO_Y, stream));
+        CK(v100_bn_finalize_train(st, parts1, (long long)B * T, (const float*)P[2], (const float*)P[3], (float*)P[4], (float*)P[5], (long long*)P[6],
+                                  kMom, kEps, s1, t1, m1, r1, hid, stream));
+        CK(v100_dwconv_fwd_train_io(a1, wd, s1, t1, a2, st, G, B, hid, T, K, DW_IO_X | DW_IO_Y, stream));
+        CK(v100_bn_finalize_train(st, G, (long long)B * T2, (const float*)P[8], (const float*)P[9], (float*)P[10], (float*)P[11], (long long*)P[12],
+                                  kMom, kEps, s2, t2, m2, r2, hid, stream));
+        CK(v100_pw_gemm_io(w3bf, a2, nullptr, s2, t2, nullptr, 1, a3, nullptr, nullptr, nullptr, 1, st, B, cout, hid, T2, PW_IO_X, stream));
+        CK(v100_bn_finalize_train(st, parts3, (long long)B * T2, (const float*)P[14], (const float*)P[15], (float*)P[16], (float*)P[17], (long long*)P[18],
+                                  kMom, kEps, s3, t3, m3, r3, cout, stream));
+        CK(v100_chan_affine2(a3, res ? x : nullptr, s3, nullptr, t3, y, B, cout, T2, stream));
+        return V100_OK;
+    }
     CK(v100_pw_gemm(w1, w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, bf, stream));
     CK(v100_bn_finalize_train(st, parts1, (long long)B * T, (const float*)P[2], (const float*)P[3], (float*)P[4], (float*)P[5], (long long*)P[6],
                               kMom, kEps, s1, t1, m1, r1, hid, stream));
@@ -119,8 +150,15 @@ static size_t ir_bwd_carve(const int* sh, void* base, IrBwdWs& w) {
     m = (size_t)v100_dw_num_groups(B, hid) * hid * 2; if (m > n) n = m;
     w.part = c.take<float>(n);
     w.da3 = c.take<float>((size_t)B * cout * T2);
-    w.dz2 = c.take<float>((size_t)B * hid * T2);
-    w.dz1 = c.take<float>((size_t)B * hid * T);
+    // act16 == 2: the two hidden gradients are bf16 with pitched rows (half the bytes; the fp32 size is an upper bound
+    // only when pitch16(T) <= 2*T, i.e. always)
+    if (sh[IR_ACT16] == 2) {
+        w.dz2 = (float*)c.take<u16>((size_t)B * hid * pitch16(T2));
+        w.dz1 = (float*)c.take<u16>((size_t)B * hid * pitch16(T));
+    } else {
+        w.dz2 = c.take<float>((size_t)B * hid * T2);
+        w.dz1 = c.take<float>((size_t)B * hid * T);
+    }
     n = (size_t)v100_pw_wgrad_splits(B, cout, hid) * cout * hid;
     m = (size_t)v100_pw_wgrad_splits(B, hid, cin) * hid * cin; if (m > n) n = m;
     m = (size_t)v100_dw_num_groups(B, hid) * hid * K; if (m > n) n = m;
@@ -162,6 +200,26 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     CK(v100_chan_reduce2(dy, a3, w.part, Gr, B, cout, T2, stream));
     CK(v100_bn_bwd_finalize(w.part, Gr, (long long)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], cout, stream));
     CK(v100_chan_affine2(dy, a3, pp, qq, rr, w.da3, B, cout, T2, stream));
+    if (sh[IR_ACT16]) {
+        if (!v100_ir_act16_supported(sh)) return V100_ERR_SHAPE;
+        const bool g16 = sh[IR_ACT16] == 2;
+        CK(v100_pw_wgrad_io(w.da3, nullptr, nullptr, nullptr, nullptr, 0, a2, s2, t2, 1, w.slab, (float*)P[19], v100_pw_wgrad_splits(B, cout, hid),
+                            B, cout, hid, T2, WG_IO_X, stream));
+        const int parts16 = v100_pw_num_parts(B, T2);
+        CK(v100_pw_gemm_io(pw.w3tbf, w.da3, nullptr, nullptr, nullptr, nullptr, 0, w.dz2, s2, t2, a2, 4, w.part, B, hid, cout, T2,
+                           PW_IO_R | (g16 ? PW_IO_Y : 0), stream));
+        CK(v100_bn_bwd_finalize(w.part, parts16, (long long)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], hid, stream));
+        const int G16 = v100_dw_num_groups(B, hid);
+        CK(v100_dwconv_bwd_io(w.dz2, a2, wd, pp, qq, rr, a1, s1, t1, w.dz1, w.part, w.slab, (float*)P[16], G16, B, hid, T, K,
+                              g16 ? (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y) : (DW_IO_X2 | DW_IO_AUX), stream));
+        CK(v100_bn_bwd_finalize(w.part, G16, (long long)B * T, g1, m1, r1, pp, qq, rr, (float*)P[14], (float*)P[15], hid, stream));
+        CK(v100_pw_wgrad_io(w.dz1, a1, pp, qq, rr, 2, x, nullptr, nullptr, 0, w.slab, (float*)P[13], v100_pw_wgrad_splits(B, hid, cin),
+                            B, hid, cin, T, WG_IO_G2 | (g16 ? WG_IO_G : 0), stream));
+        if (dx)
+            CK(v100_pw_gemm_io(pw.w1tbf, w.dz1, a1, pp, qq, rr, 2, dx, nullptr, nullptr, res ? dy : nullptr, res ? 5 : 0, nullptr,
+                               B, cin, hid, T, PW_IO_X2 | (g16 ? PW_IO_X : 0), stream));
+        return V100_OK;
+    }
     // pw-linear: weight grad, then data grad through ReLU6 with BN2-backward sums
     CK(v100_pw_wgrad(w.da3, nullptr, nullptr, nullptr, nullptr, 0, a2, s2, t2, 1, w.slab, (float*)P[19], v100_pw_wgrad_splits(B, cout, hid),
                      B, cout, hid, T2, bf, stream));

@@ -37,7 +37,12 @@ struct DwParams {
     float* stats;        // [G][C][2]
     int B, C, Tin, Tout, K, stride, pad, flip, upsample, G, in_mode, out_mode;
     float* wpartial;     // [G][C][K]  backward-weight partial sums of the fused backward kernel (else null)
+    // 16-bit storage of the big hidden tensors ("act16", bf16 mode): DW_IO_* mask -- those tensors are bf16 [B][C][P], row
+    // pitch P = dw_pitch16(T) (multiple of 8 elements); x / x2 / aux / y then point at bf16 data.  MFMA kernels only.
+    int io16;
 };
+enum { DW_IO_X = 1, DW_IO_X2 = 2, DW_IO_AUX = 4, DW_IO_Y = 8 };
+__host__ __device__ __forceinline__ int dw_pitch16(int T) { return (T + 7) & ~7; }
 
 struct DwWgradParams {
     const float* g;      // [B,C,Tout] upstream gradient stream 1
@@ -379,22 +384,24 @@ static inline DwPathConfig dw_path_config() {
 #ifndef DW_FUSED_R
 #define DW_FUSED_R 4
 #endif
-template <int IM, int OM, bool WG = false>
+template <int IM, int OM, bool WG = false, int IO = 0>
 static bool dw_launch_specialised(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl) {
     dim3 grid(p.C, p.G);
     {
         const DwPathConfig cfg = dw_path_config();
-        if (cfg.mfma && p.stride == 1 && p.upsample == 1) {
+        if ((cfg.mfma || IO != 0) && p.stride == 1 && p.upsample == 1) {
 #define X(KK)                                                                                                           \
     if (p.K == KK) {                                                                                                    \
-        if (cfg.digits == 2) V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 2, WG>), grid, dim3(256), 0, st, p);      \
-        else V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 3, WG>), grid, dim3(256), 0, st, p);                      \
+        if (cfg.digits == 2 && IO == 0) V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 2, WG, IO>), grid, dim3(256), 0, st, p); \
+        else V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 3, WG, IO>), grid, dim3(256), 0, st, p);                  \
         return true;                                                                                                    \
     }
             V100_DW_SPECIALISED(X)
 #undef X
         }
     }
+    if constexpr (IO != 0) return false;      // 16-bit storage exists on the MFMA kernels only
+    else {
     const bool big = p.Tout > 256 && !(WG && DW_FUSED_R == 4);
     // rows of any length take the 16-byte (dword-aligned) global path; tails are masked per element
 #define DW_GO(KK, SS)                                                                                             \
@@ -411,8 +418,12 @@ static bool dw_launch_specialised(const DwParams& p, hipStream_t st, const V100T
     }
 #undef DW_GO
     return false;
+    }
 }
 
+bool dw_launch_fwd_train16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);     // a1 in, a2 out stored as bf16
+bool dw_launch_bwd_fused16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);     // a2 (x2) and a1 (aux) stored as bf16
+bool dw_launch_bwd_fused16g(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);    // ... and dz2 in, dz1 out too
 bool dw_launch_fwd_train(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);   // in AFFINE_RELU6, out RAW_STATS
 bool dw_launch_fwd_eval(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);    // in NONE,         out AFFINE_RELU6
 bool dw_launch_bwd_data(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);    // in AFFINE2,      out MASK_STATS

@@ -83,11 +83,37 @@ __device__ __forceinline__ void dwm_split(float v, unsigned (&d)[3]) {
     const float r2 = r1 - __builtin_bit_cast(float, d[1]);
     d[2] = __builtin_bit_cast(unsigned, r2) & 0xffff0000u;
 }
+// two fp32 -> one dword of two bf16, round to nearest even, by plain casts (hipcc emits v_cvt_pk_bf16_f32 and -- unlike for an
+// inline-asm statement -- its hazard recognizer pads the MFMA-result -> VALU-read wait states: common.h's pack_bf16 asm read
+// the accumulators too early here and stored stale registers)
+typedef __bf16 dwm_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned dwm_pack_rne(float lo, float hi) {
+    const dwm_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
 // two digits (high halves of lo / hi) -> one dword of two bf16
 __device__ __forceinline__ unsigned dwm_pack(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
-template <int K, int IM, int OM, int NT, bool WG = false>
+// element e (0..3) of a 4-sample run held either as f32x4 or as two dwords of packed bf16
+__device__ __forceinline__ float dwm_elem(const f32x4& r, int e) { return r[e]; }
+__device__ __forceinline__ float dwm_elem(const dwm_u32x2& r, int e) {
+    const unsigned w = r[e >> 1];
+    return __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+template <bool B16>
+struct DwmRun { typedef f32x4 type; };
+template <>
+struct DwmRun<true> { typedef dwm_u32x2 type; };
+template <bool B16>
+__device__ __forceinline__ typename DwmRun<B16>::type dwm_load_run(__amdgpu_buffer_rsrc_t r, int voff_elems, unsigned row_elems) {
+    // voff_elems: element offset inside the row, or a huge value for "out of range" (hardware returns zero)
+    if constexpr (B16) return __builtin_amdgcn_raw_buffer_load_b64(r, voff_elems < 0x20000000 ? voff_elems * 2 : 0x7ffffff0, (int)(row_elems * 2u), 0);
+    else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_elems < 0x20000000 ? voff_elems * 4 : 0x7ffffff0, (int)(row_elems * 4u), 0));
+}
+
+template <int K, int IM, int OM, int NT, bool WG = false, int IO = 0>
 __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p) {
+    constexpr bool XB = (IO & DW_IO_X) != 0, X2B = (IO & DW_IO_X2) != 0, AUXB = (IO & DW_IO_AUX) != 0, YB = (IO & DW_IO_Y) != 0;
     using G_ = DwMfmaGeom<K>;
     constexpr int SUBS = G_::SUBS, TILE = G_::TILE, STEPS = G_::STEPS, NV = G_::NV, IMGP = G_::IMGP, WPAD = G_::WPAD, WLEN = G_::WLEN;
     constexpr int IB = G_::IB;
@@ -150,10 +176,15 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
     const int ntiles = (Tout + TILE - 1) / TILE;
 
     float s0 = 0.f, s1 = 0.f;
-    DwRaw<NV, TWO> raw;
-    const unsigned xbytes = (unsigned)((size_t)p.B * p.C * Tin * 4);
-    const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, xbytes);
-    const __amdgpu_buffer_rsrc_t rx2 = dw_make_rsrc(TWO ? p.x2 : p.x, xbytes);
+    // row pitches (elements): bf16-stored tensors are padded to a multiple of 8 samples per row
+    const int PinX = XB ? dw_pitch16(Tin) : Tin, PinX2 = X2B ? dw_pitch16(Tin) : Tin;
+    const int PoutA = AUXB ? dw_pitch16(Tout) : Tout, PoutY = YB ? dw_pitch16(Tout) : Tout;
+    typename DwmRun<XB>::type rawx[NV];
+    typename DwmRun<X2B>::type rawx2[TWO ? NV : 1];
+    const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, (unsigned)((size_t)p.B * p.C * PinX * (XB ? 2 : 4)));
+    const __amdgpu_buffer_rsrc_t rx2 = TWO ? dw_make_rsrc(p.x2, (unsigned)((size_t)p.B * p.C * PinX2 * (X2B ? 2 : 4))) : rx;
+    const __amdgpu_buffer_rsrc_t raux = dw_make_rsrc(OM == DW_OUT_MASK_STATS ? p.aux : p.x,
+                                                     OM == DW_OUT_MASK_STATS ? (unsigned)((size_t)p.B * p.C * PoutA * (AUXB ? 2 : 4)) : 0u);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     unsigned short* img = reinterpret_cast<unsigned short*>(lds_raw) + wave_u * WAVE_U16;
     unsigned short* ximg = img + NT * IMGP;                  // WG only
@@ -171,15 +202,15 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
         for (int v = 0; v < NV; ++v) {
             const int ia = in0a + 4 * (lane + 64 * v);
             const bool ok = ia >= 0 && ia < Tin && 4 * (lane + 64 * v) < G_::IMG;
-            vo[v] = ok ? ia * 4 : 0x7ffffff0;
+            vo[v] = ok ? ia : 0x7ffffff0;                      // element offset inside the row
         }
         int bi = wave_u;
         if (bi < nb) {
-            const unsigned rb = (unsigned)(((size_t)(b0 + bi) * p.C + c) * Tin * 4);
+            const unsigned row = (unsigned)((b0 + bi) * p.C + c);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                raw.v[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo[v], (int)rb, 0));
-                if constexpr (TWO) raw.v2[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, vo[v], (int)rb, 0));
+                rawx[v] = dwm_load_run<XB>(rx, vo[v], row * (unsigned)PinX);
+                if constexpr (TWO) rawx2[v] = dwm_load_run<X2B>(rx2, vo[v], row * (unsigned)PinX2);
             }
         }
         for (; bi < nb; bi += 4) {
@@ -189,7 +220,13 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
 #pragma unroll
                 for (int sub = 0; sub < SUBS; ++sub) {
                     const int t0 = out0 + 256 * sub + 16 * n_ + 4 * q_;
-                    dw_load_run<4, true>(auxv[sub], p.aux + ((size_t)b * p.C + c) * Tout + t0, t0, Tout);
+                    if constexpr (AUXB) {
+                        const dwm_u32x2 a2 = dwm_load_run<true>(raux, t0 < Tout ? t0 : 0x7ffffff0, (unsigned)(b * p.C + c) * (unsigned)PoutA);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) auxv[sub][r] = (t0 + r < Tout) ? dwm_elem(a2, r) : 0.f;
+                    } else {
+                        dw_load_run<4, true>(auxv[sub], p.aux + ((size_t)b * p.C + c) * Tout + t0, t0, Tout);
+                    }
                 }
             }
             // ---- stage: transform, zero outside the row, split into bf16 digits, 8-byte LDS stores ----
@@ -200,9 +237,9 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float val;
-                    if constexpr (IM == DW_IN_AFFINE_RELU6) val = relu6f(fmaf(raw.v[v][e], ca, cb));
-                    else if constexpr (IM == DW_IN_AFFINE2) val = fmaf(raw.v[v][e], ca, fmaf(raw.v2[v][e], cb, cc));
-                    else val = raw.v[v][e];
+                    if constexpr (IM == DW_IN_AFFINE_RELU6) val = relu6f(fmaf(dwm_elem(rawx[v], e), ca, cb));
+                    else if constexpr (IM == DW_IN_AFFINE2) val = fmaf(dwm_elem(rawx[v], e), ca, fmaf(dwm_elem(rawx2[v], e), cb, cc));
+                    else val = dwm_elem(rawx[v], e);
                     // zero padding applies to the TRANSFORMED tensor; a float4 that straddles the row end (Tin % 4 != 0) holds the
                     // next row's first samples, so the plain copy needs the mask too (ia is a multiple of 4: ia >= 0 covers e)
                     val = (ia >= 0 && ia + e < Tin) ? val : 0.f;
@@ -235,11 +272,11 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
 
             // prefetch the next row of this tile while this one computes
             if (bi + 4 < nb) {
-                const unsigned rb = (unsigned)(((size_t)(b + 4) * p.C + c) * Tin * 4);
+                const unsigned row = (unsigned)((b + 4) * p.C + c);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    raw.v[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo[v], (int)rb, 0));
-                    if constexpr (TWO) raw.v2[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx2, vo[v], (int)rb, 0));
+                    rawx[v] = dwm_load_run<XB>(rx, vo[v], row * (unsigned)PinX);
+                    if constexpr (TWO) rawx2[v] = dwm_load_run<X2B>(rx2, vo[v], row * (unsigned)PinX2);
                 }
             }
 
@@ -288,7 +325,13 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
                     }
                     outv[r] = yv;
                 }
-                if (t0 + 3 < Tout) {
+                if constexpr (YB) {
+                    // 4 bf16 = one 8-byte store (the pitch keeps it aligned; samples past Tout land in the row's padding)
+                    if (t0 < Tout) {
+                        const dwm_u32x2 o2 = {dwm_pack_rne(outv[0], outv[1]), dwm_pack_rne(outv[2], outv[3])};
+                        *reinterpret_cast<dwm_u32x2*>(reinterpret_cast<unsigned short*>(p.y) + ((size_t)b * p.C + c) * PoutY + t0) = o2;
+                    }
+                } else if (t0 + 3 < Tout) {
                     const f32x4 o = {outv[0], outv[1], outv[2], outv[3]};
                     *reinterpret_cast<f32x4u*>(p.y + oo) = o;
                 } else {

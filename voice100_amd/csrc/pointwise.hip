@@ -24,6 +24,8 @@ void pw_launch_gemm_bf16(const PwParams& p, dim3 grid, hipStream_t st);
 bool pw_launch_gemm_f16(const PwParams& p, dim3 grid, hipStream_t st);
 void pw_launch_wgrad_f32(const WgParams& p, dim3 grid, hipStream_t st);
 void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st);
+bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st);
+bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st);
 bool pw_taps_fit_bf16(int B, int M, int cx, int ntap, int T, int Tx);
 bool pw_launch_gemm_taps_bf16(const PwParams& p, dim3 grid, hipStream_t st);
 bool pw_launch_wgrad_taps_bf16(const WgParams& p, dim3 grid, hipStream_t st);
@@ -129,6 +131,47 @@ extern "C" int v100_pw_wgrad(const float* G, const float* G2, const float* ga, c
     return v100_launch_status();
 }
 
+
+// bf16-operand GEMMs over tensors of which some are STORED as bf16 (io16: PW_IO_* / WG_IO_* masks, include/voice100_hip.h):
+// the block executor's "act16" mode.  Same semantics as v100_pw_gemm / v100_pw_wgrad; V100_ERR_SHAPE when the
+// (modes, mask, shape) combination has no kernel -- there is no fallback, the caller picks fp32 storage instead.
+extern "C" int v100_pw_gemm_io(const void* A_bf16, const void* X, const void* X2, const float* xa, const float* xb, const float* xc,
+                               int x_mode, void* Y, const float* ea, const float* eb, const void* R, int epi_mode, float* stats,
+                               int B, int M, int K, int T, int io16, void* stream) {
+    if (!A_bf16 || !X || !Y) return V100_ERR_NULL;
+    if (B <= 0 || M <= 0 || K <= 0 || T <= 0 || io16 <= 0 || io16 > 15) return V100_ERR_SHAPE;
+    if (x_mode != PW_X_NONE && (!xa || !xb)) return V100_ERR_NULL;
+    if (x_mode == PW_X_AFFINE2 && (!X2 || !xc)) return V100_ERR_NULL;
+    if (epi_mode == PW_EPI_MASK_STATS && (!ea || !eb)) return V100_ERR_NULL;
+    if ((epi_mode == PW_EPI_MASK_STATS || epi_mode == PW_EPI_ADD) && !R) return V100_ERR_NULL;
+    if ((epi_mode == PW_EPI_STATS || epi_mode == PW_EPI_MASK_STATS) && !stats) return V100_ERR_NULL;
+    PwParams p{nullptr, (const u16*)A_bf16, (const float*)X, (const float*)X2, xa, xb, xc, (float*)Y, nullptr, ea, eb, (const float*)R, stats,
+               B, M, K, T, x_mode, epi_mode, ceil_div(M, PW_BM), ceil_div(T, PW_BN), 1, 0, 0, 0, 0u, io16};
+    hipStream_t st = (hipStream_t)stream;
+    V100TimedRegion timed(V100_T_PW_GEMM, st);
+    if (!pw_launch_gemm_bf16_io(p, st)) return V100_ERR_SHAPE;
+    return v100_launch_status();
+}
+
+extern "C" int v100_pw_wgrad_io(const void* G, const void* G2, const float* ga, const float* gb, const float* gc, int g_mode,
+                                const void* X, const float* xa, const float* xb, int x_mode, float* partial, float* dW, int S, int B,
+                                int M, int K, int T, int io16, void* stream) {
+    if (!G || !X || !partial || !dW) return V100_ERR_NULL;
+    if (B <= 0 || M <= 0 || K <= 0 || T <= 0 || S <= 0 || S > B || io16 <= 0 || io16 > 7) return V100_ERR_SHAPE;
+    if (g_mode != PW_X_NONE && (!ga || !gb)) return V100_ERR_NULL;
+    if (g_mode == PW_X_AFFINE2 && (!G2 || !gc)) return V100_ERR_NULL;
+    if (x_mode != PW_X_NONE && (!xa || !xb)) return V100_ERR_NULL;
+    const int nmt = ceil_div(M, PW_BM), nkt = ceil_div(K, PW_BN);
+    WgParams p{(const float*)G, (const float*)G2, ga, gb, gc, (const float*)X, xa, xb, partial, B, M, K, T, S, g_mode, x_mode, nmt, nkt,
+               0, 0, 0, 0, 0, 0u, io16};
+    dim3 grid((unsigned)(nmt * nkt * S));
+    hipStream_t st = (hipStream_t)stream;
+    V100TimedRegion timed(V100_T_PW_WGRAD, st);
+    if (!pw_launch_wgrad_bf16_io(p, grid, st)) return V100_ERR_SHAPE;
+    const long n = (long)M * K;
+    hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, dW, S, n);
+    return v100_launch_status();
+}
 
 // ---------------------------------------------------------------------------------------------
 // Dense k-tap Conv1d / ConvTranspose1d phases as ONE GEMM over a zero-padded copy of the input (no im2col):

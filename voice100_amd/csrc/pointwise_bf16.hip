@@ -165,9 +165,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <int XM, int EPI, int BM, bool F16 = false, bool TAPS = false>
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int XM, int EPI, int BM, bool F16 = false, bool TAPS = false, int IO = 0>
 __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     static_assert(!TAPS || XM == PW_X_NONE, "tap-addressed X has no prologue");
+    static_assert(!(IO != 0 && (TAPS || F16)), "16-bit activation storage: bf16 training combinations only");
+    constexpr bool XB = (IO & PW_IO_X) != 0, X2B = (IO & PW_IO_X2) != 0;    // operand tensors stored as bf16 (pitched rows)
+    using XReg = std::conditional_t<XB, u32x2, u32x4>;
+    using X2Reg = std::conditional_t<X2B, u32x2, u32x4>;
     // BM x 128 block tile, BM/64 x 2 waves of 64x64.  BM = 256 (8 waves, one block per CU) halves the L2 traffic of
     // the X operand, which is what bounds these GEMMs (each X tile is re-read by every M-tile); BM = 128 for M <= 128.
     constexpr int NT = BM * 2;                      // threads
@@ -187,11 +193,16 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     // tap-addressed X: physical rows are the cx channels of the padded tensor, row pitch Tx (see PwParams)
     const int Tx = TAPS ? p.Tx : T;
     const int Kx = TAPS ? p.cx : K;
-    const size_t xoff = (size_t)b * Kx * Tx;
+    const int P16 = pw_pitch16(T);                  // row pitch of the bf16-stored tensors
+    const int TxX = XB ? P16 : Tx, TxX2 = X2B ? P16 : Tx;
+    constexpr int EX = XB ? 2 : 4, EX2 = X2B ? 2 : 4;      // bytes per element
 
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.Abf, (PW_ABLATE & 2) ? 0u : (unsigned)M * K * 2u);
-    const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.X + xoff, (PW_ABLATE & 1) ? 0u : (unsigned)Kx * Tx * 4u);
-    const __amdgpu_buffer_rsrc_t rX2 = make_rsrc((XM == PW_X_AFFINE2 ? p.X2 : p.X) + xoff, (PW_ABLATE & 1) ? 0u : (unsigned)Kx * Tx * 4u);
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(reinterpret_cast<const char*>(p.X) + (size_t)b * Kx * TxX * EX,
+                                                (PW_ABLATE & 1) ? 0u : (unsigned)Kx * TxX * EX);
+    const __amdgpu_buffer_rsrc_t rX2 = make_rsrc(reinterpret_cast<const char*>(XM == PW_X_AFFINE2 ? p.X2 : p.X) +
+                                                     (size_t)b * Kx * (XM == PW_X_AFFINE2 ? TxX2 * EX2 : TxX * EX),
+                                                 (PW_ABLATE & 1) ? 0u : (unsigned)Kx * (XM == PW_X_AFFINE2 ? TxX2 * EX2 : TxX * EX));
     const __amdgpu_buffer_rsrc_t rCa = make_rsrc(XM != PW_X_NONE ? p.xa : p.X, (unsigned)K * 4u);
     const __amdgpu_buffer_rsrc_t rCb = make_rsrc(XM != PW_X_NONE ? p.xb : p.X, (unsigned)K * 4u);
     const __amdgpu_buffer_rsrc_t rCc = make_rsrc(XM == PW_X_AFFINE2 ? p.xc : p.X, (unsigned)K * 4u);
@@ -206,9 +217,12 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         voA[i] = ((m0 + row) * K + ch * 8) * 2;
         ldsA[i] = bf_off(row, ch);
     }
-    int voX[KPT];
+    int voX[KPT], voX2[XM == PW_X_AFFINE2 ? KPT : 1];
 #pragma unroll
-    for (int e = 0; e < KPT; ++e) voX[e] = ((KPT * b_kg + e) * Tx + t0 + b_tq) * 4;
+    for (int e = 0; e < KPT; ++e) {
+        voX[e] = ((KPT * b_kg + e) * TxX + t0 + b_tq) * EX;
+        if constexpr (XM == PW_X_AFFINE2) voX2[e] = ((KPT * b_kg + e) * TxX2 + t0 + b_tq) * EX2;
+    }
     const int voC = KPT * b_kg * 4;
     int ldsB[4];
 #pragma unroll
@@ -219,20 +233,26 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     // (XM == AFFINE2) keeps one stage at BM = 128 (register budget); at BM = 256 its patch is half as large.
     constexpr int NST = (XM == PW_X_AFFINE2 && KPT == 8) ? 1 : 2;
     constexpr int NC = KPT / 4;                     // float4 coefficient loads per array
-    u32x4 ra[NST][4], rb[NST][KPT], rb2[NST][XM == PW_X_AFFINE2 ? KPT : 1], rca[NC], rcb[NC], rcc[XM == PW_X_AFFINE2 ? NC : 1];
+    u32x4 ra[NST][4], rca[NC], rcb[NC], rcc[XM == PW_X_AFFINE2 ? NC : 1];
+    XReg rb[NST][KPT];
+    X2Reg rb2[NST][XM == PW_X_AFFINE2 ? KPT : 1];
     auto load_tiles = [&](int k0, auto stg) {
         constexpr int SG = decltype(stg)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[SG][i] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA[i], k0 * 2, 0);
-        int so = k0 * T * 4;
+        int so = k0 * TxX * EX;
         if constexpr (TAPS) {                  // a k-tile never straddles two taps (cx % 64 == 0, checked by the launcher)
             const int tap = k0 / p.cx;
             so = ((k0 - tap * p.cx) * Tx + pw_tap_shift(p.shifts, tap)) * 4;
         }
 #pragma unroll
         for (int e = 0; e < KPT; ++e) {
-            rb[SG][e] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX[e], so, 0);
-            if constexpr (XM == PW_X_AFFINE2) rb2[SG][e] = __builtin_amdgcn_raw_buffer_load_b128(rX2, voX[e], so, 0);
+            if constexpr (XB) rb[SG][e] = __builtin_amdgcn_raw_buffer_load_b64(rX, voX[e], so, 0);
+            else rb[SG][e] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX[e], so, 0);
+            if constexpr (XM == PW_X_AFFINE2) {
+                if constexpr (X2B) rb2[SG][e] = __builtin_amdgcn_raw_buffer_load_b64(rX2, voX2[e], k0 * TxX2 * EX2, 0);
+                else rb2[SG][e] = __builtin_amdgcn_raw_buffer_load_b128(rX2, voX2[e], k0 * TxX2 * EX2, 0);
+            }
         }
     };
     // BN coefficients of the tile that is about to be STORED: tiny, L2-resident, single register stage
@@ -255,13 +275,20 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         float v[KPT];
 #pragma unroll
         for (int e = 0; e < KPT; ++e) {
-            const float x = __builtin_bit_cast(f32x4, rb[SG][e])[q];
+            float x;
+            if constexpr (XB) x = pw_bf16_at(rb[SG][e], q);
+            else x = __builtin_bit_cast(f32x4, rb[SG][e])[q];
             if constexpr (XM == PW_X_NONE) v[e] = x;
             else {
                 const float ca = __builtin_bit_cast(f32x4, rca[e >> 2])[e & 3];
                 const float cb = __builtin_bit_cast(f32x4, rcb[e >> 2])[e & 3];
                 if constexpr (XM == PW_X_AFFINE_RELU6) v[e] = relu6f(fmaf(x, ca, cb));
-                else v[e] = fmaf(x, ca, fmaf(__builtin_bit_cast(f32x4, rb2[SG][e])[q], cb, __builtin_bit_cast(f32x4, rcc[e >> 2])[e & 3]));
+                else {
+                    float x2;
+                    if constexpr (X2B) x2 = pw_bf16_at(rb2[SG][e], q);
+                    else x2 = __builtin_bit_cast(f32x4, rb2[SG][e])[q];
+                    v[e] = fmaf(x, ca, fmaf(x2, cb, __builtin_bit_cast(f32x4, rcc[e >> 2])[e & 3]));
+                }
             }
         }
         unsigned char* dst = Bs + buf * (128 * 128) + ldsB[q];
@@ -429,7 +456,7 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         if (s == 12345.678f) p.Y[0] = s;
         return;
     }
-    pw_epilogue_lds<EPI, BM>(p, acc, reinterpret_cast<float*>(smem), b, m0, t0, tt, wm, wn, tid);
+    pw_epilogue_lds<EPI, BM, IO>(p, acc, reinterpret_cast<float*>(smem), b, m0, t0, tt, wm, wn, tid);
 }
 
 // Backward-weight, bf16: contraction index is t; both operands are read as 8 consecutive t
@@ -561,9 +588,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgParams p) {
 
 // Fast path of the backward-weight kernel for T % 64 == 0: buffer loads with per-batch descriptors
 // (rows past M / K read as zero in hardware), per-lane offsets computed once.
-template <int GM, int XM, bool TAIL, bool TAPS = false>
+template <int GM, int XM, bool TAIL, bool TAPS = false, int IO = 0>
 __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
     static_assert(!TAPS || (GM == PW_X_NONE && XM == PW_X_NONE), "tap-addressed X has no prologues");
+    static_assert(!(IO != 0 && TAPS), "16-bit activation storage: plain operands only");
+    // operands stored as bf16 [B][rows][pw_pitch16(T)]: the 8 consecutive t of a piece are ONE 16-byte load
+    constexpr bool GB = (IO & WG_IO_G) != 0, G2B = (IO & WG_IO_G2) != 0, XB = (IO & WG_IO_X) != 0;
     __shared__ __attribute__((aligned(16))) unsigned char As[2][128 * 128];   // [m][t] bf16
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][128 * 128];   // [k][t] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -576,13 +606,16 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
     const int b_lo = s * bper, b_hi = min(p.B, b_lo + bper);
 
     float ga[4], gb[4], gc[4], xa[4], xb[4];
-    int voG[4], voX[4], ldsO[4];
+    int voG[4], voX[4], ldsO[4], voG16[4], voX16[4];
+    const int P16 = pw_pitch16(T);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int piece = tid + 256 * i;
         const int row = piece >> 3, ch = piece & 7;
         const int m = m0 + row, k = n0 + row;
         const bool mv = m < M, kv = k < K;
+        voG16[i] = (m * P16 + ch * 8) * 2;
+        voX16[i] = (k * P16 + ch * 8) * 2;
         ga[i] = (GM != PW_X_NONE) ? p.ga[mv ? m : 0] : 1.f;
         gb[i] = (GM != PW_X_NONE) ? p.gb[mv ? m : 0] : 0.f;
         gc[i] = (GM == PW_X_AFFINE2) ? p.gc[mv ? m : 0] : 0.f;
@@ -599,18 +632,26 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
     }
     const int Tg = TAPS ? p.Tg : T, Kx = TAPS ? p.cx : K, Tx = TAPS ? p.Tx : T;
 
-    u32x4 ra[4][2], ra2[4][2], rb[4][2];
+    u32x4 ra[4][GB ? 1 : 2], ra2[4][G2B ? 1 : 2], rb[4][XB ? 1 : 2];
     auto load_tiles = [&](int b, int t0) {
-        const __amdgpu_buffer_rsrc_t rG = make_rsrc(p.G + (size_t)b * M * Tg, (unsigned)M * Tg * 4u);
-        const __amdgpu_buffer_rsrc_t rG2 = make_rsrc((GM == PW_X_AFFINE2 ? p.G2 : p.G) + (size_t)b * M * Tg, (unsigned)M * Tg * 4u);
-        const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.X + (size_t)b * Kx * Tx, (unsigned)Kx * Tx * 4u);
+        const __amdgpu_buffer_rsrc_t rG = GB ? make_rsrc(reinterpret_cast<const u16*>(p.G) + (size_t)b * M * P16, (unsigned)M * P16 * 2u)
+                                             : make_rsrc(p.G + (size_t)b * M * Tg, (unsigned)M * Tg * 4u);
+        const float* g2p = GM == PW_X_AFFINE2 ? p.G2 : p.G;
+        const __amdgpu_buffer_rsrc_t rG2 = (GM == PW_X_AFFINE2 ? G2B : GB)
+                                               ? make_rsrc(reinterpret_cast<const u16*>(g2p) + (size_t)b * M * P16, (unsigned)M * P16 * 2u)
+                                               : make_rsrc(g2p + (size_t)b * M * Tg, (unsigned)M * Tg * 4u);
+        const __amdgpu_buffer_rsrc_t rX = XB ? make_rsrc(reinterpret_cast<const u16*>(p.X) + (size_t)b * Kx * P16, (unsigned)Kx * P16 * 2u)
+                                             : make_rsrc(p.X + (size_t)b * Kx * Tx, (unsigned)Kx * Tx * 4u);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if constexpr (GB) ra[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rG, voG16[i], t0 * 2, 0);
+            if constexpr (GM == PW_X_AFFINE2 && G2B) ra2[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rG2, voG16[i], t0 * 2, 0);
+            if constexpr (XB) rb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX16[i], t0 * 2, 0);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                ra[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rG, voG[i] + 16 * h, t0 * 4, 0);
-                if constexpr (GM == PW_X_AFFINE2) ra2[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rG2, voG[i] + 16 * h, t0 * 4, 0);
-                rb[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX[i] + 16 * h, t0 * 4, 0);
+                if constexpr (!GB) ra[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rG, voG[i] + 16 * h, t0 * 4, 0);
+                if constexpr (GM == PW_X_AFFINE2 && !G2B) ra2[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rG2, voG[i] + 16 * h, t0 * 4, 0);
+                if constexpr (!XB) rb[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX[i] + 16 * h, t0 * 4, 0);
             }
         }
     };
@@ -621,14 +662,20 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
             float va[8], vb[8];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const f32x4 g1 = __builtin_bit_cast(f32x4, ra[i][h]);
-                const f32x4 x1 = __builtin_bit_cast(f32x4, rb[i][h]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float gv = g1[e];
-                    if constexpr (GM == PW_X_AFFINE2) gv = fmaf(gv, ga[i], fmaf(__builtin_bit_cast(f32x4, ra2[i][h])[e], gb[i], gc[i]));
-                    else if constexpr (GM == PW_X_AFFINE_RELU6) gv = relu6f(fmaf(gv, ga[i], gb[i]));
-                    float xv = x1[e];
+                    float gv;
+                    if constexpr (GB) gv = pw_bf16_at(ra[i][0], 4 * h + e);
+                    else gv = __builtin_bit_cast(f32x4, ra[i][h])[e];
+                    if constexpr (GM == PW_X_AFFINE2) {
+                        float g2;
+                        if constexpr (G2B) g2 = pw_bf16_at(ra2[i][0], 4 * h + e);
+                        else g2 = __builtin_bit_cast(f32x4, ra2[i][h])[e];
+                        gv = fmaf(gv, ga[i], fmaf(g2, gb[i], gc[i]));
+                    } else if constexpr (GM == PW_X_AFFINE_RELU6) gv = relu6f(fmaf(gv, ga[i], gb[i]));
+                    float xv;
+                    if constexpr (XB) xv = pw_bf16_at(rb[i][0], 4 * h + e);
+                    else xv = __builtin_bit_cast(f32x4, rb[i][h])[e];
                     if constexpr (XM == PW_X_AFFINE_RELU6) xv = relu6f(fmaf(xv, xa[i], xb[i]));
                     va[4 * h + e] = gv;
                     vb[4 * h + e] = xv;
@@ -692,8 +739,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
         asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));   // accumulators stay in AGPRs
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            asm volatile("" : "+v"(ra[i][0]), "+v"(ra[i][1]), "+v"(rb[i][0]), "+v"(rb[i][1]));
-            if constexpr (GM == PW_X_AFFINE2) asm volatile("" : "+v"(ra2[i][0]), "+v"(ra2[i][1]));
+            asm volatile("" : "+v"(ra[i][0]), "+v"(rb[i][0]));
+            if constexpr (!GB) asm volatile("" : "+v"(ra[i][1]));
+            if constexpr (!XB) asm volatile("" : "+v"(rb[i][1]));
+            if constexpr (GM == PW_X_AFFINE2) {
+                asm volatile("" : "+v"(ra2[i][0]));
+                if constexpr (!G2B) asm volatile("" : "+v"(ra2[i][1]));
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (nxt < nsteps) store_tiles(cur ^ 1, (nxt % nt) * BF_BK);
@@ -807,6 +859,49 @@ void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
     else hipLaunchKernelGGL((pw_wgrad_bf16_kernel<-1, -1, false>), grid, dim3(256), 0, st, p);
 }
 
+
+// 16-bit activation storage (PwParams::io16 / WgParams::io16): the combinations the block executor issues in "act16" mode.
+// false = no instantiation for this (modes, mask) or the shape does not fit the buffer-addressed kernels.
+bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
+    const int P = pw_pitch16(p.T);
+    const bool full = (p.K & 1) == 0 && (long)(p.K + 64) * P * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL &&
+                      (long)p.B * p.M * P * 4 < 0x7fffff00L;
+    if (!full) return false;
+    const bool big = p.M >= 256;
+    PwParams pb = p;
+    pb.n_mtiles = (p.M + (big ? 255 : 127)) / (big ? 256 : 128);
+    const dim3 grid((unsigned)((long)pb.n_mtiles * p.n_ttiles * p.B));
+#define X(XM, EP, IOV)                                                                                                          \
+    if (p.x_mode == XM && p.epi_mode == EP && p.io16 == (IOV)) {                                                                \
+        if (big) hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP, 256, false, false, (IOV)>), grid, dim3(512), 0, st, pb);  \
+        else hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP, 128, false, false, (IOV)>), grid, dim3(256), 0, st, pb);      \
+        return true;                                                                                                            \
+    }
+    X(0, 1, PW_IO_Y)                      // expand forward: a1 out
+    X(1, 1, PW_IO_X)                      // project forward: a2 in (BN2 + ReLU6 on load)
+    X(0, 4, PW_IO_R)                      // project backward-data: ReLU6 mask / BN2-backward sums from a2
+    X(2, 5, PW_IO_X2) X(2, 0, PW_IO_X2)   // expand backward-data: BN1-backward affine of (dz1, a1)
+    X(0, 4, PW_IO_R | PW_IO_Y)            // ... with the hidden gradients stored as bf16 too
+    X(2, 5, PW_IO_X | PW_IO_X2) X(2, 0, PW_IO_X | PW_IO_X2)
+#undef X
+    return false;
+}
+
+bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
+    const int P = pw_pitch16(p.T);
+    if (!((long)(p.M + 128) * P * 4 < 0x7fffffffL && (long)(p.K + 128) * P * 4 < 0x7fffffffL)) return false;
+#define X(GM, XM, IOV)                                                                                                              \
+    if (p.g_mode == GM && p.x_mode == XM && p.io16 == (IOV)) {                                                                      \
+        if (p.T % BF_BK == 0) hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<GM, XM, false, false, (IOV)>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<GM, XM, true, false, (IOV)>), grid, dim3(256), 0, st, p);                \
+        return true;                                                                                                                \
+    }
+    X(2, 0, WG_IO_G2)                     // expand backward-weight: G = BN1-backward affine of (dz1, a1), X = block input
+    X(0, 1, WG_IO_X)                      // project backward-weight: X = relu6(bn2(a2))
+    X(2, 0, WG_IO_G | WG_IO_G2)           // ... with dz1 stored as bf16
+#undef X
+    return false;
+}
 
 // Tap-addressed X operand (PwParams / WgParams): plain store (+bias) or +R epilogue, no prologues.  false = the shape
 // does not fit the buffer-addressed kernels (the caller falls back to an explicit im2col copy).

@@ -49,7 +49,20 @@ struct PwParams {
     // t + shift(tap); shifts are >= 0 (the padding absorbs the negative taps), 4 bits each in `shifts`.  K = ntap * cx.
     int ntap, cx, Tx;
     unsigned shifts;
+    // 16-bit storage of the big hidden tensors (bf16 mode, "act16"): bit mask of PW_IO_* -- those tensors are bf16 [B][C][P]
+    // with the row pitch P = pw_pitch16(T) (a multiple of 8 elements, so every 4- or 8-element access is 8 / 16-byte aligned
+    // whatever T is); X / X2 / Y / R then point at bf16 data.  0 = everything fp32 (pitch T).
+    int io16;
 };
+enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8 };
+enum { WG_IO_G = 1, WG_IO_G2 = 2, WG_IO_X = 4 };
+__host__ __device__ __forceinline__ int pw_pitch16(int T) { return (T + 7) & ~7; }
+// element q of a run of bf16 values held as dwords (two per dword, low half first)
+template <class V>
+__device__ __forceinline__ float pw_bf16_at(const V& r, int q) {
+    const unsigned w = r[q >> 1];
+    return __builtin_bit_cast(float, (q & 1) ? (w & 0xffff0000u) : (w << 16));
+}
 
 __device__ __forceinline__ int pw_tap_shift(unsigned shifts, int tap) { return (int)((shifts >> (4 * tap)) & 15u); }
 
@@ -189,9 +202,12 @@ __device__ __forceinline__ float half_wave_sum_dpp(float v) {
 // Epilogue through LDS: the 128x128 fp32 accumulator tile is parked in the (now idle) 64 KB staging buffers,
 // then every half-wave streams one output row per pass as 16-byte accesses (R read, Y write: 512 B contiguous
 // per row) and reduces the row's BatchNorm partial sums with DPP.  `ct` = 128*128 floats of LDS.
-template <int EPI_, int BM>
+template <int EPI_, int BM, int IO = 0>
 __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)[2][2], float* ct, int b, int m0, int t0, int tt,
                                                 int wm, int wn, int tid) {
+    constexpr bool YB = (IO & PW_IO_Y) != 0, RB = (IO & PW_IO_R) != 0;
+    typedef unsigned int epi_u32x2 __attribute__((ext_vector_type(2)));
+    const int P16 = pw_pitch16(p.T);
     constexpr int epi = EPI_;
     const int lane = tid & 63, col = lane & 31, half = lane >> 5;
 #pragma unroll
@@ -208,7 +224,8 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
     constexpr bool use_e = (epi == PW_EPI_AFFINE_RELU6 || epi == PW_EPI_AFFINE_RES || epi == PW_EPI_MASK_STATS);
     const bool use_r = (epi == PW_EPI_MASK_STATS || epi == PW_EPI_ADD || (epi == PW_EPI_AFFINE_RES && p.R != nullptr));
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_r ? p.R : p.X), 0,
-                                                                       (int)((size_t)p.B * p.M * p.T * 4), 0x00020000);
+                                                                       (int)(RB ? (size_t)p.B * p.M * P16 * 2 : (size_t)p.B * p.M * p.T * 4),
+                                                                       0x00020000);
     const int wave = tid >> 6;
     const int t = t0 + col * 4;
     const size_t part = (size_t)b * p.n_ttiles + tt;
@@ -224,7 +241,16 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
         const float bs = p.bias ? p.bias[mv ? m : 0] : 0.f;
         const size_t o = ((size_t)b * p.M + m) * p.T + t;
         f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-        if (use_r) rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, (mv && t < p.T) ? (int)(o * 4) : 0x7ffffff0, 0, 0));
+        const size_t o16 = ((size_t)b * p.M + m) * P16 + t;        // element offset in a bf16 (pitched) tensor
+        if (use_r) {
+            if constexpr (RB) {
+                const epi_u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rR, (mv && t < p.T) ? (int)(o16 * 2) : 0x7ffffff0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[e] = pw_bf16_at(r2, e);
+            } else {
+                rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, (mv && t < p.T) ? (int)(o * 4) : 0x7ffffff0, 0, 0));
+            }
+        }
         f32x4 v;
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -248,7 +274,13 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
             v[e] = x;
         }
         if (mv && !(PW_ABLATE & 4)) {
-            if (t + 3 < p.T) *reinterpret_cast<f32x4u*>(p.Y + o) = v;
+            if constexpr (YB) {
+                // 4 bf16 = one 8-byte store; the pitch keeps it aligned, columns past T inside the pitch are padding
+                if (t < p.T) {
+                    const epi_u32x2 o2 = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                    *reinterpret_cast<epi_u32x2*>(reinterpret_cast<u16*>(p.Y) + o16) = o2;
+                }
+            } else if (t + 3 < p.T) *reinterpret_cast<f32x4u*>(p.Y + o) = v;
             else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -284,6 +316,7 @@ struct WgParams {
     // X [B][cx][Tx] shifted by shift(tap); G may itself sit in a padded buffer: row pitch Tg, first column g_off.
     int ntap, cx, Tx, Tg, g_off;
     unsigned shifts;
+    int io16;        // WG_IO_* mask: G / G2 / X are bf16 [B][rows][pw_pitch16(T)] (see PwParams::io16)
 };
 
 

@@ -37,6 +37,22 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 _PRECISION = "fp32"
+# Storage of the big hidden tensors of a training-mode block under precision "bf16" (include/voice100_hip.h, "act16"):
+# 0 = fp32 everywhere, 1 = a1 / a2 (the tensors saved for backward) as bf16, 2 = also the hidden gradients dz2 / dz1.
+# The reference under bf16 autocast keeps exactly these tensors in bf16; statistics and accumulators stay fp32 here.
+_ACT16 = int(os.environ.get("VOICE100_ACT16", "2"))
+
+
+def set_activation_storage(level: int) -> None:
+    """0: fp32 activations; 1: saved hidden activations bf16; 2: hidden gradients bf16 as well (bf16 precision only)."""
+    global _ACT16
+    if level not in (0, 1, 2):
+        raise ValueError("activation storage level must be 0, 1 or 2")
+    _ACT16 = level
+
+
+def get_activation_storage() -> int:
+    return _ACT16
 
 
 def set_matmul_precision(p: str) -> None:
@@ -153,9 +169,15 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         T2 = conv_out_len(T, k, stride)
         bf16 = _fmt(precision)
         _no_fp16_training(bf16, "InvertedResidual (training mode)")
-        shape = (ctypes.c_int * 10)(B, cin, hid, cout, T, k, int(stride), int(bool(use_residual)), int(bf16), int(prep is not None))
-        a1 = _f32(B, hid, T, like=x)
-        a2 = _f32(B, hid, T2, like=x)
+        shape = (ctypes.c_int * 11)(B, cin, hid, cout, T, k, int(stride), int(bool(use_residual)), int(bf16), int(prep is not None), 0)
+        if bf16 == 1 and _ACT16 and N.helper("v100_ir_act16_supported", shape):
+            shape[10] = _ACT16
+            pitch = (T + 7) & ~7                       # bf16 rows are padded to a multiple of 8 samples (aligned 8 / 16-byte accesses)
+            a1 = torch.empty((B, hid, pitch), dtype=torch.bfloat16, device=x.device)
+            a2 = torch.empty((B, hid, pitch), dtype=torch.bfloat16, device=x.device)
+        else:
+            a1 = _f32(B, hid, T, like=x)
+            a2 = _f32(B, hid, T2, like=x)
         a3 = _f32(B, cout, T2, like=x)
         y = _f32(B, cout, T2, like=x)
         coef = _f32(12, max(hid, cout), like=x)
@@ -208,8 +230,8 @@ def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
             raise RuntimeError("InvertedResidual: parameters must be CUDA tensors (no CPU fallback)")
         hid, cin = w1.shape[0], w1.shape[1]
         cout = w3.shape[0]
-        shape = (0, cin, hid, cout, 0, 0, 1, 0, int(bf16), 1)
-        nbytes = N.helper("v100_ir_prep_bytes", (ctypes.c_int * 10)(*shape))
+        shape = (0, cin, hid, cout, 0, 0, 1, 0, int(bf16), 1, 0)
+        nbytes = N.helper("v100_ir_prep_bytes", (ctypes.c_int * 11)(*shape))
         todo.append((blk, shape, w1, w3, total, nbytes))
         total += (nbytes + 255) // 256 * 256
     if not todo:
@@ -218,7 +240,7 @@ def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
     bufs = [pool[off:off + nbytes] for _, _, _, _, off, nbytes in todo]
     for i in range(0, len(todo), 32):
         chunk = todo[i:i + 32]
-        shapes = (ctypes.c_int * (10 * len(chunk)))(*[v for c in chunk for v in c[1]])
+        shapes = (ctypes.c_int * (11 * len(chunk)))(*[v for c in chunk for v in c[1]])
         N.call("v100_ir_prep_batched", shapes, _ptr_table([c[2] for c in chunk]), _ptr_table([c[3] for c in chunk]),
                _ptr_table(bufs[i:i + 32]), len(chunk))
     for (blk, _, _, _, _, _), buf in zip(todo, bufs):
@@ -249,7 +271,7 @@ def inverted_residual_eval_cached(blk, x, precision: Optional[str] = None):
     B, cin, T = x.shape
     hid, cout, k = w1.shape[0], w3.shape[0], int(blk.kernel_size)
     T2 = conv_out_len(T, k, blk.stride)
-    shape = (ctypes.c_int * 10)(B, cin, hid, cout, T, k, int(blk.stride), int(bool(blk.use_residual)), int(bf16), 0)
+    shape = (ctypes.c_int * 11)(B, cin, hid, cout, T, k, int(blk.stride), int(bool(blk.use_residual)), int(bf16), 0, 0)
     params = (w1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
               w3, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var)
     key = (bf16,) + tuple((t.data_ptr(), t._version) for t in params) + (wd.data_ptr(), wd._version)
