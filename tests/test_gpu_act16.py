@@ -125,8 +125,16 @@ def test_wgrad_io_variants(cuda, B, M, K, T):
     assert rel_err(run("v100_pw_wgrad_io", gm, None, 0, x16, 1, WX), run("v100_pw_wgrad", gm, None, 0, xr, 1)) < 1e-6
 
 
-@pytest.mark.parametrize("B,C,T,K", [(2, 8, 48, 19), (3, 6, 133, 83), (2, 4, 700, 51), (5, 12, 512, 5), (2, 4, 1100, 35)])
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("B,C,T,K", [(2, 8, 48, 19), (3, 6, 133, 83), (2, 4, 700, 51), (5, 12, 512, 5), (2, 4, 1100, 35), (2, 3, 260, 27)])
 def test_dwconv_io_variants(cuda, B, C, T, K):
+    """Depthwise kernels with 16-bit storage.  In this mode the conv's data operand is a bf16 tensor by definition (as under
+    autocast): the transformed input relu6(bn1(a1)) -- and in backward the BN2-backward affine g' and xin -- are rounded once
+    to bf16, taps and accumulation stay fp32.  Reference: torch on exactly those rounded operands (fp32 accumulate)."""
+    import torch.nn.functional as F
     N = _native()
     g = torch.Generator().manual_seed(C * 7 + T + K)
     pad = (K - 1) // 2
@@ -135,42 +143,39 @@ def test_dwconv_io_variants(cuda, B, C, T, K):
     w = (torch.randn(C, K, generator=g) * 0.2).to(cuda)
     s1, t1 = torch.rand(C, generator=g).to(cuda) + 0.5, torch.randn(C, generator=g).to(cuda)
     G = N.helper("v100_dw_num_groups", B, C)
-    # forward: bf16 in, bf16 out
-    y0 = torch.empty(B, C, T, device=cuda)
-    st0 = torch.zeros(G, C, 2, device=cuda)
-    N.call("v100_dwconv", a1r, None, w, s1, t1, None, 1, y0, None, None, None, 0, st0, G, B, C, T, T, K, 1, pad, 0, 1, 0)
+    pre = a1r * s1[None, :, None] + t1[None, :, None]
+    xin = _bf(torch.clamp(pre, 0, 6))
+    # forward: bf16 in, bf16 out, BN2 partial sums from the fp32 accumulators
+    ref = F.conv1d(xin, w[:, None, :], padding=pad, groups=C)
     y1 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
     st1 = torch.zeros(G, C, 2, device=cuda)
     N.call("v100_dwconv_fwd_train_io", a116, w, s1, t1, y1, st1, G, B, C, T, K, DX | DY)
-    assert torch.equal(from16(y1, T), y0.to(torch.bfloat16).to(torch.float32))
-    assert rel_err(st1, st0) < 1e-6
+    assert rel_err(from16(y1, T), ref) < 6e-3                     # one bf16 rounding of the stored output
+    assert float((from16(y1, T) - _bf(ref)).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())    # ... and nothing more
+    assert rel_err(st1.sum(0)[:, 0], ref.sum((0, 2))) < 1e-5 and rel_err(st1.sum(0)[:, 1], (ref * ref).sum((0, 2))) < 1e-5
     # fused backward: dz2 fp32 | bf16, a2 bf16, a1 bf16 -> dz1 fp32 | bf16, BN1-backward sums, dW
     dz2 = torch.randn(B, C, T, generator=g).to(cuda)
     dz216, dz2r = to16(dz2)
     a2 = torch.randn(B, C, T, generator=g).to(cuda)
     a216, a2r = to16(a2)
     ga, gb, gc = torch.rand(C, generator=g).to(cuda) + 0.5, (torch.randn(C, generator=g) * 0.3).to(cuda), (torch.randn(C, generator=g) * 0.1).to(cuda)
-
-    def ref(dzin):
-        dz1 = torch.empty(B, C, T, device=cuda)
-        st = torch.zeros(G, C, 2, device=cuda)
-        part = torch.empty(G, C, K, device=cuda)
-        dw = torch.empty(C, K, device=cuda)
-        N.call("v100_dwconv_bwd", dzin, a2r, w, ga, gb, gc, a1r, s1, t1, dz1, st, part, dw, G, B, C, T, T, K, 1, pad, 0)
-        return dz1, st, dw
-
     for mask, dzin16, dzref in ((DX2 | DAUX, dz2, dz2), (DX | DX2 | DAUX | DY, dz216, dz2r)):
-        dz1r, str_, dwr = ref(dzref)
+        gp = _bf(ga[None, :, None] * dzref + gb[None, :, None] * a2r + gc[None, :, None])
+        xv, wv = xin.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        (F.conv1d(xv, wv[:, None, :], padding=pad, groups=C) * gp).sum().backward()
+        dz1r = xv.grad * ((pre > 0) & (pre < 6))
+        s0r, s1r = dz1r.sum((0, 2)), (dz1r * a1r).sum((0, 2))
         dz1 = (torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda) if mask & DY else torch.empty(B, C, T, device=cuda))
         st = torch.zeros(G, C, 2, device=cuda)
         part = torch.empty(G, C, K, device=cuda)
         dw = torch.empty(C, K, device=cuda)
         N.call("v100_dwconv_bwd_io", dzin16, a216, w, ga, gb, gc, a116, s1, t1, dz1, st, part, dw, G, B, C, T, K, mask)
         if mask & DY:
-            assert torch.equal(from16(dz1, T), dz1r.to(torch.bfloat16).to(torch.float32))
+            assert rel_err(from16(dz1, T), dz1r) < 6e-3
         else:
-            assert rel_err(dz1, dz1r) < 1e-6
-        assert rel_err(st, str_) < 1e-5 and rel_err(dw, dwr) < 1e-5
+            assert rel_err(dz1, dz1r) < 1e-5
+        assert rel_err(st.sum(0)[:, 0], s0r) < 1e-4 and rel_err(st.sum(0)[:, 1], s1r) < 1e-4
+        assert rel_err(dw, wv.grad) < 5e-4      # fp32 summation order over B*T terms of size O(10)
 
 
 @pytest.mark.parametrize("level", [1, 2])

@@ -45,19 +45,19 @@ __device__ __forceinline__ dwm_bf16x8 dwm_tr_fragment(const unsigned short* tile
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// acc += sum over the digit pairs (i, j) with i + j <= NT - 1 (0-based) of a[i] x b[j], smallest terms first
-template <int NT>
-__device__ __forceinline__ dwm_f32x4 dwm_mfma_digits(const dwm_bf16x8 (&a)[NT], const dwm_bf16x8 (&b)[NT], dwm_f32x4 acc) {
-    if constexpr (NT >= 3) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
-    }
-    if constexpr (NT >= 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
-    }
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+// acc += sum over the digit pairs (i, j), i < NA, j < NB, i + j <= max(NA, NB) - 1, of a[i] x b[j], smallest terms first
+// (3 x 3 digits: six products, fp32-exact; 3 x 1: three products, exact for a bf16-valued b)
+template <int NA, int NB>
+__device__ __forceinline__ dwm_f32x4 dwm_mfma_digits(const dwm_bf16x8 (&a)[NA], const dwm_bf16x8 (&b)[NB], dwm_f32x4 acc) {
+    constexpr int LIM = (NA > NB ? NA : NB) - 1;
+#pragma unroll
+    for (int s = LIM; s >= 0; --s)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int j = s - i;
+            if (j >= 0 && j < NB) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc, 0, 0, 0);
+        }
+    return acc;
 }
 
 template <int K>
@@ -114,6 +114,9 @@ __device__ __forceinline__ typename DwmRun<B16>::type dwm_load_run(__amdgpu_buff
 template <int K, int IM, int OM, int NT, bool WG = false, int IO = 0>
 __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p) {
     constexpr bool XB = (IO & DW_IO_X) != 0, X2B = (IO & DW_IO_X2) != 0, AUXB = (IO & DW_IO_AUX) != 0, YB = (IO & DW_IO_Y) != 0;
+    // digits of the DATA operand (the staged images): with 16-bit activation storage the conv input is a bf16 tensor by
+    // definition (as under autocast), so the transformed sample is rounded once (RNE) to ONE digit; the taps keep NT digits
+    constexpr int NX = IO != 0 ? 1 : NT;
     using G_ = DwMfmaGeom<K>;
     constexpr int SUBS = G_::SUBS, TILE = G_::TILE, STEPS = G_::STEPS, NV = G_::NV, IMGP = G_::IMGP, WPAD = G_::WPAD, WLEN = G_::WLEN;
     constexpr int IB = G_::IB;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
 
     // per wave: NT digit images of the staged span (+ NT digit images of xin over the tile when WG); the E tiles of the
     // fused backward-weight are spilled over the same bytes at the very end
-    constexpr int WAVE_U16 = NT * IMGP + (WG ? NT * TILE : 0);
+    constexpr int WAVE_U16 = NX * IMGP + (WG ? NX * TILE : 0);
     constexpr int E_FLOATS = WG ? 16 * IB * 16 : 0;
     constexpr int LDS_BYTES = (4 * WAVE_U16 * 2 > 4 * E_FLOATS * 4) ? 4 * WAVE_U16 * 2 : 4 * E_FLOATS * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
                                                      OM == DW_OUT_MASK_STATS ? (unsigned)((size_t)p.B * p.C * PoutA * (AUXB ? 2 : 4)) : 0u);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     unsigned short* img = reinterpret_cast<unsigned short*>(lds_raw) + wave_u * WAVE_U16;
-    unsigned short* ximg = img + NT * IMGP;                  // WG only
+    unsigned short* ximg = img + NX * IMGP;                  // WG only
     const unsigned short* bsrc = img + 16 * n_ + 8 * q_;
     dwm_f32x4 eacc[WG ? IB : 1];
 #pragma unroll
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
             for (int v = 0; v < NV; ++v) {
                 const int ia = in0a + 4 * (lane + 64 * v);
                 unsigned dg[4][3];
+                float vals[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float val;
@@ -243,12 +247,18 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
                     // zero padding applies to the TRANSFORMED tensor; a float4 that straddles the row end (Tin % 4 != 0) holds the
                     // next row's first samples, so the plain copy needs the mask too (ia is a multiple of 4: ia >= 0 covers e)
                     val = (ia >= 0 && ia + e < Tin) ? val : 0.f;
-                    dwm_split(val, dg[e]);
+                    vals[e] = val;
+                    if constexpr (NX > 1) dwm_split(val, dg[e]);
                 }
+                if constexpr (NX == 1) {
+                    const dwm_u32x2 w2 = {dwm_pack_rne(vals[0], vals[1]), dwm_pack_rne(vals[2], vals[3])};
+                    *reinterpret_cast<dwm_u32x2*>(img + 4 * (lane + 64 * v)) = w2;
+                } else {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const dwm_u32x2 w2 = {dwm_pack(dg[0][t], dg[1][t]), dwm_pack(dg[2][t], dg[3][t])};
-                    *reinterpret_cast<dwm_u32x2*>(img + t * IMGP + 4 * (lane + 64 * v)) = w2;
+                    for (int t = 0; t < NX; ++t) {
+                        const dwm_u32x2 w2 = {dwm_pack(dg[0][t], dg[1][t]), dwm_pack(dg[2][t], dg[3][t])};
+                        *reinterpret_cast<dwm_u32x2*>(img + t * IMGP + 4 * (lane + 64 * v)) = w2;
+                    }
                 }
             }
             if constexpr (WG) {
@@ -257,12 +267,21 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
                 for (int sub = 0; sub < SUBS; ++sub) {
                     const int t0 = out0 + 256 * sub + 16 * n_ + 4 * q_;
                     unsigned dg[4][3];
+                    float xv[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dwm_split((t0 + r < Tout) ? relu6f(fmaf(auxv[sub][r], oa, ob)) : 0.f, dg[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        xv[r] = (t0 + r < Tout) ? relu6f(fmaf(auxv[sub][r], oa, ob)) : 0.f;
+                        if constexpr (NX > 1) dwm_split(xv[r], dg[r]);
+                    }
+                    if constexpr (NX == 1) {
+                        const dwm_u32x2 w2 = {dwm_pack_rne(xv[0], xv[1]), dwm_pack_rne(xv[2], xv[3])};
+                        *reinterpret_cast<dwm_u32x2*>(ximg + 256 * sub + 16 * n_ + 4 * q_) = w2;
+                    } else {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const dwm_u32x2 w2 = {dwm_pack(dg[0][t], dg[1][t]), dwm_pack(dg[2][t], dg[3][t])};
-                        *reinterpret_cast<dwm_u32x2*>(ximg + t * TILE + 256 * sub + 16 * n_ + 4 * q_) = w2;
+                        for (int t = 0; t < NX; ++t) {
+                            const dwm_u32x2 w2 = {dwm_pack(dg[0][t], dg[1][t]), dwm_pack(dg[2][t], dg[3][t])};
+                            *reinterpret_cast<dwm_u32x2*>(ximg + t * TILE + 256 * sub + 16 * n_ + 4 * q_) = w2;
+                        }
                     }
                 }
             }
@@ -282,15 +301,15 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
 
             if constexpr (WG) {
                 // E[16*ib + m][r] += sum_p g'img[16*(p + ib) + m] * ximg[16*p + r]: one contraction step = the whole tile
-                dwm_bf16x8 xfr[NT];
+                dwm_bf16x8 xfr[NX];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) xfr[t] = dwm_tr_fragment(ximg + t * TILE, lane);
+                for (int t = 0; t < NX; ++t) xfr[t] = dwm_tr_fragment(ximg + t * TILE, lane);
 #pragma unroll
                 for (int ib = 0; ib < IB; ++ib) {
-                    dwm_bf16x8 gfr[NT];
+                    dwm_bf16x8 gfr[NX];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) gfr[t] = dwm_tr_fragment(img + t * IMGP + 16 * ib, lane);
-                    eacc[ib] = dwm_mfma_digits<NT>(gfr, xfr, eacc[ib]);
+                    for (int t = 0; t < NX; ++t) gfr[t] = dwm_tr_fragment(img + t * IMGP + 16 * ib, lane);
+                    eacc[ib] = dwm_mfma_digits<NX, NX>(gfr, xfr, eacc[ib]);
                 }
             }
 
@@ -302,11 +321,11 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
                 dwm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < STEPS; ++s) {
-                    dwm_bf16x8 bfr[NT];
+                    dwm_bf16x8 bfr[NX];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
+                    for (int t = 0; t < NX; ++t)
                         bfr[t] = *reinterpret_cast<const dwm_bf16x8*>(bsrc + t * IMGP + 256 * sub + 32 * s);
-                    acc = dwm_mfma_digits<NT>(afr[s], bfr, acc);
+                    acc = dwm_mfma_digits<NT, NX>(afr[s], bfr, acc);
                 }
                 // ---- epilogue: 4 consecutive outputs per lane ----
                 float outv[4];
