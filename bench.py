@@ -199,6 +199,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--diag-no-timestretch", action="store_true", help="diagnostic only (NOT the benchmark workload): never draw a time-stretch")
     args = ap.parse_args()
 
     from voice100_amd.trainer import TrainStep, init_distributed, launch_ranks
@@ -237,6 +238,8 @@ def main():
     torch.manual_seed(1234)
     model = AudioToTextCTC(N_MEL, 512, VOCAB, 512, learning_rate=1e-3, weight_decay=4e-5).to(device)
     step = TrainStep(model)
+    if args.diag_no_timestretch:
+        model.batch_augment.do_timestretch = False
     batch = synth_batch(device, B_PER_GPU, 1234 + rank)
 
     def sync():
@@ -315,7 +318,7 @@ def main():
                     "algorithmic_bytes_per_launch": round(nbytes / n), "algorithmic_bytes_nominal_step": dw_bytes,
                     "measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
         out = {
-            "metric": "audio frames/sec (fwd+bwd) asr_en_base, B=32x1024-frame mel",
+            "metric": "audio frames/sec (fwd+bwd) asr_en_base, B=32x1024-frame mel" + (" [DIAGNOSTIC: time-stretch off]" if args.diag_no_timestretch else ""),
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "world_size": world,
