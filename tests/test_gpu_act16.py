@@ -152,7 +152,8 @@ def test_dwconv_io_variants(cuda, B, C, T, K):
     N.call("v100_dwconv_fwd_train_io", a116, w, s1, t1, y1, st1, G, B, C, T, K, DX | DY)
     assert rel_err(from16(y1, T), ref) < 6e-3                     # one bf16 rounding of the stored output
     assert float((from16(y1, T) - _bf(ref)).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())    # ... and nothing more
-    assert rel_err(st1.sum(0)[:, 0], ref.sum((0, 2))) < 1e-5 and rel_err(st1.sum(0)[:, 1], (ref * ref).sum((0, 2))) < 1e-5
+    # (taps carry two bf16 digits in this mode: 2^-16 relative)
+    assert rel_err(st1.sum(0)[:, 0], ref.sum((0, 2))) < 5e-5 and rel_err(st1.sum(0)[:, 1], (ref * ref).sum((0, 2))) < 5e-5
     # fused backward: dz2 fp32 | bf16, a2 bf16, a1 bf16 -> dz1 fp32 | bf16, BN1-backward sums, dW
     dz2 = torch.randn(B, C, T, generator=g).to(cuda)
     dz216, dz2r = to16(dz2)
@@ -173,7 +174,7 @@ def test_dwconv_io_variants(cuda, B, C, T, K):
         if mask & DY:
             assert rel_err(from16(dz1, T), dz1r) < 6e-3
         else:
-            assert rel_err(dz1, dz1r) < 1e-5
+            assert rel_err(dz1, dz1r) < 5e-5
         assert rel_err(st.sum(0)[:, 0], s0r) < 1e-4 and rel_err(st.sum(0)[:, 1], s1r) < 1e-4
         assert rel_err(dw, wv.grad) < 5e-4      # fp32 summation order over B*T terms of size O(10)
 

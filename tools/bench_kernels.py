@@ -39,12 +39,12 @@ def main():
         N.LIB_PATH = os.path.abspath(args.lib)
     dev = torch.device("cuda:0")
     B, T = args.B, args.T
-    tot = {"dw_fwd": [0, 0.0], "dw_bwd": [0, 0.0], "dw_wgrad": [0, 0.0], "dw_bwd_fused": [0, 0.0]}
+    tot = {"dw_fwd": [0, 0.0], "dw_bwd": [0, 0.0], "dw_wgrad": [0, 0.0], "dw_bwd_fused": [0, 0.0], "dw16_fwd": [0, 0.0], "dw16_bwd_fused": [0, 0.0]}
     t = T
     for (cin, hid, cout, k, s) in SPECS:
         tout = (t - 1) // s + 1
         pad = (k - 1) // 2
-        if "dw" in args.what:
+        if "dw" in args.what.split(","):
             x = torch.randn(B, hid, t, device=dev)
             w = torch.randn(hid, k, device=dev) * 0.1
             a, b, c = (torch.randn(hid, device=dev) for _ in range(3))
@@ -67,7 +67,27 @@ def main():
                 tot[name][0] += nb; tot[name][1] += dt
                 fl = 2 * B * hid * k * tout
                 print(f"{name:12s} C={hid:5d} k={k:3d} s={s} T={t:5d}: {dt*1e6:8.1f} us  {nb/dt/1e9:7.0f} GB/s ({nb/dt/8e12*100:5.1f}% of 8TB/s)  {fl/dt/1e12:6.1f} TFLOP/s")
-        if "pw" in args.what:
+        if "dw16" in args.what.split(",") and s == 1:
+            # bf16 storage of the hidden tensors (act16): same layers, bf16 [B, C, pitch] in / out
+            P = (t + 7) & ~7
+            x16 = torch.randn(B, hid, P, device=dev).to(torch.bfloat16)
+            y16 = torch.empty(B, hid, P, device=dev, dtype=torch.bfloat16)
+            g16 = torch.randn(B, hid, P, device=dev).to(torch.bfloat16)
+            a216 = torch.randn(B, hid, P, device=dev).to(torch.bfloat16)
+            dz116 = torch.empty(B, hid, P, device=dev, dtype=torch.bfloat16)
+            w = torch.randn(hid, k, device=dev) * 0.1
+            a, b, c = (torch.randn(hid, device=dev) for _ in range(3))
+            G = N.helper("v100_dw_num_groups", B, hid)
+            st = torch.empty(G, hid, 2, device=dev)
+            part = torch.empty(G, hid, k, device=dev)
+            dw = torch.empty(hid, k, device=dev)
+            f16 = lambda: N.call("v100_dwconv_fwd_train_io", x16, w, a, b, y16, st, G, B, hid, t, k, 9)
+            b16 = lambda: N.call("v100_dwconv_bwd_io", g16, a216, w, a, b, c, x16, a, b, dz116, st, part, dw, G, B, hid, t, k, 15)
+            for name, fn, nb in (("dw16_fwd", f16, 2 * B * hid * 2 * t), ("dw16_bwd_fused", b16, 2 * B * hid * 4 * t)):
+                dt = timeit(fn, args.iters)
+                tot[name][0] += nb; tot[name][1] += dt
+                print(f"{name:14s} C={hid:5d} k={k:3d} T={t:5d}: {dt*1e6:8.1f} us  {nb/dt/1e9:7.0f} GB/s ({nb/dt/8e12*100:5.1f}% of 8TB/s)")
+        if "pw" in args.what.split(","):
             for bf in (0, 1):
                 for (M, K, TT, tag) in ((hid, cin, t, "pw1"), (cout, hid, tout, "pw2")):
                     X = torch.randn(B, K, TT, device=dev)

@@ -363,14 +363,17 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
 // Which stride-1 path runs: the Toeplitz-MFMA kernel (default) or the register-window VALU kernel (V100_DW_PATH=valu, kept
 // for A/B measurements and as the path for shapes the MFMA kernel does not cover); V100_DW_DIGITS = 2 | 3 bf16 digits per
 // fp32 operand (default 3: fp32-exact products).  Read once.
-struct DwPathConfig { bool mfma; int digits; };
+// With 16-bit activation storage the taps default to TWO digits (16 mantissa bits against data rounded to 8): V100_DW_DIGITS=3
+// restores the third.
+struct DwPathConfig { bool mfma; int digits; bool digits3; };
 static inline DwPathConfig dw_path_config() {
     static const DwPathConfig cfg = [] {
-        DwPathConfig c{true, 3};
+        DwPathConfig c{true, 3, false};
         const char* e = getenv("V100_DW_PATH");
         if (e && e[0] == 'v') c.mfma = false;
         const char* d = getenv("V100_DW_DIGITS");
         if (d && d[0] == '2') c.digits = 2;
+        if (d && d[0] == '3') c.digits3 = true;
         return c;
     }();
     return cfg;
@@ -392,7 +395,7 @@ static bool dw_launch_specialised(const DwParams& p, hipStream_t st, const V100T
         if ((cfg.mfma || IO != 0) && p.stride == 1 && p.upsample == 1) {
 #define X(KK)                                                                                                           \
     if (p.K == KK) {                                                                                                    \
-        if (cfg.digits == 2 && IO == 0) V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 2, WG, IO>), grid, dim3(256), 0, st, p); \
+        if (cfg.digits == 2 || (IO != 0 && !cfg.digits3)) V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 2, WG, IO>), grid, dim3(256), 0, st, p); \
         else V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 3, WG, IO>), grid, dim3(256), 0, st, p);                  \
         return true;                                                                                                    \
     }

@@ -60,17 +60,20 @@ __device__ __forceinline__ dwm_f32x4 dwm_mfma_digits(const dwm_bf16x8 (&a)[NA], 
     return acc;
 }
 
-template <int K>
+// OFFMAX = 3: image element 0 sits at a position that is a multiple of 4 (4-sample loads); 7: a multiple of 8 (8-sample, 16-byte
+// loads of bf16 rows).  off = (-pad) & OFFMAX is folded into the Toeplitz block, which therefore spans K + 15 + OFFMAX columns.
+template <int K, int OFFMAX = 3>
 struct DwMfmaGeom {
     static constexpr int SUBS = 2;
     static constexpr int TILE = 256 * SUBS;                       // outputs per wave item
-    static constexpr int STEPS = (K + 15 + 3 + 31) / 32;          // contraction steps of 32 (off <= 3)
+    static constexpr int STEPS = (K + 15 + OFFMAX + 31) / 32;     // contraction steps of 32
     static constexpr int IMG = 256 * (SUBS - 1) + 240 + 32 * STEPS;   // image elements the B reads touch
-    static constexpr int NV = (IMG + 255) / 256;                  // float4 loads per lane
-    static constexpr int IMGP = NV * 256;                         // image elements written (all finite: zero or real samples)
-    static constexpr int WPAD = 18;                               // zero taps in front of w[0] (m + off <= 18)
+    static constexpr int NV = (IMG + 255) / 256;                  // 4-sample loads per lane
+    static constexpr int NV8 = (IMG + 511) / 512;                 // 8-sample loads per lane (all inputs bf16)
+    static constexpr int IMGP = NV * 256 > NV8 * 512 ? NV * 256 : NV8 * 512;   // image elements written (all finite: zero or real samples)
+    static constexpr int WPAD = 15 + OFFMAX;                      // zero taps in front of w[0] (m + off <= WPAD)
     static constexpr int WLEN = WPAD + 32 * STEPS;
-    static constexpr int IB = (K + 15 + 3 + 15) / 16;             // 16-row blocks of E (fused backward-weight)
+    static constexpr int IB = (K + 15 + OFFMAX + 15) / 16;        // 16-row blocks of E (fused backward-weight)
 };
 
 // bf16 digit t of an fp32 value by truncation: v = d0 + d1 + d2 exactly (24 mantissa bits), each digit's low 16 bits zero
@@ -100,6 +103,13 @@ __device__ __forceinline__ float dwm_elem(const dwm_u32x2& r, int e) {
     const unsigned w = r[e >> 1];
     return __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
 }
+__device__ __forceinline__ float dwm_elem8(const dwm_u32x4& r, int e) {      // 8 bf16 in four dwords
+    const unsigned w = r[e >> 1];
+    return __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+__device__ __forceinline__ dwm_u32x4 dwm_load_run8(__amdgpu_buffer_rsrc_t r, int voff_elems, unsigned row_elems) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff_elems < 0x20000000 ? voff_elems * 2 : 0x7ffffff0, (int)(row_elems * 2u), 0);
+}
 template <bool B16>
 struct DwmRun { typedef f32x4 type; };
 template <>
@@ -114,10 +124,13 @@ __device__ __forceinline__ typename DwmRun<B16>::type dwm_load_run(__amdgpu_buff
 template <int K, int IM, int OM, int NT, bool WG = false, int IO = 0>
 __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p) {
     constexpr bool XB = (IO & DW_IO_X) != 0, X2B = (IO & DW_IO_X2) != 0, AUXB = (IO & DW_IO_AUX) != 0, YB = (IO & DW_IO_Y) != 0;
+    // every input stream bf16: a lane stages 8 consecutive samples per load (16-byte loads, 16-byte LDS stores)
+    constexpr bool W8 = XB && (IM != DW_IN_AFFINE2 || X2B);
+    constexpr int OFFMAX = W8 ? 7 : 3;
     // digits of the DATA operand (the staged images): with 16-bit activation storage the conv input is a bf16 tensor by
     // definition (as under autocast), so the transformed sample is rounded once (RNE) to ONE digit; the taps keep NT digits
     constexpr int NX = IO != 0 ? 1 : NT;
-    using G_ = DwMfmaGeom<K>;
+    using G_ = DwMfmaGeom<K, OFFMAX>;
     constexpr int SUBS = G_::SUBS, TILE = G_::TILE, STEPS = G_::STEPS, NV = G_::NV, IMGP = G_::IMGP, WPAD = G_::WPAD, WLEN = G_::WLEN;
     constexpr int IB = G_::IB;
     constexpr bool TWO = IM == DW_IN_AFFINE2;
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
     __syncthreads();
 
     // A fragments: lane (m = n_, q_) holds A[m][32*s + 8*q + jj] = w[32*s + 8*q + jj - m - off], jj = 0..7, as NT digit packs
-    const int off = (-p.pad) & 3;
+    const int off = (-p.pad) & OFFMAX;
     dwm_bf16x8 afr[STEPS][NT];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
@@ -182,8 +195,10 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
     // row pitches (elements): bf16-stored tensors are padded to a multiple of 8 samples per row
     const int PinX = XB ? dw_pitch16(Tin) : Tin, PinX2 = X2B ? dw_pitch16(Tin) : Tin;
     const int PoutA = AUXB ? dw_pitch16(Tout) : Tout, PoutY = YB ? dw_pitch16(Tout) : Tout;
-    typename DwmRun<XB>::type rawx[NV];
-    typename DwmRun<X2B>::type rawx2[TWO ? NV : 1];
+    constexpr int NV8 = G_::NV8;
+    typename DwmRun<XB>::type rawx[W8 ? 1 : NV];
+    typename DwmRun<X2B>::type rawx2[(TWO && !W8) ? NV : 1];
+    dwm_u32x4 raw8[W8 ? NV8 : 1], raw8b[(W8 && TWO) ? NV8 : 1];
     const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, (unsigned)((size_t)p.B * p.C * PinX * (XB ? 2 : 4)));
     const __amdgpu_buffer_rsrc_t rx2 = TWO ? dw_make_rsrc(p.x2, (unsigned)((size_t)p.B * p.C * PinX2 * (X2B ? 2 : 4))) : rx;
     const __amdgpu_buffer_rsrc_t raux = dw_make_rsrc(OM == DW_OUT_MASK_STATS ? p.aux : p.x,
@@ -198,24 +213,31 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
 
     for (int tile = 0; tile < ntiles; ++tile) {
         const int out0 = tile * TILE;
-        const int in0a = (out0 - p.pad) & ~3;                 // input position of image element 0 (multiple of 4)
+        const int in0a = (out0 - p.pad) & ~OFFMAX;            // input position of image element 0 (multiple of 4, or of 8)
         // per-lane load positions of this tile (row-invariant)
-        int vo[NV];
+        constexpr int EPL = W8 ? 8 : 4, NVL = W8 ? NV8 : NV;
+        int vo[NVL];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int ia = in0a + 4 * (lane + 64 * v);
-            const bool ok = ia >= 0 && ia < Tin && 4 * (lane + 64 * v) < G_::IMG;
+        for (int v = 0; v < NVL; ++v) {
+            const int ia = in0a + EPL * (lane + 64 * v);
+            // in0a is a multiple of EPL: a run lies wholly before the row or starts inside it
+            const bool ok = ia >= 0 && ia < Tin && EPL * (lane + 64 * v) < G_::IMG;
             vo[v] = ok ? ia : 0x7ffffff0;                      // element offset inside the row
         }
-        int bi = wave_u;
-        if (bi < nb) {
-            const unsigned row = (unsigned)((b0 + bi) * p.C + c);
+        auto issue_loads = [&](unsigned row) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                rawx[v] = dwm_load_run<XB>(rx, vo[v], row * (unsigned)PinX);
-                if constexpr (TWO) rawx2[v] = dwm_load_run<X2B>(rx2, vo[v], row * (unsigned)PinX2);
+            for (int v = 0; v < NVL; ++v) {
+                if constexpr (W8) {
+                    raw8[v] = dwm_load_run8(rx, vo[v], row * (unsigned)PinX);
+                    if constexpr (TWO) raw8b[v] = dwm_load_run8(rx2, vo[v], row * (unsigned)PinX2);
+                } else {
+                    rawx[v] = dwm_load_run<XB>(rx, vo[v], row * (unsigned)PinX);
+                    if constexpr (TWO) rawx2[v] = dwm_load_run<X2B>(rx2, vo[v], row * (unsigned)PinX2);
+                }
             }
-        }
+        };
+        int bi = wave_u;
+        if (bi < nb) issue_loads((unsigned)((b0 + bi) * p.C + c));
         for (; bi < nb; bi += 4) {
             const int b = b0 + bi;
             float auxv[SUBS][4];
@@ -232,7 +254,25 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
                     }
                 }
             }
-            // ---- stage: transform, zero outside the row, split into bf16 digits, 8-byte LDS stores ----
+            // ---- stage: transform, zero outside the row, split into bf16 digits, 8- / 16-byte LDS stores ----
+            if constexpr (W8) {
+#pragma unroll
+                for (int v = 0; v < NV8; ++v) {
+                    const int ia = in0a + 8 * (lane + 64 * v);
+                    float vals[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float val;
+                        if constexpr (IM == DW_IN_AFFINE_RELU6) val = relu6f(fmaf(dwm_elem8(raw8[v], e), ca, cb));
+                        else if constexpr (IM == DW_IN_AFFINE2) val = fmaf(dwm_elem8(raw8[v], e), ca, fmaf(dwm_elem8(raw8b[v], e), cb, cc));
+                        else val = dwm_elem8(raw8[v], e);
+                        vals[e] = (ia + e >= 0 && ia + e < Tin) ? val : 0.f;
+                    }
+                    const dwm_u32x4 w4 = {dwm_pack_rne(vals[0], vals[1]), dwm_pack_rne(vals[2], vals[3]), dwm_pack_rne(vals[4], vals[5]),
+                                          dwm_pack_rne(vals[6], vals[7])};
+                    *reinterpret_cast<dwm_u32x4*>(img + 8 * (lane + 64 * v)) = w4;
+                }
+            } else {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int ia = in0a + 4 * (lane + 64 * v);
@@ -260,6 +300,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
                         *reinterpret_cast<dwm_u32x2*>(img + t * IMGP + 4 * (lane + 64 * v)) = w2;
                     }
                 }
+            }
             }
             if constexpr (WG) {
                 // xin = relu6(bn1(a1)) at this lane's 2 x 4 output positions -> digit images of the tile
@@ -290,14 +331,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
             asm volatile("" ::: "memory");
 
             // prefetch the next row of this tile while this one computes
-            if (bi + 4 < nb) {
-                const unsigned row = (unsigned)((b + 4) * p.C + c);
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    rawx[v] = dwm_load_run<XB>(rx, vo[v], row * (unsigned)PinX);
-                    if constexpr (TWO) rawx2[v] = dwm_load_run<X2B>(rx2, vo[v], row * (unsigned)PinX2);
-                }
-            }
+            if (bi + 4 < nb) issue_loads((unsigned)((b + 4) * p.C + c));
 
             if constexpr (WG) {
                 // E[16*ib + m][r] += sum_p g'img[16*(p + ib) + m] * ximg[16*p + r]: one contraction step = the whole tile
