@@ -112,6 +112,11 @@ int v100_chan_affine2(const float* u, const float* v, const float* A, const floa
                       int B, int C, int T, void* stream);
 /* out = u*m*s  (nn.Dropout(0.2) with a pre-drawn keep mask, asr.py:90) */
 int v100_mul_scale(const float* u, const float* m, float s, float* out, long long n, void* stream);
+/* nn.Dropout(p), training mode (asr.py:90), one pass: element i is kept when a 32-bit uniform mixed from (seed, i) is >= p * 2^32;
+ * y = keep ? x / (1 - p) : 0, mask[i] = keep (one byte per element, for v100_dropout_bwd: dx = mask ? dy / (1 - p) : 0).
+ * Tensor storage must be 16-byte aligned (float4 path); n elements. */
+int v100_dropout_fwd(const float* x, long long seed, float p, float* y, void* mask, long long n, void* stream);
+int v100_dropout_bwd(const float* dy, const void* mask, float p, float* dx, long long n, void* stream);
 /* [B][R][Cc] -> [B][Cc][R]  (torch.transpose(x,1,2) at the model edges, asr.py:111,114; tts.py:177,179) */
 int v100_transpose_last2(const float* in, float* out, int B, int R, int Cc, void* stream);
 /* out[b][c][t] = table[idx[b][t]][c]  (nn.Embedding + transpose, tts.py:81-83,176-177) and its backward */
@@ -235,6 +240,16 @@ int v100_dwconv_bwd_io(const void* g, const void* g2, const float* w, const floa
 /* 1 when v100_ir_fwd_train / v100_ir_bwd accept shape[10] (act16) != 0 for this block */
 int v100_ir_act16_supported(const int* shape);
 
+/* ---- Adam step of every parameter in one launch (torch.optim.Adam as configured by asr.py:169-176 / tts.py:132-135, 239-241:
+ * grad += weight_decay * p; m = lerp(m, grad, 1-beta1); v = beta2*v + (1-beta2)*grad^2; p -= lr/(1-beta1^step) * m /
+ * (sqrt(v)/sqrt(1-beta2^step) + eps)).  chunks: DEVICE array of nchunks records {int tensor; int count; long long offset}
+ * (count <= v100_adam_chunk_elems() elements of one tensor each); params / grads / exp_avg / exp_avg_sq: DEVICE arrays of float
+ * pointers indexed by tensor.  Hyper-parameters are doubles: 1 - beta is formed in double, as torch does (1.f - 0.999f is 1.3e-5 off). */
+int v100_adam_chunk_elems(void);
+int v100_adam_step(const void* chunks, int nchunks, const void* params, const void* grads, const void* exp_avg,
+                   const void* exp_avg_sq, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                   void* stream);
+
 /* ---- K10 log_softmax + CTC (asr.py:148-152: F.log_softmax(-1) then nn.CTCLoss(blank, 'mean', zero_infinity=True)) --
  * logits [B][T][V] fp32, targets [B][Lmax] int64, in_len / tgt_len [B] int32 (device).  Writes nll[b] =
  * -log p(target_b | logits_b) (inf when infeasible) and grad[b][t][c] = d nll_b / d logits[b][t][c] (zero for
@@ -243,6 +258,10 @@ int v100_ir_act16_supported(const int* shape);
  * (256 threads x up to 16 lattice states each).  Labels outside [0, V) are treated as blank (the host wrapper can validate
  * them first: VOICE100_CHECK_IDS=1). */
 int v100_ctc_workspace_floats(int B, int T, int Lmax);
+/* v100_ctc_loss plus the 'mean' reduction in the library: loss[0] = mean over b of (nll_b finite ? nll_b / max(tgt_len_b, 1) : 0),
+ * grad = d loss[0] / d logits */
+int v100_ctc_loss_mean(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace,
+                       float* nll, float* loss, float* grad, int B, int T, int V, int Lmax, int blank, void* stream);
 int v100_ctc_loss(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace,
                   float* nll, float* grad, int B, int T, int V, int Lmax, int blank, void* stream);
 

@@ -410,3 +410,57 @@ def test_tap_addressed_gemm_and_wgrad(cuda, B, M, cx, T, shifts, lpad, bf16):
     dW = torch.empty(M, ntap * cx, device=cuda)
     N.call("v100_pw_wgrad_taps", Gp.to(cuda), tg, g_off, xp, partial, dW, S, B, M, cx, T, tx, ntap, sh, bf16)
     assert rel_err(dW, torch.einsum("bmt,bkt->mk", G, xv)) < tol
+
+
+def test_dropout_fused(cuda):
+    """nn.Dropout(0.2) as one kernel each way: kept elements scaled by 1/(1-p), dropped ones zero, keep rate ~ 1-p, the byte mask
+    drives backward, a seed repeats and another seed differs."""
+    from voice100_amd import functional as F_
+    x = torch.randn(7, 96, 333, device=cuda)        # numel not a multiple of 4: tail path
+    torch.manual_seed(11)
+    xg = x.clone().requires_grad_(True)
+    y = F_.dropout(xg, 0.2, True)
+    kept = y != 0
+    assert abs(float(kept.float().mean()) - 0.8) < 5e-3
+    assert torch.allclose(y[kept], x[kept] / 0.8, rtol=1e-6)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    assert torch.equal(xg.grad != 0, kept & (gy != 0))
+    assert torch.allclose(xg.grad[kept], gy[kept] / 0.8, rtol=1e-6)
+    torch.manual_seed(11)
+    assert torch.equal(F_.dropout(x, 0.2, True), y.detach())
+    assert not torch.equal(F_.dropout(x, 0.2, True), y.detach())
+    assert F_.dropout(x, 0.2, False) is x
+    # no visible structure along the fastest axis: neighbours are kept independently
+    k = kept.float()
+    assert abs(float((k[..., 1:] * k[..., :-1]).mean()) - 0.64) < 5e-3
+
+
+def test_fused_adam_matches_torch(cuda):
+    """FusedAdam (csrc/adam.hip) against torch.optim.Adam on the same parameters / gradients over several steps, with
+    weight decay and a StepLR schedule (asr.py:169-176); state_dict round trip continues the same trajectory."""
+    from voice100_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(512, 64, 1), (512,), (2048, 1, 83), (29, 512, 1), (3,), (70001,)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).to(cuda)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FusedAdam(pa, lr=1e-3, weight_decay=4e-5)
+    ob = torch.optim.Adam(pb, lr=1e-3, weight_decay=4e-5)
+    sa, sb = torch.optim.lr_scheduler.StepLR(oa, 1, 0.98), torch.optim.lr_scheduler.StepLR(ob, 1, 0.98)
+    for step in range(6):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(cuda) * (10.0 ** (step - 3))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+        if step % 2:
+            sa.step(); sb.step()
+        if step == 3:                                   # resume from a checkpoint of the optimizer
+            sd = oa.state_dict()
+            oa = FusedAdam(pa, lr=1e-3, weight_decay=4e-5)
+            oa.load_state_dict(sd)
+            sa.optimizer = oa                           # the schedule goes on with the restored optimizer
+    for a, b in zip(pa, pb):
+        assert rel_err(a, b) < 2e-6, (a.shape, rel_err(a, b))
+    for a, b in zip(pa, pb):
+        assert rel_err(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) < 1e-5
+        assert rel_err(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) < 1e-5

@@ -20,6 +20,7 @@ _CTYPES = {
     "int": ctypes.c_int,
     "float": ctypes.c_float,
     "long long": ctypes.c_longlong,
+    "double": ctypes.c_double,
 }
 
 _lock = threading.Lock()

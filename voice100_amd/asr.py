@@ -128,8 +128,11 @@ class AudioToTextCTC(Voice100ModelBase):
         # same update rule as the reference's torch.optim.Adam (asr.py:169-176); on the GPU PyTorch's single fused
         # multi-tensor kernel replaces the ~12 foreach launches per step
         params = list(self.parameters())
-        optimizer = torch.optim.Adam(params, lr=self.hparams.learning_rate, weight_decay=self.hparams.weight_decay,
-                                     fused=all(p.is_cuda for p in params))
+        if all(p.is_cuda for p in params):
+            from .optim import FusedAdam                    # the same update as one launch for the whole model (csrc/adam.hip)
+            optimizer = FusedAdam(params, lr=self.hparams.learning_rate, weight_decay=self.hparams.weight_decay)
+        else:
+            optimizer = torch.optim.Adam(params, lr=self.hparams.learning_rate, weight_decay=self.hparams.weight_decay)
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=1, gamma=0.98)
         return {"optimizer": optimizer, "lr_scheduler": scheduler}
 

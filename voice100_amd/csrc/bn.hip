@@ -170,6 +170,60 @@ __global__ void mul_scale_kernel(const float* __restrict__ u, const float* __res
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = u[i] * m[i] * s;
 }
 
+// nn.Dropout(p) in ONE pass (asr.py:90): the keep decision of element i is bit-mixing of (seed, i) -- splitmix64, two 32-bit
+// uniforms per call -- compared with p * 2^32; y = keep ? x / (1 - p) : 0 and a byte mask for the backward pass.  Replaces
+// torch.rand + compare + cast + multiply (4 kernels, a float mask of the activation's size written and read twice).
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, unsigned long long seed, unsigned thresh, float scale, float* __restrict__ y,
+                                   unsigned char* __restrict__ mask, long n4, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const unsigned long long r0 = splitmix64(seed ^ (unsigned long long)(2 * i) * 0xD6E8FEB86659FD93ull);
+        const unsigned long long r1 = splitmix64(seed ^ (unsigned long long)(2 * i + 1) * 0xD6E8FEB86659FD93ull);
+        const unsigned u[4] = {(unsigned)r0, (unsigned)(r0 >> 32), (unsigned)r1, (unsigned)(r1 >> 32)};
+        const long e0 = i * 4;
+        if (e0 + 3 < n) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + e0);
+            f32x4 o;
+            unsigned m = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool keep = u[e] >= thresh;
+                o[e] = keep ? v[e] * scale : 0.f;
+                m |= (keep ? 1u : 0u) << (8 * e);
+            }
+            *reinterpret_cast<f32x4*>(y + e0) = o;
+            *reinterpret_cast<unsigned*>(mask + e0) = m;
+        } else {
+            for (int e = 0; e < 4 && e0 + e < n; ++e) {
+                const bool keep = u[e] >= thresh;
+                y[e0 + e] = keep ? x[e0 + e] * scale : 0.f;
+                mask[e0 + e] = keep ? 1 : 0;
+            }
+        }
+    }
+}
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ mask, float scale, float* __restrict__ dx,
+                                   long n4, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long e0 = i * 4;
+        if (e0 + 3 < n) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dy + e0);
+            const unsigned m = *reinterpret_cast<const unsigned*>(mask + e0);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ((m >> (8 * e)) & 1u) ? v[e] * scale : 0.f;
+            *reinterpret_cast<f32x4*>(dx + e0) = o;
+        } else {
+            for (int e = 0; e < 4 && e0 + e < n; ++e) dx[e0 + e] = mask[e0 + e] ? dy[e0 + e] * scale : 0.f;
+        }
+    }
+}
+
 // [B][R][Cc] -> [B][Cc][R]   (model-edge layouts: asr.py:111,114; tts.py:177,179)
 __global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
     __shared__ float tile[32][33];
@@ -288,6 +342,30 @@ extern "C" int v100_mul_scale(const float* u, const float* m, float s, float* ou
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(mul_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, u, m, s, out, (long)n);
+    return v100_launch_status();
+}
+
+extern "C" int v100_dropout_fwd(const float* x, long long seed, float p, float* y, void* mask, long long n, void* stream) {
+    if (!x || !y || !mask) return V100_ERR_NULL;
+    if (n <= 0 || !(p >= 0.f && p < 1.f)) return V100_ERR_SHAPE;
+    const long n4 = (n + 3) / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    const double t = (double)p * 4294967296.0;
+    const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (unsigned long long)seed, thresh,
+                       1.0f / (1.0f - p), y, (unsigned char*)mask, n4, (long)n);
+    return v100_launch_status();
+}
+
+extern "C" int v100_dropout_bwd(const float* dy, const void* mask, float p, float* dx, long long n, void* stream) {
+    if (!dy || !dx || !mask) return V100_ERR_NULL;
+    if (n <= 0 || !(p >= 0.f && p < 1.f)) return V100_ERR_SHAPE;
+    const long n4 = (n + 3) / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, (const unsigned char*)mask,
+                       1.0f / (1.0f - p), dx, n4, (long)n);
     return v100_launch_status();
 }
 

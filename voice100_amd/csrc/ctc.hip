@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                                                        const long long* __restrict__ targets, const int* __restrict__ in_len,
                                                        const int* __restrict__ tgt_len, const float* __restrict__ alpha,
                                                        const float* __restrict__ beta, const float* __restrict__ nll,
-                                                       float* __restrict__ grad, int B, int T, int V, int Lmax, int Smax, int blank) {
+                                                       float* __restrict__ grad, int B, int T, int V, int Lmax, int Smax, int blank,
+                                                       int mean_scale) {
     __shared__ float bins[4][CTC_MAXV];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long w = (long)blockIdx.x * 4 + wave;
@@ -168,12 +169,25 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     asm volatile("" ::: "memory");       // wave-local LDS hand-off between lanes: keep program order for the compiler too
     const float z = lse[(size_t)b * T + t];
     const float* lg = logits + ((size_t)b * T + t) * V;
+    // mean_scale: gradient of CTCLoss(reduction='mean') = mean_b(nll_b / max(len_b, 1)) instead of nll_b
+    const float gs = mean_scale ? 1.f / ((float)max(tgt_len[b], 1) * (float)B) : 1.f;
     for (int c = lane; c < V; c += 64) {
         const float lpc = lg[c] - z;
         const float acc = bins[wave][c];
         const float occ = (acc > 0.f) ? expf(m + logf(acc) + n - lpc) : 0.f;
-        g[c] = expf(lpc) - occ;
+        g[c] = (expf(lpc) - occ) * gs;
     }
+}
+
+// loss = mean_b( finite(nll_b) ? nll_b / max(len_b, 1) : 0 )   (reduction='mean', zero_infinity=True)
+__global__ void ctc_mean_kernel(const float* __restrict__ nll, const int* __restrict__ tgt_len, int B, float* __restrict__ loss) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        const float v = nll[b];
+        if (v < INFINITY && v > -INFINITY) s += v / (float)max(tgt_len[b], 1);
+    }
+    s = wave_sum(s);
+    if (threadIdx.x == 0) loss[0] = s / (float)B;
 }
 
 extern "C" int v100_ctc_workspace_floats(int B, int T, int Lmax) {      // alpha + beta + lse
@@ -181,8 +195,24 @@ extern "C" int v100_ctc_workspace_floats(int B, int T, int Lmax) {      // alpha
     return n > 0x7fffffffL ? -1 : (int)n;
 }
 
+static int ctc_run(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace, float* nll,
+                   float* loss, float* grad, int B, int T, int V, int Lmax, int blank, void* stream);
+
 extern "C" int v100_ctc_loss(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace,
                              float* nll, float* grad, int B, int T, int V, int Lmax, int blank, void* stream) {
+    return ctc_run(logits, targets, in_len, tgt_len, workspace, nll, nullptr, grad, B, T, V, Lmax, blank, stream);
+}
+
+// The same plus the reduction of nn.CTCLoss(reduction='mean', zero_infinity=True): loss[0] = mean_b(nll_b / max(len_b, 1)) over
+// the feasible utterances, grad = d loss / d logits (asr.py:105, 152) -- no host-side elementwise kernels around the call.
+extern "C" int v100_ctc_loss_mean(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace,
+                                  float* nll, float* loss, float* grad, int B, int T, int V, int Lmax, int blank, void* stream) {
+    if (!loss) return V100_ERR_NULL;
+    return ctc_run(logits, targets, in_len, tgt_len, workspace, nll, loss, grad, B, T, V, Lmax, blank, stream);
+}
+
+static int ctc_run(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace, float* nll,
+                   float* loss, float* grad, int B, int T, int V, int Lmax, int blank, void* stream) {
     if (!logits || !targets || !in_len || !tgt_len || !workspace || !nll || !grad) return V100_ERR_NULL;
     if (B <= 0 || T <= 0 || V <= 0 || V > CTC_MAXV || Lmax < 0 || 2 * Lmax + 1 > 4096 || blank < 0 || blank >= V) return V100_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -204,6 +234,7 @@ extern "C" int v100_ctc_loss(const float* logits, const long long* targets, cons
     else { CTC_LATTICE(16); }
 #undef CTC_LATTICE
     hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len,
-                       alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank);
+                       alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank, loss ? 1 : 0);
+    if (loss) hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, st, nll, tgt_len, B, loss);
     return v100_launch_status();
 }

@@ -409,13 +409,40 @@ class DropoutMaskFn(torch.autograd.Function):
         return dx, None, None
 
 
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) in training mode as one kernel each way (v100_dropout_fwd / _bwd): the keep mask is generated in the
+    kernel from a 64-bit seed drawn from torch's CPU generator (so torch.manual_seed makes a run repeatable) and kept as
+    one byte per element for backward."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _check(x, "dropout")
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mask = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
+        N.call("v100_dropout_fwd", x, int(seed), float(p), y, mask, x.numel())
+        ctx.save_for_backward(mask)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        N.call("v100_dropout_bwd", dy, mask, ctx.p, dx, dy.numel())
+        return dx, None, None
+
+
 def dropout(x, p: float, training: bool, keep: Optional[torch.Tensor] = None):
-    """Inverted dropout. `keep` (0/1 float mask) can be injected for reproducible parity runs."""
+    """Inverted dropout. `keep` (0/1 float mask) can be injected for reproducible parity runs; otherwise the mask comes
+    from the in-kernel generator."""
     if not training or p == 0.0:
         return x
-    if keep is None:
-        keep = (torch.rand(x.shape, device=x.device) >= p).to(torch.float32)
-    return DropoutMaskFn.apply(x, keep, 1.0 / (1.0 - p))
+    if keep is not None:
+        return DropoutMaskFn.apply(x, keep, 1.0 / (1.0 - p))
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())        # CPU generator: no device sync
+    return DropoutFn.apply(x, p, seed)
 
 
 class EmbeddingBCTFn(torch.autograd.Function):
@@ -840,19 +867,17 @@ class CTCLossFn(torch.autograd.Function):
             raise RuntimeError("ctc_loss: workspace too large")
         ws = _f32(nws, like=logits)
         nll = _f32(B, like=logits)
+        loss = _f32(1, like=logits)
         grad = torch.empty_like(logits)
-        N.call("v100_ctc_loss", logits, targets, il, tl, ws, nll, grad, B, T, V, lmax, int(blank))
-        finite = torch.isfinite(nll)
-        denom = tl.clamp_min(1).to(torch.float32)
-        loss = (torch.where(finite, nll, torch.zeros_like(nll)) / denom).mean()
-        ctx.save_for_backward(grad, denom)
-        return loss
+        # the 'mean' reduction (finite utterances, / target length, / B) and its factor on the gradient happen in the library
+        N.call("v100_ctc_loss_mean", logits, targets, il, tl, ws, nll, loss, grad, B, T, V, lmax, int(blank))
+        ctx.save_for_backward(grad)
+        return loss[0]
 
     @staticmethod
     def backward(ctx, gout):
-        grad, denom = ctx.saved_tensors
-        scale = (gout / (denom * denom.shape[0]))[:, None, None]
-        return grad * scale, None, None, None, None
+        (grad,) = ctx.saved_tensors
+        return grad * gout, None, None, None, None
 
 
 def ctc_loss(logits_btv, targets, input_lengths, target_lengths, blank: int = 0):

@@ -207,8 +207,11 @@ class TextToAlignTextModel(Voice100ModelBase):
         return {"val_loss": loss}
 
     def configure_optimizers(self):
-        params = list(self.parameters())
-        return torch.optim.Adam(params, lr=self.hparams.learning_rate, fused=all(p.is_cuda for p in params))
+        params = [p for p in self.parameters() if p.requires_grad]
+        if all(p.is_cuda for p in params):
+            from .optim import FusedAdam
+            return FusedAdam(params, lr=self.hparams.learning_rate)
+        return torch.optim.Adam(params, lr=self.hparams.learning_rate)
 
     @staticmethod
     def add_model_specific_args(parent_parser):
@@ -289,8 +292,11 @@ class AlignTextToAudioModel(Voice100ModelBase):
         return {"test_loss": self._step("test", batch)}
 
     def configure_optimizers(self):
-        params = list(self.parameters())
-        return torch.optim.Adam(params, lr=self.hparams.learning_rate, fused=all(p.is_cuda for p in params))
+        params = [p for p in self.parameters() if p.requires_grad]
+        if all(p.is_cuda for p in params):
+            from .optim import FusedAdam
+            return FusedAdam(params, lr=self.hparams.learning_rate)
+        return torch.optim.Adam(params, lr=self.hparams.learning_rate)
 
     @staticmethod
     def add_model_specific_args(parent_parser):
