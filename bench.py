@@ -310,7 +310,9 @@ def main():
             # run's launches times the ratio rocprofv3 measured for these kernels (separate --pmc passes, 2*FETCH_SIZE +
             # WRITE_SIZE with the gfx950 correction; tools/pmc_passes.sh), null when that file is absent
             pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else None
-            roof = {"bound": "hbm", "kernel": "dwconv_mfma_kernel (depthwise forward: 8 Toeplitz-MFMA launches + the stride-2 first layer per step)",
+            act16 = F_.get_activation_storage() if args.precision == "bf16" else 0
+            roof = {"bound": "hbm", "kernel": "dwconv_mfma_kernel (depthwise forward: 8 Toeplitz-MFMA launches + the stride-2 first layer per step; "
+                                              + ("hidden activations stored as bf16: algorithmic bytes at 2 B/sample)" if act16 else "fp32 activations)"),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": round(pmc["ratio"] * nbytes / n) if pmc else None,
                     "traffic_source": (f"{pmc['ratio']} x algorithmic bytes (rocprofv3 PMC, profiles/{os.path.basename(PMC_FILE)})" if pmc else None),
@@ -327,8 +329,9 @@ def main():
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: asr_en_base (AudioToTextCTC 64/512/29/512) training step, "
                                    "batch=32 x 1024-frame synthetic log-mel + CTC targets [32,100] per GPU, "
-                                   "augmentation+dropout on, Adam; 1x1 GEMM operands bf16 (fp32 accumulate), "
-                                   "activations/depthwise/BatchNorm fp32" if args.precision == "bf16" else
+                                   "augmentation+dropout on, Adam; 1x1 GEMM operands bf16 (fp32 accumulate), hidden (4x-wide) activations and "
+                                   "their gradients stored as bf16, block inputs/outputs, BatchNorm statistics and all accumulation fp32"
+                                   if args.precision == "bf16" else
                                    "configs[1] at fp32 throughout",
                        "global_batch": B_PER_GPU * world, "frames_per_utterance": T_FRAMES, "parallelism": f"dp{world}"},
             "loss": round(float(loss), 4),
