@@ -84,6 +84,13 @@ def test_gemm_io_variants(cuda, B, M, K, T):
     assert rel_err(y1, y0) < 1e-6 and rel_err(s1, s0) < 1e-6
     y1, s1 = io(0, 4, x, None, r16, R | Y)
     assert torch.equal(from16(y1, T), y0.to(torch.bfloat16).to(torch.float32)) and rel_err(s1, s0) < 1e-6
+    # level 3: project forward with a bf16 output as well, project backward-data with a bf16 X (da3)
+    y0, s0 = ref(1, 1, xr, None, None)
+    y1, s1 = io(1, 1, x16, None, None, X | Y)
+    assert torch.equal(from16(y1, T), y0.to(torch.bfloat16).to(torch.float32)) and rel_err(s1, s0) < 1e-6
+    y0, s0 = ref(0, 4, xr, None, rr)
+    y1, s1 = io(0, 4, x16, None, r16, X | R | Y)
+    assert torch.equal(from16(y1, T), y0.to(torch.bfloat16).to(torch.float32)) and rel_err(s1, s0) < 1e-6
     # expand backward-data: affine of (X fp32 | bf16, X2 bf16), + residual / plain
     for ep in (5, 0):
         res = r if ep == 5 else None
@@ -123,6 +130,7 @@ def test_wgrad_io_variants(cuda, B, M, K, T):
     assert rel_err(run("v100_pw_wgrad_io", gm, g216, 2, xm, 0, G2_), run("v100_pw_wgrad", gm, g2r, 2, xm, 0)) < 1e-6
     assert rel_err(run("v100_pw_wgrad_io", g16, g216, 2, xm, 0, G_ | G2_), run("v100_pw_wgrad", gr, g2r, 2, xm, 0)) < 1e-6
     assert rel_err(run("v100_pw_wgrad_io", gm, None, 0, x16, 1, WX), run("v100_pw_wgrad", gm, None, 0, xr, 1)) < 1e-6
+    assert rel_err(run("v100_pw_wgrad_io", g16, None, 0, x16, 1, G_ | WX), run("v100_pw_wgrad", gr, None, 0, xr, 1)) < 1e-6
 
 
 def _bf(t):
@@ -179,7 +187,32 @@ def test_dwconv_io_variants(cuda, B, C, T, K):
         assert rel_err(dw, wv.grad) < 5e-4      # fp32 summation order over B*T terms of size O(10)
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("B,C,T", [(2, 8, 48), (3, 6, 133), (2, 16, 700)])
+def test_chan_passes_io(cuda, B, C, T):
+    """Block-boundary passes with a bf16-stored a3 / da3: y = s3*a3 + t3 (+ x), sums of (dy, dy*a3), da3 = p*dy + q*a3 + r."""
+    N = _native()
+    g = torch.Generator().manual_seed(C + T)
+    a3 = torch.randn(B, C, T, generator=g).to(cuda)
+    a316, a3r = to16(a3)
+    x = torch.randn(B, C, T, generator=g).to(cuda)
+    dy = torch.randn(B, C, T, generator=g).to(cuda)
+    p_, q_, r_ = (torch.randn(C, generator=g).to(cuda) for _ in range(3))
+    for res in (x, None):
+        y = torch.empty(B, C, T, device=cuda)
+        N.call("v100_chan_affine2_io", a316, res, p_, None, r_, y, B, C, T, 1)
+        ref = a3r * p_[None, :, None] + r_[None, :, None] + (res if res is not None else 0)
+        assert rel_err(y, ref) < 1e-6
+    G = N.helper("v100_dw_num_groups", B, C)
+    part = torch.zeros(G, C, 2, device=cuda)
+    N.call("v100_chan_reduce2_io", dy, a316, part, G, B, C, T, 2)
+    assert rel_err(part.sum(0)[:, 0], dy.sum((0, 2))) < 1e-5 and rel_err(part.sum(0)[:, 1], (dy * a3r).sum((0, 2))) < 1e-5
+    da3 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    N.call("v100_chan_affine2_io", dy, a316, p_, q_, r_, da3, B, C, T, 6)
+    ref = p_[None, :, None] * dy + q_[None, :, None] * a3r + r_[None, :, None]
+    assert torch.equal(from16(da3, T), ref.to(torch.bfloat16).to(torch.float32)) or rel_err(from16(da3, T), ref) < 5e-3
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_block_act16_matches_fp32_storage(cuda, level):
     """A training-mode block at bf16 precision with the hidden tensors stored as bf16 vs the same block with fp32 storage:
     outputs, input gradient and parameter gradients within bf16 storage error of each other (and both within the bf16 bar

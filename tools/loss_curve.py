@@ -34,7 +34,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     curves = {"fp32": run("fp32", 0, args.steps, dev), "bf16/act0": run("bf16", 0, args.steps, dev),
-              "bf16/act1": run("bf16", 1, args.steps, dev), "bf16/act2": run("bf16", 2, args.steps, dev)}
+              "bf16/act2": run("bf16", 2, args.steps, dev), "bf16/act3": run("bf16", 3, args.steps, dev)}
     print("step " + " ".join(f"{k:>10s}" for k in curves))
     for i in range(args.steps):
         print(f"{i:4d} " + " ".join(f"{v[i]:10.4f}" for v in curves.values()))

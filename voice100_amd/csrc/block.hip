@@ -26,7 +26,8 @@ const float kMom = 0.1f, kEps = 1e-5f;
 // coef  = 12 vectors of `hid` floats: s1 t1 mean1 rstd1 s2 t2 mean2 rstd2 s3 t3 mean3 rstd3
 // act16 (bf16 operands only): 0 = every activation fp32; 1 = the two hidden tensors saved for backward, a1 and a2, are
 // stored as bf16 [B][hid][pitch16(T)] (the caller allocates them so); 2 = also the hidden gradients dz2 / dz1 inside the
-// backward workspace.  Statistics and every accumulation stay fp32; only the stored copies are rounded.
+// backward workspace; 3 = also the project output a3 (saved for backward; the caller allocates it bf16 [B][cout][pitch16(T)])
+// and its BatchNorm-backward gradient da3 (workspace).  Statistics and every accumulation stay fp32; only the stored copies are rounded.
 enum { IR_B, IR_CIN, IR_HID, IR_COUT, IR_T, IR_K, IR_STRIDE, IR_RES, IR_BF16, IR_PREPPED, IR_ACT16, IR_NSHAPE };
 static inline int pitch16(int T) { return (T + 7) & ~7; }
 enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8, WG_IO_G = 1, WG_IO_G2 = 2, WG_IO_X = 4, DW_IO_X = 1, DW_IO_X2 = 2, DW_IO_AUX = 4,
@@ -119,10 +120,12 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
         CK(v100_dwconv_fwd_train_io(a1, wd, s1, t1, a2, st, G, B, hid, T, K, DW_IO_X | DW_IO_Y, stream));
         CK(v100_bn_finalize_train(st, G, (long long)B * T2, (const float*)P[8], (const float*)P[9], (float*)P[10], (float*)P[11], (long long*)P[12],
                                   kMom, kEps, s2, t2, m2, r2, hid, stream));
-        CK(v100_pw_gemm_io(w3bf, a2, nullptr, s2, t2, nullptr, 1, a3, nullptr, nullptr, nullptr, 1, st, B, cout, hid, T2, PW_IO_X, stream));
+        const bool a316 = sh[IR_ACT16] >= 3;          // the project output (saved for backward) as bf16 too
+        CK(v100_pw_gemm_io(w3bf, a2, nullptr, s2, t2, nullptr, 1, a3, nullptr, nullptr, nullptr, 1, st, B, cout, hid, T2, PW_IO_X | (a316 ? PW_IO_Y : 0), stream));
         CK(v100_bn_finalize_train(st, parts3, (long long)B * T2, (const float*)P[14], (const float*)P[15], (float*)P[16], (float*)P[17], (long long*)P[18],
                                   kMom, kEps, s3, t3, m3, r3, cout, stream));
-        CK(v100_chan_affine2(a3, res ? x : nullptr, s3, nullptr, t3, y, B, cout, T2, stream));
+        if (a316) CK(v100_chan_affine2_io(a3, res ? x : nullptr, s3, nullptr, t3, y, B, cout, T2, 1, stream));
+        else CK(v100_chan_affine2(a3, res ? x : nullptr, s3, nullptr, t3, y, B, cout, T2, stream));
         return V100_OK;
     }
     CK(v100_pw_gemm(w1, w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, bf, stream));
@@ -149,10 +152,10 @@ static size_t ir_bwd_carve(const int* sh, void* base, IrBwdWs& w) {
     size_t m = (size_t)v100_pw_num_parts(B, T2) * hid * 2; if (m > n) n = m;
     m = (size_t)v100_dw_num_groups(B, hid) * hid * 2; if (m > n) n = m;
     w.part = c.take<float>(n);
-    w.da3 = c.take<float>((size_t)B * cout * T2);
+    w.da3 = sh[IR_ACT16] >= 3 ? (float*)c.take<u16>((size_t)B * cout * pitch16(T2)) : c.take<float>((size_t)B * cout * T2);
     // act16 == 2: the two hidden gradients are bf16 with pitched rows (half the bytes; the fp32 size is an upper bound
     // only when pitch16(T) <= 2*T, i.e. always)
-    if (sh[IR_ACT16] == 2) {
+    if (sh[IR_ACT16] >= 2) {
         w.dz2 = (float*)c.take<u16>((size_t)B * hid * pitch16(T2));
         w.dz1 = (float*)c.take<u16>((size_t)B * hid * pitch16(T));
     } else {
@@ -197,17 +200,20 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     (void)w1; (void)w3;
     // BN3 backward
     const int Gr = v100_dw_num_groups(B, cout);
-    CK(v100_chan_reduce2(dy, a3, w.part, Gr, B, cout, T2, stream));
+    const bool a316 = sh[IR_ACT16] >= 3;              // a3 (saved) and da3 (workspace) stored as bf16
+    if (a316) CK(v100_chan_reduce2_io(dy, a3, w.part, Gr, B, cout, T2, 2, stream));
+    else CK(v100_chan_reduce2(dy, a3, w.part, Gr, B, cout, T2, stream));
     CK(v100_bn_bwd_finalize(w.part, Gr, (long long)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], cout, stream));
-    CK(v100_chan_affine2(dy, a3, pp, qq, rr, w.da3, B, cout, T2, stream));
+    if (a316) CK(v100_chan_affine2_io(dy, a3, pp, qq, rr, w.da3, B, cout, T2, 6, stream));
+    else CK(v100_chan_affine2(dy, a3, pp, qq, rr, w.da3, B, cout, T2, stream));
     if (sh[IR_ACT16]) {
         if (!v100_ir_act16_supported(sh)) return V100_ERR_SHAPE;
-        const bool g16 = sh[IR_ACT16] == 2;
+        const bool g16 = sh[IR_ACT16] >= 2;
         CK(v100_pw_wgrad_io(w.da3, nullptr, nullptr, nullptr, nullptr, 0, a2, s2, t2, 1, w.slab, (float*)P[19], v100_pw_wgrad_splits(B, cout, hid),
-                            B, cout, hid, T2, WG_IO_X, stream));
+                            B, cout, hid, T2, WG_IO_X | (a316 ? WG_IO_G : 0), stream));
         const int parts16 = v100_pw_num_parts(B, T2);
         CK(v100_pw_gemm_io(pw.w3tbf, w.da3, nullptr, nullptr, nullptr, nullptr, 0, w.dz2, s2, t2, a2, 4, w.part, B, hid, cout, T2,
-                           PW_IO_R | (g16 ? PW_IO_Y : 0), stream));
+                           PW_IO_R | (g16 ? PW_IO_Y : 0) | (a316 ? PW_IO_X : 0), stream));
         CK(v100_bn_bwd_finalize(w.part, parts16, (long long)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], hid, stream));
         const int G16 = v100_dw_num_groups(B, hid);
         CK(v100_dwconv_bwd_io(w.dz2, a2, wd, pp, qq, rr, a1, s1, t1, w.dz1, w.part, w.slab, (float*)P[16], G16, B, hid, T, K,

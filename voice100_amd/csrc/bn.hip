@@ -121,6 +121,94 @@ __global__ __launch_bounds__(256) void chan_reduce2_kernel(const float* __restri
     }
 }
 
+// ---- the two block-boundary passes over tensors of which some are STORED as bf16 [B][C][P], P = (T + 7) & ~7 ("act16", see
+// include/voice100_hip.h): a3 (project output, saved for backward) and da3 (its BatchNorm-backward gradient, executor-internal).
+// Row-wise addressing: fp32 operands have pitch T, bf16 operands pitch P; 4 samples per thread and step.
+typedef unsigned int bn_u32x2 __attribute__((ext_vector_type(2)));
+template <bool B16>
+__device__ __forceinline__ void chan_load4(const void* base, size_t row, int T, int P, int t, float (&o)[4]) {
+    if constexpr (B16) {
+        const bn_u32x2 w = *reinterpret_cast<const bn_u32x2*>(reinterpret_cast<const u16*>(base) + row * P + t);     // t % 4 == 0, P % 8 == 0
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned d = w[e >> 1];
+            o[e] = (t + e < T) ? __builtin_bit_cast(float, (e & 1) ? (d & 0xffff0000u) : (d << 16)) : 0.f;
+        }
+    } else {
+        const float* p = reinterpret_cast<const float*>(base) + row * T + t;
+        if (t + 3 < T) {
+            const f32x4 v = *reinterpret_cast<const f32x4u*>(p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (t + e < T) ? p[e] : 0.f;
+        }
+    }
+}
+
+// io: 1 u is bf16, 2 v is bf16
+template <int IO>
+__global__ __launch_bounds__(256) void chan_reduce2_io_kernel(const void* __restrict__ u, const void* __restrict__ v, float* __restrict__ partial,
+                                                              int B, int C, int T, int G) {
+    __shared__ float red[4][2];
+    const int c = blockIdx.x, g = blockIdx.y;
+    const int bper = (B + G - 1) / G;
+    const int b0 = g * bper, b1 = min(B, b0 + bper);
+    const int P = (T + 7) & ~7;
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const size_t row = (size_t)b * C + c;
+        for (int t = threadIdx.x * 4; t < T; t += 1024) {
+            float a[4], w[4];
+            chan_load4<(IO & 1) != 0>(u, row, T, P, t, a);
+            chan_load4<(IO & 2) != 0>(v, row, T, P, t, w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s0 += a[e]; s1 = fmaf(a[e], w[e], s1); }
+        }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[((size_t)g * C + c) * 2 + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        partial[((size_t)g * C + c) * 2 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+// out = A[c]*u + Bc[c]*v + Cc[c]; io: 1 u is bf16, 2 v is bf16, 4 out is bf16; v may be null
+template <int IO>
+__global__ __launch_bounds__(256) void chan_affine2_io_kernel(const void* __restrict__ u, const void* __restrict__ v, const float* __restrict__ A,
+                                                              const float* __restrict__ Bc, const float* __restrict__ Cc, void* __restrict__ out,
+                                                              int C, int T, long rows) {
+    const int P = (T + 7) & ~7;
+    const int T4 = (T + 3) >> 2;
+    const long total = rows * T4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const size_t row = (size_t)(i / T4);
+        const int t = (int)(i % T4) * 4;
+        const int c = (int)(row % C);
+        const float a = A ? A[c] : 1.f, b = Bc ? Bc[c] : 1.f, cc = Cc ? Cc[c] : 0.f;
+        float x[4], y[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        chan_load4<(IO & 1) != 0>(u, row, T, P, t, x);
+        if (v) chan_load4<(IO & 2) != 0>(v, row, T, P, t, y);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v ? fmaf(x[e], a, fmaf(y[e], b, cc)) : fmaf(x[e], a, cc);
+        if constexpr ((IO & 4) != 0) {
+            const bn_u32x2 w = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+            *reinterpret_cast<bn_u32x2*>(reinterpret_cast<u16*>(out) + row * P + t) = w;       // samples past T land in the row's padding
+        } else {
+            float* q = reinterpret_cast<float*>(out) + row * T + t;
+            if (t + 3 < T) { const f32x4 w = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4u*>(q) = w; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (t + e < T) q[e] = o[e];
+            }
+        }
+    }
+}
+
 // out[c] = sum_g partial[g][c][0]   (bias gradients)
 __global__ void slab_sum0_kernel(const float* __restrict__ partial, int parts, float* __restrict__ out, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -314,6 +402,31 @@ extern "C" int v100_chan_reduce2(const float* u, const float* v, float* partial,
     if (!u || !partial) return V100_ERR_NULL;
     if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || G > B) return V100_ERR_SHAPE;
     hipLaunchKernelGGL(chan_reduce2_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, u, v, partial, B, C, T, G);
+    return v100_launch_status();
+}
+
+extern "C" int v100_chan_reduce2_io(const void* u, const void* v, float* partial, int G, int B, int C, int T, int io16, void* stream) {
+    if (!u || !v || !partial) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || G > B) return V100_ERR_SHAPE;
+    if (io16 == 2) hipLaunchKernelGGL(chan_reduce2_io_kernel<2>, dim3(C, G), dim3(256), 0, (hipStream_t)stream, u, v, partial, B, C, T, G);
+    else return V100_ERR_SHAPE;
+    return v100_launch_status();
+}
+
+extern "C" int v100_chan_affine2_io(const void* u, const void* v, const float* A, const float* Bc, const float* Cc, void* out,
+                                    int B, int C, int T, int io16, void* stream) {
+    if (!u || !out) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || T <= 0) return V100_ERR_SHAPE;
+    const long rows = (long)B * C;
+    const long total = rows * ((T + 3) / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    // forward block output: u = a3 (bf16), v = x (fp32) or null -> y fp32;  backward: u = dy (fp32), v = a3 (bf16) -> da3 (bf16)
+    if (io16 == 1) hipLaunchKernelGGL(chan_affine2_io_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Bc, Cc, out, C, T, rows);
+    else if (io16 == 6) hipLaunchKernelGGL(chan_affine2_io_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Bc, Cc, out, C, T, rows);
+    else return V100_ERR_SHAPE;
     return v100_launch_status();
 }
 

@@ -883,6 +883,8 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     X(2, 5, PW_IO_X2) X(2, 0, PW_IO_X2)   // expand backward-data: BN1-backward affine of (dz1, a1)
     X(0, 4, PW_IO_R | PW_IO_Y)            // ... with the hidden gradients stored as bf16 too
     X(2, 5, PW_IO_X | PW_IO_X2) X(2, 0, PW_IO_X | PW_IO_X2)
+    X(1, 1, PW_IO_X | PW_IO_Y)            // ... and the project output a3 / its gradient da3
+    X(0, 4, PW_IO_X | PW_IO_R | PW_IO_Y)
 #undef X
     return false;
 }
@@ -899,6 +901,7 @@ bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
     X(2, 0, WG_IO_G2)                     // expand backward-weight: G = BN1-backward affine of (dz1, a1), X = block input
     X(0, 1, WG_IO_X)                      // project backward-weight: X = relu6(bn2(a2))
     X(2, 0, WG_IO_G | WG_IO_G2)           // ... with dz1 stored as bf16
+    X(0, 1, WG_IO_G | WG_IO_X)            // ... with da3 stored as bf16
 #undef X
     return false;
 }

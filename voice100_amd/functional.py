@@ -40,14 +40,16 @@ _PRECISION = "fp32"
 # Storage of the big hidden tensors of a training-mode block under precision "bf16" (include/voice100_hip.h, "act16"):
 # 0 = fp32 everywhere, 1 = a1 / a2 (the tensors saved for backward) as bf16, 2 = also the hidden gradients dz2 / dz1.
 # The reference under bf16 autocast keeps exactly these tensors in bf16; statistics and accumulators stay fp32 here.
-_ACT16 = int(os.environ.get("VOICE100_ACT16", "2"))
+# 3 = also the project output a3 (saved for backward) and its gradient da3: every tensor that is internal to a block.
+_ACT16 = int(os.environ.get("VOICE100_ACT16", "3"))
 
 
 def set_activation_storage(level: int) -> None:
-    """0: fp32 activations; 1: saved hidden activations bf16; 2: hidden gradients bf16 as well (bf16 precision only)."""
+    """0: fp32 activations; 1: saved hidden activations bf16; 2: hidden gradients bf16 as well; 3: also the project output and
+    its gradient (bf16 precision only; block inputs / outputs always stay fp32)."""
     global _ACT16
-    if level not in (0, 1, 2):
-        raise ValueError("activation storage level must be 0, 1 or 2")
+    if level not in (0, 1, 2, 3):
+        raise ValueError("activation storage level must be 0, 1, 2 or 3")
     _ACT16 = level
 
 
@@ -175,10 +177,11 @@ class InvertedResidualTrainFn(torch.autograd.Function):
             pitch = (T + 7) & ~7                       # bf16 rows are padded to a multiple of 8 samples (aligned 8 / 16-byte accesses)
             a1 = torch.empty((B, hid, pitch), dtype=torch.bfloat16, device=x.device)
             a2 = torch.empty((B, hid, pitch), dtype=torch.bfloat16, device=x.device)
+            a3 = torch.empty((B, cout, pitch), dtype=torch.bfloat16, device=x.device) if _ACT16 >= 3 else _f32(B, cout, T2, like=x)
         else:
             a1 = _f32(B, hid, T, like=x)
             a2 = _f32(B, hid, T2, like=x)
-        a3 = _f32(B, cout, T2, like=x)
+            a3 = _f32(B, cout, T2, like=x)
         y = _f32(B, cout, T2, like=x)
         coef = _f32(12, max(hid, cout), like=x)
         ws = torch.empty(N.helper("v100_ir_fwd_workspace_bytes", shape), dtype=torch.uint8, device=x.device)
