@@ -17,6 +17,7 @@
 // 128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles (64 acc VGPRs).
 // 1-D grid with an XCD-aware remap: the M-tiles that share one X tile run on one XCD (one L2).
 #include "pointwise_common.h"
+#include <stdlib.h>
 #include "timing.h"
 
 void pw_launch_gemm_f32(const PwParams& p, dim3 grid, hipStream_t st);
@@ -58,7 +59,8 @@ extern "C" int v100_pw_num_parts(int B, int T) { return B * ceil_div(T, PW_BN); 
 extern "C" int v100_pw_wgrad_splits(int B, int M, int K) {
     // enough (tile, split) workgroups to fill the chip, capped by the batch
     const int tiles = ceil_div(M, PW_BM) * ceil_div(K, PW_BN);
-    int S = ceil_div(512, tiles);
+    static const int target = [] { const char* e = getenv("V100_WG_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    int S = ceil_div(target, tiles);
     if (S > B) S = B;
     if (S < 1) S = 1;
     return S;
