@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--diag-no-timestretch", action="store_true", help="diagnostic only (NOT the benchmark workload): never draw a time-stretch")
+    ap.add_argument("--diag-stretch-rate", type=int, default=0, help="diagnostic only: every drawn time-stretch uses this rate (percent)")
     args = ap.parse_args()
 
     from voice100_amd.trainer import TrainStep, init_distributed, launch_ranks
@@ -240,6 +241,10 @@ def main():
     step = TrainStep(model)
     if args.diag_no_timestretch:
         model.batch_augment.do_timestretch = False
+    if args.diag_stretch_rate:
+        import voice100_amd.audio as _audio
+        _audio.SPECTROGRAM_AUGUMENT_RATE = 1.0          # every op of the augmentation fires: diagnostic workload
+        model.batch_augment._diag_rate = args.diag_stretch_rate
     batch = synth_batch(device, B_PER_GPU, 1234 + rank)
 
     def sync():
@@ -320,7 +325,7 @@ def main():
                     "algorithmic_bytes_per_launch": round(nbytes / n), "algorithmic_bytes_nominal_step": dw_bytes,
                     "measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
         out = {
-            "metric": "audio frames/sec (fwd+bwd) asr_en_base, B=32x1024-frame mel" + (" [DIAGNOSTIC: time-stretch off]" if args.diag_no_timestretch else ""),
+            "metric": "audio frames/sec (fwd+bwd) asr_en_base, B=32x1024-frame mel" + (" [DIAGNOSTIC: time-stretch off]" if args.diag_no_timestretch else "") + (f" [DIAGNOSTIC: stretch {args.diag_stretch_rate}% every step]" if args.diag_stretch_rate else ""),
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "world_size": world,

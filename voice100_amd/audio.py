@@ -49,6 +49,8 @@ class BatchSpectrogramAugumentation(nn.Module):
         T, F = audio.shape[1], audio.shape[2]
         if self.do_timestretch and random.random() < SPECTROGRAM_AUGUMENT_RATE:
             d.stretch_rate = random.randrange(50, 150)
+            if getattr(self, "_diag_rate", None):          # bench.py --diag-stretch-rate (diagnostics only): every stretch uses this rate
+                d.stretch_rate = int(self._diag_rate)
             T = T * d.stretch_rate // 100
         if random.random() < SPECTROGRAM_AUGUMENT_RATE:
             d.pitch_rate = 1.0 + random.random() * 0.2
