@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "libvoice100_hip.so")
+LIB_PATH = os.environ.get("VOICE100_LIB") or os.path.join(_PKG, "libvoice100_hip.so")     # VOICE100_LIB: an A/B build of the library
 HEADER_PATH = os.path.join(_ROOT, "include", "voice100_hip.h")
 
 _CTYPES = {
