@@ -276,6 +276,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(batch)
+    host_loop = time.perf_counter() - t0          # the host has ENQUEUED the last step; the GPU may still be running
     sync()
     elapsed = time.perf_counter() - t0
     kt, kt_all = {}, {}
@@ -340,6 +341,8 @@ def main():
                                    "configs[1] at fp32 throughout",
                        "global_batch": B_PER_GPU * world, "frames_per_utterance": T_FRAMES, "parallelism": f"dp{world}"},
             "loss": round(float(loss), 4),
+            # host time to enqueue a step (the loop without the final synchronise): the step is GPU-bound while this stays below ms_per_step
+            "host_enqueue_ms_per_step": round(host_loop / args.steps * 1e3, 3),
             "roofline": roof,
             "kernel_ms_per_step": kt_all,
         }

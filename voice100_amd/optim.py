@@ -73,29 +73,34 @@ class FusedAdam(torch.optim.Optimizer):
             if t is None:
                 continue
             ps = t["params"]
-            if any(p.grad is None for p in ps):
+            grads = [p.grad for p in ps]
+            if any(g is None for g in grads):
                 raise RuntimeError("FusedAdam: every parameter needs a gradient each step (the reference's models produce one)")
-            if [p.data_ptr() for p in ps] != t["p_ptrs"]:
+            for i, g in enumerate(grads):
+                if g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous():
+                    grads[i] = ps[i].grad = g.to(torch.float32).contiguous()
+            ptrs = [g.data_ptr() for g in grads]
+            t["checks"] = t.get("checks", 0) + 1
+            if t["checks"] % 64 == 1 and [p.data_ptr() for p in ps] != t["p_ptrs"]:
                 raise RuntimeError("FusedAdam: a parameter's storage moved since the optimizer was built (re-create the optimizer)")
-            slot = t["pos"] % 4
-            t["pos"] += 1
-            host = t["ring"][slot]
-            if t["events"][slot] is not None:
-                t["events"][slot].synchronize()
-            gp = host.numpy().view(np.uint64)
-            for i, p in enumerate(ps):
-                g = p.grad
-                if g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda:
-                    g = p.grad = g.to(torch.float32).contiguous()
-                gp[i] = g.data_ptr()
-            t["g"].copy_(host, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            t["events"][slot] = ev
+            if ptrs != t.get("g_ptrs"):
+                # the gradient tensors moved (the caching allocator usually hands back the same blocks every step): upload
+                slot = t["pos"] % 4
+                t["pos"] += 1
+                host = t["ring"][slot]
+                if t["events"][slot] is not None:
+                    t["events"][slot].synchronize()
+                host.numpy().view(np.uint64)[:] = ptrs
+                t["g"].copy_(host, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                t["events"][slot] = ev
+                t["g_ptrs"] = ptrs
             t["step"] += 1
             b1, b2 = group["betas"]
             N.call("v100_adam_step", t["chunks"], t["nchunks"], t["p"], t["g"], t["m"], t["v"], float(group["lr"]), float(b1), float(b2),
                    float(group["eps"]), float(group["weight_decay"]), t["step"])
+            t["step_tensor"] = torch.tensor(float(t["step"]))
             for p in ps:
-                self.state[p]["step"] = torch.tensor(float(t["step"]))
+                self.state[p]["step"] = t["step_tensor"]
         return loss

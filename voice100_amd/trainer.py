@@ -58,7 +58,8 @@ class TrainStep:
         self.step_idx = 0
 
     def __call__(self, batch) -> torch.Tensor:
-        self.model.train()
+        if not self.model.training:           # (train() walks every sub-module: ~0.5 ms of host time per call on asr_en_base)
+            self.model.train()
         self.buckets.begin_step()
         loss = self.model.training_step(batch, self.step_idx)
         if isinstance(loss, dict):
