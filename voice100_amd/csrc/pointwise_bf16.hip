@@ -867,7 +867,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     const bool full = (p.K & 1) == 0 && (long)(p.K + 64) * P * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL &&
                       (long)p.B * p.M * P * 4 < 0x7fffff00L;
     if (!full) return false;
-    const bool big = p.M >= 256;
+    const bool big = p.M >= 256 && p.K > PW_BM128_MAXK;
     PwParams pb = p;
     pb.n_mtiles = (p.M + (big ? 255 : 127)) / (big ? 256 : 128);
     const dim3 grid((unsigned)((long)pb.n_mtiles * p.n_ttiles * p.B));
