@@ -102,7 +102,8 @@ def test_gemm_io_variants(cuda, B, M, K, T):
         assert rel_err(y1, y0) < 1e-6
 
 
-@pytest.mark.parametrize("B,M,K,T", [(2, 32, 8, 48), (4, 256, 64, 100), (3, 64, 256, 133), (2, 512, 128, 704)])
+@pytest.mark.parametrize("B,M,K,T", [(2, 32, 8, 48), (4, 256, 64, 100), (3, 64, 256, 133), (2, 512, 128, 704), (3, 300, 260, 133),
+                                     (2, 128, 512, 192), (5, 640, 384, 77)])   # the last three: 256-row tiles, ragged rows, T tails
 def test_wgrad_io_variants(cuda, B, M, K, T):
     N = _native()
     g = torch.Generator().manual_seed(M * 3 + T)

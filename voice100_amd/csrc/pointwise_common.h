@@ -42,6 +42,9 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #else
 #define PW_EPI_UNROLL 4
 #endif
+#ifndef PW_WG_WIDE
+#define PW_WG_WIDE 1         /* 256 x 128 backward-weight tiles for the act16 combinations (0: the 128 x 128 kernel everywhere) */
+#endif
 #ifndef PW_BM128_MAXK
 #define PW_BM128_MAXK 0      /* A/B knob: 128-row tiles (two workgroups per CU) for GEMMs with K <= this */
 #endif
