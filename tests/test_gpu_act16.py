@@ -36,7 +36,8 @@ def from16(t16, T):
     return t16[:, :, :T].to(torch.float32)
 
 
-SHAPES = [(2, 32, 8, 48), (3, 256, 64, 100), (2, 64, 256, 133), (1, 512, 128, 700)]
+SHAPES = [(2, 32, 8, 48), (3, 256, 64, 100), (2, 64, 256, 133), (1, 512, 128, 700),
+          (32, 1024, 64, 512), (16, 2048, 128, 1024)]      # 512 / 1024 block tiles: persistent workgroups (2 / 4 tiles each)
 
 
 @pytest.mark.parametrize("B,M,K,T", SHAPES)

@@ -167,10 +167,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-template <int XM, int EPI, int BM, bool F16 = false, bool TAPS = false, int IO = 0>
+template <int XM, int EPI, int BM, bool F16 = false, bool TAPS = false, int IO = 0, bool PERSIST = false>
 __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     static_assert(!TAPS || XM == PW_X_NONE, "tap-addressed X has no prologue");
     static_assert(!(IO != 0 && (TAPS || F16)), "16-bit activation storage: bf16 training combinations only");
+    // PERSIST: the grid is a divisor of the tile count and a workgroup walks tiles v = blockIdx.x, + gridDim.x, ...; the first two
+    // k-tiles of the NEXT tile are requested into the (idle) staging registers before the epilogue of the current one, so a
+    // tile's start does not wait a memory latency (2.5 us of the ~15 us a 256 x 128 x 512 tile takes) and the epilogue's
+    // stores overlap the next tile's loads.  For the short-K GEMMs (several tiles per CU); XM == NONE only (register budget).
+    static_assert(!PERSIST || (XM == PW_X_NONE && !TAPS), "persistent form: plain X operand");
     constexpr bool XB = (IO & PW_IO_X) != 0, X2B = (IO & PW_IO_X2) != 0;    // operand tensors stored as bf16 (pitched rows)
     using XReg = std::conditional_t<XB, u32x2, u32x4>;
     using X2Reg = std::conditional_t<X2B, u32x2, u32x4>;
@@ -187,8 +192,11 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int b, tt, mt;
-    pw_work(p, b, tt, mt);
-    const int m0 = mt * BM, t0 = tt * PW_BN;
+    int vtile = blockIdx.x;
+    const int ntiles_all = PERSIST ? p.n_mtiles * p.n_ttiles * p.B : 0;
+    if constexpr (PERSIST) pw_work_v(p, vtile, ntiles_all, b, tt, mt);
+    else pw_work(p, b, tt, mt);
+    int m0 = mt * BM, t0 = tt * PW_BN;
     const int M = p.M, K = p.K, T = p.T;
     // tap-addressed X: physical rows are the cx channels of the padded tensor, row pitch Tx (see PwParams)
     const int Tx = TAPS ? p.Tx : T;
@@ -198,8 +206,8 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     constexpr int EX = XB ? 2 : 4, EX2 = X2B ? 2 : 4;      // bytes per element
 
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.Abf, (PW_ABLATE & 2) ? 0u : (unsigned)M * K * 2u);
-    const __amdgpu_buffer_rsrc_t rX = make_rsrc(reinterpret_cast<const char*>(p.X) + (size_t)b * Kx * TxX * EX,
-                                                (PW_ABLATE & 1) ? 0u : (unsigned)Kx * TxX * EX);
+    __amdgpu_buffer_rsrc_t rX = make_rsrc(reinterpret_cast<const char*>(p.X) + (size_t)b * Kx * TxX * EX,
+                                          (PW_ABLATE & 1) ? 0u : (unsigned)Kx * TxX * EX);
     const __amdgpu_buffer_rsrc_t rX2 = make_rsrc(reinterpret_cast<const char*>(XM == PW_X_AFFINE2 ? p.X2 : p.X) +
                                                      (size_t)b * Kx * (XM == PW_X_AFFINE2 ? TxX2 * EX2 : TxX * EX),
                                                  (PW_ABLATE & 1) ? 0u : (unsigned)Kx * (XM == PW_X_AFFINE2 ? TxX2 * EX2 : TxX * EX));
@@ -227,6 +235,16 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     int ldsB[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) ldsB[q] = bf_off(b_tq + q, (KPT * b_kg) >> 3) + ((KPT * b_kg) & 7) * 2;
+    // PERSIST: re-aim the X descriptor and the per-lane offsets at tile v
+    auto retarget = [&](int v) {
+        pw_work_v(p, v, ntiles_all, b, tt, mt);
+        m0 = mt * BM; t0 = tt * PW_BN;
+        rX = make_rsrc(reinterpret_cast<const char*>(p.X) + (size_t)b * Kx * TxX * EX, (PW_ABLATE & 1) ? 0u : (unsigned)Kx * TxX * EX);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) voA[i] = ((m0 + ((tid + NT * i) >> 3)) * K + ((tid + NT * i) & 7) * 8) * 2;
+#pragma unroll
+        for (int e = 0; e < KPT; ++e) voX[e] = ((KPT * b_kg + e) * TxX + t0 + b_tq) * EX;
+    };
 
     // NST register stages of global loads in flight: with two, the loads of tile k+2 are issued
     // before the MFMA block of tile k and first used during the MFMA block of tile k+1.  The two-tensor prologue
@@ -311,12 +329,15 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     };
 
     f32x16 acc[2][2];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
 
     const int nk = (PW_ABLATE & 16) ? 0 : (K + BF_BK - 1) / BF_BK;      // bit 4 (timing-only): no main loop
     const int lr = lane & 31, lh = lane >> 5;
@@ -356,6 +377,11 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         }                                                                                                     \
         asm volatile("" : "+v"(ra[SG][0]), "+v"(ra[SG][1]), "+v"(ra[SG][2]), "+v"(ra[SG][3]));                \
     } while (0)
+    if constexpr (PERSIST) {               // first tile: k-tiles 0 and 1 (later tiles: requested before the previous epilogue)
+        load_tiles(0, S0{});
+        if (nk > 1) load_tiles(BF_BK, S1{});
+    }
+    for (;;) {
     if constexpr (NST == 1) {
         load_tiles(0, S0{});
         load_coefs(0);
@@ -376,9 +402,11 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         }
     } else {
         // tile t lives in register stage t&1 and LDS buffer t&1
-        load_tiles(0, S0{});
-        load_coefs(0);
-        if (nk > 1) load_tiles(BF_BK, S1{});
+        if constexpr (!PERSIST) {
+            load_tiles(0, S0{});
+            load_coefs(0);
+            if (nk > 1) load_tiles(BF_BK, S1{});
+        }
         store_tiles(0, S0{});
         __syncthreads();
         // Steady state: the tile to be stored was loaded a whole iteration ago, so its transform + LDS writes are
@@ -456,7 +484,32 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         if (s == 12345.678f) p.Y[0] = s;
         return;
     }
-    pw_epilogue_lds<EPI, BM, IO>(p, acc, reinterpret_cast<float*>(smem), b, m0, t0, tt, wm, wn, tid);
+    if constexpr (PERSIST) {
+        const int eb_ = b, em0 = m0, et0 = t0, ett = tt;
+        const int vnext = vtile + (int)gridDim.x;
+        const bool more_tiles = vnext < ntiles_all;               // block-uniform
+        // this tile's R / coefficient loads first, the next tile's first k-tiles queued behind them, then the epilogue proper
+        const bool lean = pw_tile_is_full(p, BM, em0, et0);
+        PwEpilogueFull<EPI, BM, IO> ef;
+        if (lean) ef.issue(p, eb_, em0, et0, tid);
+        if (more_tiles) {
+            retarget(vnext);
+            load_tiles(0, S0{});
+            if (nk > 1) load_tiles(BF_BK, S1{});
+        }
+        if (lean) ef.finish(p, acc, reinterpret_cast<float*>(smem), eb_, ett, wm, wn, tid);
+        else pw_epilogue_lds<EPI, BM, IO>(p, acc, reinterpret_cast<float*>(smem), eb_, em0, et0, ett, wm, wn, tid);
+        if (more_tiles) {
+            vtile = vnext;
+            zero_acc();
+            __syncthreads();               // the epilogue's reads of the parked tile are done: the stage buffers are free again
+            continue;
+        }
+    } else {
+        pw_epilogue_lds<EPI, BM, IO>(p, acc, reinterpret_cast<float*>(smem), b, m0, t0, tt, wm, wn, tid);
+    }
+    break;
+    }
 }
 
 // Backward-weight, bf16: contraction index is t; both operands are read as 8 consecutive t
@@ -1180,6 +1233,23 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
         else hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP, 128, false, false, (IOV)>), grid, dim3(256), 0, st, pb);      \
         return true;                                                                                                            \
     }
+#if PW_PERSIST
+    // short-K GEMMs with several tiles per CU: persistent workgroups (grid = tiles / 2 or / 4 when that divides evenly)
+#define XP(XM, EP, IOV)                                                                                                         \
+    if (big && p.x_mode == XM && p.epi_mode == EP && p.io16 == (IOV) && p.K <= 512) {                                           \
+        const long nt_ = (long)pb.n_mtiles * p.n_ttiles * p.B;                                                                  \
+        const long per = (nt_ % 1024 == 0 && nt_ >= 1024) ? 4 : ((nt_ % 512 == 0 && nt_ >= 512) ? 2 : 1);                       \
+        if (per > 1) {                                                                                                          \
+            hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP, 256, false, false, (IOV), true>), dim3((unsigned)(nt_ / per)),  \
+                               dim3(512), 0, st, pb);                                                                           \
+            return true;                                                                                                        \
+        }                                                                                                                       \
+    }
+    XP(0, 1, PW_IO_Y)          // expand forward: 61 -> 56.5 us at 2048 x 512 x (32 x 512)
+    // (the project backward-data GEMM, same shape, does not fit: its mask epilogue keeps 96 registers of R / coefficient /
+    //  statistics values beside the two staging stages -- 59 VGPRs spilled, 69 -> 118 us)
+#undef XP
+#endif
     X(0, 1, PW_IO_Y)                      // expand forward: a1 out
     X(1, 1, PW_IO_X)                      // project forward: a2 in (BN2 + ReLU6 on load)
     X(0, 4, PW_IO_R)                      // project backward-data: ReLU6 mask / BN2-backward sums from a2

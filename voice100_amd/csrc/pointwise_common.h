@@ -42,6 +42,9 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #else
 #define PW_EPI_UNROLL 4
 #endif
+#ifndef PW_PERSIST
+#define PW_PERSIST 1         /* persistent workgroups with cross-tile prefetch for the short-K training GEMMs */
+#endif
 #ifndef PW_WG_WIDE
 #define PW_WG_WIDE 1         /* 256 x 128 backward-weight tiles for the act16 combinations (0: the 128 x 128 kernel everywhere) */
 #endif
@@ -223,123 +226,141 @@ __device__ __forceinline__ float half_wave_sum_dpp(float v) {
 // memory.  Here: buffer addressing (one per-lane offset, the row advance is a scalar), no masks, R / coefficient loads of
 // all 16 passes in flight before the accumulators go through LDS, statistics written once at the end.
 template <int EPI_, int BM, int IO>
-__device__ __forceinline__ void pw_epilogue_full(const PwParams& p, f32x16 (&acc)[2][2], float* ct, int b, int m0, int t0, int tt,
-                                                 int wm, int wn, int tid) {
-    constexpr bool YB = (IO & PW_IO_Y) != 0, RB = (IO & PW_IO_R) != 0;
+struct PwEpilogueFull {
+    static constexpr bool YB = (IO & PW_IO_Y) != 0, RB = (IO & PW_IO_R) != 0;
     typedef unsigned int epi_u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int epi_u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int epi = EPI_;
-    constexpr bool do_stats = (epi == PW_EPI_STATS || epi == PW_EPI_MASK_STATS);
-    constexpr bool use_e = (epi == PW_EPI_AFFINE_RELU6 || epi == PW_EPI_AFFINE_RES || epi == PW_EPI_MASK_STATS);
-    constexpr bool may_r = (epi == PW_EPI_MASK_STATS || epi == PW_EPI_ADD || epi == PW_EPI_AFFINE_RES);
-    const bool use_r = (epi == PW_EPI_MASK_STATS || epi == PW_EPI_ADD || (epi == PW_EPI_AFFINE_RES && p.R != nullptr));
-    const int P16 = pw_pitch16(p.T);
-    const int lane = tid & 63, col = lane & 31, half = lane >> 5, wave = tid >> 6;
-    constexpr int RPP = BM / 16;             // rows per pass: one row per half-wave
-    const int mrow = m0 + wave * 2 + half;   // this lane's row in pass 0
-    const int PY = YB ? P16 : p.T, PR = RB ? P16 : p.T;
-    constexpr int EY = YB ? 2 : 4, ER = RB ? 2 : 4;
-    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)((size_t)p.B * p.M * PY * EY), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_r ? p.R : p.X), 0,
-                                                                       use_r ? (int)((size_t)p.B * p.M * PR * ER) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rEa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_e ? p.ea : p.X), 0, use_e ? p.M * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rEb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_e ? p.eb : p.X), 0, use_e ? p.M * 4 : 0, 0x00020000);
-    const int voY = ((b * p.M + mrow) * PY + t0 + col * 4) * EY;
-    const int voR = ((b * p.M + mrow) * PR + t0 + col * 4) * ER;
-    const int stepY = RPP * PY * EY, stepR = RPP * PR * ER;
+    static constexpr int epi = EPI_;
+    static constexpr bool do_stats = (epi == PW_EPI_STATS || epi == PW_EPI_MASK_STATS);
+    static constexpr bool use_e = (epi == PW_EPI_AFFINE_RELU6 || epi == PW_EPI_AFFINE_RES || epi == PW_EPI_MASK_STATS);
+    static constexpr bool may_r = (epi == PW_EPI_MASK_STATS || epi == PW_EPI_ADD || epi == PW_EPI_AFFINE_RES);
+    static constexpr int RPP = BM / 16;             // rows per pass: one row per half-wave
+    static constexpr int EY = YB ? 2 : 4, ER = RB ? 2 : 4;
     using RReg = std::conditional_t<RB, epi_u32x2, epi_u32x4>;
     RReg rpre[may_r ? 16 : 1];
     float eav[use_e ? 16 : 1], ebv[use_e ? 16 : 1];
-    if constexpr (may_r) {
-        if (use_r) {
-#pragma unroll
-            for (int pass = 0; pass < 16; ++pass) {
-                if constexpr (RB) rpre[pass] = __builtin_amdgcn_raw_buffer_load_b64(rR, voR, pass * stepR, 0);
-                else rpre[pass] = __builtin_amdgcn_raw_buffer_load_b128(rR, voR, pass * stepR, 0);
-            }
-        }
-    }
-    if constexpr (use_e) {
-#pragma unroll
-        for (int pass = 0; pass < 16; ++pass) {
-            eav[pass] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rEa, mrow * 4, pass * RPP * 4, 0));
-            ebv[pass] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rEb, mrow * 4, pass * RPP * 4, 0));
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                ct[row * 128 + wn * 64 + j * 32 + col] = acc[i][j][r];
-            }
-    __syncthreads();
-    float sv0[do_stats ? 16 : 1], sv1[do_stats ? 16 : 1];
-    const float* crow = ct + (wave * 2 + half) * 128 + col * 4;
-#pragma unroll
-    for (int pass = 0; pass < 16; ++pass) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(crow + pass * RPP * 128);
-        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+    bool use_r;
+    int voY, stepY, mrow;
+
+    // part 1: request the R tile and the per-row coefficients of all 16 passes
+    __device__ __forceinline__ void issue(const PwParams& p, int b, int m0, int t0, int tid) {
+        use_r = (epi == PW_EPI_MASK_STATS || epi == PW_EPI_ADD || (epi == PW_EPI_AFFINE_RES && p.R != nullptr));
+        const int P16 = pw_pitch16(p.T);
+        const int lane = tid & 63, col = lane & 31, half = lane >> 5, wave = tid >> 6;
+        mrow = m0 + wave * 2 + half;            // this lane's row in pass 0
+        const int PY = YB ? P16 : p.T, PR = RB ? P16 : p.T;
+        const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_r ? p.R : p.X), 0,
+                                                                           use_r ? (int)((size_t)p.B * p.M * PR * ER) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rEa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_e ? p.ea : p.X), 0, use_e ? p.M * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rEb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_e ? p.eb : p.X), 0, use_e ? p.M * 4 : 0, 0x00020000);
+        voY = ((b * p.M + mrow) * PY + t0 + col * 4) * EY;
+        stepY = RPP * PY * EY;
+        const int voR = ((b * p.M + mrow) * PR + t0 + col * 4) * ER;
+        const int stepR = RPP * PR * ER;
         if constexpr (may_r) {
             if (use_r) {
-                if constexpr (RB) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rv[e] = pw_bf16_at(rpre[pass], e);
-                } else {
-                    rv = __builtin_bit_cast(f32x4, rpre[pass]);
+                for (int pass = 0; pass < 16; ++pass) {
+                    if constexpr (RB) rpre[pass] = __builtin_amdgcn_raw_buffer_load_b64(rR, voR, pass * stepR, 0);
+                    else rpre[pass] = __builtin_amdgcn_raw_buffer_load_b128(rR, voR, pass * stepR, 0);
                 }
             }
         }
-        f32x4 v;
-        float s0 = 0.f, s1 = 0.f;
+        if constexpr (use_e) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = a[e];
-            if constexpr (epi == PW_EPI_STATS) {
-                s0 += x; s1 = fmaf(x, x, s1);
-            } else if constexpr (epi == PW_EPI_AFFINE_RELU6) {
-                x = relu6f(fmaf(x, eav[pass], ebv[pass]));
-            } else if constexpr (epi == PW_EPI_AFFINE_RES) {
-                x = fmaf(x, eav[pass], ebv[pass]) + rv[e];
-            } else if constexpr (epi == PW_EPI_MASK_STATS) {
-                const float pre = fmaf(rv[e], eav[pass], ebv[pass]);
-                x = (pre > 0.f && pre < 6.f) ? x : 0.f;
-                s0 += x; s1 = fmaf(x, rv[e], s1);
-            } else if constexpr (epi == PW_EPI_ADD) {
-                x += rv[e];
+            for (int pass = 0; pass < 16; ++pass) {
+                eav[pass] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rEa, mrow * 4, pass * RPP * 4, 0));
+                ebv[pass] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rEb, mrow * 4, pass * RPP * 4, 0));
             }
-            v[e] = x;
         }
-        if constexpr (!(PW_ABLATE & 4)) {
-            if constexpr (YB) {
-                const epi_u32x2 o2 = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                __builtin_amdgcn_raw_buffer_store_b64(o2, rY, voY, pass * stepY, 0);
-            } else {
-                // NOT a buffer store: `buffer_store_dwordx4 v[96:99], v65, s[0:3], s4 offen` directly followed by a VALU write of
-                // v99 stored the NEW v99 on gfx950 (sporadic wrong 4th elements) -- hipcc's hazard recognizer assumes that a
-                // > 64-bit MUBUF store with an SGPR soffset needs no wait states before its data registers are overwritten.
-                // For FLAT / global stores it pads.
-                *reinterpret_cast<f32x4u*>(reinterpret_cast<char*>(p.Y) + (size_t)pass * stepY + (unsigned)voY) = v;
+    }
+
+    // part 2: accumulators through LDS, 16 row passes, statistics
+    __device__ __forceinline__ void finish(const PwParams& p, f32x16 (&acc)[2][2], float* ct, int b, int tt, int wm, int wn, int tid) {
+        const int P16 = pw_pitch16(p.T);
+        const int lane = tid & 63, col = lane & 31, half = lane >> 5, wave = tid >> 6;
+        const int PY = YB ? P16 : p.T;
+        const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)((size_t)p.B * p.M * PY * EY), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    ct[row * 128 + wn * 64 + j * 32 + col] = acc[i][j][r];
+                }
+        __syncthreads();
+        float sv0[do_stats ? 16 : 1], sv1[do_stats ? 16 : 1];
+        const float* crow = ct + (wave * 2 + half) * 128 + col * 4;
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(crow + pass * RPP * 128);
+            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (may_r) {
+                if (use_r) {
+                    if constexpr (RB) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rv[e] = pw_bf16_at(rpre[pass], e);
+                    } else {
+                        rv = __builtin_bit_cast(f32x4, rpre[pass]);
+                    }
+                }
+            }
+            f32x4 v;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = a[e];
+                if constexpr (epi == PW_EPI_STATS) {
+                    s0 += x; s1 = fmaf(x, x, s1);
+                } else if constexpr (epi == PW_EPI_AFFINE_RELU6) {
+                    x = relu6f(fmaf(x, eav[pass], ebv[pass]));
+                } else if constexpr (epi == PW_EPI_AFFINE_RES) {
+                    x = fmaf(x, eav[pass], ebv[pass]) + rv[e];
+                } else if constexpr (epi == PW_EPI_MASK_STATS) {
+                    const float pre = fmaf(rv[e], eav[pass], ebv[pass]);
+                    x = (pre > 0.f && pre < 6.f) ? x : 0.f;
+                    s0 += x; s1 = fmaf(x, rv[e], s1);
+                } else if constexpr (epi == PW_EPI_ADD) {
+                    x += rv[e];
+                }
+                v[e] = x;
+            }
+            if constexpr (!(PW_ABLATE & 4)) {
+                if constexpr (YB) {
+                    const epi_u32x2 o2 = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(o2, rY, voY, pass * stepY, 0);
+                } else {
+                    // NOT a buffer store: `buffer_store_dwordx4 v[96:99], v65, s[0:3], s4 offen` directly followed by a VALU write of
+                    // v99 stored the NEW v99 on gfx950 (sporadic wrong 4th elements) -- hipcc's hazard recognizer assumes that a
+                    // > 64-bit MUBUF store with an SGPR soffset needs no wait states before its data registers are overwritten.
+                    // For FLAT / global stores it pads.
+                    *reinterpret_cast<f32x4u*>(reinterpret_cast<char*>(p.Y) + (size_t)pass * stepY + (unsigned)voY) = v;
+                }
+            }
+            if constexpr (do_stats) {
+                sv0[pass] = half_wave_sum_dpp(s0);
+                sv1[pass] = half_wave_sum_dpp(s1);
             }
         }
         if constexpr (do_stats) {
-            sv0[pass] = half_wave_sum_dpp(s0);
-            sv1[pass] = half_wave_sum_dpp(s1);
-        }
-    }
-    if constexpr (do_stats) {
-        if (col == 31) {
-            const size_t part = (size_t)b * p.n_ttiles + tt;
-            float* sp = p.stats + (part * p.M + mrow) * 2;
+            if (col == 31) {
+                const size_t part = (size_t)b * p.n_ttiles + tt;
+                float* sp = p.stats + (part * p.M + mrow) * 2;
 #pragma unroll
-            for (int pass = 0; pass < 16; ++pass) {
-                const epi_u32x2 o2 = {__builtin_bit_cast(unsigned, sv0[pass]), __builtin_bit_cast(unsigned, sv1[pass])};
-                *reinterpret_cast<epi_u32x2*>(sp + pass * RPP * 2) = o2;
+                for (int pass = 0; pass < 16; ++pass) {
+                    const epi_u32x2 o2 = {__builtin_bit_cast(unsigned, sv0[pass]), __builtin_bit_cast(unsigned, sv1[pass])};
+                    *reinterpret_cast<epi_u32x2*>(sp + pass * RPP * 2) = o2;
+                }
             }
         }
     }
+};
+
+// block-uniform: does the tile at (m0, t0) take the lean epilogue?
+__device__ __forceinline__ bool pw_tile_is_full(const PwParams& p, int BM, int m0, int t0) {
+    return PW_EPI_FAST != 0 && t0 + 128 <= p.T && m0 + BM <= p.M && p.bias == nullptr;
 }
 
 // Epilogue through LDS: the 128x128 fp32 accumulator tile is parked in the (now idle) 64 KB staging buffers,
@@ -353,11 +374,11 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
     typedef unsigned int epi_u32x4 __attribute__((ext_vector_type(4)));
     const int P16 = pw_pitch16(p.T);
     constexpr int epi = EPI_;
-    if constexpr (PW_EPI_FAST != 0) {
-        if (t0 + 128 <= p.T && m0 + BM <= p.M && p.bias == nullptr) {       // block-uniform
-            pw_epilogue_full<EPI_, BM, IO>(p, acc, ct, b, m0, t0, tt, wm, wn, tid);
-            return;
-        }
+    if (pw_tile_is_full(p, BM, m0, t0)) {
+        PwEpilogueFull<EPI_, BM, IO> ef;
+        ef.issue(p, b, m0, t0, tid);
+        ef.finish(p, acc, ct, b, tt, wm, wn, tid);
+        return;
     }
     const int lane = tid & 63, col = lane & 31, half = lane >> 5;
     constexpr bool do_stats = (epi == PW_EPI_STATS || epi == PW_EPI_MASK_STATS);
@@ -474,6 +495,16 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
 // work item -> (b, t-tile, m-tile), m-tile fastest
 __device__ __forceinline__ void pw_work(const PwParams& p, int& b, int& tt, int& mt) {
     const int w = xcd_remap(blockIdx.x, gridDim.x);
+    mt = w % p.n_mtiles;
+    const int rest = w / p.n_mtiles;
+    tt = rest % p.n_ttiles;
+    b = rest / p.n_ttiles;
+}
+
+// the same for a virtual tile index v of `total` (persistent workgroups: v = blockIdx.x + i * gridDim.x; gridDim.x % 8 == 0
+// keeps every tile of a workgroup on the workgroup's own XCD)
+__device__ __forceinline__ void pw_work_v(const PwParams& p, int v, int total, int& b, int& tt, int& mt) {
+    const int w = xcd_remap(v, total);
     mt = w % p.n_mtiles;
     const int rest = w / p.n_mtiles;
     tt = rest % p.n_ttiles;
