@@ -17,14 +17,24 @@ T = int(sys.argv[sys.argv.index("--T") + 1]) if "--T" in sys.argv else 1024
 
 
 def load(name):
-    """{kernel: {counter: mean value per dispatch}} (the warm-up dispatches of the micro-benchmark are identical launches)"""
+    """{kernel: {counter: mean value per dispatch}} (the warm-up dispatches of the micro-benchmark are identical launches);
+    "_dur_ns" = mean dispatch duration, "_per_grid" = {grid size: {counter: mean}} (one kernel at several problem sizes)"""
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
     path = os.path.join(d, name + ".csv")
     if not os.path.exists(path):
         return {}
     for r in csv.DictReader(open(path)):
-        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+        k = r["Kernel_Name"]
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        acc[k]["_dur_ns"].append(dur)
+        per[k][r["Grid_Size"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        per[k][r["Grid_Size"]]["_dur_ns"].append(dur)
+    out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+    for k in out:
+        out[k]["_per_grid"] = {g: {c: sum(v) / len(v) for c, v in cs.items()} for g, cs in per[k].items()}
+    return out
 
 
 sq, fe, wr = load("sq"), load("fetch"), load("write")
@@ -72,3 +82,14 @@ for n, c in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
     print(f"{n[:86]:86s} wait_any {100 * c.get('SQ_WAIT_ANY', 0) / wc:5.1f}%  wait_inst {100 * c.get('SQ_WAIT_INST_ANY', 0) / wc:5.1f}%  "
           f"active {100 * c.get('SQ_ACTIVE_INST_ANY', 0) / wc:5.1f}%  lds_conflict/wave_cycles {100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / wc:5.2f}%  "
           f"mfma_busy/sq_busy {c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / busy if busy else 0:5.2f}")
+
+print()
+print("Matrix-pipe utilisation of the GEMM kernels per problem size: SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration x 2.4 GHz x 1024 SIMDs)")
+print("(busy cycles = 32 per v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md; the duration is the PMC pass's own dispatch time, a few % longer than an unprofiled launch)")
+for n, c in sorted(sq.items()):
+    if not any(s_ in n for s_ in ("pw_gemm", "pw_wgrad")):
+        continue
+    for g, cc in sorted(c.get("_per_grid", {}).items(), key=lambda kv: int(kv[0])):
+        busy, dur = cc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), cc.get("_dur_ns", 0.0)
+        if busy and dur:
+            print(f"{n[:80]:80s} grid {int(g):8d}: {dur / 1e3:7.1f} us  mfma busy {100 * busy / (dur * 2.4 * 1024):5.1f} %")

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s += acc[i][j][r];
         if (s == 12345.678f) p.Y[0] = s;
-        return;
+        if constexpr (!PERSIST) return;
     }
     if constexpr (PERSIST) {
         const int eb_ = b, em0 = m0, et0 = t0, ett = tt;
@@ -491,14 +491,16 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         // this tile's R / coefficient loads first, the next tile's first k-tiles queued behind them, then the epilogue proper
         const bool lean = pw_tile_is_full(p, BM, em0, et0);
         PwEpilogueFull<EPI, BM, IO> ef;
-        if (lean) ef.issue(p, eb_, em0, et0, tid);
+        if (lean && !(PW_ABLATE & 8)) ef.issue(p, eb_, em0, et0, tid);
         if (more_tiles) {
             retarget(vnext);
             load_tiles(0, S0{});
             if (nk > 1) load_tiles(BF_BK, S1{});
         }
-        if (lean) ef.finish(p, acc, reinterpret_cast<float*>(smem), eb_, ett, wm, wn, tid);
-        else pw_epilogue_lds<EPI, BM, IO>(p, acc, reinterpret_cast<float*>(smem), eb_, em0, et0, ett, wm, wn, tid);
+        if constexpr (!(PW_ABLATE & 8)) {
+            if (lean) ef.finish(p, acc, reinterpret_cast<float*>(smem), eb_, ett, wm, wn, tid);
+            else pw_epilogue_lds<EPI, BM, IO>(p, acc, reinterpret_cast<float*>(smem), eb_, em0, et0, ett, wm, wn, tid);
+        }
         if (more_tiles) {
             vtile = vnext;
             zero_acc();
