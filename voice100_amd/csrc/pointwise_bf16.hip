@@ -1252,6 +1252,16 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     //  statistics values beside the two staging stages -- 59 VGPRs spilled, 69 -> 118 us)
 #undef XP
 #endif
+    // project backward-data at K <= 256 (4 k-tiles per block tile: prologue and epilogue are most of a tile's time): 128-row tiles,
+    // two workgroups per CU, so one's epilogue runs under the other's main loop (30.7 -> 27.5 us at 1024 x 256 x (32 x 512); the
+    // expand forward GEMM of that shape loses, 23 -> 30 us: its fp32 X operand is then staged twice as often)
+    if (p.x_mode == 0 && p.epi_mode == 4 && p.io16 == (PW_IO_X | PW_IO_R | PW_IO_Y) && p.K <= 256 && big) {
+        PwParams ps = p;
+        ps.n_mtiles = (p.M + 127) / 128;
+        hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<0, 4, 128, false, false, (PW_IO_X | PW_IO_R | PW_IO_Y)>),
+                           dim3((unsigned)((long)ps.n_mtiles * p.n_ttiles * p.B)), dim3(256), 0, st, ps);
+        return true;
+    }
     X(0, 1, PW_IO_Y)                      // expand forward: a1 out
     X(1, 1, PW_IO_X)                      // project forward: a2 in (BN2 + ReLU6 on load)
     X(0, 4, PW_IO_R)                      // project backward-data: ReLU6 mask / BN2-backward sums from a2
