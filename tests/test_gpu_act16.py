@@ -135,6 +135,53 @@ def test_wgrad_io_variants(cuda, B, M, K, T):
     assert rel_err(run("v100_pw_wgrad_io", g16, None, 0, x16, 1, G_ | WX), run("v100_pw_wgrad", gr, None, 0, xr, 1)) < 1e-6
 
 
+def test_io_gemms_repeatable(cuda):
+    """The persistent expand GEMM (cross-tile prefetch), the 256-row backward-weight kernels (two register stages) and the lean
+    epilogue are re-run on the same inputs: every run must reproduce the first bit for bit (a missing barrier or an early LDS
+    read shows up as rare differing tiles)."""
+    N = _native()
+    g = torch.Generator().manual_seed(77)
+    B, C, hid, T = 32, 256, 1024, 512
+    P = pitch(T)
+    x = torch.randn(B, C, T, generator=g).to(cuda)
+    bf = lambda *shape: (torch.randn(*shape, generator=g) * 0.5).to(cuda).to(torch.bfloat16)
+    a1, a2, dz1, da3 = bf(B, hid, P), bf(B, hid, P), bf(B, hid, P), bf(B, C, P)
+    W1 = (torch.randn(hid, C, generator=g) / C ** 0.5).to(cuda).to(torch.bfloat16)
+    W2t = (torch.randn(hid, C, generator=g) / hid ** 0.5).to(cuda).to(torch.bfloat16)
+    ch = [torch.randn(hid, generator=g).to(cuda) for _ in range(3)]
+    parts = N.helper("v100_pw_num_parts", B, T)
+    S1, S2 = N.helper("v100_pw_wgrad_splits", B, hid, C), N.helper("v100_pw_wgrad_splits", B, C, hid)
+
+    def expand_fwd():
+        y = torch.empty(B, hid, P, dtype=torch.bfloat16, device=cuda)
+        st = torch.empty(parts, hid, 2, device=cuda)
+        N.call("v100_pw_gemm_io", W1, x, None, None, None, None, 0, y, None, None, None, 1, st, B, hid, C, T, Y)
+        return y[:, :, :T].clone(), st
+
+    def project_bwdd():
+        y = torch.empty(B, hid, P, dtype=torch.bfloat16, device=cuda)
+        st = torch.empty(parts, hid, 2, device=cuda)
+        N.call("v100_pw_gemm_io", W2t, da3, None, None, None, None, 0, y, ch[0], ch[1], a2, 4, st, B, hid, C, T, X | R | Y)
+        return y[:, :, :T].clone(), st
+
+    def expand_wgrad():
+        part, dW = torch.empty(S1, hid, C, device=cuda), torch.empty(hid, C, device=cuda)
+        N.call("v100_pw_wgrad_io", dz1, a1, ch[0], ch[1], ch[2], 2, x, None, None, 0, part, dW, S1, B, hid, C, T, G_ | G2_)
+        return (dW,)
+
+    def project_wgrad():
+        part, dW = torch.empty(S2, C, hid, device=cuda), torch.empty(C, hid, device=cuda)
+        N.call("v100_pw_wgrad_io", da3, None, None, None, None, 0, a2, ch[0], ch[1], 1, part, dW, S2, B, C, hid, T, G_ | WX)
+        return (dW,)
+
+    for fn in (expand_fwd, project_bwdd, expand_wgrad, project_wgrad):
+        first = fn()
+        for _ in range(6):
+            again = fn()
+            for u, v in zip(first, again):
+                assert torch.equal(u, v), fn.__name__
+
+
 def _bf(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
