@@ -29,6 +29,7 @@
 // ((K+18) x 16 fp32) stays in the accumulators for all rows of the workgroup and its diagonals are summed once at the end.
 // K+15 over K more work than the K*T products needed, no extra HBM traffic, no K accumulators per lane.
 #pragma once
+#include <type_traits>
 
 typedef float dwm_f32x4 __attribute__((ext_vector_type(4)));
 typedef short dwm_bf16x8 __attribute__((ext_vector_type(8)));
@@ -90,9 +91,11 @@ __device__ __forceinline__ void dwm_split(float v, unsigned (&d)[3]) {
 // inline-asm statement -- its hazard recognizer pads the MFMA-result -> VALU-read wait states: common.h's pack_bf16 asm read
 // the accumulators too early here and stored stale registers)
 typedef __bf16 dwm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dwm_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned dwm_pack_rne(float lo, float hi) {
-    const dwm_bf16x2 v = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(unsigned, v);
+    // a VECTOR conversion: one v_cvt_pk_bf16_f32 (two scalar casts compile to two conversions and a v_perm)
+    const dwm_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, dwm_bf16x2));
 }
 // two digits (high halves of lo / hi) -> one dword of two bf16
 __device__ __forceinline__ unsigned dwm_pack(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
@@ -120,6 +123,10 @@ __device__ __forceinline__ typename DwmRun<B16>::type dwm_load_run(__amdgpu_buff
     if constexpr (B16) return __builtin_amdgcn_raw_buffer_load_b64(r, voff_elems < 0x20000000 ? voff_elems * 2 : 0x7ffffff0, (int)(row_elems * 2u), 0);
     else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_elems < 0x20000000 ? voff_elems * 4 : 0x7ffffff0, (int)(row_elems * 4u), 0));
 }
+
+#ifndef DWM_SINGLE
+#define DWM_SINGLE 1
+#endif
 
 template <int K, int IM, int OM, int NT, bool WG = false, int IO = 0>
 __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p) {
@@ -224,6 +231,26 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
             const bool ok = ia >= 0 && ia < Tin && EPL * (lane + 64 * v) < G_::IMG;
             vo[v] = ok ? ia : 0x7ffffff0;                      // element offset inside the row
         }
+        // Rows that fit ONE tile (T <= 512: the benchmark's T' = 512) with all streams bf16: a lane stages exactly one run, the run
+        // at positions 8 * lane ... + 7, and the image's zero padding on both sides of the row is written once per wave instead of
+        // being re-derived from out-of-range loads on every row (half the staging instructions, no bounds selects).
+        // Forward only: A/B on one box, 9-layer totals -- forward 167.4 -> 160.0 us, the fused backward (two input streams, xin images;
+        // its own staging is not what bounds it) 347-358 -> 354-372 us.
+        const bool single = DWM_SINGLE && W8 && !WG && ntiles == 1 && Tin <= TILE && (Tin & 7) == 0;        // kernel-uniform
+        const int lpad = -in0a;
+        if constexpr (W8) {
+            if (single) {
+                for (int c8 = lane; c8 < IMGP / 8; c8 += 64)
+                    if (c8 < lpad / 8 || c8 >= (lpad + Tin) / 8) {
+#pragma unroll
+                        for (int t = 0; t < NX; ++t) *reinterpret_cast<dwm_u32x4*>(img + t * IMGP + 8 * c8) = dwm_u32x4{0u, 0u, 0u, 0u};
+                    }
+                asm volatile("" ::: "memory");
+                vo[0] = 8 * lane < Tin ? 8 * lane : 0x7ffffff0;
+#pragma unroll
+                for (int v = 1; v < NVL; ++v) vo[v] = 0x7ffffff0;
+            }
+        }
         auto issue_loads = [&](unsigned row) {
 #pragma unroll
             for (int v = 0; v < NVL; ++v) {
@@ -255,7 +282,20 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
                 }
             }
             // ---- stage: transform, zero outside the row, split into bf16 digits, 8- / 16-byte LDS stores ----
-            if constexpr (W8) {
+            if (W8 && single) {
+                if constexpr (W8) {
+                    float vals[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if constexpr (IM == DW_IN_AFFINE_RELU6) vals[e] = relu6f(fmaf(dwm_elem8(raw8[0], e), ca, cb));
+                        else if constexpr (IM == DW_IN_AFFINE2) vals[e] = fmaf(dwm_elem8(raw8[0], e), ca, fmaf(dwm_elem8(raw8b[0], e), cb, cc));
+                        else vals[e] = dwm_elem8(raw8[0], e);
+                    }
+                    const dwm_u32x4 w4 = {dwm_pack_rne(vals[0], vals[1]), dwm_pack_rne(vals[2], vals[3]), dwm_pack_rne(vals[4], vals[5]),
+                                          dwm_pack_rne(vals[6], vals[7])};
+                    if (8 * lane < Tin) *reinterpret_cast<dwm_u32x4*>(img + lpad + 8 * lane) = w4;     // the padding stays zero
+                }
+            } else if constexpr (W8) {
 #pragma unroll
                 for (int v = 0; v < NV8; ++v) {
                     const int ia = in0a + 8 * (lane + 64 * v);
@@ -361,23 +401,27 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
                         bfr[t] = *reinterpret_cast<const dwm_bf16x8*>(bsrc + t * IMGP + 256 * sub + 32 * s);
                     acc = dwm_mfma_digits<NT, NX>(afr[s], bfr, acc);
                 }
-                // ---- epilogue: 4 consecutive outputs per lane ----
+                // ---- epilogue: 4 consecutive outputs per lane (FULL: the 256 outputs of this half all lie inside the row) ----
                 float outv[4];
+                auto epi = [&](auto full_t) {
+                    constexpr bool FULL = decltype(full_t)::value;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool valid = t0 + r < Tout;
-                    float yv = acc[r];
-                    if constexpr (OM == DW_OUT_RAW_STATS) {
-                        if (valid) { s0 += yv; s1 = fmaf(yv, yv, s1); }
-                    } else if constexpr (OM == DW_OUT_AFFINE_RELU6) {
-                        yv = relu6f(fmaf(yv, oa, ob));
-                    } else if constexpr (OM == DW_OUT_MASK_STATS) {
-                        const float pre = fmaf(auxv[sub][r], oa, ob);
-                        yv = (pre > 0.f && pre < 6.f) ? yv : 0.f;
-                        if (valid) { s0 += yv; s1 = fmaf(yv, auxv[sub][r], s1); }
+                    for (int r = 0; r < 4; ++r) {
+                        const bool valid = FULL || t0 + r < Tout;
+                        float yv = acc[r];
+                        if constexpr (OM == DW_OUT_RAW_STATS) {
+                            if (valid) { s0 += yv; s1 = fmaf(yv, yv, s1); }
+                        } else if constexpr (OM == DW_OUT_AFFINE_RELU6) {
+                            yv = relu6f(fmaf(yv, oa, ob));
+                        } else if constexpr (OM == DW_OUT_MASK_STATS) {
+                            const float pre = fmaf(auxv[sub][r], oa, ob);
+                            yv = (pre > 0.f && pre < 6.f) ? yv : 0.f;
+                            if (valid) { s0 += yv; s1 = fmaf(yv, auxv[sub][r], s1); }
+                        }
+                        outv[r] = yv;
                     }
-                    outv[r] = yv;
-                }
+                };
+                if (out0 + 256 * sub + 256 <= Tout) epi(std::true_type{}); else epi(std::false_type{});
                 if constexpr (YB) {
                     // 4 bf16 = one 8-byte store (the pitch keeps it aligned; samples past Tout land in the row's padding)
                     if (t0 < Tout) {
