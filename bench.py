@@ -31,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate ~6300
+TRACE_FILE = os.path.join(ROOT, "profiles", "r02k_step_breakdown.txt")   # tools/trace_step.py over a rocprofv3 kernel trace of this command
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_dw_fwd_pmc.json")   # HBM bytes / algorithmic bytes of the depthwise forward kernels (rocprofv3 PMC passes)
 B_PER_GPU, T_FRAMES, N_MEL, VOCAB, TEXT_LEN = 32, 1024, 64, 29, 100
 
@@ -190,6 +191,15 @@ def other_configs(device, N, F_):
     return out
 
 
+def _launches_per_step():
+    """Kernel launches per training step, from the committed kernel trace of this command (counting them live would need a profiler)."""
+    try:
+        first = open(TRACE_FILE).readline()
+        return {"value": int(first.split(" launches/step")[0].split()[-1]), "source": "profiles/" + os.path.basename(TRACE_FILE)}
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,6 +353,7 @@ def main():
             "loss": round(float(loss), 4),
             # host time to enqueue a step (the loop without the final synchronise): the step is GPU-bound while this stays below ms_per_step
             "host_enqueue_ms_per_step": round(host_loop / args.steps * 1e3, 3),
+            "launches_per_step": _launches_per_step(),
             "roofline": roof,
             "kernel_ms_per_step": kt_all,
         }
