@@ -5,6 +5,7 @@
 // This replaces ~12 (forward) / ~20 (backward) Python->C crossings per block with one.
 #include "common.h"
 #include "../../include/voice100_hip.h"
+#include "depthwise_common.h"   // DwFin: BatchNorm finalisation inside the depthwise kernels
 
 namespace {
 struct Carver {
@@ -30,8 +31,7 @@ const float kMom = 0.1f, kEps = 1e-5f;
 // and its BatchNorm-backward gradient da3 (workspace).  Statistics and every accumulation stay fp32; only the stored copies are rounded.
 enum { IR_B, IR_CIN, IR_HID, IR_COUT, IR_T, IR_K, IR_STRIDE, IR_RES, IR_BF16, IR_PREPPED, IR_ACT16, IR_NSHAPE };
 static inline int pitch16(int T) { return (T + 7) & ~7; }
-enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8, WG_IO_G = 1, WG_IO_G2 = 2, WG_IO_X = 4, DW_IO_X = 1, DW_IO_X2 = 2, DW_IO_AUX = 4,
-       DW_IO_Y = 8 };
+enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8, WG_IO_G = 1, WG_IO_G2 = 2, WG_IO_X = 4 };   // DW_IO_*: depthwise_common.h
 
 // 1 when a block of this shape can run with act16 != 0 (stride 1, a depthwise kernel size with an MFMA kernel, bf16 operands,
 // tensors addressable by the buffer-descriptor kernels)
@@ -117,9 +117,15 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
         CK(v100_pw_gemm_io(w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, PW_IO_Y, stream));
         CK(v100_bn_finalize_train(st, parts1, (long long)B * T, (const float*)P[2], (const float*)P[3], (float*)P[4], (float*)P[5], (long long*)P[6],
                                   kMom, kEps, s1, t1, m1, r1, hid, stream));
-        CK(v100_dwconv_fwd_train_io(a1, wd, s1, t1, a2, st, G, B, hid, T, K, DW_IO_X | DW_IO_Y, stream));
-        CK(v100_bn_finalize_train(st, G, (long long)B * T2, (const float*)P[8], (const float*)P[9], (float*)P[10], (float*)P[11], (long long*)P[12],
-                                  kMom, kEps, s2, t2, m2, r2, hid, stream));
+        if (G == 1) {          // the depthwise kernel finalises BatchNorm 2 itself (its workgroup owns the channel's sums)
+            const DwFin fin{1, (double)B * T2, (const float*)P[8], (const float*)P[9], nullptr, s2, t2, nullptr, m2, r2,
+                            (float*)P[10], (float*)P[11], (long long*)P[12], kMom, kEps};
+            CK(dw_fwd_train_io_fin(a1, wd, s1, t1, a2, st, G, B, hid, T, K, DW_IO_X | DW_IO_Y, fin, stream));
+        } else {
+            CK(v100_dwconv_fwd_train_io(a1, wd, s1, t1, a2, st, G, B, hid, T, K, DW_IO_X | DW_IO_Y, stream));
+            CK(v100_bn_finalize_train(st, G, (long long)B * T2, (const float*)P[8], (const float*)P[9], (float*)P[10], (float*)P[11], (long long*)P[12],
+                                      kMom, kEps, s2, t2, m2, r2, hid, stream));
+        }
         const bool a316 = sh[IR_ACT16] >= 3;          // the project output (saved for backward) as bf16 too
         CK(v100_pw_gemm_io(w3bf, a2, nullptr, s2, t2, nullptr, 1, a3, nullptr, nullptr, nullptr, 1, st, B, cout, hid, T2, PW_IO_X | (a316 ? PW_IO_Y : 0), stream));
         CK(v100_bn_finalize_train(st, parts3, (long long)B * T2, (const float*)P[14], (const float*)P[15], (float*)P[16], (float*)P[17], (long long*)P[18],
@@ -166,7 +172,7 @@ static size_t ir_bwd_carve(const int* sh, void* base, IrBwdWs& w) {
     m = (size_t)v100_pw_wgrad_splits(B, hid, cin) * hid * cin; if (m > n) n = m;
     m = (size_t)v100_dw_num_groups(B, hid) * hid * K; if (m > n) n = m;
     w.slab = c.take<float>(n);
-    w.pqr = c.take<float>((size_t)3 * (hid > cout ? hid : cout));
+    w.pqr = c.take<float>((size_t)6 * (hid > cout ? hid : cout));       // two coefficient sets (see DwFin in v100_ir_bwd)
     return c.used + 256;
 }
 
@@ -216,9 +222,19 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
                            PW_IO_R | (g16 ? PW_IO_Y : 0) | (a316 ? PW_IO_X : 0), stream));
         CK(v100_bn_bwd_finalize(w.part, parts16, (long long)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], hid, stream));
         const int G16 = v100_dw_num_groups(B, hid);
-        CK(v100_dwconv_bwd_io(w.dz2, a2, wd, pp, qq, rr, a1, s1, t1, w.dz1, w.part, w.slab, (float*)P[16], G16, B, hid, T, K,
-                              g16 ? (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y) : (DW_IO_X2 | DW_IO_AUX), stream));
-        CK(v100_bn_bwd_finalize(w.part, G16, (long long)B * T, g1, m1, r1, pp, qq, rr, (float*)P[14], (float*)P[15], hid, stream));
+        if (G16 == 1) {        // BatchNorm-1 backward coefficients by the depthwise backward kernel itself
+            // p / q / r are INPUTS of this kernel (BatchNorm-2 backward) and outputs of its finalisation (BatchNorm-1 backward):
+            // the outputs go to the second coefficient set
+            float *pp2 = w.pqr + 3 * mc, *qq2 = w.pqr + 4 * mc, *rr2 = w.pqr + 5 * mc;
+            const DwFin fin{2, (double)B * T, g1, m1, r1, pp2, qq2, rr2, (float*)P[14], (float*)P[15], nullptr, nullptr, nullptr, 0.f, 0.f};
+            CK(dw_bwd_io_fin(w.dz2, a2, wd, pp, qq, rr, a1, s1, t1, w.dz1, w.part, w.slab, (float*)P[16], G16, B, hid, T, K,
+                             g16 ? (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y) : (DW_IO_X2 | DW_IO_AUX), fin, stream));
+            pp = pp2; qq = qq2; rr = rr2;
+        } else {
+            CK(v100_dwconv_bwd_io(w.dz2, a2, wd, pp, qq, rr, a1, s1, t1, w.dz1, w.part, w.slab, (float*)P[16], G16, B, hid, T, K,
+                                  g16 ? (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y) : (DW_IO_X2 | DW_IO_AUX), stream));
+            CK(v100_bn_bwd_finalize(w.part, G16, (long long)B * T, g1, m1, r1, pp, qq, rr, (float*)P[14], (float*)P[15], hid, stream));
+        }
         CK(v100_pw_wgrad_io(w.dz1, a1, pp, qq, rr, 2, x, nullptr, nullptr, 0, w.slab, (float*)P[13], v100_pw_wgrad_splits(B, hid, cin),
                             B, hid, cin, T, WG_IO_G2 | (g16 ? WG_IO_G : 0), stream));
         if (dx)

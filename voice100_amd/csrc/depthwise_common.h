@@ -23,6 +23,21 @@
 enum { DW_IN_NONE = 0, DW_IN_AFFINE_RELU6 = 1, DW_IN_AFFINE2 = 2 };
 enum { DW_OUT_RAW_STATS = 0, DW_OUT_AFFINE_RELU6 = 1, DW_OUT_MASK_STATS = 2, DW_OUT_RAW = 3 };
 
+// BatchNorm finalisation by the PRODUCING depthwise kernel (G == 1 only: the workgroup of channel c then owns c's complete sums,
+// so the one-wave-per-channel finaliser launch -- ~5 us of latency between two dependent kernels, 54 times a step -- is not needed).
+// Same arithmetic as bn_finalize_train_kernel / bn_bwd_finalize_kernel (double precision on the one float partial): identical results.
+struct DwFin {
+    int mode;               // 0 none; 1 training statistics -> scale / shift (+ saved mean / rstd, running stats); 2 backward -> p, q, r (+ dgamma, dbeta)
+    double count;           // B * T
+    const float* gamma;
+    const float* a;         // mode 1: beta;      mode 2: saved mean
+    const float* b;         // mode 2: saved rstd
+    float* o0; float* o1; float* o2;    // mode 1: scale, shift, -;          mode 2: p, q, r
+    float* o3; float* o4;               // mode 1: save_mean, save_rstd;     mode 2: dgamma, dbeta
+    float* running_mean; float* running_var; long long* num_batches_tracked;
+    float momentum, eps;
+};
+
 struct DwParams {
     const float* x;      // [B,C,Tin]
     const float* x2;     // [B,C,Tin]   second stream for DW_IN_AFFINE2
@@ -40,8 +55,49 @@ struct DwParams {
     // 16-bit storage of the big hidden tensors ("act16", bf16 mode): DW_IO_* mask -- those tensors are bf16 [B][C][P], row
     // pitch P = dw_pitch16(T) (multiple of 8 elements); x / x2 / aux / y then point at bf16 data.  MFMA kernels only.
     int io16;
+    DwFin fin;           // mode 0 unless the caller asked for in-kernel finalisation (G == 1)
 };
 enum { DW_IO_X = 1, DW_IO_X2 = 2, DW_IO_AUX = 4, DW_IO_Y = 8 };
+
+// thread 0 of the workgroup of channel c, with the channel's complete sums (G == 1)
+__device__ __forceinline__ void dw_finalize(const DwFin& f, int c, float sum0, float sum1) {
+    const double s0 = (double)sum0, s1 = (double)sum1;
+    if (f.mode == 1) {
+        if (c == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
+        const double mean = s0 / f.count;
+        double var = s1 / f.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float sc = f.gamma[c] * rstd;
+        f.o0[c] = sc;
+        f.o1[c] = f.a[c] - (float)mean * sc;
+        if (f.o3) f.o3[c] = (float)mean;
+        if (f.o4) f.o4[c] = rstd;
+        if (f.running_mean) {
+            const double unbiased = f.count > 1.0 ? var * (f.count / (f.count - 1.0)) : var;
+            f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+        }
+    } else if (f.mode == 2) {
+        const double mu = f.a[c], rs = f.b[c], ga = f.gamma[c];
+        const double dg = rs * (s1 - mu * s0);
+        const double pp = ga * rs;
+        const double qq = -ga * rs * rs * dg / f.count;
+        const double rr = -pp * s0 / f.count - qq * mu;
+        f.o0[c] = (float)pp;
+        f.o1[c] = (float)qq;
+        f.o2[c] = (float)rr;
+        if (f.o3) f.o3[c] = (float)dg;
+        if (f.o4) f.o4[c] = (float)s0;
+    }
+}
+
+// the act16 entry points with in-kernel BatchNorm finalisation (block executor; fin.mode != 0 requires G == 1)
+int dw_fwd_train_io_fin(const void* a1, const float* w, const float* in_a, const float* in_b, void* a2, float* stats, int G, int B, int C,
+                        int T, int K, int io16, const DwFin& fin, void* stream);
+int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc, const void* xpre,
+                  const float* xa, const float* xb, void* dxin, float* stats, float* wpartial, float* dw, int G, int B, int C, int T, int K,
+                  int io16, const DwFin& fin, void* stream);
 __host__ __device__ __forceinline__ int dw_pitch16(int T) { return (T + 7) & ~7; }
 
 struct DwWgradParams {

@@ -469,8 +469,11 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
         if (lane == 0) { lds_red[wave][0] = s0; lds_red[wave][1] = s1; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            p.stats[((size_t)g * p.C + c) * 2 + 0] = (lds_red[0][0] + lds_red[1][0]) + (lds_red[2][0] + lds_red[3][0]);
-            p.stats[((size_t)g * p.C + c) * 2 + 1] = (lds_red[0][1] + lds_red[1][1]) + (lds_red[2][1] + lds_red[3][1]);
+            const float t0s = (lds_red[0][0] + lds_red[1][0]) + (lds_red[2][0] + lds_red[3][0]);
+            const float t1s = (lds_red[0][1] + lds_red[1][1]) + (lds_red[2][1] + lds_red[3][1]);
+            p.stats[((size_t)g * p.C + c) * 2 + 0] = t0s;
+            p.stats[((size_t)g * p.C + c) * 2 + 1] = t1s;
+            if (p.fin.mode != 0) dw_finalize(p.fin, c, t0s, t1s);      // G == 1: these ARE the channel's sums
         }
     }
 }
