@@ -293,3 +293,36 @@ def test_block_act16_matches_fp32_storage(cuda, level, cin):                    
     finally:
         F_.set_activation_storage(keep)
         F_.set_matmul_precision("fp32")
+
+
+@pytest.mark.parametrize("cin,k,B,T", [(320, 19, 2, 133), (256, 51, 3, 512), (64, 27, 32, 2048), (512, 83, 2, 640), (384, 35, 2, 77),
+                                       (256, 19, 4, 302)])
+def test_block_act16_wide_shapes(cuda, cin, k, B, T):
+    """Level-3 bf16 storage against fp32 storage (both with bf16 GEMM operands) on shapes that reach the kernels the small
+    cases do not: 256-row backward-weight tiles with ragged rows and T tails, persistent expand GEMM (512 block tiles), one
+    depthwise group with BatchNorm finalised in-kernel, time-stretched (odd) lengths."""
+    from voice100_amd import functional as F_
+    from voice100_amd.layers import InvertedResidual
+    F_.set_matmul_precision("bf16")
+    keep = F_.get_activation_storage()
+    try:
+        outs = []
+        for lv in (0, 3):
+            F_.set_activation_storage(lv)
+            torch.manual_seed(11)
+            blk = InvertedResidual(cin, cin, kernel_size=k).to(cuda).train()
+            x = torch.randn(B, cin, T, generator=torch.Generator().manual_seed(5)).to(cuda).requires_grad_(True)
+            y = blk(x)
+            (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(6)).to(cuda)).sum().backward()
+            outs.append((y.detach(), x.grad, {n: p.grad for n, p in blk.named_parameters()},
+                         torch.cat([blk.conv[i][1].running_var for i in (0, 1)] + [blk.conv[3].running_mean])))
+            del blk, x, y
+        (y0, gx0, gp0, rv0), (y1, gx1, gp1, rv1) = outs
+        assert rel_err(y1, y0) < 2e-2 and rel_err(rv1, rv0) < 2e-2
+        assert float((gx1 - gx0).norm() / gx0.norm()) < 5e-2
+        scale = max(float(v.norm()) for v in gp0.values())
+        errs = {n: float((gp1[n] - gp0[n]).norm()) / max(float(gp0[n].norm()), 1e-2 * scale) for n in gp0}
+        assert max(errs.values()) < 8e-2, errs
+    finally:
+        F_.set_activation_storage(keep)
+        F_.set_matmul_precision("fp32")
