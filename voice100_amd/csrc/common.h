@@ -47,16 +47,27 @@ __device__ __forceinline__ float wave_sum_dpp_hi(float v) {
     return v;
 }
 
+#ifndef PACK_BF16_ASM
+#define PACK_BF16_ASM 0
+#endif
 // fp32 -> bf16 round-to-nearest-even; plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ u16 f2bf(float f) {
     __bf16 h = (__bf16)f;
     return __builtin_bit_cast(u16, h);
 }
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    // one v_cvt_pk_bf16_f32 (RNE, NaN-preserving) instead of two conversions + shift + or
+    // one v_cvt_pk_bf16_f32 (RNE, NaN-preserving).  As a VECTOR conversion, not inline asm: hipcc emits the same instruction, can
+    // schedule it, and pads the MFMA-result -> VALU-read hazard that it does not see through an asm statement
+#if PACK_BF16_ASM
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
+#else
+    typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+    const pk_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, pk_bf16x2));
+#endif
 }
 
 // 16-bit operand formats of the MFMA GEMMs: bf16 (training + inference) or IEEE fp16 (inference), fp32 accumulate
