@@ -31,16 +31,8 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #ifndef PW_ABLATE
 #define PW_ABLATE 0
 #endif
-#ifndef PW_EPI_PREFETCH
-#define PW_EPI_PREFETCH 0
-#endif
 #ifndef PW_EPI_FAST
 #define PW_EPI_FAST 1
-#endif
-#if PW_EPI_PREFETCH
-#define PW_EPI_UNROLL 16
-#else
-#define PW_EPI_UNROLL 4
 #endif
 #ifndef PW_PERSIST
 #define PW_PERSIST 1         /* persistent workgroups with cross-tile prefetch for the short-K training GEMMs */
@@ -391,22 +383,6 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
     const int t = t0 + col * 4;
     const size_t part = (size_t)b * p.n_ttiles + tt;
     constexpr int RPP = BM / 16;             // rows per pass: one row per half-wave, BM/64*2 waves
-    // The R tile of ALL 16 passes is requested before the accumulators go through LDS: with a few loads per thread in flight a
-    // CU has ~16 KB outstanding and the epilogue runs at the memory LATENCY (2.9 TB/s for the mask epilogue's 134 MB), not at
-    // the bandwidth.  The staging registers of the main loop are dead here, so the 32 / 64 VGPRs are free.
-    using RReg = std::conditional_t<RB, epi_u32x2, epi_u32x4>;
-    RReg rpre[PW_EPI_PREFETCH ? 16 : 1];
-    if constexpr (PW_EPI_PREFETCH != 0) {
-        if (use_r) {
-#pragma unroll
-            for (int pass = 0; pass < 16; ++pass) {
-                const int m = m0 + pass * RPP + wave * 2 + half;
-                const bool ok = m < p.M && t < p.T;
-                if constexpr (RB) rpre[pass] = __builtin_amdgcn_raw_buffer_load_b64(rR, ok ? (int)((((size_t)b * p.M + m) * P16 + t) * 2) : 0x7ffffff0, 0, 0);
-                else rpre[pass] = __builtin_amdgcn_raw_buffer_load_b128(rR, ok ? (int)((((size_t)b * p.M + m) * p.T + t) * 4) : 0x7ffffff0, 0, 0);
-            }
-        }
-    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -417,7 +393,7 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
                 ct[row * 128 + wn * 64 + j * 32 + col] = acc[i][j][r];
             }
     __syncthreads();
-#pragma unroll PW_EPI_UNROLL
+#pragma unroll 4
     for (int pass = 0; pass < 16; ++pass) {
         const int row = pass * RPP + wave * 2 + half;
         const int m = m0 + row;
@@ -430,14 +406,7 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
         f32x4 rv = {0.f, 0.f, 0.f, 0.f};
         const size_t o16 = ((size_t)b * p.M + m) * P16 + t;        // element offset in a bf16 (pitched) tensor
         if (use_r) {
-            if constexpr (PW_EPI_PREFETCH != 0) {
-                if constexpr (RB) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rv[e] = pw_bf16_at(rpre[pass], e);
-                } else {
-                    rv = __builtin_bit_cast(f32x4, rpre[pass]);
-                }
-            } else if constexpr (RB) {
+            if constexpr (RB) {
                 const epi_u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rR, (mv && t < p.T) ? (int)(o16 * 2) : 0x7ffffff0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) rv[e] = pw_bf16_at(r2, e);
