@@ -338,7 +338,10 @@ extern "C" int v100_dw_num_groups(int B, int C) {
     int G = ceil_div(2048, C > 0 ? C : 1);
     // 1024 channels are already 1024 workgroups (one round at 4 per CU): ONE group, so a workgroup owns its channel's complete
     // sums -- no slab to reduce for the weight gradient, BatchNorm finalised by the producing kernel (DwFin)
-    if (C >= 1024) G = 1;
+#ifndef DW_G1_MINC
+#define DW_G1_MINC 1024
+#endif
+    if (C >= DW_G1_MINC) G = 1;
     if (G > B) G = B;
     if (G < 1) G = 1;
     return G;
