@@ -322,17 +322,38 @@ struct PrepBatch {
     const float* w[2 * MAXN]; u16* wbf[2 * MAXN]; float* wt[2 * MAXN]; u16* wtbf[2 * MAXN];
     int rows[2 * MAXN], cols[2 * MAXN];
 };
+// 64 x 64 tiles through LDS: the row-major bf16 copy and BOTH transposed copies are written in full lines (the element-wise
+// form scattered the transposed copies 2 / 4 bytes at a time: 58 us per step for 46 MB of weights).
 __global__ __launch_bounds__(256) void weight_prep_batched_kernel(PrepBatch t) {
+    __shared__ float tile[64][65];
     const int e = blockIdx.y;
     const float* __restrict__ w = t.w[e];
     const int rows = t.rows[e], cols = t.cols[e];
-    const long n = (long)rows * cols;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int r = (int)(i / cols), c = (int)(i % cols);
-        const float v = w[i];
-        if (t.wbf[e]) t.wbf[e][i] = f2bf(v);
-        if (t.wt[e]) t.wt[e][(size_t)c * rows + r] = v;
-        if (t.wtbf[e]) t.wtbf[e][(size_t)c * rows + r] = f2bf(v);
+    const int tr = (rows + 63) >> 6, tc = (cols + 63) >> 6;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;            // 64 columns x 4 row groups
+    for (int tl = blockIdx.x; tl < tr * tc; tl += gridDim.x) {
+        const int r0 = (tl / tc) << 6, c0 = (tl % tc) << 6;
+        __syncthreads();                                               // the previous tile's reads are done
+#pragma unroll 4
+        for (int i = ty; i < 64; i += 4) {
+            const int r = r0 + i, c = c0 + tx;
+            float v = 0.f;
+            if (r < rows && c < cols) {
+                v = w[(size_t)r * cols + c];
+                if (t.wbf[e]) t.wbf[e][(size_t)r * cols + c] = f2bf(v);
+            }
+            tile[i][tx] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = ty; i < 64; i += 4) {
+            const int c = c0 + i, r = r0 + tx;                         // transposed: consecutive threads walk the ROWS of w
+            if (c < cols && r < rows) {
+                const float v = tile[tx][i];
+                if (t.wt[e]) t.wt[e][(size_t)c * rows + r] = v;
+                if (t.wtbf[e]) t.wtbf[e][(size_t)c * rows + r] = f2bf(v);
+            }
+        }
     }
 }
 extern "C" int v100_ir_prep_batched(const int* shapes, const void* const* w1s, const void* const* w3s, void* const* preps, int n,
@@ -355,8 +376,9 @@ extern "C" int v100_ir_prep_batched(const int* shapes, const void* const* w1s, c
         if (b > maxn) maxn = b;
         if (a <= 0 || b <= 0) return V100_ERR_SHAPE;
     }
-    long gx = (maxn + 255) / 256;
-    if (gx > 512) gx = 512;
+    long gx = (maxn + 4095) / 4096;           // 64 x 64 tiles of the largest matrix
+    if (gx > 256) gx = 256;
+    if (gx < 1) gx = 1;
     hipLaunchKernelGGL(weight_prep_batched_kernel, dim3((unsigned)gx, 2 * n), dim3(256), 0, (hipStream_t)stream, t);
     return v100_launch_status();
 }
