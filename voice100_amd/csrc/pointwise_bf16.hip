@@ -909,7 +909,20 @@ __global__ __launch_bounds__(512) void pw_wgrad_bf16_wide_kernel(WgParams p) {
     // of step st + 1 (with one stage a step lasts about one memory latency: 8 waves per CU, nothing else to run meanwhile).
     // Measured: the project gradient 57 -> 53.5 us; the expand gradient, whose fp32 X pieces make a stage 48 registers, spills
     // with two stages (69 -> 82 us) and keeps one.
-    u32x4 ra[NST][NG][GB ? 1 : 2], ra2[NST][GM == PW_X_AFFINE2 ? NG : 1][G2B ? 1 : 2], rb[NST][NX][XB ? 1 : 2];
+    // NST = 3: two stages for G, ONE for X -- for the expand gradient: its X (the block input, fp32, 33 MB re-read by all 16 row
+    // tiles: L2 hits) is requested one step ahead, its G streams (dz1 and a1 from HBM) two steps ahead; 64 staging registers.
+    constexpr int NSG = NST >= 2 ? 2 : 1, NSX = NST == 2 ? 2 : 1;
+    u32x4 ra[NSG][NG][GB ? 1 : 2], ra2[NSG][GM == PW_X_AFFINE2 ? NG : 1][G2B ? 1 : 2], rb[NSX][NX][XB ? 1 : 2];
+    auto load_x = [&](auto stg, int b, int t0) {
+        constexpr int SX = NSX == 2 ? decltype(stg)::value : 0;
+        const __amdgpu_buffer_rsrc_t rX = XB ? make_rsrc(reinterpret_cast<const u16*>(p.X) + (size_t)b * K * P16, (unsigned)K * P16 * 2u)
+                                             : make_rsrc(p.X + (size_t)b * K * T, (unsigned)K * T * 4u);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+            for (int h = 0; h < (XB ? 1 : 2); ++h) rb[SX][i][h] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX[i] + 16 * h, t0 * (XB ? 2 : 4), 0);
+        }
+    };
     auto load_tiles = [&](auto stg, int b, int t0) {
         constexpr int SG = decltype(stg)::value;
         const __amdgpu_buffer_rsrc_t rG = GB ? make_rsrc(reinterpret_cast<const u16*>(p.G) + (size_t)b * M * P16, (unsigned)M * P16 * 2u)
@@ -917,8 +930,6 @@ __global__ __launch_bounds__(512) void pw_wgrad_bf16_wide_kernel(WgParams p) {
         const float* g2p = GM == PW_X_AFFINE2 ? p.G2 : p.G;
         const __amdgpu_buffer_rsrc_t rG2 = G2B ? make_rsrc(reinterpret_cast<const u16*>(g2p) + (size_t)b * M * P16, (unsigned)M * P16 * 2u)
                                                : make_rsrc(g2p + (size_t)b * M * T, (unsigned)M * T * 4u);
-        const __amdgpu_buffer_rsrc_t rX = XB ? make_rsrc(reinterpret_cast<const u16*>(p.X) + (size_t)b * K * P16, (unsigned)K * P16 * 2u)
-                                             : make_rsrc(p.X + (size_t)b * K * T, (unsigned)K * T * 4u);
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
 #pragma unroll
@@ -929,14 +940,11 @@ __global__ __launch_bounds__(512) void pw_wgrad_bf16_wide_kernel(WgParams p) {
                     ra2[SG][i][h] = __builtin_amdgcn_raw_buffer_load_b128(rG2, voG2[i] + 16 * h, t0 * (G2B ? 2 : 4), 0);
             }
         }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-#pragma unroll
-            for (int h = 0; h < (XB ? 1 : 2); ++h) rb[SG][i][h] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX[i] + 16 * h, t0 * (XB ? 2 : 4), 0);
-        }
+        if constexpr (NST != 3) load_x(stg, b, t0);        // NST 3: X is requested separately, one step ahead
     };
     auto store_tiles = [&](auto stg, int buf, int t0) {
         constexpr int SG = decltype(stg)::value;
+        constexpr int SX = NSX == 2 ? SG : 0;
         if constexpr (PW_ABLATE & 32) return;              // timing-only: no transform / LDS stores
         const bool tail = TAIL && (t0 + BF_BK > T);        // contraction index past T must contribute zero
 #pragma unroll
@@ -976,14 +984,14 @@ __global__ __launch_bounds__(512) void pw_wgrad_bf16_wide_kernel(WgParams p) {
         for (int i = 0; i < NX; ++i) {
             u32x4 ob;
             if (XCOPY && !tail) {
-                ob = rb[SG][i][0];
+                ob = rb[SX][i][0];
             } else {
                 float vb[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float xv;
-                    if constexpr (XB) xv = pw_bf16_at(rb[SG][i][0], e);
-                    else xv = __builtin_bit_cast(f32x4, rb[SG][i][e >> 2])[e & 3];
+                    if constexpr (XB) xv = pw_bf16_at(rb[SX][i][0], e);
+                    else xv = __builtin_bit_cast(f32x4, rb[SX][i][e >> 2])[e & 3];
                     if constexpr (XM == PW_X_AFFINE_RELU6) xv = relu6f(fmaf(xv, xa[i], xb[i]));
                     vb[e] = xv;
                 }
@@ -1015,12 +1023,16 @@ __global__ __launch_bounds__(512) void pw_wgrad_bf16_wide_kernel(WgParams p) {
     const int sw = (lr >> 1) & 7;
     const int rdA0 = (wm * 64 + lr) * 128, rdB0 = (wn * 64 + lr) * 128;
     using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, NST - 1>;
+    using S1 = std::integral_constant<int, NSG - 1>;
     // step -> (batch element, t offset); indices past the end are clamped to the last step (an unconditional, redundant load:
     // a conditional one would make hipcc wait for the YOUNGER stage at the join)
     auto issue = [&](auto stg, int step) {
         const int q = min(step, nsteps - 1);
         load_tiles(stg, b_lo + q / nt, (q % nt) * BF_BK);
+    };
+    auto issue_x = [&](int step) {
+        const int q = min(step, nsteps - 1);
+        load_x(S0{}, b_lo + q / nt, (q % nt) * BF_BK);
     };
     auto mfma_block = [&](int cur) {
 #pragma unroll
@@ -1051,8 +1063,8 @@ __global__ __launch_bounds__(512) void pw_wgrad_bf16_wide_kernel(WgParams p) {
             }                                                                                       \
         }                                                                                           \
         _Pragma("unroll") for (int i_ = 0; i_ < NX; ++i_) {                                         \
-            asm volatile("" : "+v"(rb[SG][i_][0]));                                                 \
-            if constexpr (!XB) asm volatile("" : "+v"(rb[SG][i_][1]));                              \
+            asm volatile("" : "+v"(rb[NSX == 2 ? SG : 0][i_][0]));                                  \
+            if constexpr (!XB) asm volatile("" : "+v"(rb[NSX == 2 ? SG : 0][i_][1]));               \
         }                                                                                           \
     } while (0)
     if constexpr (NST == 1) {
@@ -1073,12 +1085,14 @@ __global__ __launch_bounds__(512) void pw_wgrad_bf16_wide_kernel(WgParams p) {
     } else {
     if (nsteps > 0) {
         issue(S0{}, 0);
+        if constexpr (NST == 3) issue_x(0);
         issue(S1{}, 1);
         store_tiles(S0{}, 0, 0);
     }
     __syncthreads();
     for (int st = 0; st < nsteps; st += 2) {
         // even step st: LDS 0; stage 1 holds step st + 1; stage 0 is free -> step st + 2
+        if constexpr (NST == 3) issue_x(st + 1);           // X first: it is needed a step sooner than the G tiles requested below
         issue(S0{}, st + 2);
         __builtin_amdgcn_sched_barrier(0);
         mfma_block(0);
@@ -1088,6 +1102,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_bf16_wide_kernel(WgParams p) {
         __syncthreads();
         if (st + 1 >= nsteps) break;
         // odd step st + 1: LDS 1; stage 0 holds step st + 2; stage 1 is free -> step st + 3
+        if constexpr (NST == 3) issue_x(st + 2);
         issue(S1{}, st + 3);
         __builtin_amdgcn_sched_barrier(0);
         mfma_block(1);
@@ -1289,7 +1304,7 @@ bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
         else hipLaunchKernelGGL((pw_wgrad_bf16_wide_kernel<GM, XM, true, (IOV), GR, XR, NS>), gw, dim3(512), 0, st, pw);                \
         return true;                                                                                                                \
     }
-    XW(2, 0, WG_IO_G | WG_IO_G2, 128, 256, 1)      // expand: G = affine2(dz1, a1), X = block input (plain fp32)
+    XW(2, 0, WG_IO_G | WG_IO_G2, 128, 256, PW_WG_EXPAND_NST)      // expand: G = affine2(dz1, a1), X = block input (plain fp32)
     XW(0, 1, WG_IO_G | WG_IO_X, 256, 128, 2)       // project: G = da3 (plain bf16, copied), X = relu6(bn2(a2))
 #undef XW
 #endif

@@ -37,6 +37,9 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #ifndef PW_PERSIST
 #define PW_PERSIST 1         /* persistent workgroups with cross-tile prefetch for the short-K training GEMMs */
 #endif
+#ifndef PW_WG_EXPAND_NST
+#define PW_WG_EXPAND_NST 3    /* register staging of the expand backward-weight kernel: 1 one stage, 2 two (spills), 3 two for G + one for X */
+#endif
 #ifndef PW_WG_WIDE
 #define PW_WG_WIDE 1         /* 256 x 128 backward-weight tiles for the act16 combinations (0: the 128 x 128 kernel everywhere) */
 #endif
