@@ -219,7 +219,8 @@ int v100_timing_read(int tag, double* ms, long long* count, double* bytes);
 /* ---- "act16": bf16 STORAGE of the big hidden tensors in bf16-operand training (csrc/block.hip) ---------------
  * In bf16 mode the reference under autocast keeps its conv activations in bf16; here the two tensors a block saves for
  * backward (a1 = expand output, a2 = depthwise output, each 4x the block's width) and optionally the two hidden gradients
- * (act16 level 2; level 3 adds the project output a3, saved for backward, and its gradient da3) are stored as bf16 [B][C][P], P = (T + 7) & ~7 (pitched rows: every 4- / 8-sample access stays 8 / 16-byte aligned for any
+ * (act16 level 2; level 3 adds the project output a3, saved for backward, and its gradient da3; level 4 a bf16 shadow of the block
+ * output for the next block's X operand, v100_chan_affine2_shadow) are stored as bf16 [B][C][P], P = (T + 7) & ~7 (pitched rows: every 4- / 8-sample access stays 8 / 16-byte aligned for any
  * T).  Accumulators, BatchNorm statistics and reductions stay fp32.  io16 masks select which operands are such tensors:
  *   v100_pw_gemm_io:   1 X, 2 X2, 4 Y, 8 R        v100_pw_wgrad_io: 1 G, 2 G2, 4 X
  *   v100_dwconv_*_io:  1 x (first stream), 2 x2, 4 aux (a1), 8 y
@@ -240,6 +241,11 @@ int v100_dwconv_bwd_io(const void* g, const void* g2, const float* w, const floa
 /* the two block-boundary passes with a bf16-stored operand: io16 of v100_chan_reduce2_io: 2 = v is bf16 (sums of dy, dy*a3);
  * of v100_chan_affine2_io: 1 = u is bf16 (y = s3*a3 + t3 (+ x)), 6 = v and out are bf16 (da3 = p*dy + q*a3 + r) */
 int v100_chan_reduce2_io(const void* u, const void* v, float* partial, int G, int B, int C, int T, int io16, void* stream);
+/* the forward block output (asr.py:55-59) with a bf16 shadow beside it (act16 level 4): out = A*u + Cc (+ v) as fp32 [B][C][T] AND
+ * rounded to bf16 in shadow [B][C][(T + 7) & ~7]; u is bf16 (pitched) when u_bf16, else fp32.  The shadow is what the NEXT block's
+ * expand GEMM / expand weight gradient read as X (io16 bit PW_IO_X / WG_IO_X): same results, half the operand bytes. */
+int v100_chan_affine2_shadow(const void* u, const float* v, const float* A, const float* Cc, float* out, void* shadow,
+                             int B, int C, int T, int u_bf16, void* stream);
 int v100_chan_affine2_io(const void* u, const void* v, const float* A, const float* Bc, const float* Cc, void* out,
                          int B, int C, int T, int io16, void* stream);
 /* 1 when v100_ir_fwd_train / v100_ir_bwd accept shape[10] (act16) != 0 for this block */

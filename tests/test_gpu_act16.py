@@ -75,6 +75,10 @@ def test_gemm_io_variants(cuda, B, M, K, T):
     y1, s1 = io(0, 1, x, None, None, Y)
     assert torch.equal(from16(y1, T), y0.to(torch.bfloat16).to(torch.float32))
     assert rel_err(s1, s0) < 1e-6
+    # expand forward reading the bf16 shadow of the block input (level 4): the kernel rounds X to bf16 either way -> identical
+    y2, s2 = io(0, 1, x16, None, None, X | Y)
+    y3, s3 = io(0, 1, xr, None, None, Y)
+    assert torch.equal(from16(y2, T), from16(y3, T)) and torch.equal(s2, s3)
     # project forward: BN + ReLU6 on load of a bf16 X
     y0, s0 = ref(1, 1, xr, None, None)
     y1, s1 = io(1, 1, x16, None, None, X)
@@ -133,6 +137,8 @@ def test_wgrad_io_variants(cuda, B, M, K, T):
     assert rel_err(run("v100_pw_wgrad_io", g16, g216, 2, xm, 0, G_ | G2_), run("v100_pw_wgrad", gr, g2r, 2, xm, 0)) < 1e-6
     assert rel_err(run("v100_pw_wgrad_io", gm, None, 0, x16, 1, WX), run("v100_pw_wgrad", gm, None, 0, xr, 1)) < 1e-6
     assert rel_err(run("v100_pw_wgrad_io", g16, None, 0, x16, 1, G_ | WX), run("v100_pw_wgrad", gr, None, 0, xr, 1)) < 1e-6
+    # expand gradient with X = the bf16 shadow (level 4)
+    assert rel_err(run("v100_pw_wgrad_io", g16, g216, 2, x16, 0, G_ | G2_ | WX), run("v100_pw_wgrad", gr, g2r, 2, xr, 0)) < 1e-6
 
 
 def test_io_gemms_repeatable(cuda):
@@ -261,7 +267,54 @@ def test_chan_passes_io(cuda, B, C, T):
     assert torch.equal(from16(da3, T), ref.to(torch.bfloat16).to(torch.float32)) or rel_err(from16(da3, T), ref) < 5e-3
 
 
-@pytest.mark.parametrize("level,cin", [(1, 64), (2, 64), (3, 64), (3, 256)])    # cin 256: hidden 1024 = ONE depthwise group, BatchNorm
+def test_chan_affine2_shadow(cuda):
+    N = _native()
+    g = torch.Generator().manual_seed(8)
+    for (B, C, T) in ((2, 12, 133), (3, 64, 512)):
+        a3 = torch.randn(B, C, T, generator=g).to(cuda)
+        a316, a3r = to16(a3)
+        res = torch.randn(B, C, T, generator=g).to(cuda)
+        p_, r_ = torch.rand(C, generator=g).to(cuda) + 0.5, torch.randn(C, generator=g).to(cuda)
+        for ub, u, uref in ((1, a316, a3r), (0, a3, a3)):
+            for rr in (res, None):
+                y = torch.empty(B, C, T, device=cuda)
+                sh = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+                N.call("v100_chan_affine2_shadow", u, rr, p_, r_, y, sh, B, C, T, ub)
+                ref = uref * p_[None, :, None] + r_[None, :, None] + (rr if rr is not None else 0)
+                assert rel_err(y, ref) < 1e-6
+                assert torch.equal(from16(sh, T), y.to(torch.bfloat16).to(torch.float32))
+
+
+def test_stack_with_shadow_equals_stack_without(cuda):
+    """Level 4 (bf16 shadow of block outputs feeding the next block's GEMMs) against level 3 on a stack that starts with a
+    stride-2 (fp32-storage) block: the GEMMs round their X operand to bf16 either way, so outputs and gradients must be IDENTICAL."""
+    from voice100_amd import functional as F_
+    from voice100_amd.layers import InvertedResidual
+    F_.set_matmul_precision("bf16")
+    keep = F_.get_activation_storage()
+    try:
+        outs = []
+        for lv in (3, 4):
+            F_.set_activation_storage(lv)
+            torch.manual_seed(9)
+            net = torch.nn.Sequential(InvertedResidual(16, 64, kernel_size=11, stride=2, use_residual=False),
+                                      InvertedResidual(64, 64, kernel_size=19), InvertedResidual(64, 256, kernel_size=27, use_residual=False),
+                                      InvertedResidual(256, 256, kernel_size=5)).to(cuda).train()
+            x = torch.randn(2, 16, 313, generator=torch.Generator().manual_seed(4)).to(cuda).requires_grad_(True)
+            y = net(x)
+            assert (getattr(y, "_v100_shadow", None) is not None) == (lv == 4)
+            (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(6)).to(cuda)).sum().backward()
+            outs.append((y.detach(), x.grad, [p.grad for p in net.parameters()]))
+        (y0, gx0, gp0), (y1, gx1, gp1) = outs
+        assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+        for a, b in zip(gp0, gp1):
+            assert torch.equal(a, b)
+    finally:
+        F_.set_activation_storage(keep)
+        F_.set_matmul_precision("fp32")
+
+
+@pytest.mark.parametrize("level,cin", [(1, 64), (2, 64), (3, 64), (3, 256), (4, 256)])    # cin 256: hidden 1024 = ONE depthwise group, BatchNorm
 def test_block_act16_matches_fp32_storage(cuda, level, cin):                        # finalised inside the depthwise kernels (DwFin)
     """A training-mode block at bf16 precision with the hidden tensors stored as bf16 vs the same block with fp32 storage:
     outputs, input gradient and parameter gradients within bf16 storage error of each other (and both within the bf16 bar
@@ -307,7 +360,7 @@ def test_block_act16_wide_shapes(cuda, cin, k, B, T):
     keep = F_.get_activation_storage()
     try:
         outs = []
-        for lv in (0, 3):
+        for lv in (0, 4):
             F_.set_activation_storage(lv)
             torch.manual_seed(11)
             blk = InvertedResidual(cin, cin, kernel_size=k).to(cuda).train()

@@ -85,6 +85,8 @@ extern "C" long long v100_ir_fwd_workspace_bytes(const int* shape) {
 
 // ptrs: 0 x | 1 w1 2 g1 3 b1 4 rm1 5 rv1 6 nbt1 | 7 wd 8 g2 9 b2 10 rm2 11 rv2 12 nbt2 | 13 w3 14 g3 15 b3 16 rm3 17 rv3 18 nbt3 |
 //       19 a1 20 a2 21 a3 22 y 23 coef 24 workspace 25 prepared-weights buffer (v100_ir_prep_bytes)
+//       26 x16 27 y16 (act16 >= 4 only, each may be NULL): bf16 shadow [B][C][(T + 7) & ~7] of the block input (written by the
+//       previous block) / of this block's output (for the next block)
 extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stream) {
     if (!sh || !P) return V100_ERR_NULL;
     const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T], K = sh[IR_K], S = sh[IR_STRIDE];
@@ -107,14 +109,17 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
     // both orientations in one pass per weight: forward uses w*_bf, backward the transposed copies
     // (skipped when the caller has already filled `prep` for these weights, e.g. for every block of a stack in one
     // v100_ir_prep_batched launch)
-    if (!sh[IR_PREPPED]) {
+    if (!(sh[IR_PREPPED] & 1)) {          // bit 0: prepared by v100_ir_prep_batched; bit 1: the pointer table has the shadow slots 26 / 27
         CK(v100_weight_prep(w1, hid, cin, pw.w1bf, pw.w1t, pw.w1tbf, stream));
         CK(v100_weight_prep(w3, cout, hid, pw.w3bf, pw.w3t, pw.w3tbf, stream));
     }
     const int parts1 = v100_pw_num_parts(B, T), parts3 = v100_pw_num_parts(B, T2), G = v100_dw_num_groups(B, hid);
     if (sh[IR_ACT16]) {
         if (!v100_ir_act16_supported(sh)) return V100_ERR_SHAPE;
-        CK(v100_pw_gemm_io(w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, PW_IO_Y, stream));
+        const void* x16 = (sh[IR_ACT16] >= 4 && (sh[IR_PREPPED] & 2)) ? P[26] : nullptr;
+        void* y16 = (sh[IR_ACT16] >= 4 && (sh[IR_PREPPED] & 2)) ? const_cast<void*>(P[27]) : nullptr;
+        if (x16) CK(v100_pw_gemm_io(w1bf, x16, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, PW_IO_X | PW_IO_Y, stream));
+        else CK(v100_pw_gemm_io(w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, PW_IO_Y, stream));
         CK(v100_bn_finalize_train(st, parts1, (long long)B * T, (const float*)P[2], (const float*)P[3], (float*)P[4], (float*)P[5], (long long*)P[6],
                                   kMom, kEps, s1, t1, m1, r1, hid, stream));
         if (G == 1) {          // the depthwise kernel finalises BatchNorm 2 itself (its workgroup owns the channel's sums)
@@ -130,7 +135,8 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
         CK(v100_pw_gemm_io(w3bf, a2, nullptr, s2, t2, nullptr, 1, a3, nullptr, nullptr, nullptr, 1, st, B, cout, hid, T2, PW_IO_X | (a316 ? PW_IO_Y : 0), stream));
         CK(v100_bn_finalize_train(st, parts3, (long long)B * T2, (const float*)P[14], (const float*)P[15], (float*)P[16], (float*)P[17], (long long*)P[18],
                                   kMom, kEps, s3, t3, m3, r3, cout, stream));
-        if (a316) CK(v100_chan_affine2_io(a3, res ? x : nullptr, s3, nullptr, t3, y, B, cout, T2, 1, stream));
+        if (y16) CK(v100_chan_affine2_shadow(a3, res ? x : nullptr, s3, t3, y, y16, B, cout, T2, a316 ? 1 : 0, stream));
+        else if (a316) CK(v100_chan_affine2_io(a3, res ? x : nullptr, s3, nullptr, t3, y, B, cout, T2, 1, stream));
         else CK(v100_chan_affine2(a3, res ? x : nullptr, s3, nullptr, t3, y, B, cout, T2, stream));
         return V100_OK;
     }
@@ -143,7 +149,10 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
     CK(v100_pw_gemm(w3, w3bf, a2, nullptr, s2, t2, nullptr, 1, a3, nullptr, nullptr, nullptr, nullptr, 1, st, B, cout, hid, T2, bf, stream));
     CK(v100_bn_finalize_train(st, parts3, (long long)B * T2, (const float*)P[14], (const float*)P[15], (float*)P[16], (float*)P[17], (long long*)P[18],
                               kMom, kEps, s3, t3, m3, r3, cout, stream));
-    CK(v100_chan_affine2(a3, res ? x : nullptr, s3, nullptr, t3, y, B, cout, T2, stream));
+    // a block that itself keeps fp32 storage (the stride-2 first layer) still emits the shadow its successor reads: the caller
+    // passes P[27] only in bf16 precision at act16 level 4 (26 / 27 are not read otherwise)
+    if (bf == 1 && (sh[IR_PREPPED] & 2) && P[27]) CK(v100_chan_affine2_shadow(a3, res ? x : nullptr, s3, t3, y, const_cast<void*>(P[27]), B, cout, T2, 0, stream));
+    else CK(v100_chan_affine2(a3, res ? x : nullptr, s3, nullptr, t3, y, B, cout, T2, stream));
     return V100_OK;
 }
 
@@ -183,6 +192,7 @@ extern "C" long long v100_ir_bwd_workspace_bytes(const int* shape) {
 
 // ptrs: 0 x 1 a1 2 a2 3 a3 | 4 w1 5 wd 6 w3 | 7 g1 8 g2 9 g3 | 10 coef | 11 dy | 12 dx (may be NULL) |
 //       13 dW1 14 dg1 15 db1 16 dWd 17 dg2 18 db2 19 dW3 20 dg3 21 db3 | 22 workspace | 23 prepared weights (from forward)
+//       24 x16 (act16 >= 4 only, may be NULL): the bf16 shadow of x the forward read
 extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     if (!sh || !P) return V100_ERR_NULL;
     const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T], K = sh[IR_K], S = sh[IR_STRIDE];
@@ -235,8 +245,9 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
                                   g16 ? (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y) : (DW_IO_X2 | DW_IO_AUX), stream));
             CK(v100_bn_bwd_finalize(w.part, G16, (long long)B * T, g1, m1, r1, pp, qq, rr, (float*)P[14], (float*)P[15], hid, stream));
         }
-        CK(v100_pw_wgrad_io(w.dz1, a1, pp, qq, rr, 2, x, nullptr, nullptr, 0, w.slab, (float*)P[13], v100_pw_wgrad_splits(B, hid, cin),
-                            B, hid, cin, T, WG_IO_G2 | (g16 ? WG_IO_G : 0), stream));
+        const void* x16 = (sh[IR_ACT16] >= 4 && (sh[IR_PREPPED] & 2)) ? P[24] : nullptr;
+        CK(v100_pw_wgrad_io(w.dz1, a1, pp, qq, rr, 2, x16 ? x16 : (const void*)x, nullptr, nullptr, 0, w.slab, (float*)P[13], v100_pw_wgrad_splits(B, hid, cin),
+                            B, hid, cin, T, WG_IO_G2 | (g16 ? WG_IO_G : 0) | (x16 ? WG_IO_X : 0), stream));
         if (dx)
             CK(v100_pw_gemm_io(pw.w1tbf, w.dz1, a1, pp, qq, rr, 2, dx, nullptr, nullptr, res ? dy : nullptr, res ? 5 : 0, nullptr,
                                B, cin, hid, T, PW_IO_X2 | (g16 ? PW_IO_X : 0), stream));

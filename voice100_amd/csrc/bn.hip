@@ -209,6 +209,38 @@ __global__ __launch_bounds__(256) void chan_affine2_io_kernel(const void* __rest
     }
 }
 
+// The forward block output with a bf16 SHADOW beside it: out = A[c]*u + Cc[c] (+ v) as fp32 [rows][T] and the same values rounded
+// to bf16 in a pitched copy [rows][(T + 7) & ~7] -- what the next block's expand GEMM and expand weight gradient load as their X
+// operand (they round X to bf16 anyway: identical results, half the bytes through the CU's 64 B/clk vector-memory path, which is
+// what bounds the 256-row backward-weight kernel once its fp32 X tile is 64 of the 96 KB it stages per step).  UB: u is bf16 (pitched).
+template <bool UB>
+__global__ __launch_bounds__(256) void chan_affine2_shadow_kernel(const void* __restrict__ u, const float* __restrict__ v, const float* __restrict__ A,
+                                                                  const float* __restrict__ Cc, float* __restrict__ out, u16* __restrict__ shadow,
+                                                                  int C, int T, long rows) {
+    const int P = (T + 7) & ~7;
+    const int T4 = (T + 3) >> 2;
+    const long total = rows * T4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const size_t row = (size_t)(i / T4);
+        const int t = (int)(i % T4) * 4;
+        const int c = (int)(row % C);
+        const float a = A ? A[c] : 1.f, cc = Cc ? Cc[c] : 0.f;
+        float x[4], y[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        chan_load4<UB>(u, row, T, P, t, x);
+        if (v) chan_load4<false>(v, row, T, P, t, y);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v ? fmaf(x[e], a, fmaf(y[e], 1.f, cc)) : fmaf(x[e], a, cc);    // as chan_affine2(_io) rounds it
+        float* q = out + row * T + t;
+        if (t + 3 < T) { const f32x4 w = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4u*>(q) = w; }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (t + e < T) q[e] = o[e];
+        }
+        const bn_u32x2 w16 = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+        *reinterpret_cast<bn_u32x2*>(shadow + row * P + t) = w16;          // samples past T land in the row's padding
+    }
+}
+
 // out[c] = sum_g partial[g][c][0]   (bias gradients)
 __global__ void slab_sum0_kernel(const float* __restrict__ partial, int parts, float* __restrict__ out, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -427,6 +459,21 @@ extern "C" int v100_chan_affine2_io(const void* u, const void* v, const float* A
     if (io16 == 1) hipLaunchKernelGGL(chan_affine2_io_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Bc, Cc, out, C, T, rows);
     else if (io16 == 6) hipLaunchKernelGGL(chan_affine2_io_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Bc, Cc, out, C, T, rows);
     else return V100_ERR_SHAPE;
+    return v100_launch_status();
+}
+
+extern "C" int v100_chan_affine2_shadow(const void* u, const float* v, const float* A, const float* Cc, float* out, void* shadow,
+                                        int B, int C, int T, int u_bf16, void* stream) {
+    if (!u || !out || !shadow) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || T <= 0) return V100_ERR_SHAPE;
+    const long rows = (long)B * C;
+    const long total = rows * ((T + 3) / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (u_bf16) hipLaunchKernelGGL(chan_affine2_shadow_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Cc, out, (u16*)shadow, C, T, rows);
+    else hipLaunchKernelGGL(chan_affine2_shadow_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Cc, out, (u16*)shadow, C, T, rows);
     return v100_launch_status();
 }
 

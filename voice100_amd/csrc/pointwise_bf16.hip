@@ -1263,6 +1263,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
         }                                                                                                                       \
     }
     XP(0, 1, PW_IO_Y)          // expand forward: 61 -> 56.5 us at 2048 x 512 x (32 x 512)
+    XP(0, 1, PW_IO_X | PW_IO_Y)    // ... reading the bf16 shadow of the block input (act16 level 4)
     // (the project backward-data GEMM, same shape, does not fit: its mask epilogue keeps 96 registers of R / coefficient /
     //  statistics values beside the two staging stages -- 59 VGPRs spilled, 69 -> 118 us)
 #undef XP
@@ -1278,6 +1279,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
         return true;
     }
     X(0, 1, PW_IO_Y)                      // expand forward: a1 out
+    X(0, 1, PW_IO_X | PW_IO_Y)            // ... X = bf16 shadow of the block input
     X(1, 1, PW_IO_X)                      // project forward: a2 in (BN2 + ReLU6 on load)
     X(0, 4, PW_IO_R)                      // project backward-data: ReLU6 mask / BN2-backward sums from a2
     X(2, 5, PW_IO_X2) X(2, 0, PW_IO_X2)   // expand backward-data: BN1-backward affine of (dz1, a1)
@@ -1304,6 +1306,7 @@ bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
         else hipLaunchKernelGGL((pw_wgrad_bf16_wide_kernel<GM, XM, true, (IOV), GR, XR, NS>), gw, dim3(512), 0, st, pw);                \
         return true;                                                                                                                \
     }
+    XW(2, 0, WG_IO_G | WG_IO_G2 | WG_IO_X, 128, 256, 2)      // ... X = bf16 shadow of the block input: copied as loaded, 32 registers a stage
     XW(2, 0, WG_IO_G | WG_IO_G2, 128, 256, PW_WG_EXPAND_NST)      // expand: G = affine2(dz1, a1), X = block input (plain fp32)
     XW(0, 1, WG_IO_G | WG_IO_X, 256, 128, 2)       // project: G = da3 (plain bf16, copied), X = relu6(bn2(a2))
 #undef XW
@@ -1317,6 +1320,7 @@ bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
     X(2, 0, WG_IO_G2)                     // expand backward-weight: G = BN1-backward affine of (dz1, a1), X = block input
     X(0, 1, WG_IO_X)                      // project backward-weight: X = relu6(bn2(a2))
     X(2, 0, WG_IO_G | WG_IO_G2)           // ... with dz1 stored as bf16
+    X(2, 0, WG_IO_G | WG_IO_G2 | WG_IO_X) // ... and X = bf16 shadow of the block input
     X(0, 1, WG_IO_G | WG_IO_X)            // ... with da3 stored as bf16
 #undef X
     return false;

@@ -41,15 +41,16 @@ _PRECISION = "fp32"
 # 0 = fp32 everywhere, 1 = a1 / a2 (the tensors saved for backward) as bf16, 2 = also the hidden gradients dz2 / dz1.
 # The reference under bf16 autocast keeps exactly these tensors in bf16; statistics and accumulators stay fp32 here.
 # 3 = also the project output a3 (saved for backward) and its gradient da3: every tensor that is internal to a block.
-_ACT16 = int(os.environ.get("VOICE100_ACT16", "3"))
+_ACT16 = int(os.environ.get("VOICE100_ACT16", "4"))
 
 
 def set_activation_storage(level: int) -> None:
     """0: fp32 activations; 1: saved hidden activations bf16; 2: hidden gradients bf16 as well; 3: also the project output and
-    its gradient (bf16 precision only; block inputs / outputs always stay fp32)."""
+    its gradient; 4: plus a bf16 shadow of every block output beside the fp32 tensor, which the next block's expand GEMM and
+    expand weight gradient load as their X operand (bf16 precision only; block inputs / outputs themselves always stay fp32)."""
     global _ACT16
-    if level not in (0, 1, 2, 3):
-        raise ValueError("activation storage level must be 0, 1, 2 or 3")
+    if level not in (0, 1, 2, 3, 4):
+        raise ValueError("activation storage level must be 0 ... 4")
     _ACT16 = level
 
 
@@ -162,7 +163,7 @@ class InvertedResidualTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, wd, g2, b2, w3, g3, b3, rm1, rv1, nbt1, rm2, rv2, nbt2, rm3, rv3, nbt3,
-                kernel_size, stride, use_residual, precision, prep=None):
+                kernel_size, stride, use_residual, precision, prep=None, x16=None, want_shadow=False):
         _check(x, "InvertedResidual")
         x = x.contiguous()
         B, cin, T = x.shape
@@ -171,7 +172,10 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         T2 = conv_out_len(T, k, stride)
         bf16 = _fmt(precision)
         _no_fp16_training(bf16, "InvertedResidual (training mode)")
-        shape = (ctypes.c_int * 11)(B, cin, hid, cout, T, k, int(stride), int(bool(use_residual)), int(bf16), int(prep is not None), 0)
+        # shape[9]: bit 0 = weights prepared by the stack, bit 1 = the pointer table carries the bf16-shadow slots (level 4)
+        shadows = bf16 == 1 and _ACT16 >= 4
+        shape = (ctypes.c_int * 11)(B, cin, hid, cout, T, k, int(stride), int(bool(use_residual)), int(bf16),
+                                    int(prep is not None) | (2 if shadows else 0), 0)
         if bf16 == 1 and _ACT16 and N.helper("v100_ir_act16_supported", shape):
             shape[10] = _ACT16
             pitch = (T + 7) & ~7                       # bf16 rows are padded to a multiple of 8 samples (aligned 8 / 16-byte accesses)
@@ -183,22 +187,34 @@ class InvertedResidualTrainFn(torch.autograd.Function):
             a2 = _f32(B, hid, T2, like=x)
             a3 = _f32(B, cout, T2, like=x)
         y = _f32(B, cout, T2, like=x)
+        # level 4: a bf16 copy of y (pitched rows) for the next block's expand GEMM / expand weight gradient; x16 = the copy
+        # of x the previous block wrote (only the act16 executor reads it)
+        y16 = torch.empty((B, cout, (T2 + 7) & ~7), dtype=torch.bfloat16, device=x.device) if (shadows and want_shadow) else None
+        if not (shadows and shape[10] >= 4):
+            x16 = None
         coef = _f32(12, max(hid, cout), like=x)
         ws = torch.empty(N.helper("v100_ir_fwd_workspace_bytes", shape), dtype=torch.uint8, device=x.device)
         if prep is None:
             prep = torch.empty(N.helper("v100_ir_prep_bytes", shape), dtype=torch.uint8, device=x.device)
         tensors = (x, w1, g1, b1, rm1, rv1, nbt1, wd, g2, b2, rm2, rv2, nbt2, w3, g3, b3, rm3, rv3, nbt3, a1, a2, a3, y, coef, ws, prep)
+        if shadows:
+            tensors = tensors + (x16, y16)
         for t in tensors[:19]:
             if not t.is_contiguous() or not t.is_cuda:
                 raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors")
         N.call("v100_ir_fwd_train", shape, _ptr_table(tensors))
-        ctx.save_for_backward(x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, prep)
+        ctx.save_for_backward(x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, prep, x16 if x16 is not None else coef)
+        ctx.has_x16 = x16 is not None
         ctx.shape = shape
-        return y
+        if y16 is not None:
+            ctx.mark_non_differentiable(y16)
+        return y, y16
 
     @staticmethod
-    def backward(ctx, dy):
-        x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, prep = ctx.saved_tensors
+    def backward(ctx, dy, _dy16=None):
+        x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, prep, x16 = ctx.saved_tensors
+        if not ctx.has_x16:
+            x16 = None
         shape = ctx.shape
         dy = dy.contiguous()
         hid, cin = w1.shape[0], w1.shape[1]
@@ -212,9 +228,10 @@ class InvertedResidualTrainFn(torch.autograd.Function):
             off += n
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ws = torch.empty(N.helper("v100_ir_bwd_workspace_bytes", shape), dtype=torch.uint8, device=x.device)
-        N.call("v100_ir_bwd", shape, _ptr_table((x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, dy, dx) + tuple(parts) + (ws, prep)))
+        extra = (x16,) if (shape[9] & 2) else ()
+        N.call("v100_ir_bwd", shape, _ptr_table((x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, dy, dx) + tuple(parts) + (ws, prep) + extra))
         dW1, dg1, db1, dWd, dg2, db2, dW3, dg3, db3 = parts
-        return (dx, dW1.view_as(w1), dg1, db1, dWd.view_as(wd), dg2, db2, dW3.view_as(w3), dg3, db3) + (None,) * 14
+        return (dx, dW1.view_as(w1), dg1, db1, dWd.view_as(wd), dg2, db2, dW3.view_as(w3), dg3, db3) + (None,) * 16
 
 
 def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:

@@ -71,12 +71,20 @@ class InvertedResidual(nn.Module):
         bn1, bn2 = pw[1], dw[1]
         prec = F_.get_matmul_precision()
         if self.training:
-            return F_.InvertedResidualTrainFn.apply(
+            # the bf16 shadow the previous block wrote beside x (activation storage level 4): valid only for exactly this
+            # version of x -- any in-place edit of x in between invalidates it
+            sh = getattr(x, "_v100_shadow", None)
+            x16 = sh[0] if (sh is not None and sh[1] == x._version and sh[0].shape[:2] == x.shape[:2]
+                            and sh[0].shape[2] == ((x.shape[2] + 7) & ~7)) else None
+            y, y16 = F_.InvertedResidualTrainFn.apply(
                 x, pw[0].weight, bn1.weight, bn1.bias, dw[0].weight, bn2.weight, bn2.bias, pl.weight, bn3.weight, bn3.bias,
                 bn1.running_mean, bn1.running_var, bn1.num_batches_tracked,
                 bn2.running_mean, bn2.running_var, bn2.num_batches_tracked,
                 bn3.running_mean, bn3.running_var, bn3.num_batches_tracked,
-                self.kernel_size, self.stride, self.use_residual, prec, F_.prepared_weights_of(self, prec))
+                self.kernel_size, self.stride, self.use_residual, prec, F_.prepared_weights_of(self, prec), x16, True)
+            if y16 is not None:
+                y._v100_shadow = (y16, y._version)
+            return y
         # eval mode: frozen statistics, inference only (autograd through eval-mode BN is not on the
         # reference's training path and is not built) -- say so instead of silently returning a constant
         if torch.is_grad_enabled() and x.requires_grad:
