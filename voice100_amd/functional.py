@@ -208,6 +208,10 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         ctx.shape = shape
         if y16 is not None:
             ctx.mark_non_differentiable(y16)
+        # autograd would otherwise hand backward() a zero-FILLED gradient for the (non-differentiable) shadow output: a 17 MB
+        # fill launch per block and step
+        ctx.set_materialize_grads(False)
+        ctx.y_shape = y.shape
         return y, y16
 
     @staticmethod
@@ -216,6 +220,8 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         if not ctx.has_x16:
             x16 = None
         shape = ctx.shape
+        if dy is None:                     # the block output was not used downstream (materialize_grads is off)
+            dy = torch.zeros(ctx.y_shape, dtype=torch.float32, device=x.device)
         dy = dy.contiguous()
         hid, cin = w1.shape[0], w1.shape[1]
         cout, k = w3.shape[0], wd.shape[2]
