@@ -11,6 +11,9 @@
 #include "common.h"
 #include <math.h>
 
+#ifndef CTC_SKEW
+#define CTC_SKEW 1
+#endif
 #define CTC_CHUNK 64
 #define CTC_MAXV 128
 #define NEG_INF (-INFINITY)
@@ -125,6 +128,144 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same lattice as a WAVE PIPELINE (2 * Lmax + 1 <= 1024 states).  The kernel above pays, on every one of the T dependent
+// frames, an LDS write -> barrier -> LDS read round trip of the whole row across 4 waves (~0.33 us per frame: 170 us at
+// T' = 512).  Here a lane owns ONE state in direction order (u = s for alpha, u = S-1-s for beta, so both recursions read
+// u, u-1, u-2), keeps it in a register and gets its neighbours by DPP (wave_shr:1); only the two states at a wave's upper edge
+// go through LDS, into a ring slot per frame, and the waves run SKEWED: wave w may start frame q as soon as wave w-1 has
+// published frame q-1 (a progress word per wave; no workgroup barrier in the recursion).  Emission log-probabilities are
+// gathered straight from global memory eight frames ahead.
+// log2-domain log-sum-exp of three terms on the raw v_exp_f32 / v_log_f32 (no range scaling: the sum lies in [1, 3] or is exactly
+// 0), branch-free: an all -inf input gives mm + log2(0) = -inf, never inf - inf
+__device__ __forceinline__ float ctc_lse3_log2(float a, float b, float c) {
+    const float mm = fmaxf(fmaxf(fmaxf(a, b), c), -1e30f);
+    const float sum = __builtin_amdgcn_exp2f(a - mm) + __builtin_amdgcn_exp2f(b - mm) + __builtin_amdgcn_exp2f(c - mm);
+    return mm + __builtin_amdgcn_logf(sum);
+}
+#define CTC_RING 32
+#define CTC_SPIN_MAX (1 << 20)      /* a wave never waits forever on a neighbour (all waves of a workgroup are resident: this bound is never reached) */
+#define CTC_PF 8
+__device__ __forceinline__ float ctc_wave_shr1(float fill, float v) {       // lane l gets v of lane l-1; lane 0 gets `fill`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+
+__global__ __launch_bounds__(1024) void ctc_lattice_skew_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                                const long long* __restrict__ targets, const int* __restrict__ in_len,
+                                                                const int* __restrict__ tgt_len, float* __restrict__ alpha,
+                                                                float* __restrict__ beta, float* __restrict__ nll, int T, int V, int Lmax,
+                                                                int Smax, int blank) {
+    __shared__ float bnd[16][CTC_RING][2];
+    __shared__ int progress[16];
+    __shared__ float fin[2];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, NW = blockDim.x >> 6;
+    int Tb = in_len[b];
+    if (Tb > T) Tb = T;
+    int L = tgt_len[b];
+    if (L > Lmax) L = Lmax;
+    const int S = 2 * L + 1;
+    float* lat = (dir == 0 ? alpha : beta) + (size_t)b * T * Smax;
+    const long long* tg = targets + (size_t)b * Lmax;
+    if (lane == 0) progress[w] = -1;
+    if (tid < 2) fin[tid] = NEG_INF;
+    __syncthreads();
+    if (Tb <= 0) { if (dir == 0 && tid == 0) nll[b] = INFINITY; return; }
+
+    const int u = tid;                                   // state in direction order
+    const int sidx = dir == 0 ? u : S - 1 - u;           // lattice state
+    const bool active = u < S;
+    int cls = blank;
+    bool skip = false;
+    if (active && (sidx & 1)) {
+        cls = (int)tg[sidx >> 1];
+        if (dir == 0) skip = sidx >= 2 && tg[sidx >> 1] != tg[(sidx >> 1) - 1];
+        else skip = sidx + 2 < S && tg[sidx >> 1] != tg[(sidx >> 1) + 1];
+    }
+    if (cls < 0 || cls >= V) cls = blank;
+
+    // frame q of the recursion is time t = q (alpha) / Tb-1-q (beta); emissions of frames q0+8 .. q0+15 are in flight while q0 .. q0+7 compute
+    const float* lg = logits + (size_t)b * T * V + cls;
+    const float* ls = lse + (size_t)b * T;
+    auto emission = [&](int q) -> float {
+        const int qq = q < Tb ? q : Tb - 1;
+        const int t = dir == 0 ? qq : Tb - 1 - qq;
+        return (lg[(size_t)t * V] - ls[t]) * 1.44269504088896340736f;       // log2 units: the recursion runs on exp2 / log2 directly
+    };
+    float cur[CTC_PF], nxt[CTC_PF];
+#pragma unroll
+    for (int j = 0; j < CTC_PF; ++j) cur[j] = emission(j);
+
+    // relaxed workgroup-scope atomics: plain ds_read / ds_write that the compiler neither caches nor fences (a `volatile` access
+    // is bracketed by vmcnt(0) waits, i.e. by the acknowledgement of the previous frame's lattice store: 240 us instead of 170).
+    // LDS executes one wave's operations in order, so "edge values, then progress word" needs no fence -- only program order.
+    auto prog_load = [&](int i) { return __hip_atomic_load(&progress[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    float a_prev = NEG_INF;
+    int pnext = -2;
+    float n63 = NEG_INF, n62 = NEG_INF;
+    for (int q0 = 0; q0 < Tb; q0 += CTC_PF) {
+#pragma unroll
+        for (int j = 0; j < CTC_PF; ++j) nxt[j] = emission(q0 + CTC_PF + j);
+#pragma unroll
+        for (int j = 0; j < CTC_PF; ++j) {
+            const int q = q0 + j;
+            if (q >= Tb) break;                                  // workgroup-uniform
+            const int t = dir == 0 ? q : Tb - 1 - q;
+            float v63 = NEG_INF, v62 = NEG_INF;
+            if (w > 0) {
+                if (q > 0) {
+                    // (the progress word travels as an opaque VGPR until here: as a plain uniform value hipcc moves it to an SGPR --
+                    //  and waits for the LDS read -- right where it was issued, which puts the read's latency back on the chain)
+                    asm volatile("" : "+v"(pnext));
+                    if (__builtin_amdgcn_readfirstlane(pnext) >= q - 1) {    // the copy fetched during the previous frame is valid
+                        v63 = n63; v62 = n62;
+                    } else {
+                        // wait until the upstream wave is TWO frames ahead (or done): with a skew of one, the speculative fetch
+                        // below would find frame q unpublished on every frame and this slow path would run each time
+                        const int need = min(q + 1, Tb - 1);
+                        for (int guard = 0; prog_load(w - 1) < need && guard < CTC_SPIN_MAX; ++guard) __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
+                        v63 = bnd[w - 1][(q - 1) & (CTC_RING - 1)][0];
+                        v62 = bnd[w - 1][(q - 1) & (CTC_RING - 1)][1];
+                    }
+                }
+                // speculative fetch for frame q + 1 (edge values of frame q): progress word FIRST -- if it already says >= q, the slot
+                // read after it (LDS keeps a wave's operations in order) is complete; used next frame, so its latency hides here
+                pnext = prog_load(w - 1);
+                asm volatile("" ::: "memory");
+                n63 = bnd[w - 1][q & (CTC_RING - 1)][0];
+                n62 = bnd[w - 1][q & (CTC_RING - 1)][1];
+            }
+            const float sm1 = ctc_wave_shr1(v63, a_prev);
+            const float sm2 = ctc_wave_shr1(v62, sm1);
+            float v;
+            if (q == 0) v = (u <= 1) ? cur[j] : NEG_INF;
+            else v = cur[j] + ctc_lse3_log2(a_prev, sm1, skip ? sm2 : NEG_INF);
+            if (!active) v = NEG_INF;
+            if (w < NW - 1) {
+                // back-pressure, once per half ring: frames q .. q + RING/2 - 1 reuse the slots of frames q - RING .. q - RING/2 - 1, which
+                // wave w+1 has read once it has published frame q - RING/2
+                if ((q & (CTC_RING / 2 - 1)) == 0 && q >= CTC_RING / 2)
+                    for (int guard = 0; prog_load(w + 1) < q - CTC_RING / 2 && guard < CTC_SPIN_MAX; ++guard) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                if (lane >= 62) bnd[w][q & (CTC_RING - 1)][63 - lane] = v;
+            }
+            asm volatile("" ::: "memory");       // program order only: LDS performs one wave's writes in the order they were issued
+            if (lane == 0) __hip_atomic_store(&progress[w], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            a_prev = v;
+            if (active) lat[(size_t)t * Smax + sidx] = v * 0.69314718055994530942f;      // the lattice is stored in natural-log units
+        }
+#pragma unroll
+        for (int j = 0; j < CTC_PF; ++j) cur[j] = nxt[j];
+    }
+    if (dir == 0) {
+        if (u == S - 1) fin[0] = a_prev;
+        if (S >= 2 && u == S - 2) fin[1] = a_prev;
+        __syncthreads();
+        if (tid == 0) nll[b] = -(S >= 2 ? lse2(fin[0] * 0.69314718055994530942f, fin[1] * 0.69314718055994530942f) : fin[0] * 0.69314718055994530942f);
+    }
+}
+
 // one wave per (b, t): grad[b][t][c] = softmax - exp(lcab + nll - logprob); zero for padded frames / infeasible utterances
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
                                                        const long long* __restrict__ targets, const int* __restrict__ in_len,
@@ -228,7 +369,11 @@ static int ctc_run(const float* logits, const long long* targets, const int* in_
         (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);       \
     hipLaunchKernelGGL(ctc_lattice_kernel<NS_>, dim3(B, 2), dim3(256), shmem, st, logits, lse, targets, in_len, tgt_len, alpha, beta, \
                        nll, T, V, Lmax, Smax, blank)
-    if (Smax <= 512) { CTC_LATTICE(2); }
+    if (CTC_SKEW && Smax <= 1024) {
+        const int nw = (Smax + 63) / 64;
+        hipLaunchKernelGGL(ctc_lattice_skew_kernel, dim3(B, 2), dim3(64 * nw), 0, st, logits, lse, targets, in_len, tgt_len, alpha, beta,
+                           nll, T, V, Lmax, Smax, blank);
+    } else if (Smax <= 512) { CTC_LATTICE(2); }
     else if (Smax <= 1024) { CTC_LATTICE(4); }
     else if (Smax <= 2048) { CTC_LATTICE(8); }
     else { CTC_LATTICE(16); }
