@@ -10,6 +10,7 @@
 // wave per frame with LDS float atomics into the <= 128 class bins.
 #include "common.h"
 #include <math.h>
+#include <type_traits>
 
 #ifndef CTC_SKEW
 #define CTC_SKEW 1
@@ -203,61 +204,87 @@ __global__ __launch_bounds__(1024) void ctc_lattice_skew_kernel(const float* __r
     float a_prev = NEG_INF;
     int pnext = -2;
     float n63 = NEG_INF, n62 = NEG_INF;
-    for (int q0 = 0; q0 < Tb; q0 += CTC_PF) {
-#pragma unroll
-        for (int j = 0; j < CTC_PF; ++j) nxt[j] = emission(q0 + CTC_PF + j);
-#pragma unroll
-        for (int j = 0; j < CTC_PF; ++j) {
-            const int q = q0 + j;
-            if (q >= Tb) break;                                  // workgroup-uniform
-            const int t = dir == 0 ? q : Tb - 1 - q;
-            float v63 = NEG_INF, v62 = NEG_INF;
-            if (w > 0) {
-                if (q > 0) {
-                    // (the progress word travels as an opaque VGPR until here: as a plain uniform value hipcc moves it to an SGPR --
-                    //  and waits for the LDS read -- right where it was issued, which puts the read's latency back on the chain)
-                    asm volatile("" : "+v"(pnext));
-                    if (__builtin_amdgcn_readfirstlane(pnext) >= q - 1) {    // the copy fetched during the previous frame is valid
-                        v63 = n63; v62 = n62;
-                    } else {
-                        // wait until the upstream wave is TWO frames ahead (or done): with a skew of one, the speculative fetch
-                        // below would find frame q unpublished on every frame and this slow path would run each time
-                        const int need = min(q + 1, Tb - 1);
-                        for (int guard = 0; prog_load(w - 1) < need && guard < CTC_SPIN_MAX; ++guard) __builtin_amdgcn_s_sleep(1);
-                        asm volatile("" ::: "memory");
-                        v63 = bnd[w - 1][(q - 1) & (CTC_RING - 1)][0];
-                        v62 = bnd[w - 1][(q - 1) & (CTC_RING - 1)][1];
-                    }
+    // lattice row pointer of frame q, advanced by one row per frame (alpha walks up, beta down)
+    float* lrow = lat + (size_t)(dir == 0 ? 0 : Tb - 1) * Smax + sidx;
+    const long lstep = dir == 0 ? (long)Smax : -(long)Smax;
+    // one frame; UP: there is an upstream wave (w > 0), DOWN: a downstream wave (w < NW - 1), FIRST: q == 0.  The roles are fixed
+    // per wave, so the loop below is instantiated per role instead of testing them on every frame.
+    auto frame = [&](auto up_t, auto down_t, auto first_t, int q, float e) {
+        constexpr bool UP = decltype(up_t)::value, DOWN = decltype(down_t)::value, FIRST = decltype(first_t)::value;
+        float v63 = NEG_INF, v62 = NEG_INF;
+        if constexpr (UP) {
+            if constexpr (!FIRST) {
+                // (the progress word travels as an opaque VGPR until here: as a plain uniform value hipcc moves it to an SGPR --
+                //  and waits for the LDS read -- right where it was issued, which puts the read's latency back on the chain)
+                asm volatile("" : "+v"(pnext));
+                if (__builtin_amdgcn_readfirstlane(pnext) >= q - 1) {    // the copy fetched during the previous frame is valid
+                    v63 = n63; v62 = n62;
+                } else {
+                    // wait until the upstream wave is TWO frames ahead (or done): with a skew of one, the speculative fetch
+                    // below would find frame q unpublished on every frame and this slow path would run each time
+                    const int need = min(q + 1, Tb - 1);
+                    for (int guard = 0; prog_load(w - 1) < need && guard < CTC_SPIN_MAX; ++guard) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    v63 = bnd[w - 1][(q - 1) & (CTC_RING - 1)][0];
+                    v62 = bnd[w - 1][(q - 1) & (CTC_RING - 1)][1];
                 }
-                // speculative fetch for frame q + 1 (edge values of frame q): progress word FIRST -- if it already says >= q, the slot
-                // read after it (LDS keeps a wave's operations in order) is complete; used next frame, so its latency hides here
-                pnext = prog_load(w - 1);
-                asm volatile("" ::: "memory");
-                n63 = bnd[w - 1][q & (CTC_RING - 1)][0];
-                n62 = bnd[w - 1][q & (CTC_RING - 1)][1];
             }
+            // speculative fetch for frame q + 1 (edge values of frame q): progress word FIRST -- if it already says >= q, the slot
+            // read after it (LDS keeps a wave's operations in order) is complete; used next frame, so its latency hides here
+            pnext = prog_load(w - 1);
+            asm volatile("" ::: "memory");
+            n63 = bnd[w - 1][q & (CTC_RING - 1)][0];
+            n62 = bnd[w - 1][q & (CTC_RING - 1)][1];
+        }
+        float v;
+        if constexpr (FIRST) {
+            v = (u <= 1) ? e : NEG_INF;
+        } else {
             const float sm1 = ctc_wave_shr1(v63, a_prev);
             const float sm2 = ctc_wave_shr1(v62, sm1);
-            float v;
-            if (q == 0) v = (u <= 1) ? cur[j] : NEG_INF;
-            else v = cur[j] + ctc_lse3_log2(a_prev, sm1, skip ? sm2 : NEG_INF);
-            if (!active) v = NEG_INF;
-            if (w < NW - 1) {
-                // back-pressure, once per half ring: frames q .. q + RING/2 - 1 reuse the slots of frames q - RING .. q - RING/2 - 1, which
-                // wave w+1 has read once it has published frame q - RING/2
-                if ((q & (CTC_RING / 2 - 1)) == 0 && q >= CTC_RING / 2)
-                    for (int guard = 0; prog_load(w + 1) < q - CTC_RING / 2 && guard < CTC_SPIN_MAX; ++guard) __builtin_amdgcn_s_sleep(1);
-                asm volatile("" ::: "memory");
-                if (lane >= 62) bnd[w][q & (CTC_RING - 1)][63 - lane] = v;
-            }
-            asm volatile("" ::: "memory");       // program order only: LDS performs one wave's writes in the order they were issued
-            if (lane == 0) __hip_atomic_store(&progress[w], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            a_prev = v;
-            if (active) lat[(size_t)t * Smax + sidx] = v * 0.69314718055994530942f;      // the lattice is stored in natural-log units
+            v = e + ctc_lse3_log2(a_prev, sm1, skip ? sm2 : NEG_INF);
         }
+        if (!active) v = NEG_INF;
+        if constexpr (DOWN) {
+            // back-pressure, once per half ring: frames q .. q + RING/2 - 1 reuse the slots of frames q - RING .. q - RING/2 - 1, which
+            // wave w+1 has read once it has published frame q - RING/2
+            if ((q & (CTC_RING / 2 - 1)) == 0 && q >= CTC_RING / 2)
+                for (int guard = 0; prog_load(w + 1) < q - CTC_RING / 2 && guard < CTC_SPIN_MAX; ++guard) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            if (lane >= 62) bnd[w][q & (CTC_RING - 1)][63 - lane] = v;
+        }
+        asm volatile("" ::: "memory");       // program order only: LDS performs one wave's writes in the order they were issued
+        if (lane == 0) __hip_atomic_store(&progress[w], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        a_prev = v;
+        if (active) *lrow = v * 0.69314718055994530942f;      // the lattice is stored in natural-log units
+        lrow += lstep;
+    };
+    auto run = [&](auto up_t, auto down_t) {
+        for (int q0 = 0; q0 < Tb; q0 += CTC_PF) {
 #pragma unroll
-        for (int j = 0; j < CTC_PF; ++j) cur[j] = nxt[j];
-    }
+            for (int j = 0; j < CTC_PF; ++j) nxt[j] = emission(q0 + CTC_PF + j);
+            if (q0 == 0) {
+                frame(up_t, down_t, std::true_type{}, 0, cur[0]);
+#pragma unroll
+                for (int j = 1; j < CTC_PF; ++j)
+                    if (j < Tb) frame(up_t, down_t, std::false_type{}, j, cur[j]);
+            } else if (q0 + CTC_PF <= Tb) {
+#pragma unroll
+                for (int j = 0; j < CTC_PF; ++j) frame(up_t, down_t, std::false_type{}, q0 + j, cur[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < CTC_PF; ++j)
+                    if (q0 + j < Tb) frame(up_t, down_t, std::false_type{}, q0 + j, cur[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < CTC_PF; ++j) cur[j] = nxt[j];
+        }
+    };
+    const bool has_up = w > 0, has_down = w < NW - 1;
+    if (has_up && has_down) run(std::true_type{}, std::true_type{});
+    else if (has_up) run(std::true_type{}, std::false_type{});
+    else if (has_down) run(std::false_type{}, std::true_type{});
+    else run(std::false_type{}, std::false_type{});
     if (dir == 0) {
         if (u == S - 1) fin[0] = a_prev;
         if (S >= 2 && u == S - 2) fin[1] = a_prev;
