@@ -6,6 +6,9 @@
 #include "common.h"
 #include "../../include/voice100_hip.h"
 #include "depthwise_common.h"   // DwFin: BatchNorm finalisation inside the depthwise kernels
+#ifndef IR_FUSE_BN3
+#define IR_FUSE_BN3 1
+#endif
 
 namespace {
 struct Carver {
@@ -217,9 +220,14 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     // BN3 backward
     const int Gr = v100_dw_num_groups(B, cout);
     const bool a316 = sh[IR_ACT16] >= 3;              // a3 (saved) and da3 (workspace) stored as bf16
-    if (a316) CK(v100_chan_reduce2_io(dy, a3, w.part, Gr, B, cout, T2, 2, stream));
-    else CK(v100_chan_reduce2(dy, a3, w.part, Gr, B, cout, T2, stream));
-    CK(v100_bn_bwd_finalize(w.part, Gr, (long long)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], cout, stream));
+    if (a316 && IR_FUSE_BN3) {     // one workgroup per channel sums (dy, dy * a3) and finalises BatchNorm 3's backward itself
+        const DwFin fin{2, (double)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], nullptr, nullptr, nullptr, 0.f, 0.f};
+        CK(chan_reduce2_io_fin(dy, a3, w.part, B, cout, T2, fin, stream));
+    } else {
+        if (a316) CK(v100_chan_reduce2_io(dy, a3, w.part, Gr, B, cout, T2, 2, stream));
+        else CK(v100_chan_reduce2(dy, a3, w.part, Gr, B, cout, T2, stream));
+        CK(v100_bn_bwd_finalize(w.part, Gr, (long long)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], cout, stream));
+    }
     if (a316) CK(v100_chan_affine2_io(dy, a3, pp, qq, rr, w.da3, B, cout, T2, 6, stream));
     else CK(v100_chan_affine2(dy, a3, pp, qq, rr, w.da3, B, cout, T2, stream));
     if (sh[IR_ACT16]) {

@@ -10,6 +10,7 @@
 // [parts][C][2] slab; the finalisers below reduce the slab in double (fixed order, deterministic)
 // and emit  scale = gamma * rstd,  shift = beta - mean * scale  for the consumer's prologue.
 #include "common.h"
+#include "depthwise_common.h"     // DwFin / dw_finalize: BatchNorm finalisation inside a producing kernel
 
 __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int parts, double count,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -174,6 +175,39 @@ __global__ __launch_bounds__(256) void chan_reduce2_io_kernel(const void* __rest
     if (threadIdx.x == 0) {
         partial[((size_t)g * C + c) * 2 + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
         partial[((size_t)g * C + c) * 2 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+// The same sums with ONE 1024-thread workgroup per channel, which therefore owns the channel's complete sums and runs the
+// BatchNorm-backward finaliser itself (DwFin mode 2: p / q / r, dgamma, dbeta) -- no slab, no finaliser launch.
+template <int IO>
+__global__ __launch_bounds__(1024) void chan_reduce2_fin_kernel(const void* __restrict__ u, const void* __restrict__ v, float* __restrict__ partial,
+                                                                int B, int C, int T, DwFin fin) {
+    __shared__ float red[16][2];
+    const int c = blockIdx.x;
+    const int P = (T + 7) & ~7;
+    const int T4 = (T + 3) >> 2;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = threadIdx.x; i < B * T4; i += 1024) {
+        const int b = i / T4, t = (i - b * T4) * 4;
+        const size_t row = (size_t)b * C + c;
+        float a[4], w[4];
+        chan_load4<(IO & 1) != 0>(u, row, T, P, t, a);
+        chan_load4<(IO & 2) != 0>(v, row, T, P, t, w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0 += a[e]; s1 = fmaf(a[e], w[e], s1); }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { t0 += red[k][0]; t1 += red[k][1]; }       // fixed order
+        partial[(size_t)c * 2 + 0] = t0;
+        partial[(size_t)c * 2 + 1] = t1;
+        dw_finalize(fin, c, t0, t1);
     }
 }
 
@@ -442,6 +476,14 @@ extern "C" int v100_chan_reduce2_io(const void* u, const void* v, float* partial
     if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || G > B) return V100_ERR_SHAPE;
     if (io16 == 2) hipLaunchKernelGGL(chan_reduce2_io_kernel<2>, dim3(C, G), dim3(256), 0, (hipStream_t)stream, u, v, partial, B, C, T, G);
     else return V100_ERR_SHAPE;
+    return v100_launch_status();
+}
+
+// block executor: sums of (dy, dy * a3) per channel + BatchNorm-3 backward coefficients in one launch (u fp32, v bf16)
+int chan_reduce2_io_fin(const void* u, const void* v, float* partial, int B, int C, int T, const DwFin& fin, void* stream) {
+    if (!u || !v || !partial) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || fin.mode != 2) return V100_ERR_SHAPE;
+    hipLaunchKernelGGL(chan_reduce2_fin_kernel<2>, dim3(C), dim3(1024), 0, (hipStream_t)stream, u, v, partial, B, C, T, fin);
     return v100_launch_status();
 }
 

@@ -92,6 +92,7 @@ __device__ __forceinline__ void dw_finalize(const DwFin& f, int c, float sum0, f
     }
 }
 
+int chan_reduce2_io_fin(const void* u, const void* v, float* partial, int B, int C, int T, const DwFin& fin, void* stream);   // bn.hip
 // the act16 entry points with in-kernel BatchNorm finalisation (block executor; fin.mode != 0 requires G == 1)
 int dw_fwd_train_io_fin(const void* a1, const float* w, const float* in_a, const float* in_b, void* a2, float* stats, int G, int B, int C,
                         int T, int K, int io16, const DwFin& fin, void* stream);
