@@ -136,6 +136,12 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
         }
         const bool a316 = sh[IR_ACT16] >= 3;          // the project output (saved for backward) as bf16 too
         CK(v100_pw_gemm_io(w3bf, a2, nullptr, s2, t2, nullptr, 1, a3, nullptr, nullptr, nullptr, 1, st, B, cout, hid, T2, PW_IO_X | (a316 ? PW_IO_Y : 0), stream));
+        if (IR_FUSE_BN3) {     // BatchNorm 3 finalised by the block-output pass itself (one workgroup per channel)
+            const DwPre pre{{1, (double)B * T2, (const float*)P[14], (const float*)P[15], nullptr, s3, t3, nullptr, m3, r3,
+                             (float*)P[16], (float*)P[17], (long long*)P[18], kMom, kEps}, st, parts3};
+            CK(chan_affine2_fin(a3, res ? x : nullptr, y, y16, B, cout, T2, a316 ? 1 : 0, pre, stream));
+            return V100_OK;
+        }
         CK(v100_bn_finalize_train(st, parts3, (long long)B * T2, (const float*)P[14], (const float*)P[15], (float*)P[16], (float*)P[17], (long long*)P[18],
                                   kMom, kEps, s3, t3, m3, r3, cout, stream));
         if (y16) CK(v100_chan_affine2_shadow(a3, res ? x : nullptr, s3, t3, y, y16, B, cout, T2, a316 ? 1 : 0, stream));

@@ -59,9 +59,9 @@ struct DwParams {
 };
 enum { DW_IO_X = 1, DW_IO_X2 = 2, DW_IO_AUX = 4, DW_IO_Y = 8 };
 
-// thread 0 of the workgroup of channel c, with the channel's complete sums (G == 1)
-__device__ __forceinline__ void dw_finalize(const DwFin& f, int c, float sum0, float sum1) {
-    const double s0 = (double)sum0, s1 = (double)sum1;
+// one lane, with the channel's complete sums in double: the arithmetic of bn_finalize_train_kernel / bn_bwd_finalize_kernel.
+// coef (may be null) receives the three per-channel coefficients the consumer applies: mode 1 (scale, shift, 0), mode 2 (p, q, r).
+__device__ __forceinline__ void dw_finalize_d(const DwFin& f, int c, double s0, double s1, float* coef) {
     if (f.mode == 1) {
         if (c == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
         const double mean = s0 / f.count;
@@ -69,8 +69,9 @@ __device__ __forceinline__ void dw_finalize(const DwFin& f, int c, float sum0, f
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
         const float sc = f.gamma[c] * rstd;
+        const float sh = f.a[c] - (float)mean * sc;
         f.o0[c] = sc;
-        f.o1[c] = f.a[c] - (float)mean * sc;
+        f.o1[c] = sh;
         if (f.o3) f.o3[c] = (float)mean;
         if (f.o4) f.o4[c] = rstd;
         if (f.running_mean) {
@@ -78,6 +79,7 @@ __device__ __forceinline__ void dw_finalize(const DwFin& f, int c, float sum0, f
             f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
             f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
         }
+        if (coef) { coef[0] = sc; coef[1] = sh; coef[2] = 0.f; }
     } else if (f.mode == 2) {
         const double mu = f.a[c], rs = f.b[c], ga = f.gamma[c];
         const double dg = rs * (s1 - mu * s0);
@@ -89,9 +91,32 @@ __device__ __forceinline__ void dw_finalize(const DwFin& f, int c, float sum0, f
         f.o2[c] = (float)rr;
         if (f.o3) f.o3[c] = (float)dg;
         if (f.o4) f.o4[c] = (float)s0;
+        if (coef) { coef[0] = (float)pp; coef[1] = (float)qq; coef[2] = (float)rr; }
     }
 }
+// thread 0 of the workgroup of channel c, with the channel's complete sums (G == 1)
+__device__ __forceinline__ void dw_finalize(const DwFin& f, int c, float sum0, float sum1) { dw_finalize_d(f, c, (double)sum0, (double)sum1, nullptr); }
 
+// BatchNorm finalisation by the CONSUMING kernel from a producer's slab of partial sums [parts][C][2] (a GEMM epilogue's): for
+// kernels that run ONE workgroup per channel.  Executed by one whole wave (EXEC all ones) before the workgroup's first barrier:
+// lanes stride over the slab rows, butterfly in double -- the finaliser kernels' own order, so the results are identical.
+struct DwPre {
+    DwFin f;                // mode 0: none
+    const float* stats;     // [parts][C][2]
+    int parts;
+};
+__device__ __forceinline__ void dw_finalize_parts(const DwPre& pre, int C, int c, int lane, float* coef) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int g = lane; g < pre.parts; g += 64) {
+        s0 += (double)pre.stats[((size_t)g * C + c) * 2 + 0];
+        s1 += (double)pre.stats[((size_t)g * C + c) * 2 + 1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+    if (lane == 0) dw_finalize_d(pre.f, c, s0, s1, coef);
+}
+
+int chan_affine2_fin(const void* u, const float* v, float* out, void* shadow, int B, int C, int T, int u_bf16, const DwPre& pre, void* stream);   // bn.hip
 int chan_reduce2_io_fin(const void* u, const void* v, float* partial, int B, int C, int T, const DwFin& fin, void* stream);   // bn.hip
 // the act16 entry points with in-kernel BatchNorm finalisation (block executor; fin.mode != 0 requires G == 1)
 int dw_fwd_train_io_fin(const void* a1, const float* w, const float* in_a, const float* in_b, void* a2, float* stats, int G, int B, int C,
