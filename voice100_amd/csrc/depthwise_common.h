@@ -38,6 +38,13 @@ struct DwFin {
     float momentum, eps;
 };
 
+// ... or by the CONSUMING kernel, from a producer's slab of partial sums (dw_finalize_parts below)
+struct DwPre {
+    DwFin f;                // mode 0: none
+    const float* stats;     // [parts][C][2]
+    int parts;
+};
+
 struct DwParams {
     const float* x;      // [B,C,Tin]
     const float* x2;     // [B,C,Tin]   second stream for DW_IN_AFFINE2
@@ -56,6 +63,8 @@ struct DwParams {
     // pitch P = dw_pitch16(T) (multiple of 8 elements); x / x2 / aux / y then point at bf16 data.  MFMA kernels only.
     int io16;
     DwFin fin;           // mode 0 unless the caller asked for in-kernel finalisation (G == 1)
+    DwPre pre;           // f.mode 0 unless the kernel also finalises the BatchNorm whose coefficients it applies on load (G == 1): then
+                         // in_a / in_b / in_c are ignored and the coefficients come from pre (and are written to pre.f.o0 .. o2)
 };
 enum { DW_IO_X = 1, DW_IO_X2 = 2, DW_IO_AUX = 4, DW_IO_Y = 8 };
 
@@ -100,11 +109,6 @@ __device__ __forceinline__ void dw_finalize(const DwFin& f, int c, float sum0, f
 // BatchNorm finalisation by the CONSUMING kernel from a producer's slab of partial sums [parts][C][2] (a GEMM epilogue's): for
 // kernels that run ONE workgroup per channel.  Executed by one whole wave (EXEC all ones) before the workgroup's first barrier:
 // lanes stride over the slab rows, butterfly in double -- the finaliser kernels' own order, so the results are identical.
-struct DwPre {
-    DwFin f;                // mode 0: none
-    const float* stats;     // [parts][C][2]
-    int parts;
-};
 __device__ __forceinline__ void dw_finalize_parts(const DwPre& pre, int C, int c, int lane, float* coef) {
     double s0 = 0.0, s1 = 0.0;
     for (int g = lane; g < pre.parts; g += 64) {
@@ -120,10 +124,10 @@ int chan_affine2_fin(const void* u, const float* v, float* out, void* shadow, in
 int chan_reduce2_io_fin(const void* u, const void* v, float* partial, int B, int C, int T, const DwFin& fin, void* stream);   // bn.hip
 // the act16 entry points with in-kernel BatchNorm finalisation (block executor; fin.mode != 0 requires G == 1)
 int dw_fwd_train_io_fin(const void* a1, const float* w, const float* in_a, const float* in_b, void* a2, float* stats, int G, int B, int C,
-                        int T, int K, int io16, const DwFin& fin, void* stream);
+                        int T, int K, int io16, const DwFin& fin, const DwPre& pre, void* stream);
 int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc, const void* xpre,
                   const float* xa, const float* xb, void* dxin, float* stats, float* wpartial, float* dw, int G, int B, int C, int T, int K,
-                  int io16, const DwFin& fin, void* stream);
+                  int io16, const DwFin& fin, const DwPre& pre, void* stream);
 __host__ __device__ __forceinline__ int dw_pitch16(int T) { return (T + 7) & ~7; }
 
 struct DwWgradParams {

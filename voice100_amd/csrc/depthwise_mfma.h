@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     __shared__ float lds_w[WLEN];
     __shared__ float lds_red[4][2];
+    __shared__ float lds_coef[3];
 
     const int c = blockIdx.x;
     const int g = blockIdx.y;
@@ -164,6 +165,9 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
         const int j = i - WPAD;
         lds_w[i] = (j >= 0 && j < K) ? p.w[(size_t)c * K + (p.flip ? (K - 1 - j) : j)] : 0.f;
     }
+    // one group (G == 1): this workgroup is the only consumer of channel c's input BatchNorm, so its first wave finalises it from
+    // the producing GEMM's slab of partial sums (DwPre) while the others stage the taps
+    if (p.pre.f.mode != 0 && wave == 0) dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
     __syncthreads();
 
     // A fragments: lane (m = n_, q_) holds A[m][32*s + 8*q + jj] = w[32*s + 8*q + jj - m - off], jj = 0..7, as NT digit packs
@@ -188,8 +192,11 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
     }
 
     float ca = 1.f, cb = 0.f, cc = 0.f, oa = 1.f, ob = 0.f;
-    if constexpr (IM != DW_IN_NONE) { ca = p.in_a[c]; cb = p.in_b[c]; }
-    if constexpr (IM == DW_IN_AFFINE2) cc = p.in_c[c];
+    if (p.pre.f.mode != 0) { ca = lds_coef[0]; cb = lds_coef[1]; cc = lds_coef[2]; }
+    else {
+        if constexpr (IM != DW_IN_NONE) { ca = p.in_a[c]; cb = p.in_b[c]; }
+        if constexpr (IM == DW_IN_AFFINE2) cc = p.in_c[c];
+    }
     if constexpr (OM == DW_OUT_AFFINE_RELU6 || OM == DW_OUT_MASK_STATS) { oa = p.out_a[c]; ob = p.out_b[c]; }
 
     const int Tin = p.Tin, Tout = p.Tout;
