@@ -345,8 +345,10 @@ def main():
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: asr_en_base (AudioToTextCTC 64/512/29/512) training step, "
                                    "batch=32 x 1024-frame synthetic log-mel + CTC targets [32,100] per GPU, "
-                                   "augmentation+dropout on, Adam; 1x1 GEMM operands bf16 (fp32 accumulate), hidden (4x-wide) activations and "
-                                   "their gradients stored as bf16, block inputs/outputs, BatchNorm statistics and all accumulation fp32"
+                                   "augmentation+dropout on, Adam; 1x1 GEMM operands bf16 (fp32 accumulate); activation storage level "
+                                   + str(F_.get_activation_storage()) + " (0 fp32 everywhere; >= 1 the tensors internal to a block -- and their "
+                                   "gradients from 2 -- stored as bf16; 4 adds a bf16 copy of each block output as the next block's GEMM "
+                                   "operand); block inputs/outputs, BatchNorm statistics and all accumulation fp32"
                                    if args.precision == "bf16" else
                                    "configs[1] at fp32 throughout",
                        "global_batch": B_PER_GPU * world, "frames_per_utterance": T_FRAMES, "parallelism": f"dp{world}"},
