@@ -7,7 +7,7 @@
 #include "../../include/voice100_hip.h"
 #include "depthwise_common.h"   // DwFin: BatchNorm finalisation inside the depthwise kernels
 #ifndef IR_FUSE_BN3
-#define IR_FUSE_BN3 1
+#define IR_FUSE_BN3 2      /* 1: reduce + finalise in one kernel; 2: ... + the affine, from registers */
 #endif
 // consumer-side BatchNorm finalisation in the depthwise kernels (DwPre): bit 0 forward (BatchNorm 1 from the expand GEMM's slab),
 // bit 1 backward (BatchNorm-2 backward from the project backward-data GEMM's slab).  Bit-identical results; measured on one box:
@@ -238,15 +238,21 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     // BN3 backward
     const int Gr = v100_dw_num_groups(B, cout);
     const bool a316 = sh[IR_ACT16] >= 3;              // a3 (saved) and da3 (workspace) stored as bf16
-    if (a316 && IR_FUSE_BN3) {     // one workgroup per channel sums (dy, dy * a3) and finalises BatchNorm 3's backward itself
+    bool da3_done = false;
+    if (a316 && IR_FUSE_BN3) {     // one workgroup per channel sums (dy, dy * a3) and finalises BatchNorm 3's backward itself ...
         const DwFin fin{2, (double)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], nullptr, nullptr, nullptr, 0.f, 0.f};
-        CK(chan_reduce2_io_fin(dy, a3, w.part, B, cout, T2, fin, stream));
+        // ... and, when the channel's samples fit its registers, applies the affine to them in the same launch
+        if (IR_FUSE_BN3 >= 2 && chan_bn3_bwd(dy, a3, w.part, w.da3, B, cout, T2, fin, stream)) {
+            if ((rc = v100_launch_status()) != V100_OK) return rc;
+            da3_done = true;
+        } else CK(chan_reduce2_io_fin(dy, a3, w.part, B, cout, T2, fin, stream));
     } else {
         if (a316) CK(v100_chan_reduce2_io(dy, a3, w.part, Gr, B, cout, T2, 2, stream));
         else CK(v100_chan_reduce2(dy, a3, w.part, Gr, B, cout, T2, stream));
         CK(v100_bn_bwd_finalize(w.part, Gr, (long long)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], cout, stream));
     }
-    if (a316) CK(v100_chan_affine2_io(dy, a3, pp, qq, rr, w.da3, B, cout, T2, 6, stream));
+    if (da3_done) {}
+    else if (a316) CK(v100_chan_affine2_io(dy, a3, pp, qq, rr, w.da3, B, cout, T2, 6, stream));
     else CK(v100_chan_affine2(dy, a3, pp, qq, rr, w.da3, B, cout, T2, stream));
     if (sh[IR_ACT16]) {
         if (!v100_ir_act16_supported(sh)) return V100_ERR_SHAPE;

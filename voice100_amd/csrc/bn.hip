@@ -211,6 +211,67 @@ __global__ __launch_bounds__(1024) void chan_reduce2_fin_kernel(const void* __re
     }
 }
 
+// The whole BatchNorm-3 backward of a block in ONE pass over (dy, a3): the channel's B x T samples of both tensors stay in the
+// registers of its 1024-thread workgroup between the reduction (sum dy, sum dy*a3 -> p, q, r, dgamma, dbeta) and the affine
+// da3 = p*dy + q*a3 + r (bf16, pitched) that the two-kernel form re-read from memory.  NQ float4-quads per thread: B * ceil(T/4)
+// <= 1024 * NQ (the caller checks).  u = dy fp32, v = a3 bf16 (pitched), out = da3 bf16 (pitched).
+template <int NQ>
+__global__ __launch_bounds__(1024) void chan_bn3_bwd_kernel(const float* __restrict__ u, const void* __restrict__ v, float* __restrict__ partial,
+                                                            void* __restrict__ out, int B, int C, int T, DwFin fin) {
+    __shared__ float red[16][2];
+    __shared__ float coef[3];
+    const int c = blockIdx.x;
+    const int P = (T + 7) & ~7;
+    const int T4 = (T + 3) >> 2;
+    const int n = B * T4;
+    float a[NQ][4], w[NQ][4];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const int i = threadIdx.x + 1024 * k;
+        if (i < n) {
+            const int b = i / T4, t = (i - b * T4) * 4;
+            const size_t row = (size_t)b * C + c;
+            chan_load4<false>(u, row, T, P, t, a[k]);
+            chan_load4<true>(v, row, T, P, t, w[k]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[k][e] = 0.f; w[k][e] = 0.f; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0 += a[k][e]; s1 = fmaf(a[k][e], w[k][e], s1); }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { t0 += red[k][0]; t1 += red[k][1]; }       // fixed order
+        partial[(size_t)c * 2 + 0] = t0;
+        partial[(size_t)c * 2 + 1] = t1;
+        dw_finalize_d(fin, c, (double)t0, (double)t1, coef);
+    }
+    __syncthreads();
+    const float pa = coef[0], qb = coef[1], rc = coef[2];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const int i = threadIdx.x + 1024 * k;
+        if (i < n) {
+            const int b = i / T4, t = (i - b * T4) * 4;
+            const size_t row = (size_t)b * C + c;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(a[k][e], pa, fmaf(w[k][e], qb, rc));       // as chan_affine2_io rounds it
+            const bn_u32x2 w16 = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+            *reinterpret_cast<bn_u32x2*>(reinterpret_cast<u16*>(out) + row * P + t) = w16;      // samples past T land in the row's padding
+        }
+    }
+}
+
 // out = A[c]*u + Bc[c]*v + Cc[c]; io: 1 u is bf16, 2 v is bf16, 4 out is bf16; v may be null
 template <int IO>
 __global__ __launch_bounds__(256) void chan_affine2_io_kernel(const void* __restrict__ u, const void* __restrict__ v, const float* __restrict__ A,
@@ -523,6 +584,21 @@ int chan_affine2_fin(const void* u, const float* v, float* out, void* shadow, in
     else { if (shadow) CAF(false, true); else CAF(false, false); }
 #undef CAF
     return v100_launch_status();
+}
+
+// block executor: BatchNorm-3 backward in one pass (sums, coefficients, da3); 0 = shape not covered (more than 8 quads per thread)
+int chan_bn3_bwd(const float* u, const void* v, float* partial, void* out, int B, int C, int T, const DwFin& fin, void* stream) {
+    if (!u || !v || !partial || !out || fin.mode != 2) return 0;
+    const long n = (long)B * ((T + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+#define CB3(NQ_) hipLaunchKernelGGL(chan_bn3_bwd_kernel<NQ_>, dim3(C), dim3(1024), 0, st, u, v, partial, out, B, C, T, fin)
+    if (n <= 1024 * 2) CB3(2);
+    else if (n <= 1024 * 4) CB3(4);
+    else if (n <= 1024 * 6) CB3(6);
+    else if (n <= 1024 * 8) CB3(8);
+    else return 0;
+#undef CB3
+    return 1;
 }
 
 // block executor: sums of (dy, dy * a3) per channel + BatchNorm-3 backward coefficients in one launch (u fp32, v bf16)
