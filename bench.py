@@ -31,7 +31,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate ~6300
-TRACE_FILE = os.path.join(ROOT, "profiles", "r02n_step_breakdown.txt")   # tools/trace_step.py over a rocprofv3 kernel trace of this command
+TRACE_FILE = os.path.join(ROOT, "profiles", "r02o_step_breakdown.txt")   # tools/trace_step.py over a rocprofv3 kernel trace of this command
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_dw_fwd_pmc.json")   # HBM bytes / algorithmic bytes of the depthwise forward kernels (rocprofv3 PMC passes)
 B_PER_GPU, T_FRAMES, N_MEL, VOCAB, TEXT_LEN = 32, 1024, 64, 29, 100
 
