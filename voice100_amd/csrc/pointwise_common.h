@@ -32,7 +32,7 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #define PW_ABLATE 0
 #endif
 #ifndef PW_EPI_FAST
-#define PW_EPI_FAST 1
+#define PW_EPI_FAST 2      /* 1: lean epilogue for interior tiles; 2: also for the partial last t-tile (PT) */
 #endif
 #ifndef PW_DMA
 #define PW_DMA 0             /* bit 0: expand forward (on the bf16 shadow), bit 1: project backward-data, by the LDS-DMA kernel: measured +-0 in the step, off */
@@ -226,7 +226,9 @@ __device__ __forceinline__ float half_wave_sum_dpp(float v) {
 // is bound by instruction ISSUE (~1000 VALU per wave and tile: 3-5 us of the 16 us a 256 x 128 x 512 tile takes), not by
 // memory.  Here: buffer addressing (one per-lane offset, the row advance is a scalar), no masks, R / coefficient loads of
 // all 16 passes in flight before the accumulators go through LDS, statistics written once at the end.
-template <int EPI_, int BM, int IO>
+// PT: the tile's rows all lie inside the tensor but its last columns do not (t0 + 128 > T: the last t-tile of a time-stretched length):
+// same path with a per-lane column test -- lanes past T neither store nor count; a lane that straddles T masks per element.
+template <int EPI_, int BM, int IO, bool PT = false>
 struct PwEpilogueFull {
     static constexpr bool YB = (IO & PW_IO_Y) != 0, RB = (IO & PW_IO_R) != 0;
     typedef unsigned int epi_u32x2 __attribute__((ext_vector_type(2)));
@@ -241,7 +243,7 @@ struct PwEpilogueFull {
     RReg rpre[may_r ? 16 : 1];
     float eav[use_e ? 16 : 1], ebv[use_e ? 16 : 1];
     bool use_r;
-    int voY, stepY, mrow;
+    int voY, stepY, mrow, tcol;
 
     // part 1: request the R tile and the per-row coefficients of all 16 passes
     __device__ __forceinline__ void issue(const PwParams& p, int b, int m0, int t0, int tid) {
@@ -249,6 +251,7 @@ struct PwEpilogueFull {
         const int P16 = pw_pitch16(p.T);
         const int lane = tid & 63, col = lane & 31, half = lane >> 5, wave = tid >> 6;
         mrow = m0 + wave * 2 + half;            // this lane's row in pass 0
+        tcol = t0 + col * 4;                    // this lane's first column
         const int PY = YB ? P16 : p.T, PR = RB ? P16 : p.T;
         const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(use_r ? p.R : p.X), 0,
                                                                            use_r ? (int)((size_t)p.B * p.M * PR * ER) : 0, 0x00020000);
@@ -312,26 +315,36 @@ struct PwEpilogueFull {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                const bool ok = !PT || tcol + e < p.T;          // PT only: columns past T contribute nothing
                 float x = a[e];
+                const float r = (PT && !ok) ? 0.f : rv[e];
                 if constexpr (epi == PW_EPI_STATS) {
-                    s0 += x; s1 = fmaf(x, x, s1);
+                    if (ok) { s0 += x; s1 = fmaf(x, x, s1); }
                 } else if constexpr (epi == PW_EPI_AFFINE_RELU6) {
                     x = relu6f(fmaf(x, eav[pass], ebv[pass]));
                 } else if constexpr (epi == PW_EPI_AFFINE_RES) {
-                    x = fmaf(x, eav[pass], ebv[pass]) + rv[e];
+                    x = fmaf(x, eav[pass], ebv[pass]) + r;
                 } else if constexpr (epi == PW_EPI_MASK_STATS) {
-                    const float pre = fmaf(rv[e], eav[pass], ebv[pass]);
+                    const float pre = fmaf(r, eav[pass], ebv[pass]);
                     x = (pre > 0.f && pre < 6.f) ? x : 0.f;
-                    s0 += x; s1 = fmaf(x, rv[e], s1);
+                    if (ok) { s0 += x; s1 = fmaf(x, r, s1); }
                 } else if constexpr (epi == PW_EPI_ADD) {
-                    x += rv[e];
+                    x += r;
                 }
                 v[e] = x;
             }
             if constexpr (!(PW_ABLATE & 4)) {
                 if constexpr (YB) {
-                    const epi_u32x2 o2 = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                    __builtin_amdgcn_raw_buffer_store_b64(o2, rY, voY, pass * stepY, 0);
+                    // (PT: the pitch keeps a straddling lane's 8 bytes inside the row; columns past T are padding)
+                    if (!PT || tcol < p.T) {
+                        const epi_u32x2 o2 = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                        __builtin_amdgcn_raw_buffer_store_b64(o2, rY, voY, pass * stepY, 0);
+                    }
+                } else if (PT && tcol + 3 >= p.T) {
+                    float* yq = reinterpret_cast<float*>(reinterpret_cast<char*>(p.Y) + (size_t)pass * stepY + (unsigned)voY);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tcol + e < p.T) yq[e] = v[e];
                 } else {
                     // NOT a buffer store: `buffer_store_dwordx4 v[96:99], v65, s[0:3], s4 offen` directly followed by a VALU write of
                     // v99 stored the NEW v99 on gfx950 (sporadic wrong 4th elements) -- hipcc's hazard recognizer assumes that a
@@ -363,6 +376,10 @@ struct PwEpilogueFull {
 __device__ __forceinline__ bool pw_tile_is_full(const PwParams& p, int BM, int m0, int t0) {
     return PW_EPI_FAST != 0 && t0 + 128 <= p.T && m0 + BM <= p.M && p.bias == nullptr;
 }
+// ... or at least in its rows (the last t-tile of a length that is not a multiple of 128)
+__device__ __forceinline__ bool pw_tile_rows_full(const PwParams& p, int BM, int m0) {
+    return PW_EPI_FAST >= 2 && m0 + BM <= p.M && p.bias == nullptr;
+}
 
 // Epilogue through LDS: the 128x128 fp32 accumulator tile is parked in the (now idle) 64 KB staging buffers,
 // then every half-wave streams one output row per pass as 16-byte accesses (R read, Y write: 512 B contiguous
@@ -377,6 +394,12 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
     constexpr int epi = EPI_;
     if (pw_tile_is_full(p, BM, m0, t0)) {
         PwEpilogueFull<EPI_, BM, IO> ef;
+        ef.issue(p, b, m0, t0, tid);
+        ef.finish(p, acc, ct, b, tt, wm, wn, tid);
+        return;
+    }
+    if (pw_tile_rows_full(p, BM, m0)) {
+        PwEpilogueFull<EPI_, BM, IO, true> ef;
         ef.issue(p, b, m0, t0, tid);
         ef.finish(p, acc, ct, b, tt, wm, wn, tid);
         return;
