@@ -256,7 +256,8 @@ def test_errors_are_loud(cuda):
 
 
 @pytest.mark.parametrize("B,T,V,L", [(3, 40, 29, 7), (4, 130, 71, 30), (2, 9, 5, 6), (5, 64, 29, 1),
-                                     (3, 700, 29, 300), (2, 1300, 71, 600), (2, 2500, 29, 1200)])   # L > 255: 4 / 8 / 16 states per thread
+                                     (3, 700, 29, 300), (2, 1300, 71, 600), (2, 2500, 29, 1200),    # L > 255: 4 / 8 / 16 states per thread
+                                     (2, 1100, 29, 505)])                                           # 1011 states: the 16-wave pipeline
 def test_ctc_loss_fused(cuda, B, T, V, L):
     """Fused log_softmax + CTC (value and gradient) vs torch's CPU F.ctc_loss, ragged lengths, repeated labels,
     an infeasible utterance (zero_infinity) and an empty target."""
@@ -271,7 +272,9 @@ def test_ctc_loss_fused(cuda, B, T, V, L):
     if B >= 4:
         in_len[1] = max(1, int(tgt_len[1]) - 1)            # too short: infinite loss -> zeroed
         tgt_len[2] = 0                                      # empty target
-    ref_in = logits.clone().requires_grad_(True)
+    # reference in float64: torch's own fp32 CPU lattice is itself 8e-4 (T = 700) ... 4e-3 (T = 1100) off the exact gradient -- more
+    # than the kernel under test (5e-4 / 2e-3, tools/micro/ctc_acc.py) -- so two fp32 implementations can differ by the sum
+    ref_in = logits.double().clone().requires_grad_(True)
     ref = F.ctc_loss(F.log_softmax(ref_in.transpose(0, 1), dim=-1), targets, in_len, tgt_len, blank=0, reduction="mean",
                      zero_infinity=True)
     ref.backward()
@@ -281,7 +284,7 @@ def test_ctc_loss_fused(cuda, B, T, V, L):
     assert abs(float(loss.detach()) - float(ref.detach())) < 1e-4 * max(1.0, abs(float(ref.detach())))
     # lattice values grow with T (|alpha + beta| ~ 1e3 at T = 700: one fp32 ulp there is 6e-5 in the log domain, and the
     # occupancy exp(alpha + beta + nll - logp) inherits it), so the long cases compare at a wider fp32 bar
-    assert rel_err(x.grad, ref_in.grad) < (2e-4 if T <= 200 else 5e-3)
+    assert rel_err(x.grad, ref_in.grad.float()) < (2e-4 if T <= 200 else 5e-3)
 
 
 @pytest.mark.parametrize("B,C,T,K,S", [(5, 12, 130, 19, 1), (3, 8, 77, 83, 1), (2, 6, 40, 9, 1), (4, 10, 61, 11, 2), (2, 4, 600, 51, 1)])
