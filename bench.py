@@ -31,9 +31,18 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate ~6300
-TRACE_FILE = os.path.join(ROOT, "profiles", "r02o_step_breakdown.txt")   # tools/trace_step.py over a rocprofv3 kernel trace of this command
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_dw_fwd_pmc.json")   # HBM bytes / algorithmic bytes of the depthwise forward kernels (rocprofv3 PMC passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "dw_fwd_pmc.json")   # HBM bytes / algorithmic bytes of the depthwise forward kernels (rocprofv3 PMC passes, tools/pmc_table.py --json), tagged with the kernel sources' hash
 B_PER_GPU, T_FRAMES, N_MEL, VOCAB, TEXT_LEN = 32, 1024, 64, 29, 100
+
+
+def dw_source_sha():
+    """sha256 (16 hex) over the depthwise kernel sources: a stored PMC ratio is only quoted for the kernels it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "voice100_amd", "csrc", "depthwise*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def encoder_dw_bytes(B, T):
@@ -172,6 +181,23 @@ def other_configs(device, N, F_):
             "voice_decoder_dw_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1) if n else None,
             "voice_decoder_dw_frac_of_8tbs": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if n else None,
             "voice_decoder_dw_launches": n}
+        # configs[2] is "align + audio model": the align model alone, then the whole chain text -> TextToAlignTextModel -> align()
+        # -> AlignTextToAudioModel.predict -> mcep -> log-spectrum GEMM -> exp/clip on the device (voice100_amd.infer.TTSPipeline;
+        # tts.py:79-110, 172-201, vocoder.py:89-99), B = 16 sentences of 128 tokens
+        from voice100_amd.tts import TextToAlignTextModel
+        from voice100_amd.vocoder import WORLDVocoder
+        from voice100_amd.infer import TTSPipeline
+        al = TextToAlignTextModel(vocab_size=VOCAB, hidden_size=512).to(device).eval()
+        text = torch.randint(1, VOCAB, (16, 128), device=device)
+        tlen = torch.randint(64, 129, (16,), device=device)
+        dt_al = timeit(lambda: al(text))
+        chain = TTSPipeline(al, AlignTextToAudioModel(vocab_size=VOCAB, hidden_size=512, use_mcep=True).to(device).eval(),
+                            WORLDVocoder(use_mcep=True).to(device))
+        dt_ch = timeit(lambda: chain(text, tlen))
+        wf = int(chain(text, tlen)["frames"].sum())
+        out["config3_align_model_B16_L128"] = {"ms": round(dt_al * 1e3, 3), "tokens_per_s": round(16 * 128 / dt_al, 1)}
+        out["config3_chain_text_to_spc_B16_L128"] = {"ms": round(dt_ch * 1e3, 3), "world_frames": wf,
+                                                    "world_frames_per_s": round(wf / dt_ch, 1)}
         F_.set_matmul_precision("fp16")                 # config 5 names fp16
         mel = MelSpectrogramAudioTransform().to(device)
         B = 256
@@ -191,21 +217,13 @@ def other_configs(device, N, F_):
     return out
 
 
-def _launches_per_step():
-    """Kernel launches per training step, from the committed kernel trace of this command (counting them live would need a profiler)."""
-    try:
-        first = open(TRACE_FILE).readline()
-        return {"value": int(first.split(" launches/step")[0].split()[-1]), "source": "profiles/" + os.path.basename(TRACE_FILE)}
-    except (OSError, ValueError, IndexError):
-        return None
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--windows", type=int, default=5, help="extra timed windows of --steps steps after the reported one (spread only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -218,9 +236,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torchrun rendezvous on
         # 127.0.0.1) as a child process, BEFORE this process touches the GPU, and leave with the child's exit code.
-        have = torch.cuda.device_count()               # does not initialise HIP
-        if have < args.gpus:
-            raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}")
+        # (no device query here: this process must not hold a GPU handle; a rank that finds no device for its LOCAL_RANK
+        # fails with torch's own message and the launcher returns its exit code)
         raise SystemExit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     from voice100_amd import functional as F_, _native as N
@@ -283,15 +300,30 @@ def main():
         # events in the dispatch packet (hipExtLaunchKernelGGL: the pair reads the kernel's own start/stop timestamps);
         # bracketing all ~130 hot launches of a step with hipEventRecord costs ~0.8 ms of it, hence the separate pass below
         N.timing_enable(["dw_fwd"])
+    launches0 = N.launch_count()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(batch)
     host_loop = time.perf_counter() - t0          # the host has ENQUEUED the last step; the GPU may still be running
     sync()
     elapsed = time.perf_counter() - t0
+    launches = (N.launch_count() - launches0) / args.steps      # the library's own launches, counted in this run (torch adds ~5 tiny elementwise ones)
+    if not args.no_kernel_timing:
+        kt_main = N.timing_read()
+        N.timing_enable(False)
+    # The contract's window above is `value`.  A 20-step window is ~0.07 s, and which of its steps draw a time-stretch moves it
+    # by several %: `windows` repeats it (same barrier + synchronise bracket, RNG streams running on) to show the spread.
+    windows = []
+    for _ in range(args.windows):
+        sync()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            step(batch)
+        sync()
+        windows.append((time.perf_counter() - tw) / args.steps * 1e3)
     kt, kt_all = {}, {}
     if not args.no_kernel_timing:
-        kt = N.timing_read()
+        kt = kt_main
         # per-kernel-family breakdown: a separate pass after the timed region (it slows the step, see above)
         N.timing_enable(True)
         nb = max(2, min(5, args.steps))
@@ -315,6 +347,14 @@ def main():
             dst.copy_(src)
         e1.record(); sync()
         copy_gbs = 10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        # the same 1 GiB -> 1 GiB copy by the library's own 16-byte-per-lane kernel (v100_copy_probe): torch's copy_ is not the
+        # best a kernel can do on this box, so both yardsticks are reported
+        N.call("v100_copy_probe", src, dst, src.numel() * 4); sync()
+        e0.record()
+        for _ in range(10):
+            N.call("v100_copy_probe", src, dst, src.numel() * 4)
+        e1.record(); sync()
+        probe_gbs = 10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
         frames = B_PER_GPU * T_FRAMES * world * args.steps
         dw_bytes, _ = encoder_dw_bytes(B_PER_GPU, T_FRAMES)
@@ -326,6 +366,8 @@ def main():
             # run's launches times the ratio rocprofv3 measured for these kernels (separate --pmc passes, 2*FETCH_SIZE +
             # WRITE_SIZE with the gfx950 correction; tools/pmc_passes.sh), null when that file is absent
             pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else None
+            if pmc is not None and pmc.get("kernel_src_sha") != dw_source_sha():
+                pmc = None                      # the kernels changed since the counters were taken: no stale ratio
             act16 = F_.get_activation_storage() if args.precision == "bf16" else 0
             roof = {"bound": "hbm", "kernel": "dwconv_mfma_kernel (depthwise forward: 8 Toeplitz-MFMA launches + the stride-2 first layer per step; "
                                               + ("hidden activations stored as bf16: algorithmic bytes at 2 B/sample)" if act16 else "fp32 activations)"),
@@ -334,7 +376,8 @@ def main():
                     "traffic_source": (f"{pmc['ratio']} x algorithmic bytes (rocprofv3 PMC, profiles/{os.path.basename(PMC_FILE)})" if pmc else None),
                     "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                     "algorithmic_bytes_per_launch": round(nbytes / n), "algorithmic_bytes_nominal_step": dw_bytes,
-                    "measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
+                    "measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+                    "copy_probe_gbs": round(probe_gbs, 1), "frac_of_copy_probe": round(achieved / probe_gbs, 4)}
         out = {
             "metric": "audio frames/sec (fwd+bwd) asr_en_base, B=32x1024-frame mel" + (" [DIAGNOSTIC: time-stretch off]" if args.diag_no_timestretch else "") + (f" [DIAGNOSTIC: stretch {args.diag_stretch_rate}% every step]" if args.diag_stretch_rate else ""),
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -355,16 +398,25 @@ def main():
             "loss": round(float(loss), 4),
             # host time to enqueue a step (the loop without the final synchronise): the step is GPU-bound while this stays below ms_per_step
             "host_enqueue_ms_per_step": round(host_loop / args.steps * 1e3, 3),
-            "launches_per_step": _launches_per_step(),
+            "launches_per_step": {"value": round(launches, 1), "source": "v100_launch_count() over the timed steps of this run (library launches; the "
+                                                                      "time-stretched steps of the seeded sequence take other kernel variants, not other counts)"},
+            "windows_ms_per_step": ({"n": len(windows), "median": round(float(np.median(windows)), 3), "min": round(min(windows), 3),
+                                     "max": round(max(windows), 3)} if windows else None),
             "roofline": roof,
             "kernel_ms_per_step": kt_all,
         }
+        # the extras must never cost the primary line: any failure in them is reported inside the JSON instead
         if world == 1 and not args.no_other_configs and args.precision == "bf16":
-            out["other_configs"] = other_configs(device, N, F_)
+            try:
+                out["other_configs"] = other_configs(device, N, F_)
+            except Exception as e:                                   # noqa: BLE001
+                out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
+        out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        else:
-            out["cpu_baseline"] = None
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:                                   # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

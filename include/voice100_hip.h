@@ -213,6 +213,11 @@ int v100_ln_gelu_bwd(const float* dout, const float* y, const float* gamma, cons
  * enable(mask): bit t of mask switches tag t on (0 = all off); a non-zero mask clears the counters.  read()
  * synchronises the device and returns the summed ms, launch count and (for the depthwise tags) the algorithmic bytes
  * of those launches: fp32 in + out + taps + BN coefficients. */
+/* kernel launches issued by the library in this process so far (bench.py: launches per step measured in the run itself) */
+long long v100_launch_count(void);
+/* dst = src, nbytes (a multiple of 16) in 16-byte pieces: the device-copy yardstick bench.py reports beside the HBM-bound
+ * kernels' GB/s ("fraction of both nominal and measured-copy bandwidth") */
+int v100_copy_probe(const void* src, void* dst, long long nbytes, void* stream);
 int v100_timing_enable(int tag_mask);
 int v100_timing_read(int tag, double* ms, long long* count, double* bytes);
 

@@ -68,7 +68,12 @@ for hid, k, s in SPECS:
 if tot_algo:
     print(f"forward, {len(fwd_rows)} launches: measured {tot_meas / 1e3:.3f} GB vs algorithmic {tot_algo / 1e3:.3f} GB -> ratio {tot_meas / tot_algo:.4f}")
     if jout:
-        json.dump({"ratio": round(tot_meas / tot_algo, 4), "launches": fwd_rows,
+        import glob
+        import hashlib
+        h = hashlib.sha256()
+        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "voice100_amd", "csrc", "depthwise*"))):
+            h.update(open(f, "rb").read())
+        json.dump({"ratio": round(tot_meas / tot_algo, 4), "kernel_src_sha": h.hexdigest()[:16], "launches": fwd_rows,
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 2*FETCH_SIZE + WRITE_SIZE KB (gfx950 correction), "
                              "tools/pmc_passes.sh + tools/pmc_table.py over tools/bench_kernels.py --what dw"}, open(jout, "w"), indent=1)
 print()

@@ -68,7 +68,7 @@ def load():
         for name, params in protos.items():
             fn = getattr(lib, name)        # AttributeError if the header declares a symbol the .so lacks
             fn.argtypes = [t for t, _ in params]
-            fn.restype = ctypes.c_longlong if name.endswith("_bytes") else ctypes.c_int
+            fn.restype = ctypes.c_longlong if (name.endswith("_bytes") or name == "v100_launch_count") else ctypes.c_int
         _lib, _protos = lib, protos
         return lib
 
@@ -122,6 +122,11 @@ def helper(name, *args):
 
 
 TIMING_TAGS = {"dw_fwd": 0, "dw_bwd_data": 1, "dw_wgrad": 2, "pw_gemm": 3, "pw_wgrad": 4}
+
+
+def launch_count() -> int:
+    """Kernel launches the library has issued in this process so far."""
+    return int(load().v100_launch_count())
 
 
 def timing_enable(tags=True) -> None:

@@ -54,7 +54,7 @@ extern "C" int v100_adam_step(const void* chunks, int nchunks, const void* param
     if (!chunks || !params || !grads || !exp_avg || !exp_avg_sq) return V100_ERR_NULL;
     if (nchunks <= 0 || step < 1) return V100_ERR_SHAPE;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks,
+    V100_GGL(adam_step_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks,
                        (float* const*)params, (const float* const*)grads, (float* const*)exp_avg, (float* const*)exp_avg_sq,
                        (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay,
                        (float)(1.0 / sqrt(bc2)));

@@ -88,6 +88,6 @@ extern "C" int v100_augment_fused(const float* x, const int* len, const float* u
     const long total = (long)B * Tout * F;
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(augment_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    V100_GGL(augment_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return v100_launch_status();
 }

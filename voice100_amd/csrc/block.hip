@@ -426,6 +426,6 @@ extern "C" int v100_ir_prep_batched(const int* shapes, const void* const* w1s, c
     long gx = (maxn + 4095) / 4096;           // 64 x 64 tiles of the largest matrix
     if (gx > 256) gx = 256;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(weight_prep_batched_kernel, dim3((unsigned)gx, 2 * n), dim3(256), 0, (hipStream_t)stream, t);
+    V100_GGL(weight_prep_batched_kernel, dim3((unsigned)gx, 2 * n), dim3(256), 0, (hipStream_t)stream, t);
     return v100_launch_status();
 }

@@ -536,7 +536,7 @@ extern "C" int v100_bn_finalize_train(const float* stats, int parts, long long c
                                       float eps, float* scale, float* shift, float* save_mean, float* save_rstd, int C, void* stream) {
     if (!stats || !gamma || !beta || !scale || !shift) return V100_ERR_NULL;
     if (C <= 0 || parts <= 0 || count <= 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, parts, (double)count,
+    V100_GGL(bn_finalize_train_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, parts, (double)count,
                        gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean, save_rstd, C);
     return v100_launch_status();
 }
@@ -545,7 +545,7 @@ extern "C" int v100_bn_eval_coeffs(const float* gamma, const float* beta, const 
                                    float eps, float* scale, float* shift, int C, void* stream) {
     if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) return V100_ERR_NULL;
     if (C <= 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+    V100_GGL(bn_eval_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
                        running_var, eps, scale, shift, C);
     return v100_launch_status();
 }
@@ -554,7 +554,7 @@ extern "C" int v100_bn_bwd_finalize(const float* partial, int parts, long long c
                                     const float* rstd, float* p, float* q, float* r, float* dgamma, float* dbeta, int C, void* stream) {
     if (!partial || !gamma || !mean || !rstd || !p || !q || !r) return V100_ERR_NULL;
     if (C <= 0 || parts <= 0 || count <= 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, parts, (double)count,
+    V100_GGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, parts, (double)count,
                        gamma, mean, rstd, p, q, r, dgamma, dbeta, C);
     return v100_launch_status();
 }
@@ -562,14 +562,14 @@ extern "C" int v100_bn_bwd_finalize(const float* partial, int parts, long long c
 extern "C" int v100_chan_reduce2(const float* u, const float* v, float* partial, int G, int B, int C, int T, void* stream) {
     if (!u || !partial) return V100_ERR_NULL;
     if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || G > B) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(chan_reduce2_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, u, v, partial, B, C, T, G);
+    V100_GGL(chan_reduce2_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, u, v, partial, B, C, T, G);
     return v100_launch_status();
 }
 
 extern "C" int v100_chan_reduce2_io(const void* u, const void* v, float* partial, int G, int B, int C, int T, int io16, void* stream) {
     if (!u || !v || !partial) return V100_ERR_NULL;
     if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || G > B) return V100_ERR_SHAPE;
-    if (io16 == 2) hipLaunchKernelGGL(chan_reduce2_io_kernel<2>, dim3(C, G), dim3(256), 0, (hipStream_t)stream, u, v, partial, B, C, T, G);
+    if (io16 == 2) V100_GGL(chan_reduce2_io_kernel<2>, dim3(C, G), dim3(256), 0, (hipStream_t)stream, u, v, partial, B, C, T, G);
     else return V100_ERR_SHAPE;
     return v100_launch_status();
 }
@@ -579,7 +579,7 @@ int chan_affine2_fin(const void* u, const float* v, float* out, void* shadow, in
     if (!u || !out || !pre.stats) return V100_ERR_NULL;
     if (B <= 0 || C <= 0 || T <= 0 || pre.f.mode != 1 || pre.parts <= 0) return V100_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-#define CAF(UB_, SH_) hipLaunchKernelGGL((chan_affine2_fin_kernel<UB_, SH_>), dim3(C), dim3(1024), 0, st, u, v, out, (u16*)shadow, B, C, T, pre)
+#define CAF(UB_, SH_) V100_GGL((chan_affine2_fin_kernel<UB_, SH_>), dim3(C), dim3(1024), 0, st, u, v, out, (u16*)shadow, B, C, T, pre)
     if (u_bf16) { if (shadow) CAF(true, true); else CAF(true, false); }
     else { if (shadow) CAF(false, true); else CAF(false, false); }
 #undef CAF
@@ -591,7 +591,7 @@ int chan_bn3_bwd(const float* u, const void* v, float* partial, void* out, int B
     if (!u || !v || !partial || !out || fin.mode != 2) return 0;
     const long n = (long)B * ((T + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-#define CB3(NQ_) hipLaunchKernelGGL(chan_bn3_bwd_kernel<NQ_>, dim3(C), dim3(1024), 0, st, u, v, partial, out, B, C, T, fin)
+#define CB3(NQ_) V100_GGL(chan_bn3_bwd_kernel<NQ_>, dim3(C), dim3(1024), 0, st, u, v, partial, out, B, C, T, fin)
     if (n <= 1024 * 2) CB3(2);
     else if (n <= 1024 * 4) CB3(4);
     else if (n <= 1024 * 6) CB3(6);
@@ -605,7 +605,7 @@ int chan_bn3_bwd(const float* u, const void* v, float* partial, void* out, int B
 int chan_reduce2_io_fin(const void* u, const void* v, float* partial, int B, int C, int T, const DwFin& fin, void* stream) {
     if (!u || !v || !partial) return V100_ERR_NULL;
     if (B <= 0 || C <= 0 || T <= 0 || fin.mode != 2) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(chan_reduce2_fin_kernel<2>, dim3(C), dim3(1024), 0, (hipStream_t)stream, u, v, partial, B, C, T, fin);
+    V100_GGL(chan_reduce2_fin_kernel<2>, dim3(C), dim3(1024), 0, (hipStream_t)stream, u, v, partial, B, C, T, fin);
     return v100_launch_status();
 }
 
@@ -620,8 +620,8 @@ extern "C" int v100_chan_affine2_io(const void* u, const void* v, const float* A
     if (blocks < 1) blocks = 1;
     hipStream_t st = (hipStream_t)stream;
     // forward block output: u = a3 (bf16), v = x (fp32) or null -> y fp32;  backward: u = dy (fp32), v = a3 (bf16) -> da3 (bf16)
-    if (io16 == 1) hipLaunchKernelGGL(chan_affine2_io_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Bc, Cc, out, C, T, rows);
-    else if (io16 == 6) hipLaunchKernelGGL(chan_affine2_io_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Bc, Cc, out, C, T, rows);
+    if (io16 == 1) V100_GGL(chan_affine2_io_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Bc, Cc, out, C, T, rows);
+    else if (io16 == 6) V100_GGL(chan_affine2_io_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Bc, Cc, out, C, T, rows);
     else return V100_ERR_SHAPE;
     return v100_launch_status();
 }
@@ -636,15 +636,15 @@ extern "C" int v100_chan_affine2_shadow(const void* u, const float* v, const flo
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipStream_t st = (hipStream_t)stream;
-    if (u_bf16) hipLaunchKernelGGL(chan_affine2_shadow_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Cc, out, (u16*)shadow, C, T, rows);
-    else hipLaunchKernelGGL(chan_affine2_shadow_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Cc, out, (u16*)shadow, C, T, rows);
+    if (u_bf16) V100_GGL(chan_affine2_shadow_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Cc, out, (u16*)shadow, C, T, rows);
+    else V100_GGL(chan_affine2_shadow_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, u, v, A, Cc, out, (u16*)shadow, C, T, rows);
     return v100_launch_status();
 }
 
 extern "C" int v100_slab_sum0(const float* partial, int parts, float* out, int C, void* stream) {
     if (!partial || !out) return V100_ERR_NULL;
     if (parts <= 0 || C <= 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(slab_sum0_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, partial, parts, out, C);
+    V100_GGL(slab_sum0_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, partial, parts, out, C);
     return v100_launch_status();
 }
 
@@ -656,7 +656,7 @@ extern "C" int v100_chan_affine2(const float* u, const float* v, const float* A,
     long blocks = (total / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(chan_affine2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, u, v, A, Bc, Cc, out, C, T, total);
+    V100_GGL(chan_affine2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, u, v, A, Bc, Cc, out, C, T, total);
     return v100_launch_status();
 }
 
@@ -665,7 +665,7 @@ extern "C" int v100_mul_scale(const float* u, const float* m, float s, float* ou
     if (n <= 0) return V100_ERR_SHAPE;
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(mul_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, u, m, s, out, (long)n);
+    V100_GGL(mul_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, u, m, s, out, (long)n);
     return v100_launch_status();
 }
 
@@ -677,7 +677,7 @@ extern "C" int v100_dropout_fwd(const float* x, long long seed, float p, float* 
     if (blocks > 4096) blocks = 4096;
     const double t = (double)p * 4294967296.0;
     const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
-    hipLaunchKernelGGL(dropout_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (unsigned long long)seed, thresh,
+    V100_GGL(dropout_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (unsigned long long)seed, thresh,
                        1.0f / (1.0f - p), y, (unsigned char*)mask, n4, (long)n);
     return v100_launch_status();
 }
@@ -688,7 +688,7 @@ extern "C" int v100_dropout_bwd(const float* dy, const void* mask, float p, floa
     const long n4 = (n + 3) / 4;
     long blocks = (n4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, (const unsigned char*)mask,
+    V100_GGL(dropout_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, (const unsigned char*)mask,
                        1.0f / (1.0f - p), dx, n4, (long)n);
     return v100_launch_status();
 }
@@ -696,14 +696,14 @@ extern "C" int v100_dropout_bwd(const float* dy, const void* mask, float p, floa
 extern "C" int v100_transpose_last2(const float* in, float* out, int B, int R, int Cc, void* stream) {
     if (!in || !out) return V100_ERR_NULL;
     if (B <= 0 || R <= 0 || Cc <= 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(transpose_last2_kernel, dim3(ceil_div(Cc, 32), ceil_div(R, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, R, Cc);
+    V100_GGL(transpose_last2_kernel, dim3(ceil_div(Cc, 32), ceil_div(R, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, R, Cc);
     return v100_launch_status();
 }
 
 extern "C" int v100_embedding_bct(const long long* idx, const float* table, float* out, int B, int V, int C, int T, void* stream) {
     if (!idx || !table || !out) return V100_ERR_NULL;
     if (B <= 0 || V <= 0 || C <= 0 || T <= 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(embedding_bct_kernel, dim3(ceil_div(C, 32), ceil_div(T, 32), B), dim3(256), 0, (hipStream_t)stream, idx, table, out, V, C, T);
+    V100_GGL(embedding_bct_kernel, dim3(ceil_div(C, 32), ceil_div(T, 32), B), dim3(256), 0, (hipStream_t)stream, idx, table, out, V, C, T);
     return v100_launch_status();
 }
 
@@ -714,6 +714,6 @@ extern "C" int v100_embedding_bwd(const long long* idx, const float* g, float* d
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipMemsetAsync(dtable, 0, (size_t)V * C * sizeof(float), (hipStream_t)stream);
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, idx, g, dtable, V, C, T, total);
+    V100_GGL(embedding_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, idx, g, dtable, V, C, T, total);
     return v100_launch_status();
 }

@@ -19,6 +19,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
+// every kernel launch of the library goes through these two: a process-wide launch counter (v100_launch_count(), read by bench.py
+// to report launches per step from THIS run rather than from a stored profile)
+#include <atomic>
+inline std::atomic<long long> g_v100_launches{0};
+#define V100_GGL(...) do { g_v100_launches.fetch_add(1, std::memory_order_relaxed); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#define V100_EXT_GGL(...) do { g_v100_launches.fetch_add(1, std::memory_order_relaxed); hipExtLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 static inline int v100_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? V100_OK : V100_ERR_LAUNCH;

@@ -33,8 +33,9 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
 }
 
 // lse[b][t] = logsumexp_c logits[b][t][c]
-__global__ void ctc_lse_kernel(const float* __restrict__ logits, float* __restrict__ lse, long rows, int V) {
+__global__ void ctc_lse_kernel(const float* __restrict__ logits, float* __restrict__ lse, long rows, int V, int* __restrict__ stall, int B) {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < B) stall[r] = 0;               // sticky "a pipeline wait ran into its bound" flags of the lattice kernel (read by grad / mean)
     if (r >= rows) return;
     const float* p = logits + r * V;
     float m = NEG_INF;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(1024) void ctc_lattice_skew_kernel(const float* __r
                                                                 const long long* __restrict__ targets, const int* __restrict__ in_len,
                                                                 const int* __restrict__ tgt_len, float* __restrict__ alpha,
                                                                 float* __restrict__ beta, float* __restrict__ nll, int T, int V, int Lmax,
-                                                                int Smax, int blank) {
+                                                                int Smax, int blank, int* __restrict__ stall) {
     __shared__ float bnd[16][CTC_RING][2];
     __shared__ int progress[16];
     __shared__ float fin[2];
@@ -223,7 +224,9 @@ __global__ __launch_bounds__(1024) void ctc_lattice_skew_kernel(const float* __r
                     // wait until the upstream wave is TWO frames ahead (or done): with a skew of one, the speculative fetch
                     // below would find frame q unpublished on every frame and this slow path would run each time
                     const int need = min(q + 1, Tb - 1);
-                    for (int guard = 0; prog_load(w - 1) < need && guard < CTC_SPIN_MAX; ++guard) __builtin_amdgcn_s_sleep(1);
+                    int guard = 0;
+                    for (; prog_load(w - 1) < need && guard < CTC_SPIN_MAX; ++guard) __builtin_amdgcn_s_sleep(1);
+                    if (guard >= CTC_SPIN_MAX && lane == 0) stall[b] = 1;      // never reached by design; if it is, poison the result (no silent wrong loss)
                     asm volatile("" ::: "memory");
                     v63 = bnd[w - 1][(q - 1) & (CTC_RING - 1)][0];
                     v62 = bnd[w - 1][(q - 1) & (CTC_RING - 1)][1];
@@ -248,8 +251,11 @@ __global__ __launch_bounds__(1024) void ctc_lattice_skew_kernel(const float* __r
         if constexpr (DOWN) {
             // back-pressure, once per half ring: frames q .. q + RING/2 - 1 reuse the slots of frames q - RING .. q - RING/2 - 1, which
             // wave w+1 has read once it has published frame q - RING/2
-            if ((q & (CTC_RING / 2 - 1)) == 0 && q >= CTC_RING / 2)
-                for (int guard = 0; prog_load(w + 1) < q - CTC_RING / 2 && guard < CTC_SPIN_MAX; ++guard) __builtin_amdgcn_s_sleep(1);
+            if ((q & (CTC_RING / 2 - 1)) == 0 && q >= CTC_RING / 2) {
+                int guard = 0;
+                for (; prog_load(w + 1) < q - CTC_RING / 2 && guard < CTC_SPIN_MAX; ++guard) __builtin_amdgcn_s_sleep(1);
+                if (guard >= CTC_SPIN_MAX && lane == 0) stall[b] = 1;
+            }
             asm volatile("" ::: "memory");
             if (lane >= 62) bnd[w][q & (CTC_RING - 1)][63 - lane] = v;
         }
@@ -297,15 +303,31 @@ __global__ __launch_bounds__(1024) void ctc_lattice_skew_kernel(const float* __r
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
                                                        const long long* __restrict__ targets, const int* __restrict__ in_len,
                                                        const int* __restrict__ tgt_len, const float* __restrict__ alpha,
-                                                       const float* __restrict__ beta, const float* __restrict__ nll,
+                                                       const float* __restrict__ beta, float* nll,
                                                        float* __restrict__ grad, int B, int T, int V, int Lmax, int Smax, int blank,
-                                                       int mean_scale) {
+                                                       int mean_scale, const int* __restrict__ stall, float* __restrict__ loss) {
     __shared__ float bins[4][CTC_MAXV];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long w = (long)blockIdx.x * 4 + wave;
+    if (loss && blockIdx.x == 0 && wave == 0) {
+        // loss = mean_b( finite(nll_b) ? nll_b / max(len_b, 1) : 0 )   (reduction='mean', zero_infinity=True: only +-inf is zeroed,
+        // a NaN -- or a lattice whose pipeline wait hit its bound -- stays visible)
+        float s = 0.f;
+        for (int bb = lane; bb < B; bb += 64) {
+            const float v = stall[bb] ? __builtin_nanf("") : nll[bb];
+            if (!(v == INFINITY || v == -INFINITY)) s += v / (float)max(tgt_len[bb], 1);
+        }
+        s = wave_sum(s);
+        if (lane == 0) loss[0] = s / (float)B;
+    }
     if (w >= (long)B * T) return;
     const int b = (int)(w / T), t = (int)(w % T);
     float* g = grad + ((size_t)b * T + t) * V;
+    if (stall[b]) {                                   // see ctc_lattice_skew_kernel: poison instead of a silently wrong result
+        for (int c = lane; c < V; c += 64) g[c] = __builtin_nanf("");
+        if (t == 0 && lane == 0) nll[b] = __builtin_nanf("");
+        return;
+    }
     const float n = nll[b];
     int Tb = in_len[b];
     if (Tb > T) Tb = T;
@@ -347,19 +369,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     }
 }
 
-// loss = mean_b( finite(nll_b) ? nll_b / max(len_b, 1) : 0 )   (reduction='mean', zero_infinity=True)
-__global__ void ctc_mean_kernel(const float* __restrict__ nll, const int* __restrict__ tgt_len, int B, float* __restrict__ loss) {
-    float s = 0.f;
-    for (int b = threadIdx.x; b < B; b += 64) {
-        const float v = nll[b];
-        if (v < INFINITY && v > -INFINITY) s += v / (float)max(tgt_len[b], 1);
-    }
-    s = wave_sum(s);
-    if (threadIdx.x == 0) loss[0] = s / (float)B;
-}
-
-extern "C" int v100_ctc_workspace_floats(int B, int T, int Lmax) {      // alpha + beta + lse
-    const long n = 2L * B * T * (2 * Lmax + 1) + (long)B * T;
+extern "C" int v100_ctc_workspace_floats(int B, int T, int Lmax) {      // alpha + beta + lse + stall flags
+    const long n = 2L * B * T * (2 * Lmax + 1) + (long)B * T + B;
     return n > 0x7fffffffL ? -1 : (int)n;
 }
 
@@ -389,24 +400,24 @@ static int ctc_run(const float* logits, const long long* targets, const int* in_
     float* beta = alpha + (size_t)B * T * Smax;
     float* lse = beta + (size_t)B * T * Smax;
     const long rows = (long)B * T;
-    hipLaunchKernelGGL(ctc_lse_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logits, lse, rows, V);
+    int* stall = (int*)(lse + (size_t)B * T);
+    V100_GGL(ctc_lse_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logits, lse, rows, V, stall, B);
     const size_t shmem = (size_t)(CTC_CHUNK * V + 2 * (Smax + 4)) * sizeof(float);
 #define CTC_LATTICE(NS_)                                                                                                          \
     if (shmem > 65536)                                                                                                            \
         (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);       \
-    hipLaunchKernelGGL(ctc_lattice_kernel<NS_>, dim3(B, 2), dim3(256), shmem, st, logits, lse, targets, in_len, tgt_len, alpha, beta, \
+    V100_GGL(ctc_lattice_kernel<NS_>, dim3(B, 2), dim3(256), shmem, st, logits, lse, targets, in_len, tgt_len, alpha, beta, \
                        nll, T, V, Lmax, Smax, blank)
     if (CTC_SKEW && Smax <= 1024) {
         const int nw = (Smax + 63) / 64;
-        hipLaunchKernelGGL(ctc_lattice_skew_kernel, dim3(B, 2), dim3(64 * nw), 0, st, logits, lse, targets, in_len, tgt_len, alpha, beta,
-                           nll, T, V, Lmax, Smax, blank);
+        V100_GGL(ctc_lattice_skew_kernel, dim3(B, 2), dim3(64 * nw), 0, st, logits, lse, targets, in_len, tgt_len, alpha, beta,
+                           nll, T, V, Lmax, Smax, blank, stall);
     } else if (Smax <= 512) { CTC_LATTICE(2); }
     else if (Smax <= 1024) { CTC_LATTICE(4); }
     else if (Smax <= 2048) { CTC_LATTICE(8); }
     else { CTC_LATTICE(16); }
 #undef CTC_LATTICE
-    hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len,
-                       alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank, loss ? 1 : 0);
-    if (loss) hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, st, nll, tgt_len, B, loss);
+    V100_GGL(ctc_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len,
+                       alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank, loss ? 1 : 0, stall, loss);     // (the 'mean' reduction rides in block 0)
     return v100_launch_status();
 }

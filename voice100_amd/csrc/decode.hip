@@ -144,7 +144,7 @@ __global__ void align_expand_kernel(const long long* __restrict__ text, const do
 extern "C" int v100_ctc_greedy_decode(const float* logits, const int* lens, long long* out, int* out_len, int B, int T, int V, int blank, void* stream) {
     if (!logits || !out || !out_len) return V100_ERR_NULL;
     if (B <= 0 || T <= 0 || T > 12000 || V <= 0 || blank < 0 || blank >= V) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), T * sizeof(int), (hipStream_t)stream, logits, lens, out, out_len, T, V, blank);
+    V100_GGL(ctc_greedy_kernel, dim3(B), dim3(256), T * sizeof(int), (hipStream_t)stream, logits, lens, out, out_len, T, V, blank);
     return v100_launch_status();
 }
 
@@ -153,7 +153,7 @@ extern "C" int v100_ctc_best_path(const float* logp, const long long* labels, co
     if (!logp || !labels || !back_ws || !path || !score) return V100_ERR_NULL;
     const int Smax = 2 * Lmax + 1;
     if (B <= 0 || T <= 0 || V <= 0 || Lmax < 0 || Smax > 4096 || max_move < 1 || max_move > 8) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(ctc_best_path_kernel, dim3(B), dim3(256), 2 * Smax * sizeof(float), (hipStream_t)stream, logp, labels, in_len, lab_len,
+    V100_GGL(ctc_best_path_kernel, dim3(B), dim3(256), 2 * Smax * sizeof(float), (hipStream_t)stream, logp, labels, in_len, lab_len,
                        (short*)back_ws, path, score, T, V, Lmax, Smax, max_move);
     return v100_launch_status();
 }
@@ -162,7 +162,7 @@ extern "C" int v100_align_expand(const long long* text, const double* align, con
                                  int Tmax, int head, int tail, void* stream) {
     if (!text || !align || !out || !out_len) return V100_ERR_NULL;
     if (B <= 0 || Lmax <= 0 || Tmax <= 0 || head < 0 || tail < 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(align_expand_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, text, align, text_len, out, out_len, B, Lmax,
+    V100_GGL(align_expand_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, text, align, text_len, out, out_len, B, Lmax,
                        Tmax, head, tail);
     return v100_launch_status();
 }

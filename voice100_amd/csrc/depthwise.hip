@@ -330,7 +330,7 @@ static void launch_dw_wgrad(const DwWgradParams& p, hipStream_t st) {
     dim3 grid(p.C, p.G);
     // R = 8 only: the R = 4 instantiations of K >= 67 fall out of registers (hipcc 7.2 leaves the
     // accumulator array in scratch), and short rows are not the case this kernel is tuned for.
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<K, S, 8, true>), grid, dim3(256), 0, st, p);
+    V100_GGL((dwconv_wgrad_kernel<K, S, 8, true>), grid, dim3(256), 0, st, p);
 }
 
 extern "C" int v100_dw_num_groups(int B, int C) {
@@ -403,9 +403,9 @@ extern "C" int v100_dwconv_wgrad(const float* g, const float* g2, const float* g
 #undef X
         if (!done && K == 11 && stride == 2) { launch_dw_wgrad<11, 2>(p, st); done = true; }
     }
-    if (!done) hipLaunchKernelGGL(dwconv_wgrad_generic_kernel, dim3(C, G), dim3(256), 4 * K * sizeof(float), st, p);
+    if (!done) V100_GGL(dwconv_wgrad_generic_kernel, dim3(C, G), dim3(256), 4 * K * sizeof(float), st, p);
     const int n = C * K;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, partial, dw, G, n, 0);
+    V100_GGL(slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, partial, dw, G, n, 0);
     return v100_launch_status();
 }
 
@@ -463,7 +463,7 @@ int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga
     const bool done = all16 ? dw_launch_bwd_fused16g(p, st, timed) : dw_launch_bwd_fused16(p, st, timed);
     if (!done) return V100_ERR_SHAPE;
     const int n = C * K;
-    if (G > 1) hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, wpartial, dw, G, n, 0);
+    if (G > 1) V100_GGL(slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, wpartial, dw, G, n, 0);
     return v100_launch_status();
 }
 
@@ -487,7 +487,7 @@ extern "C" int v100_dwconv_bwd(const float* g, const float* g2, const float* w, 
         const bool done = dw_launch_bwd_fused(p, st, timed);
         if (done) {
             const int n = C * K;
-            if (G > 1) hipLaunchKernelGGL(slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, wpartial, dw, G, n, 0);
+            if (G > 1) V100_GGL(slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, wpartial, dw, G, n, 0);
             return v100_launch_status();
         }
         p.wpartial = wpartial;

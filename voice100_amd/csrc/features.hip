@@ -121,7 +121,7 @@ extern "C" int v100_shift_copy(const float* in, float* out, const float* bias, i
     if (B <= 0 || C <= 0 || Tin <= 0 || Tout <= 0 || n <= 0 || in_coff < 0 || out_coff < 0 || in_coff + C > in_ctot ||
         out_coff + C > out_ctot || out_mul <= 0 || in_mul <= 0) return V100_ERR_SHAPE;
     const long total = (long)B * C * n;
-    hipLaunchKernelGGL(shift_copy_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, bias, C, Tin, Tout, in_ctot,
+    V100_GGL(shift_copy_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, bias, C, Tin, Tout, in_ctot,
                        in_coff, out_ctot, out_coff, in_mul, in_add, out_mul, out_add, n, accumulate, total);
     return v100_launch_status();
 }
@@ -131,7 +131,7 @@ extern "C" int v100_stft_frames(const float* x, float* frames, int B, int N, int
     if (B <= 0 || N <= n_fft / 2 || T <= 0 || hop <= 0 || win <= 0 || win > n_fft) return V100_ERR_SHAPE;
     if ((long)(T - 1) * hop > N) return V100_ERR_SHAPE;
     const long total = (long)B * win * T;
-    hipLaunchKernelGGL(stft_frames_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, frames, N, T, hop, win, n_fft, total);
+    V100_GGL(stft_frames_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, frames, N, T, hop, win, n_fft, total);
     return v100_launch_status();
 }
 
@@ -139,14 +139,14 @@ extern "C" int v100_power_spectrum(const float* spec, float* pw, int B, int F, i
     if (!spec || !pw) return V100_ERR_NULL;
     if (B <= 0 || F <= 0 || T <= 0) return V100_ERR_SHAPE;
     const long total = (long)B * F * T;
-    hipLaunchKernelGGL(power_spectrum_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, spec, pw, F, T, total);
+    V100_GGL(power_spectrum_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, spec, pw, F, T, total);
     return v100_launch_status();
 }
 
 extern "C" int v100_log_transpose(const float* in, float* out, int B, int C, int T, float offset, void* stream) {
     if (!in || !out) return V100_ERR_NULL;
     if (B <= 0 || C <= 0 || T <= 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(log_transpose_kernel, dim3(ceil_div(T, 32), ceil_div(C, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, C, T, offset);
+    V100_GGL(log_transpose_kernel, dim3(ceil_div(T, 32), ceil_div(C, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, C, T, offset);
     return v100_launch_status();
 }
 
@@ -156,7 +156,7 @@ extern "C" int v100_world_unnormalize(const float* x, float* f0, float* logspc, 
     if (!x || !f0 || !logspc || !codeap || !f0_mean || !f0_std || !ls_mean || !ls_std || !ca_mean || !ca_std) return V100_ERR_NULL;
     if (B <= 0 || T <= 0 || S <= 0 || Cap <= 0) return V100_ERR_SHAPE;
     const long rows = (long)B * T;
-    hipLaunchKernelGGL(world_unnormalize_kernel, dim3(grid_for(rows * (2 + S + Cap))), dim3(256), 0, (hipStream_t)stream, x, f0, logspc, codeap,
+    V100_GGL(world_unnormalize_kernel, dim3(grid_for(rows * (2 + S + Cap))), dim3(256), 0, (hipStream_t)stream, x, f0, logspc, codeap,
                        f0_mean, f0_std, ls_mean, ls_std, ca_mean, ca_std, S, Cap, rows);
     return v100_launch_status();
 }
@@ -164,6 +164,6 @@ extern "C" int v100_world_unnormalize(const float* x, float* f0, float* logspc, 
 extern "C" int v100_exp_clip(const float* x, float* y, float offset, long long n, void* stream) {
     if (!x || !y) return V100_ERR_NULL;
     if (n <= 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(exp_clip_kernel, dim3(grid_for((long)n)), dim3(256), 0, (hipStream_t)stream, x, y, offset, (long)n);
+    V100_GGL(exp_clip_kernel, dim3(grid_for((long)n)), dim3(256), 0, (hipStream_t)stream, x, y, offset, (long)n);
     return v100_launch_status();
 }

@@ -239,9 +239,9 @@ extern "C" int v100_ln_gelu_fwd(const float* y, const float* gamma, const float*
     dim3 grid(ceil_div(T, LN_TT), B);
     hipStream_t st = (hipStream_t)stream;
     const int ni = ceil_div(C, LN_ROWS);
-    if (ni <= 8) hipLaunchKernelGGL((ln_gelu_fwd_kernel<8>), grid, dim3(256), 0, st, y, gamma, beta, eps, out, mean, rstd, C, T);
-    else if (ni <= 16) hipLaunchKernelGGL((ln_gelu_fwd_kernel<16>), grid, dim3(256), 0, st, y, gamma, beta, eps, out, mean, rstd, C, T);
-    else hipLaunchKernelGGL((ln_gelu_fwd_kernel<32>), grid, dim3(256), 0, st, y, gamma, beta, eps, out, mean, rstd, C, T);
+    if (ni <= 8) V100_GGL((ln_gelu_fwd_kernel<8>), grid, dim3(256), 0, st, y, gamma, beta, eps, out, mean, rstd, C, T);
+    else if (ni <= 16) V100_GGL((ln_gelu_fwd_kernel<16>), grid, dim3(256), 0, st, y, gamma, beta, eps, out, mean, rstd, C, T);
+    else V100_GGL((ln_gelu_fwd_kernel<32>), grid, dim3(256), 0, st, y, gamma, beta, eps, out, mean, rstd, C, T);
     return v100_launch_status();
 }
 
@@ -252,16 +252,16 @@ extern "C" int v100_ln_gelu_bwd(const float* dout, const float* y, const float* 
     dim3 grid(ceil_div(T, LN_TT), B);
     hipStream_t st = (hipStream_t)stream;
     const int ni = ceil_div(C, LN_ROWS);
-    if (ni <= 8) hipLaunchKernelGGL((ln_gelu_bwd_kernel<8>), grid, dim3(256), 0, st, dout, y, gamma, beta, mean, rstd, dy, partial, C, T);
-    else if (ni <= 16) hipLaunchKernelGGL((ln_gelu_bwd_kernel<16>), grid, dim3(256), 0, st, dout, y, gamma, beta, mean, rstd, dy, partial, C, T);
-    else hipLaunchKernelGGL((ln_gelu_bwd_kernel<32>), grid, dim3(256), 0, st, dout, y, gamma, beta, mean, rstd, dy, partial, C, T);
+    if (ni <= 8) V100_GGL((ln_gelu_bwd_kernel<8>), grid, dim3(256), 0, st, dout, y, gamma, beta, mean, rstd, dy, partial, C, T);
+    else if (ni <= 16) V100_GGL((ln_gelu_bwd_kernel<16>), grid, dim3(256), 0, st, dout, y, gamma, beta, mean, rstd, dy, partial, C, T);
+    else V100_GGL((ln_gelu_bwd_kernel<32>), grid, dim3(256), 0, st, dout, y, gamma, beta, mean, rstd, dy, partial, C, T);
     return v100_launch_status();
 }
 
 extern "C" int v100_slab_sum2(const float* partial, int parts, float* out0, float* out1, int C, void* stream) {
     if (!partial || !out0 || !out1) return V100_ERR_NULL;
     if (parts <= 0 || C <= 0) return V100_ERR_SHAPE;
-    hipLaunchKernelGGL(slab_sum2_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, (hipStream_t)stream, partial, parts, out0, out1, C);
+    V100_GGL(slab_sum2_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, (hipStream_t)stream, partial, parts, out0, out1, C);
     return v100_launch_status();
 }
 
@@ -270,7 +270,7 @@ extern "C" int v100_im2col(const float* x, float* cols, int B, int Cin, int Tin,
     if (B <= 0 || Cin <= 0 || Tin <= 0 || Tout <= 0 || k <= 0 || stride <= 0 || pad < 0) return V100_ERR_SHAPE;
     if (Tout != (Tin + 2 * pad - k) / stride + 1) return V100_ERR_SHAPE;
     const long total = (long)B * k * Cin * Tout;
-    hipLaunchKernelGGL(im2col_kernel, dim3(ln_grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, cols, Cin, Tin, Tout, k, stride, pad, total);
+    V100_GGL(im2col_kernel, dim3(ln_grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, cols, Cin, Tin, Tout, k, stride, pad, total);
     return v100_launch_status();
 }
 
@@ -279,6 +279,6 @@ extern "C" int v100_col2im(const float* dcols, float* dx, int B, int Cin, int Ti
     if (B <= 0 || Cin <= 0 || Tin <= 0 || Tout <= 0 || k <= 0 || stride <= 0 || pad < 0) return V100_ERR_SHAPE;
     if (Tout != (Tin + 2 * pad - k) / stride + 1) return V100_ERR_SHAPE;
     const long total = (long)B * Cin * Tin;
-    hipLaunchKernelGGL(col2im_kernel, dim3(ln_grid_for(total)), dim3(256), 0, (hipStream_t)stream, dcols, dx, Cin, Tin, Tout, k, stride, pad, total);
+    V100_GGL(col2im_kernel, dim3(ln_grid_for(total)), dim3(256), 0, (hipStream_t)stream, dcols, dx, Cin, Tin, Tout, k, stride, pad, total);
     return v100_launch_status();
 }

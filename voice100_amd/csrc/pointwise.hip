@@ -70,7 +70,7 @@ extern "C" int v100_weight_prep(const float* w, int rows, int cols, void* w_bf, 
     if (!w) return V100_ERR_NULL;
     if (rows <= 0 || cols <= 0) return V100_ERR_SHAPE;
     const long n = (long)rows * cols;
-    hipLaunchKernelGGL(weight_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, rows, cols,
+    V100_GGL(weight_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, rows, cols,
                        (u16*)w_bf, wt, (u16*)wt_bf, 0);
     return v100_launch_status();
 }
@@ -80,7 +80,7 @@ extern "C" int v100_weight_prep_f16(const float* w, int rows, int cols, void* w1
     if (!w || !w16) return V100_ERR_NULL;
     if (rows <= 0 || cols <= 0) return V100_ERR_SHAPE;
     const long n = (long)rows * cols;
-    hipLaunchKernelGGL(weight_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, rows, cols,
+    V100_GGL(weight_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, rows, cols,
                        (u16*)w16, (float*)nullptr, (u16*)nullptr, 1);
     return v100_launch_status();
 }
@@ -129,7 +129,7 @@ extern "C" int v100_pw_wgrad(const float* G, const float* G2, const float* ga, c
     if (use_bf16) pw_launch_wgrad_bf16(p, grid, st);
     else pw_launch_wgrad_f32(p, grid, st);
     const long n = (long)M * K;
-    hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, dW, S, n);
+    V100_GGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, dW, S, n);
     return v100_launch_status();
 }
 
@@ -171,7 +171,7 @@ extern "C" int v100_pw_wgrad_io(const void* G, const void* G2, const float* ga, 
     V100TimedRegion timed(V100_T_PW_WGRAD, st);
     if (!pw_launch_wgrad_bf16_io(p, grid, st)) return V100_ERR_SHAPE;
     const long n = (long)M * K;
-    hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, dW, S, n);
+    V100_GGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, dW, S, n);
     return v100_launch_status();
 }
 
@@ -204,7 +204,7 @@ extern "C" int v100_pad_copy(const float* src, float* dst, int B, int C, int Tsr
     const unsigned gz = (unsigned)(rows < 32768 ? rows : 32768), gy = (unsigned)((rows + gz - 1) / gz);
     if (gy > 65535u) return V100_ERR_SHAPE;
     const unsigned gx = (unsigned)(ceil_div(Tx, 256) < 4 ? ceil_div(Tx, 256) : 4);
-    hipLaunchKernelGGL(pad_copy_kernel, dim3(gx, gy, gz), dim3(256), 0, (hipStream_t)stream, src, dst, Tsrc, src_step, src_off, n, Tx,
+    V100_GGL(pad_copy_kernel, dim3(gx, gy, gz), dim3(256), 0, (hipStream_t)stream, src, dst, Tsrc, src_step, src_off, n, Tx,
                        lpad, rows);
     return v100_launch_status();
 }
@@ -267,6 +267,6 @@ extern "C" int v100_pw_wgrad_taps(const float* G, int Tg, int g_off, const float
     if (use_bf16) { if (!pw_launch_wgrad_taps_bf16(p, grid, st)) return V100_ERR_SHAPE; }
     else pw_launch_wgrad_taps_f32(p, grid, st);
     const long n = (long)M * K;
-    hipLaunchKernelGGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, dW, S, n);
+    V100_GGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, dW, S, n);
     return v100_launch_status();
 }

@@ -1289,10 +1289,10 @@ bool pw_launch_gemm_f16(const PwParams& p, dim3 grid, hipStream_t st) {
     const dim3 gridb((unsigned)((long)pb.n_mtiles * p.n_ttiles * p.B));
 #define X(EP)                                                                                                           \
     if (p.epi_mode == EP) {                                                                                             \
-        if (big) hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<0, EP, 256, true>), gridb, dim3(512), 0, st, pb);        \
-        else if (full) hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<0, EP, 128, true>), grid, dim3(256), 0, st, p);     \
-        else if (tv && kv) hipLaunchKernelGGL((pw_gemm_bf16_kernel<0, EP, true, true, true>), grid, dim3(256), 0, st, p); \
-        else hipLaunchKernelGGL((pw_gemm_bf16_kernel<0, EP, false, false, true>), grid, dim3(256), 0, st, p);           \
+        if (big) V100_GGL((pw_gemm_bf16_fast_kernel<0, EP, 256, true>), gridb, dim3(512), 0, st, pb);        \
+        else if (full) V100_GGL((pw_gemm_bf16_fast_kernel<0, EP, 128, true>), grid, dim3(256), 0, st, p);     \
+        else if (tv && kv) V100_GGL((pw_gemm_bf16_kernel<0, EP, true, true, true>), grid, dim3(256), 0, st, p); \
+        else V100_GGL((pw_gemm_bf16_kernel<0, EP, false, false, true>), grid, dim3(256), 0, st, p);           \
         return true;                                                                                                    \
     }
     X(0) X(2) X(3)
@@ -1319,8 +1319,8 @@ void pw_launch_gemm_bf16(const PwParams& p_in, dim3 grid_in, hipStream_t st) {
         const dim3 gridb((unsigned)((long)pb.n_mtiles * p.n_ttiles * p.B));
 #define X(XM, EP)                                                                                                   \
         if (p.x_mode == XM && p.epi_mode == EP) {                                                                   \
-            if (big) hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP, 256>), gridb, dim3(512), 0, st, pb);     \
-            else hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP, 128>), grid, dim3(256), 0, st, p);            \
+            if (big) V100_GGL((pw_gemm_bf16_fast_kernel<XM, EP, 256>), gridb, dim3(512), 0, st, pb);     \
+            else V100_GGL((pw_gemm_bf16_fast_kernel<XM, EP, 128>), grid, dim3(256), 0, st, p);            \
             return;                                                                                                 \
         }
         PW_NN_COMBOS(X)
@@ -1329,15 +1329,15 @@ void pw_launch_gemm_bf16(const PwParams& p_in, dim3 grid_in, hipStream_t st) {
     if (kv) {
 #define X(XM, EP)                                                                                                   \
         if (p.x_mode == XM && p.epi_mode == EP) {                                                                   \
-            if (tv) hipLaunchKernelGGL((pw_gemm_bf16_kernel<XM, EP, true, true>), grid, dim3(256), 0, st, p);          \
-            else hipLaunchKernelGGL((pw_gemm_bf16_kernel<XM, EP, false, true>), grid, dim3(256), 0, st, p);            \
+            if (tv) V100_GGL((pw_gemm_bf16_kernel<XM, EP, true, true>), grid, dim3(256), 0, st, p);          \
+            else V100_GGL((pw_gemm_bf16_kernel<XM, EP, false, true>), grid, dim3(256), 0, st, p);            \
             return;                                                                                                 \
         }
         PW_NN_COMBOS(X)
 #undef X
     }
-    if (tv && kv) hipLaunchKernelGGL((pw_gemm_bf16_kernel<-1, -1, true, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((pw_gemm_bf16_kernel<-1, -1, false, false>), grid, dim3(256), 0, st, p);
+    if (tv && kv) V100_GGL((pw_gemm_bf16_kernel<-1, -1, true, true>), grid, dim3(256), 0, st, p);
+    else V100_GGL((pw_gemm_bf16_kernel<-1, -1, false, false>), grid, dim3(256), 0, st, p);
 }
 
 void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
@@ -1346,8 +1346,8 @@ void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
     if (full) {
 #define X(GM, XM)                                                                                                   \
         if (p.g_mode == GM && p.x_mode == XM) {                                                                     \
-            if (p.T % BF_BK == 0) hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<GM, XM, false>), grid, dim3(256), 0, st, p); \
-            else hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<GM, XM, true>), grid, dim3(256), 0, st, p);          \
+            if (p.T % BF_BK == 0) V100_GGL((pw_wgrad_bf16_fast_kernel<GM, XM, false>), grid, dim3(256), 0, st, p); \
+            else V100_GGL((pw_wgrad_bf16_fast_kernel<GM, XM, true>), grid, dim3(256), 0, st, p);          \
             return;                                                                                                 \
         }
         PW_WG_COMBOS(X)
@@ -1355,14 +1355,14 @@ void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
     }
 #define X(GM, XM)                                                                                                   \
     if (p.g_mode == GM && p.x_mode == XM) {                                                                         \
-        if (tv) hipLaunchKernelGGL((pw_wgrad_bf16_kernel<GM, XM, true>), grid, dim3(256), 0, st, p);                   \
-        else hipLaunchKernelGGL((pw_wgrad_bf16_kernel<GM, XM, false>), grid, dim3(256), 0, st, p);                     \
+        if (tv) V100_GGL((pw_wgrad_bf16_kernel<GM, XM, true>), grid, dim3(256), 0, st, p);                   \
+        else V100_GGL((pw_wgrad_bf16_kernel<GM, XM, false>), grid, dim3(256), 0, st, p);                     \
         return;                                                                                                     \
     }
     PW_WG_COMBOS(X)
 #undef X
-    if (tv) hipLaunchKernelGGL((pw_wgrad_bf16_kernel<-1, -1, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((pw_wgrad_bf16_kernel<-1, -1, false>), grid, dim3(256), 0, st, p);
+    if (tv) V100_GGL((pw_wgrad_bf16_kernel<-1, -1, true>), grid, dim3(256), 0, st, p);
+    else V100_GGL((pw_wgrad_bf16_kernel<-1, -1, false>), grid, dim3(256), 0, st, p);
 }
 
 
@@ -1379,8 +1379,8 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     const dim3 grid((unsigned)((long)pb.n_mtiles * p.n_ttiles * p.B));
 #define X(XM, EP, IOV)                                                                                                          \
     if (p.x_mode == XM && p.epi_mode == EP && p.io16 == (IOV)) {                                                                \
-        if (big) hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP, 256, false, false, (IOV)>), grid, dim3(512), 0, st, pb);  \
-        else hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP, 128, false, false, (IOV)>), grid, dim3(256), 0, st, pb);      \
+        if (big) V100_GGL((pw_gemm_bf16_fast_kernel<XM, EP, 256, false, false, (IOV)>), grid, dim3(512), 0, st, pb);  \
+        else V100_GGL((pw_gemm_bf16_fast_kernel<XM, EP, 128, false, false, (IOV)>), grid, dim3(256), 0, st, pb);      \
         return true;                                                                                                            \
     }
 #if PW_DMA
@@ -1388,7 +1388,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
 #define XD(EP, IOV)                                                                                                             \
     if (big && p.x_mode == 0 && p.epi_mode == EP && p.io16 == (IOV) && (p.K & 63) == 0 && p.K >= PW_DMA_MINK &&                   \
         ((PW_DMA >> (EP == 1 ? 0 : 1)) & 1)) {                                                                                   \
-        hipLaunchKernelGGL((pw_gemm_bf16_dma_kernel<EP, (IOV)>), grid, dim3(512), 0, st, pb);                                   \
+        V100_GGL((pw_gemm_bf16_dma_kernel<EP, (IOV)>), grid, dim3(512), 0, st, pb);                                   \
         return true;                                                                                                            \
     }
     XD(1, PW_IO_X | PW_IO_Y)
@@ -1402,7 +1402,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
         const long nt_ = (long)pb.n_mtiles * p.n_ttiles * p.B;                                                                  \
         const long per = (nt_ % 1024 == 0 && nt_ >= 1024) ? 4 : ((nt_ % 512 == 0 && nt_ >= 512) ? 2 : 1);                       \
         if (per > 1) {                                                                                                          \
-            hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<XM, EP, 256, false, false, (IOV), true>), dim3((unsigned)(nt_ / per)),  \
+            V100_GGL((pw_gemm_bf16_fast_kernel<XM, EP, 256, false, false, (IOV), true>), dim3((unsigned)(nt_ / per)),  \
                                dim3(512), 0, st, pb);                                                                           \
             return true;                                                                                                        \
         }                                                                                                                       \
@@ -1419,7 +1419,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     if (p.x_mode == 0 && p.epi_mode == 4 && p.io16 == (PW_IO_X | PW_IO_R | PW_IO_Y) && p.K <= 256 && big) {
         PwParams ps = p;
         ps.n_mtiles = (p.M + 127) / 128;
-        hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<0, 4, 128, false, false, (PW_IO_X | PW_IO_R | PW_IO_Y)>),
+        V100_GGL((pw_gemm_bf16_fast_kernel<0, 4, 128, false, false, (PW_IO_X | PW_IO_R | PW_IO_Y)>),
                            dim3((unsigned)((long)ps.n_mtiles * p.n_ttiles * p.B)), dim3(256), 0, st, ps);
         return true;
     }
@@ -1447,8 +1447,8 @@ bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
         pw.n_mtiles = (p.M + GR - 1) / GR;                                                                                          \
         pw.n_ktiles = (p.K + XR - 1) / XR;                                                                                          \
         const dim3 gw((unsigned)(pw.n_mtiles * pw.n_ktiles * p.S));                                                                 \
-        if (p.T % BF_BK == 0) hipLaunchKernelGGL((pw_wgrad_bf16_wide_kernel<GM, XM, false, (IOV), GR, XR, NS>), gw, dim3(512), 0, st, pw); \
-        else hipLaunchKernelGGL((pw_wgrad_bf16_wide_kernel<GM, XM, true, (IOV), GR, XR, NS>), gw, dim3(512), 0, st, pw);                \
+        if (p.T % BF_BK == 0) V100_GGL((pw_wgrad_bf16_wide_kernel<GM, XM, false, (IOV), GR, XR, NS>), gw, dim3(512), 0, st, pw); \
+        else V100_GGL((pw_wgrad_bf16_wide_kernel<GM, XM, true, (IOV), GR, XR, NS>), gw, dim3(512), 0, st, pw);                \
         return true;                                                                                                                \
     }
     XW(2, 0, WG_IO_G | WG_IO_G2 | WG_IO_X, 128, 256, 2)      // ... X = bf16 shadow of the block input: copied as loaded, 32 registers a stage
@@ -1458,8 +1458,8 @@ bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
 #endif
 #define X(GM, XM, IOV)                                                                                                              \
     if (p.g_mode == GM && p.x_mode == XM && p.io16 == (IOV)) {                                                                      \
-        if (p.T % BF_BK == 0) hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<GM, XM, false, false, (IOV)>), grid, dim3(256), 0, st, p); \
-        else hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<GM, XM, true, false, (IOV)>), grid, dim3(256), 0, st, p);                \
+        if (p.T % BF_BK == 0) V100_GGL((pw_wgrad_bf16_fast_kernel<GM, XM, false, false, (IOV)>), grid, dim3(256), 0, st, p); \
+        else V100_GGL((pw_wgrad_bf16_fast_kernel<GM, XM, true, false, (IOV)>), grid, dim3(256), 0, st, p);                \
         return true;                                                                                                                \
     }
     X(2, 0, WG_IO_G2)                     // expand backward-weight: G = BN1-backward affine of (dz1, a1), X = block input
@@ -1487,8 +1487,8 @@ bool pw_launch_gemm_taps_bf16(const PwParams& p, dim3 grid, hipStream_t st) {
     const dim3 gridb((unsigned)((long)pb.n_mtiles * p.n_ttiles * p.B));
 #define X(EP, F16)                                                                                                      \
     if (p.epi_mode == EP && (p.fmt == 2) == F16) {                                                                      \
-        if (big) hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<0, EP, 256, F16, true>), gridb, dim3(512), 0, st, pb);   \
-        else hipLaunchKernelGGL((pw_gemm_bf16_fast_kernel<0, EP, 128, F16, true>), grid, dim3(256), 0, st, p);          \
+        if (big) V100_GGL((pw_gemm_bf16_fast_kernel<0, EP, 256, F16, true>), gridb, dim3(512), 0, st, pb);   \
+        else V100_GGL((pw_gemm_bf16_fast_kernel<0, EP, 128, F16, true>), grid, dim3(256), 0, st, p);          \
         return true;                                                                                                    \
     }
     X(0, false) X(5, false) X(0, true)
@@ -1498,7 +1498,7 @@ bool pw_launch_gemm_taps_bf16(const PwParams& p, dim3 grid, hipStream_t st) {
 
 bool pw_launch_wgrad_taps_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
     if (!((p.M + 128L) * p.Tg * 4 < 0x7fffff00L && (p.cx + 128L) * p.Tx * 4 < 0x7fffff00L && p.ntap >= 1 && p.ntap <= 8)) return false;
-    if (p.T % BF_BK == 0) hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<0, 0, false, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((pw_wgrad_bf16_fast_kernel<0, 0, true, true>), grid, dim3(256), 0, st, p);
+    if (p.T % BF_BK == 0) V100_GGL((pw_wgrad_bf16_fast_kernel<0, 0, false, true>), grid, dim3(256), 0, st, p);
+    else V100_GGL((pw_wgrad_bf16_fast_kernel<0, 0, true, true>), grid, dim3(256), 0, st, p);
     return true;
 }

@@ -237,37 +237,37 @@ void pw_launch_gemm_f32(const PwParams& p, dim3 grid, hipStream_t st) {
     if (kv) {
 #define X(XM, EP)                                                                                                   \
         if (p.x_mode == XM && p.epi_mode == EP) {                                                                   \
-            if (tv) hipLaunchKernelGGL((pw_gemm_f32_kernel<XM, EP, true, true>), grid, dim3(256), 0, st, p);          \
-            else hipLaunchKernelGGL((pw_gemm_f32_kernel<XM, EP, false, true>), grid, dim3(256), 0, st, p);            \
+            if (tv) V100_GGL((pw_gemm_f32_kernel<XM, EP, true, true>), grid, dim3(256), 0, st, p);          \
+            else V100_GGL((pw_gemm_f32_kernel<XM, EP, false, true>), grid, dim3(256), 0, st, p);            \
             return;                                                                                                 \
         }
         PW_NN_COMBOS(X)
 #undef X
     }
-    if (tv && kv) hipLaunchKernelGGL((pw_gemm_f32_kernel<-1, -1, true, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((pw_gemm_f32_kernel<-1, -1, false, false>), grid, dim3(256), 0, st, p);
+    if (tv && kv) V100_GGL((pw_gemm_f32_kernel<-1, -1, true, true>), grid, dim3(256), 0, st, p);
+    else V100_GGL((pw_gemm_f32_kernel<-1, -1, false, false>), grid, dim3(256), 0, st, p);
 }
 
 void pw_launch_wgrad_f32(const WgParams& p, dim3 grid, hipStream_t st) {
     const bool tv = (p.T & 3) == 0;
 #define X(GM, XM)                                                                                                   \
     if (p.g_mode == GM && p.x_mode == XM) {                                                                         \
-        if (tv) hipLaunchKernelGGL((pw_wgrad_f32_kernel<GM, XM, true>), grid, dim3(256), 0, st, p);                   \
-        else hipLaunchKernelGGL((pw_wgrad_f32_kernel<GM, XM, false>), grid, dim3(256), 0, st, p);                     \
+        if (tv) V100_GGL((pw_wgrad_f32_kernel<GM, XM, true>), grid, dim3(256), 0, st, p);                   \
+        else V100_GGL((pw_wgrad_f32_kernel<GM, XM, false>), grid, dim3(256), 0, st, p);                     \
         return;                                                                                                     \
     }
     PW_WG_COMBOS(X)
 #undef X
-    if (tv) hipLaunchKernelGGL((pw_wgrad_f32_kernel<-1, -1, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((pw_wgrad_f32_kernel<-1, -1, false>), grid, dim3(256), 0, st, p);
+    if (tv) V100_GGL((pw_wgrad_f32_kernel<-1, -1, true>), grid, dim3(256), 0, st, p);
+    else V100_GGL((pw_wgrad_f32_kernel<-1, -1, false>), grid, dim3(256), 0, st, p);
 }
 
 
 // Tap-addressed X operand (PwParams / WgParams): plain store (+bias) or +R epilogue, no prologues.
 void pw_launch_gemm_taps_f32(const PwParams& p, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((pw_gemm_f32_kernel<0, -1, true, true, true>), grid, dim3(256), 0, st, p);
+    V100_GGL((pw_gemm_f32_kernel<0, -1, true, true, true>), grid, dim3(256), 0, st, p);
 }
 
 void pw_launch_wgrad_taps_f32(const WgParams& p, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((pw_wgrad_f32_kernel<0, 0, true, true>), grid, dim3(256), 0, st, p);
+    V100_GGL((pw_wgrad_f32_kernel<0, 0, true, true>), grid, dim3(256), 0, st, p);
 }

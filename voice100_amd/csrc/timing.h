@@ -1,6 +1,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include "common.h"
 enum { V100_T_DW_FWD = 0, V100_T_DW_BWD_DATA = 1, V100_T_DW_WGRAD = 2, V100_T_PW_GEMM = 3, V100_T_PW_WGRAD = 4 };
 void v100_timing_begin(int tag, hipStream_t st, int* slot, double bytes);
 void v100_timing_end(int slot, hipStream_t st);
@@ -13,8 +14,8 @@ struct V100TimedLaunch {
 };
 #define V100_LAUNCH(TL, kernel, grid, block, shmem, st, ...)                                                   \
     do {                                                                                                       \
-        if ((TL).a) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, (TL).a, (TL).b, 0, __VA_ARGS__);     \
-        else hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                  \
+        if ((TL).a) V100_EXT_GGL(kernel, grid, block, shmem, st, (TL).a, (TL).b, 0, __VA_ARGS__);     \
+        else V100_GGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                  \
     } while (0)
 
 struct V100TimedRegion {

@@ -79,3 +79,29 @@ extern "C" int v100_timing_read(int tag, double* ms, long long* count, double* b
     *bytes = nbytes;
     return V100_OK;
 }
+
+// kernel launches issued by this library in this process so far (every launch site goes through V100_GGL / V100_EXT_GGL)
+extern "C" long long v100_launch_count(void) { return g_v100_launches.load(std::memory_order_relaxed); }
+
+// Device-copy yardstick for the HBM-bound kernels (bench.py `measured_copy_gbs`): dst[i] = src[i] in 16-byte pieces, four
+// independent loads in flight per thread before the first store, 2048 workgroups of 256 threads walking the buffer grid-stride.
+// n16 = number of 16-byte pieces.  Same ABI conventions as every other entry point (device pointers, no sync).
+__global__ __launch_bounds__(256) void copy_probe_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long long n16) {
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const f32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride);
+        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+extern "C" int v100_copy_probe(const void* src, void* dst, long long nbytes, void* stream) {
+    if (!src || !dst) return V100_ERR_NULL;
+    if (nbytes <= 0 || (nbytes & 15)) return V100_ERR_SHAPE;
+    V100_GGL(copy_probe_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, nbytes / 16);
+    return v100_launch_status();
+}

@@ -143,8 +143,8 @@ extern "C" int v100_world_loss(const float* pred, const float* f0, const float* 
     WorldLossParams p{pred, f0, hasf0, logspc, codeap, length, f0_mean, f0_std, ls_mean, ls_std, ca_mean, ca_std, w, partial, unit,
                       B, Tp, Tt, S, Cap, l1};
     const int nparts = v100_world_loss_parts(B, Tp);
-    hipLaunchKernelGGL(world_loss_kernel, dim3(nparts), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(world_loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nparts, length, B, Tp < Tt ? Tp : Tt, loss);
+    V100_GGL(world_loss_kernel, dim3(nparts), dim3(256), 0, st, p);
+    V100_GGL(world_loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nparts, length, B, Tp < Tt ? Tp : Tt, loss);
     return v100_launch_status();
 }
 
@@ -154,6 +154,6 @@ extern "C" int v100_world_loss_bwd(const float* unit, const float* gout, float* 
     const long total = (long)B * Tp * (2 + S + Cap);
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(world_loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, unit, gout, dpred, S, Cap, total);
+    V100_GGL(world_loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, unit, gout, dpred, S, Cap, total);
     return v100_launch_status();
 }

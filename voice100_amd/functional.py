@@ -465,6 +465,8 @@ def dropout(x, p: float, training: bool, keep: Optional[torch.Tensor] = None):
     from the in-kernel generator."""
     if not training or p == 0.0:
         return x
+    if p >= 1.0:                       # nn.Dropout(p=1): all zeros (and a zero gradient); never on the reference's path (p = 0.2)
+        return x * 0.0
     if keep is not None:
         return DropoutMaskFn.apply(x, keep, 1.0 / (1.0 - p))
     seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())        # CPU generator: no device sync

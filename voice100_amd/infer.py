@@ -1,0 +1,147 @@
+"""Inference side of the hot path: the configs[2] TTS chain on the device, and the pure data-parallel scatter of
+inference requests over the GPUs of a node (SURVEY.md 8e "Inference": replicas only, no collective on the data path).
+
+Reference call sites this serves:
+  * voice100/update_samples.py:30-90 -- text -> align model -> align() -> audio model predict -> vocoder glue, one batch
+    of sample sentences (here: `TTSPipeline`, every step up to the pyworld call on the GPU);
+  * voice100/models/asr.py:110-116 -- AudioToTextCTC.forward over independent utterances / 1-second chunks
+    (here: `ASRPipeline`, log-mel -> encoder -> logits -> greedy CTC ids);
+  * BASELINE.json configs[4]: "streaming 1-second chunks at 16 kHz, 8 x MI355X" -- chunks are independent, so rank r of
+    `world` takes every world-th chunk (`shard_indices(..., "round_robin")`) or a contiguous slice of a request batch,
+    runs its replica, and only the small results (token ids, WORLD features) are gathered on rank 0 (`scatter_run`).
+
+Nothing here computes on the CPU: the pipelines call the HIP-backed modules; `scatter_run` is plumbing over
+torch.distributed ("nccl" = RCCL on the GPU box, "gloo" in the CPU tests, where a stock-op stand-in model is used).
+"""
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["shard_indices", "scatter_run", "TTSPipeline", "ASRPipeline"]
+
+
+def shard_indices(n_items: int, rank: int, world: int, mode: str = "contiguous") -> torch.Tensor:
+    """Indices (int64, ascending) of the items rank `rank` of `world` processes.
+    "contiguous": one slice per rank, ceil(n / world) items each (a request batch);
+    "round_robin": items rank, rank + world, ... (a stream of chunks: every rank stays equally loaded as chunks arrive)."""
+    if not 0 <= rank < world:
+        raise ValueError("rank must be in [0, world)")
+    if mode == "contiguous":
+        per = (n_items + world - 1) // world
+        lo = min(n_items, rank * per)
+        return torch.arange(lo, min(n_items, lo + per), dtype=torch.int64)
+    if mode == "round_robin":
+        return torch.arange(rank, max(n_items, rank), world, dtype=torch.int64)
+    raise ValueError("mode must be 'contiguous' or 'round_robin'")
+
+
+def _world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def scatter_run(fn: Callable[..., Sequence[torch.Tensor]], inputs: Sequence[torch.Tensor], mode: str = "contiguous",
+                group=None, pad_value=0) -> Optional[List[torch.Tensor]]:
+    """Run `fn` data-parallel over dim 0 of `inputs` and gather its outputs on rank 0.
+
+    Every rank holds (or can index) the full `inputs`; rank r calls fn(*[x[idx_r] for x in inputs]) on its shard -- no
+    collective touches the data path -- and gets back a sequence of tensors whose dim 0 is the shard.  Outputs may be
+    ragged in dim 1 across ranks (aligned-text / WORLD-frame counts differ): they are padded with `pad_value` to the
+    global maximum before the gather.  Returns the outputs in the ORIGINAL item order on rank 0 and None elsewhere.
+    With no process group (or a group of one) it is just fn(*inputs)."""
+    rank, world = _world(group)
+    n = inputs[0].shape[0]
+    if any(x.shape[0] != n for x in inputs):
+        raise ValueError("scatter_run: inputs must share dim 0")
+    if world == 1:
+        return [o for o in fn(*inputs)]
+    idx = shard_indices(n, rank, world, mode)
+    per = (n + world - 1) // world                       # every rank pads its shard to `per` items so gathers are regular
+    if idx.numel():
+        outs = [o for o in fn(*[x[idx.to(x.device)] for x in inputs])]
+    else:
+        outs = None
+    # Shapes and dtypes are agreed through rank 0's view of a rank that has work; ranks without items (n < world) build
+    # zero-sized placeholders after learning the trailing shapes.
+    meta = [None] * world
+    dist.all_gather_object(meta, None if outs is None else [(tuple(o.shape[1:]), str(o.dtype)) for o in outs], group=group)
+    ref = next((m for m in meta if m is not None), None)
+    if ref is None:
+        return [] if rank == 0 else None
+    dev = outs[0].device if outs is not None else inputs[0].device
+    result = []
+    for k, (_, dtname) in enumerate(ref):
+        dt = getattr(torch, dtname.replace("torch.", ""))
+        trailing = [m[k][0] for m in meta if m is not None]
+        nd = len(trailing[0])
+        full = tuple(max(t[d] for t in trailing) for d in range(nd))           # pad every ragged trailing dim to its maximum
+        buf = torch.full((per,) + full, pad_value, dtype=dt, device=dev)
+        if outs is not None:
+            o = outs[k]
+            buf[(slice(0, o.shape[0]),) + tuple(slice(0, s) for s in o.shape[1:])] = o
+        gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, gathered, dst=0, group=group)
+        if rank == 0:
+            merged = torch.full((n,) + full, pad_value, dtype=dt, device=dev)
+            for r in range(world):
+                ir = shard_indices(n, r, world, mode)
+                if ir.numel():
+                    merged[ir.to(dev)] = gathered[r][:ir.numel()]
+            result.append(merged)
+    return result if rank == 0 else None
+
+
+class TTSPipeline:
+    """BASELINE configs[2] end to end on the device (update_samples.py:46-84 up to the pyworld call):
+
+        text [B, L] int64, text_len [B]
+          -> TextToAlignTextModel.forward                 [B, L, 2]  log(gap + 1), log(len + 1)        (tts.py:79-87)
+          -> align = max(exp(pred) - 1, 0)                (_align_v2.py:39-46; v1 has no predict(): it trains on log(align + 1),
+                                                           tts.py:126.  Negative values are clamped: the reference's Python loop
+                                                           would index from the END of the tensor for a negative start)
+          -> align() per utterance, on the device         aligntext [B, La] int64, lens                (tts.py:89-110, bit-exact)
+          -> AlignTextToAudioModel.predict                f0 [B, 2La-1], logspc|mcep, codeap           (tts.py:192-201)
+          -> (use_mcep) logspc = mcep @ mc2sp             one fp32 MFMA GEMM over all B x T frames      (vocoder.py:95)
+          -> spc = max(exp(logspc) - 1e-15, 0)                                                         (vocoder.py:99)
+
+    What remains on the CPU in the reference after this is pyworld.decode_aperiodicity + pyworld.synthesize."""
+
+    def __init__(self, align_model, audio_model, vocoder=None, head: int = 5, tail: int = 5):
+        self.align_model, self.audio_model, self.vocoder = align_model, audio_model, vocoder
+        self.head, self.tail = head, tail
+
+    @torch.no_grad()
+    def __call__(self, text: torch.Tensor, text_len: torch.Tensor):
+        from .decode import align_expand
+        pred = self.align_model(text)                                        # [B, L, 2]
+        align = torch.clamp_min(torch.exp(pred) - 1.0, 0.0)
+        aligntext, at_len = align_expand(text, align, text_len, self.head, self.tail)
+        f0, feat, codeap = self.audio_model.predict(aligntext)               # 2 * La - 1 frames
+        v = self.vocoder
+        if v is not None and v.use_mcep:
+            B, T, C = feat.shape
+            logspc = v.mcep_to_logspc(feat.reshape(B * T, C)).reshape(B, T, -1)
+        else:
+            logspc = feat
+        spc = v.logspc_to_spc(logspc) if v is not None else None
+        # valid WORLD frames per utterance: 2 * len - 1 (update_samples.py:81 slices 2 * len, which yields the same)
+        frames = torch.clamp_min(2 * at_len - 1, 0)
+        return {"align": align, "aligntext": aligntext, "aligntext_len": at_len, "f0": f0, "logspc": logspc, "spc": spc,
+                "codeap": codeap, "frames": frames}
+
+
+class ASRPipeline:
+    """BASELINE configs[4] per replica: waveform chunks [B, N] fp32 (16 kHz) -> log-mel [B, T, 64] -> AudioToTextCTC logits
+    -> greedy CTC ids [B, T'] int64 (zero padded) + lengths (data_modules.py:276-291, asr.py:110-116, text.py:99-104)."""
+
+    def __init__(self, model, mel=None):
+        self.model, self.mel = model, mel
+
+    @torch.no_grad()
+    def __call__(self, wav_or_mel: torch.Tensor):
+        from .decode import ctc_greedy_decode
+        feats = self.mel(wav_or_mel) if self.mel is not None else wav_or_mel
+        ids, n = ctc_greedy_decode(self.model(feats))
+        return ids, n

@@ -7,12 +7,17 @@ reference checkpoint with strict=True); the arithmetic of a block runs as one
 fused chain of HIP kernels (voice100_amd.functional), never through the
 sub-modules' own forward().
 """
+import warnings
+
 import torch
 from torch import nn
 
 from . import _stock
 from . import functional as F_
 from ._base import tracing
+
+
+_warned_eval_detach = False
 
 
 class ConvBNActivate(nn.ModuleList):
@@ -85,13 +90,22 @@ class InvertedResidual(nn.Module):
             if y16 is not None:
                 y._v100_shadow = (y16, y._version)
             return y
-        # eval mode: frozen statistics, inference only (autograd through eval-mode BN is not on the
-        # reference's training path and is not built) -- say so instead of silently returning a constant
+        # eval mode: frozen statistics, inference only (autograd through eval-mode BN is not on the reference's training path
+        # and is not built).  The reference's inference scripts call model.eval(); model(x) without torch.no_grad(), and the
+        # embedding-fed models hand this block an x that requires grad (the table is a Parameter): that must keep working, so
+        # the result is returned detached.  Only an x the USER marked requires_grad (a leaf: somebody wants d/dx) is refused,
+        # instead of silently handing back a gradient-less constant.
         if torch.is_grad_enabled() and x.requires_grad:
-            raise RuntimeError("InvertedResidual in eval mode is inference-only (frozen-BatchNorm fine-tuning is not "
-                               "built): call it under torch.no_grad(), or switch the block to train()")
+            if x.is_leaf:
+                raise RuntimeError("InvertedResidual in eval mode is inference-only (frozen-BatchNorm fine-tuning is not "
+                                   "built): call it under torch.no_grad(), or switch the block to train()")
+            global _warned_eval_detach
+            if not _warned_eval_detach:
+                _warned_eval_detach = True
+                warnings.warn("voice100_amd: eval-mode InvertedResidual called with autograd on; its output is detached "
+                              "(inference only). Wrap inference in torch.no_grad() to silence this.", stacklevel=2)
         with torch.no_grad():
-            return F_.inverted_residual_eval_cached(self, x, prec)
+            return F_.inverted_residual_eval_cached(self, x.detach(), prec)
 
 
 class PointwiseConv1d(nn.Conv1d):

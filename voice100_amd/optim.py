@@ -17,6 +17,17 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = None
 
+    # The device-side tables (flat moment buffers, pointer arrays, step counter) are a cache of self.state / param_groups:
+    # anything that replaces those -- load_state_dict() after a step has run (in-place resume, roll-back to a checkpoint),
+    # add_param_group() -- drops the cache, and the next step() rebuilds it from self.state (keeping the loaded moments).
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = None
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._tables = None
+
     def _build(self, group):
         ps = [p for p in group["params"] if p.requires_grad]
         if not ps:
@@ -80,8 +91,7 @@ class FusedAdam(torch.optim.Optimizer):
                 if g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous():
                     grads[i] = ps[i].grad = g.to(torch.float32).contiguous()
             ptrs = [g.data_ptr() for g in grads]
-            t["checks"] = t.get("checks", 0) + 1
-            if t["checks"] % 64 == 1 and [p.data_ptr() for p in ps] != t["p_ptrs"]:
+            if [p.data_ptr() for p in ps] != t["p_ptrs"]:        # every step: far cheaper than a write into freed memory
                 raise RuntimeError("FusedAdam: a parameter's storage moved since the optimizer was built (re-create the optimizer)")
             if ptrs != t.get("g_ptrs"):
                 # the gradient tensors moved (the caching allocator usually hands back the same blocks every step): upload

@@ -2,6 +2,7 @@
 (voice100/train_asr.py:12-38): Adam (L2-style weight_decay as torch.optim.Adam), StepLR(0.98) per
 epoch, one gradient all-reduce per step when launched with one process per GPU."""
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -38,7 +39,23 @@ def launch_ranks(script: str, argv: List[str], nproc: int, timeout: Optional[flo
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "4")
-    return subprocess.run(cmd, env=env, timeout=timeout).returncode
+    # own session: on a timeout the WHOLE group (torchrun and the rank processes it forked) is ended, so no orphaned rank
+    # keeps a GPU; only the group this call created is signalled, never a pattern
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        raise
 
 
 class TrainStep:
