@@ -1,0 +1,246 @@
+"""The `_io` entry points (bf16-STORED operands, include/voice100_hip.h "act16") -- the kernels the benchmark's bf16 step runs --
+checked ELEMENTWISE against plain torch arithmetic in float64 on the operands as the kernels define them:
+
+  * every 16-bit operand is the stored bf16 value; a TRANSFORMED operand (BatchNorm affine + ReLU6 on load, BatchNorm-backward
+    affine of two tensors) is formed in fp32 and rounded once to bf16, because it feeds a bf16 MFMA;
+  * products are exact, accumulation fp32 (reference: float64);
+  * a bf16-stored OUTPUT is the fp32 result rounded once (checked to half a bf16 ulp on top of the fp32 bar).
+
+Bar: max |got - ref| <= 2e-4 * max(1, max |ref|) per tensor (the bar of test_pw_gemm_modes for the fp32-storage kernels); an L2
+norm would hide a handful of wrong elements.  tests/test_gpu_act16.py compares the same entry points with the fp32-storage HIP
+kernels; this file is the independent (non-HIP) reference the round-2 review asked for.  Shapes: small ragged ones (row length
+not a multiple of 8, partial tiles in every dimension) and the benchmark's own block shapes."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+X, X2, Y, R = 1, 2, 4, 8            # PW_IO_*
+G_, G2_, WX = 1, 2, 4               # WG_IO_*
+
+
+def _native():
+    from voice100_amd import _native as N
+    N.load()
+    return N
+
+
+def pitch(T):
+    return (T + 7) & ~7
+
+
+def bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def store16(t):
+    """fp32 [B, C, T] -> (bf16 [B, C, pitch(T)] with NaN padding -- nothing may read it --, the stored values as float64)"""
+    B, C, T = t.shape
+    out = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=t.device)
+    out[:, :, :T] = t.to(torch.bfloat16)
+    return out, out[:, :, :T].to(torch.float64)
+
+
+def close(got, ref, what, out16=False, tol=2e-4):
+    got, ref = got.double(), ref.double()
+    assert torch.isfinite(got).all(), what
+    bound = tol * max(1.0, float(ref.abs().max()))
+    err = (got - ref).abs()
+    if out16:
+        err = err - ref.abs() * 2.0 ** -8          # one rounding of the stored value (half an ulp = 2^-9 relative; 2^-8 covers ties)
+    worst = float(err.max())
+    assert worst <= bound, f"{what}: max err {worst:.3e} > {bound:.3e} (max |ref| {float(ref.abs().max()):.3e})"
+
+
+def col(v):
+    return v.double()[None, :, None]
+
+
+GEMM_SHAPES = [(2, 32, 8, 48), (3, 200, 64, 100), (2, 72, 256, 133), (1, 512, 128, 700),
+               (32, 1024, 256, 512), (8, 2048, 512, 512), (8, 512, 2048, 512)]      # the last three: the benchmark's block shapes
+
+
+@pytest.mark.parametrize("B,M,K,T", GEMM_SHAPES)
+def test_pw_gemm_io_vs_float64(cuda, B, M, K, T):
+    N = _native()
+    g = torch.Generator().manual_seed(M * 5 + K + T)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(cuda)
+    A = (rnd(M, K) / K ** 0.5).to(torch.bfloat16)
+    Ad = A.double()
+    x = rnd(B, K, T)
+    x16, xs = store16(x)
+    x2 = rnd(B, K, T) * 2
+    x216, x2s = store16(x2)
+    xa, xb, xc = torch.rand(K, generator=g).to(cuda) + 0.5, rnd(K), rnd(K) * 0.1
+    ea, eb = torch.rand(M, generator=g).to(cuda) + 0.5, rnd(M)
+    r = rnd(B, M, T) * 3
+    r16, rs = store16(r)
+    parts = N.helper("v100_pw_num_parts", B, T)
+
+    def io(xm, ep, xin, x2in, rin, mask):
+        y = (torch.full((B, M, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda) if mask & Y else
+             torch.full((B, M, T), float("nan"), device=cuda))
+        st = torch.zeros(parts, M, 2, device=cuda)
+        N.call("v100_pw_gemm_io", A, xin, x2in, xa if xm else None, xb if xm else None, xc if xm == 2 else None, xm, y,
+               ea if ep == 4 else None, eb if ep == 4 else None, rin, ep, st if ep in (1, 4) else None, B, M, K, T, mask)
+        return (y[:, :, :T] if mask & Y else y), st.sum(0).double()
+
+    def mm(xop):                                    # exact products of the bf16 operands, float64 accumulation
+        return torch.einsum("mk,bkt->bmt", Ad, xop)
+
+    def stats_close(st, y, second, what):
+        scale = max(1.0, float(y.abs().sum((0, 2)).max()))
+        assert float((st[:, 0] - y.sum((0, 2))).abs().max()) <= 2e-4 * scale, what + " sum"
+        scale2 = max(1.0, float((y * second).abs().sum((0, 2)).max()))
+        assert float((st[:, 1] - (y * second).sum((0, 2))).abs().max()) <= 2e-4 * scale2, what + " sum2"
+
+    # expand forward (asr.py:47): plain X -- fp32 (rounded by the kernel) or the bf16 shadow --, Y stored bf16, BN1 partial sums
+    ref = mm(bf(x).double())
+    for xin, mask in ((x, Y), (x16, X | Y)):
+        y, st = io(0, 1, xin, None, None, mask)
+        close(y, ref, "expand fwd", out16=True)
+        stats_close(st, ref, ref, "expand fwd stats")          # statistics come from the fp32 accumulators, not the rounded store
+    # project forward (asr.py:51): BN2 + ReLU6 applied on load of the bf16 a2; Y fp32 (level <= 2) or bf16 (level >= 3)
+    xt = bf(torch.clamp(col(xa) * xs + col(xb), 0, 6).float()).double()
+    ref = mm(xt)
+    for mask in (X, X | Y):
+        y, st = io(1, 1, x16, None, None, mask)
+        close(y, ref, "project fwd", out16=bool(mask & Y))
+        stats_close(st, ref, ref, "project fwd stats")
+    # project backward-data: dz2 = (W3^T da3) * [0 < bn2(a2) < 6], sums (dz2, dz2 * a2); X = da3 fp32 | bf16, R = a2 bf16
+    pre = rs * col(ea) + col(eb)
+    keep = ((pre > 0) & (pre < 6)).double()
+    edge = (pre.abs() < 1e-4) | ((pre - 6).abs() < 1e-4)      # fp32 vs float64 may disagree on which side of the kink these sit
+    for xin, xop, mask in ((x, bf(x).double(), R), (x, bf(x).double(), R | Y), (x16, xs, X | R | Y)):
+        y, st = io(0, 4, xin, None, r16, mask)
+        ref = mm(xop) * keep
+        yy = torch.where(edge, ref.to(y.dtype), y)
+        close(yy, ref, "project bwd-data", out16=bool(mask & Y))
+        if not bool(edge.any()):
+            stats_close(st, ref, rs, "project bwd-data stats")
+    # expand backward-data (+ residual gradient): X' = p*dz1 + q*a1 + r rounded to bf16, dx = W1^T X' (+ dy), fp32 out
+    for xin, xop, mask in ((x, x.double(), X2), (x16, xs, X | X2)):
+        xt = bf((col(xa) * xop + col(xb) * x2s + col(xc)).float()).double()
+        for ep, res in ((5, r), (0, None)):
+            y, _ = io(2, ep, xin, x216, res, mask)
+            ref = mm(xt) + (res.double() if res is not None else 0)
+            # a transformed element that lands within fp32 round-off of a bf16 rounding boundary may round the other way than the
+            # float64 reference: one bf16 ulp of one of K operand values, far inside the bar
+            close(y, ref, "expand bwd-data")
+
+
+@pytest.mark.parametrize("B,M,K,T", [(2, 32, 8, 48), (4, 200, 64, 100), (3, 64, 256, 133), (3, 300, 260, 133), (5, 640, 384, 77),
+                                     (32, 1024, 256, 512), (16, 2048, 512, 512), (16, 512, 2048, 512)])
+def test_pw_wgrad_io_vs_float64(cuda, B, M, K, T):
+    N = _native()
+    g = torch.Generator().manual_seed(M * 3 + T + K)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(cuda)
+    gm = rnd(B, M, T)
+    g16, gs = store16(gm)
+    g2 = rnd(B, M, T)
+    g216, g2s = store16(g2)
+    xm_ = rnd(B, K, T)
+    x16, xs = store16(xm_)
+    ga, gb, gc = rnd(M), rnd(M), rnd(M) * 0.1
+    xa, xb = torch.rand(K, generator=g).to(cuda) + 0.5, rnd(K)
+    S = N.helper("v100_pw_wgrad_splits", B, M, K)
+
+    def run(G, G2, gmode, Xt, xmode, mask):
+        partial = torch.empty(S, M, K, device=cuda)
+        dW = torch.full((M, K), float("nan"), device=cuda)
+        N.call("v100_pw_wgrad_io", G, G2, ga if gmode else None, gb if gmode else None, gc if gmode == 2 else None, gmode, Xt,
+               xa if xmode else None, xb if xmode else None, xmode, partial, dW, S, B, M, K, T, mask)
+        return dW
+
+    def ref(gop, xop):
+        return torch.einsum("bmt,bkt->mk", gop, xop)
+
+    # expand weight gradient (asr.py:47 backward): G' = p*dz1 + q*a1 + r rounded to bf16; X = block input fp32 | bf16 shadow
+    for Gin, gop, Xin, xop, mask in ((gm, gm.double(), xm_, bf(xm_).double(), G2_), (g16, gs, xm_, bf(xm_).double(), G_ | G2_),
+                                     (g16, gs, x16, xs, G_ | G2_ | WX)):
+        gt = bf((col(ga) * gop + col(gb) * g2s + col(gc)).float()).double()
+        # B*T products per element: the bar scales with the accumulated magnitude like the GEMM's does with max |ref|
+        close(run(Gin, g216, 2, Xin, 0, mask), ref(gt, xop), "expand wgrad", tol=3e-4)
+    # project weight gradient (asr.py:51 backward): G = da3 fp32 | bf16, X' = relu6(bn2(a2)) rounded to bf16
+    xt = bf(torch.clamp(col(xa) * xs + col(xb), 0, 6).float()).double()
+    for Gin, gop, mask in ((gm, bf(gm).double(), WX), (g16, gs, G_ | WX)):
+        close(run(Gin, None, 0, x16, 1, mask), ref(gop, xt), "project wgrad", tol=3e-4)
+
+
+@pytest.mark.parametrize("B,C,T", [(2, 8, 48), (3, 6, 133), (32, 512, 512)])
+def test_chan_passes_io_vs_float64(cuda, B, C, T):
+    """Block-boundary passes on a bf16-stored a3 / da3 (asr.py:52-59 and their backward), elementwise."""
+    N = _native()
+    g = torch.Generator().manual_seed(C + T)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(cuda)
+    a3 = rnd(B, C, T) * 2
+    a316, a3s = store16(a3)
+    x, dy = rnd(B, C, T), rnd(B, C, T)
+    p_, q_, r_ = rnd(C), rnd(C), rnd(C)
+    for res in (x, None):
+        ref = a3s * col(p_) + col(r_) + (res.double() if res is not None else 0)
+        y = torch.full((B, C, T), float("nan"), device=cuda)
+        N.call("v100_chan_affine2_io", a316, res, p_, None, r_, y, B, C, T, 1)
+        close(y, ref, "block output", tol=2e-6)
+        y = torch.full((B, C, T), float("nan"), device=cuda)
+        sh = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+        N.call("v100_chan_affine2_shadow", a316, res, p_, r_, y, sh, B, C, T, 1)
+        close(y, ref, "block output (shadow form)", tol=2e-6)
+        assert torch.equal(sh[:, :, :T], y.to(torch.bfloat16))                    # the shadow is exactly the rounded output
+    G = N.helper("v100_dw_num_groups", B, C)
+    part = torch.zeros(G, C, 2, device=cuda)
+    N.call("v100_chan_reduce2_io", dy, a316, part, G, B, C, T, 2)
+    s = part.sum(0).double()
+    n = B * T
+    assert float((s[:, 0] - dy.double().sum((0, 2))).abs().max()) <= 2e-6 * n
+    assert float((s[:, 1] - (dy.double() * a3s).sum((0, 2))).abs().max()) <= 2e-6 * n * 4
+    da3 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    N.call("v100_chan_affine2_io", dy, a316, p_, q_, r_, da3, B, C, T, 6)
+    close(da3[:, :, :T], col(p_) * dy.double() + col(q_) * a3s + col(r_), "BatchNorm-3 backward", out16=True, tol=2e-6)
+
+
+@pytest.mark.parametrize("B,C,T,K", [(2, 8, 48, 19), (3, 6, 133, 83), (2, 4, 700, 51), (2, 4, 1100, 35), (32, 64, 512, 59), (32, 64, 512, 27)])
+def test_dwconv_io_vs_float64(cuda, B, C, T, K):
+    """Depthwise forward / fused backward with 16-bit storage (asr.py:49 and its autograd), elementwise against float64 on the
+    operands as the kernels define them (transformed data operand rounded once to bf16, fp32 taps)."""
+    import torch.nn.functional as F
+    N = _native()
+    DX, DX2, DAUX, DY = 1, 2, 4, 8
+    g = torch.Generator().manual_seed(C * 7 + T + K)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(cuda)
+    pad = (K - 1) // 2
+    a116, a1s = store16(rnd(B, C, T) * 2)
+    w = rnd(C, K) * 0.2
+    s1, t1 = torch.rand(C, generator=g).to(cuda) + 0.5, rnd(C)
+    G = N.helper("v100_dw_num_groups", B, C)
+    pre = a1s * col(s1) + col(t1)
+    xin = bf(torch.clamp(pre, 0, 6).float()).double()
+    ref = F.conv1d(xin, w.double()[:, None, :], padding=pad, groups=C)
+    y = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    st = torch.zeros(G, C, 2, device=cuda)
+    N.call("v100_dwconv_fwd_train_io", a116, w, s1, t1, y, st, G, B, C, T, K, DX | DY)
+    close(y[:, :, :T], ref, "depthwise fwd", out16=True)
+    s = st.sum(0).double()
+    assert float((s[:, 0] - ref.sum((0, 2))).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().sum((0, 2)).max()))
+    assert float((s[:, 1] - (ref * ref).sum((0, 2))).abs().max()) <= 2e-4 * max(1.0, float((ref * ref).sum((0, 2)).max()))
+    dz216, dz2s = store16(rnd(B, C, T))
+    a216, a2s = store16(rnd(B, C, T))
+    ga, gb, gc = torch.rand(C, generator=g).to(cuda) + 0.5, rnd(C) * 0.3, rnd(C) * 0.1
+    gp = bf((col(ga) * dz2s + col(gb) * a2s + col(gc)).float()).double()
+    xv, wv = xin.clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+    (F.conv1d(xv, wv[:, None, :], padding=pad, groups=C) * gp).sum().backward()
+    mask = ((pre > 0) & (pre < 6)).double()
+    edge = (pre.abs() < 1e-4) | ((pre - 6).abs() < 1e-4)
+    dz1r = xv.grad * mask
+    dz1 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    st = torch.zeros(G, C, 2, device=cuda)
+    part = torch.empty(G, C, K, device=cuda)
+    dw = torch.empty(C, K, device=cuda)
+    N.call("v100_dwconv_bwd_io", dz216, a216, w, ga, gb, gc, a116, s1, t1, dz1, st, part, dw, G, B, C, T, K, DX | DX2 | DAUX | DY)
+    got = torch.where(edge, dz1r.to(torch.bfloat16), dz1[:, :, :T])
+    close(got, dz1r, "depthwise bwd-data", out16=True)
+    close(dw, wv.grad, "depthwise wgrad", tol=3e-4)
+    if not bool(edge.any()):
+        s = st.sum(0).double()
+        assert float((s[:, 0] - dz1r.sum((0, 2))).abs().max()) <= 2e-4 * max(1.0, float(dz1r.abs().sum((0, 2)).max()))
+        assert float((s[:, 1] - (dz1r * a1s).sum((0, 2))).abs().max()) <= 2e-4 * max(1.0, float((dz1r * a1s).abs().sum((0, 2)).max()))

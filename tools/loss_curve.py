@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Loss trajectory of the bench workload (asr_en_base, B=32 x 1024, seeded like bench.py) for a few precision / storage
-settings: fp32, bf16 operands with fp32 storage, bf16 operands with bf16 hidden storage (act16 1 / 2).  The curves must track
+settings: fp32, bf16 operands with fp32 storage, bf16 operands with bf16 hidden storage (act16 levels 2, 3 and 4 = the bench's).  The curves must track
 each other (same data, same augmentation and dropout draws); used to check that reduced-precision storage trains the same.
 python tools/loss_curve.py [--steps 40]"""
 import argparse
@@ -34,7 +34,8 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     curves = {"fp32": run("fp32", 0, args.steps, dev), "bf16/act0": run("bf16", 0, args.steps, dev),
-              "bf16/act2": run("bf16", 2, args.steps, dev), "bf16/act3": run("bf16", 3, args.steps, dev)}
+              "bf16/act2": run("bf16", 2, args.steps, dev), "bf16/act3": run("bf16", 3, args.steps, dev),
+              "bf16/act4": run("bf16", 4, args.steps, dev)}          # level 4 = what bench.py runs
     print("step " + " ".join(f"{k:>10s}" for k in curves))
     for i in range(args.steps):
         print(f"{i:4d} " + " ".join(f"{v[i]:10.4f}" for v in curves.values()))
