@@ -304,6 +304,21 @@ int v100_ir_fwd_train(const int* shape, const void* const* ptrs, void* stream);
 long long v100_ir_bwd_workspace_bytes(const int* shape);
 int v100_ir_bwd(const int* shape, const void* const* ptrs, void* stream);
 
+/* ---- stack executor: a run of consecutive InvertedResidual blocks (ConvVoiceEncoder.layers, asr.py:67-76; VoiceDecoder.layers[0:4] /
+ * [5:8], tts.py:17-25; TextToAlignTextModel.layers[0:4], tts.py:72-76) forward / backward in ONE host call each: the sequencing of
+ * v100_ir_prep_batched + v100_ir_fwd_train per block (resp. v100_ir_bwd in reverse), same kernels and results.
+ * desc (HOST ints): {n, B, T, bf16, act16_level, want_last_shadow} then n x {cin, hid, cout, k, stride, residual}.
+ * v100_ir_stack_plan fills plan (HOST, 8 per block + 6 long longs): per block the byte offsets into the activation blob of
+ * a1, a2, a3, y, y16 (-1: none), coef, prep and the block's output length; then {blob_bytes, bwd_ws_bytes, grad_floats, ...}; returns
+ * blob_bytes (-1: bad descriptor).  The caller allocates the blob (kept until backward), the backward workspace and the gradient
+ * buffer: grad_floats floats, per block dW1 dg1 db1 dWd dg2 db2 dW3 dg3 db3.
+ * params (HOST pointer table, 18 per block): w1 g1 b1 rm1 rv1 nbt1 | wd g2 b2 rm2 rv2 nbt2 | w3 g3 b3 rm3 rv3 nbt3.
+ * x16 (may be NULL): bf16 shadow [B][cin][(T + 7) & ~7] of x (act16 level 4). */
+long long v100_ir_stack_plan(const int* desc, long long* plan);
+int v100_ir_stack_fwd_train(const int* desc, const void* const* params, const void* x, const void* x16, void* blob, void* stream);
+int v100_ir_stack_bwd(const int* desc, const void* const* params, const void* x, const void* x16, const void* blob, const void* dy,
+                      void* dx, void* grads, void* ws, void* stream);
+
 /* ---- SURVEY 8(f) "next" rows: integer decode / alignment steps on the device (csrc/decode.hip), bit-exact ----
  * greedy CTC decode: argmax per frame (first maximum), collapse repeats, drop blanks (voice100/text.py:99-104);
  * out [B][T] int64 (zero padded), out_len [B]. */

@@ -56,6 +56,20 @@ def col(v):
     return v.double()[None, :, None]
 
 
+def fma32(a, b, c):
+    """fmaf(a, b, c) of fp32-valued float64 tensors: the product is exact in float64, one rounding of the sum to fp32 (the kernels
+    form their on-load transforms with exactly these fused operations, so the bf16 rounding that follows sees the same fp32 value)."""
+    return (a * b + c).float().double()
+
+
+def affine_relu6(x, a, b):           # relu6f(fmaf(x, a, b))
+    return torch.clamp(fma32(x, col(a), col(b)), 0, 6)
+
+
+def affine2(x, x2, a, b, c):         # fmaf(x, a, fmaf(x2, b, c))
+    return fma32(x, col(a), fma32(x2, col(b), col(c)))
+
+
 GEMM_SHAPES = [(2, 32, 8, 48), (3, 200, 64, 100), (2, 72, 256, 133), (1, 512, 128, 700),
                (32, 1024, 256, 512), (8, 2048, 512, 512), (8, 512, 2048, 512)]      # the last three: the benchmark's block shapes
 
@@ -101,16 +115,16 @@ def test_pw_gemm_io_vs_float64(cuda, B, M, K, T):
         close(y, ref, "expand fwd", out16=True)
         stats_close(st, ref, ref, "expand fwd stats")          # statistics come from the fp32 accumulators, not the rounded store
     # project forward (asr.py:51): BN2 + ReLU6 applied on load of the bf16 a2; Y fp32 (level <= 2) or bf16 (level >= 3)
-    xt = bf(torch.clamp(col(xa) * xs + col(xb), 0, 6).float()).double()
+    xt = bf(affine_relu6(xs, xa, xb).float()).double()
     ref = mm(xt)
     for mask in (X, X | Y):
         y, st = io(1, 1, x16, None, None, mask)
         close(y, ref, "project fwd", out16=bool(mask & Y))
         stats_close(st, ref, ref, "project fwd stats")
     # project backward-data: dz2 = (W3^T da3) * [0 < bn2(a2) < 6], sums (dz2, dz2 * a2); X = da3 fp32 | bf16, R = a2 bf16
-    pre = rs * col(ea) + col(eb)
+    pre = fma32(rs, col(ea), col(eb))                         # the epilogue's own fmaf(R, ea, eb): the mask is then exact
     keep = ((pre > 0) & (pre < 6)).double()
-    edge = (pre.abs() < 1e-4) | ((pre - 6).abs() < 1e-4)      # fp32 vs float64 may disagree on which side of the kink these sit
+    edge = torch.zeros_like(keep, dtype=torch.bool)
     for xin, xop, mask in ((x, bf(x).double(), R), (x, bf(x).double(), R | Y), (x16, xs, X | R | Y)):
         y, st = io(0, 4, xin, None, r16, mask)
         ref = mm(xop) * keep
@@ -120,12 +134,10 @@ def test_pw_gemm_io_vs_float64(cuda, B, M, K, T):
             stats_close(st, ref, rs, "project bwd-data stats")
     # expand backward-data (+ residual gradient): X' = p*dz1 + q*a1 + r rounded to bf16, dx = W1^T X' (+ dy), fp32 out
     for xin, xop, mask in ((x, x.double(), X2), (x16, xs, X | X2)):
-        xt = bf((col(xa) * xop + col(xb) * x2s + col(xc)).float()).double()
+        xt = bf(affine2(xop, x2s, xa, xb, xc).float()).double()
         for ep, res in ((5, r), (0, None)):
             y, _ = io(2, ep, xin, x216, res, mask)
             ref = mm(xt) + (res.double() if res is not None else 0)
-            # a transformed element that lands within fp32 round-off of a bf16 rounding boundary may round the other way than the
-            # float64 reference: one bf16 ulp of one of K operand values, far inside the bar
             close(y, ref, "expand bwd-data")
 
 
@@ -158,11 +170,11 @@ def test_pw_wgrad_io_vs_float64(cuda, B, M, K, T):
     # expand weight gradient (asr.py:47 backward): G' = p*dz1 + q*a1 + r rounded to bf16; X = block input fp32 | bf16 shadow
     for Gin, gop, Xin, xop, mask in ((gm, gm.double(), xm_, bf(xm_).double(), G2_), (g16, gs, xm_, bf(xm_).double(), G_ | G2_),
                                      (g16, gs, x16, xs, G_ | G2_ | WX)):
-        gt = bf((col(ga) * gop + col(gb) * g2s + col(gc)).float()).double()
+        gt = bf(affine2(gop, g2s, ga, gb, gc).float()).double()
         # B*T products per element: the bar scales with the accumulated magnitude like the GEMM's does with max |ref|
         close(run(Gin, g216, 2, Xin, 0, mask), ref(gt, xop), "expand wgrad", tol=3e-4)
     # project weight gradient (asr.py:51 backward): G = da3 fp32 | bf16, X' = relu6(bn2(a2)) rounded to bf16
-    xt = bf(torch.clamp(col(xa) * xs + col(xb), 0, 6).float()).double()
+    xt = bf(affine_relu6(xs, xa, xb).float()).double()
     for Gin, gop, mask in ((gm, bf(gm).double(), WX), (g16, gs, G_ | WX)):
         close(run(Gin, None, 0, x16, 1, mask), ref(gop, xt), "project wgrad", tol=3e-4)
 
@@ -213,7 +225,7 @@ def test_dwconv_io_vs_float64(cuda, B, C, T, K):
     w = rnd(C, K) * 0.2
     s1, t1 = torch.rand(C, generator=g).to(cuda) + 0.5, rnd(C)
     G = N.helper("v100_dw_num_groups", B, C)
-    pre = a1s * col(s1) + col(t1)
+    pre = fma32(a1s, col(s1), col(t1))
     xin = bf(torch.clamp(pre, 0, 6).float()).double()
     ref = F.conv1d(xin, w.double()[:, None, :], padding=pad, groups=C)
     y = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
@@ -226,11 +238,11 @@ def test_dwconv_io_vs_float64(cuda, B, C, T, K):
     dz216, dz2s = store16(rnd(B, C, T))
     a216, a2s = store16(rnd(B, C, T))
     ga, gb, gc = torch.rand(C, generator=g).to(cuda) + 0.5, rnd(C) * 0.3, rnd(C) * 0.1
-    gp = bf((col(ga) * dz2s + col(gb) * a2s + col(gc)).float()).double()
+    gp = bf(affine2(dz2s, a2s, ga, gb, gc).float()).double()
     xv, wv = xin.clone().requires_grad_(True), w.double().clone().requires_grad_(True)
     (F.conv1d(xv, wv[:, None, :], padding=pad, groups=C) * gp).sum().backward()
     mask = ((pre > 0) & (pre < 6)).double()
-    edge = (pre.abs() < 1e-4) | ((pre - 6).abs() < 1e-4)
+    edge = torch.zeros_like(mask, dtype=torch.bool)          # pre is the kernel's own fmaf: no kink ambiguity
     dz1r = xv.grad * mask
     dz1 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
     st = torch.zeros(G, C, 2, device=cuda)

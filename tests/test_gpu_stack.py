@@ -1,0 +1,69 @@
+"""Stack executor (v100_ir_stack_fwd_train / v100_ir_stack_bwd: a run of InvertedResidual blocks per host call) against the
+per-block executor it sequences: outputs, input gradient, every parameter gradient and every BatchNorm buffer must be IDENTICAL
+bit for bit -- same kernels, same order -- in fp32 and in bf16 at every activation-storage level, as one autograd node and in
+segments (the data-parallel form)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(net, x, gy, how, segment=None):
+    from voice100_amd import functional as F_
+    net = copy.deepcopy(net).train()
+    x = x.clone().requires_grad_(True)
+    y = net(x) if how == "blocks" else F_.ir_stack_train(list(net), x, segment=segment)
+    (y * gy).sum().backward()
+    bufs = {k: v.clone() for k, v in net.named_buffers()}
+    return y.detach(), x.grad, {k: p.grad for k, p in net.named_parameters()}, bufs
+
+
+@pytest.mark.parametrize("precision,level", [("fp32", 0), ("bf16", 0), ("bf16", 2), ("bf16", 3), ("bf16", 4)])
+def test_stack_equals_blocks(cuda, precision, level):
+    from voice100_amd import functional as F_
+    from voice100_amd.layers import InvertedResidual
+    F_.set_matmul_precision(precision)
+    keep = F_.get_activation_storage()
+    F_.set_activation_storage(level)
+    try:
+        torch.manual_seed(21)
+        # a stride-2 opener (fp32 storage, no MFMA depthwise), residual and non-residual blocks, a width change, hidden 1024 (one
+        # depthwise group: BatchNorm finalised in-kernel)
+        net = torch.nn.Sequential(InvertedResidual(16, 64, kernel_size=11, stride=2, use_residual=False),
+                                  InvertedResidual(64, 64, kernel_size=19), InvertedResidual(64, 256, kernel_size=27, use_residual=False),
+                                  InvertedResidual(256, 256, kernel_size=35), InvertedResidual(256, 256, kernel_size=5)).to(cuda)
+        for T in (626, 400):                                            # 313 (odd, pitched rows) and 200 after the stride
+            g = torch.Generator().manual_seed(T)
+            x = torch.randn(3, 16, T, generator=g).to(cuda)
+            gy = torch.randn(3, 256, (T + 1) // 2, generator=g).to(cuda)
+            ref = _run(net, x, gy, "blocks")
+            for seg in (None, 2, 1):
+                got = _run(net, x, gy, "stack", seg)
+                assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (T, seg)
+                for k in ref[2]:
+                    assert torch.equal(got[2][k], ref[2][k]), (T, seg, k)
+                for k in ref[3]:
+                    assert torch.equal(got[3][k], ref[3][k]), (T, seg, k)
+    finally:
+        F_.set_activation_storage(keep)
+        F_.set_matmul_precision("fp32")
+
+
+def test_stack_no_input_grad_and_reuse(cuda):
+    """x that needs no gradient (the encoder's input), and two forwards before the first backward (each keeps its own blob)."""
+    from voice100_amd import functional as F_
+    from voice100_amd.layers import InvertedResidual
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(InvertedResidual(8, 8, kernel_size=7), InvertedResidual(8, 8, kernel_size=5)).to(cuda).train()
+    x1, x2 = torch.randn(2, 8, 40, device=cuda), torch.randn(2, 8, 40, device=cuda)
+    y1 = F_.ir_stack_train(list(net), x1)
+    y2 = F_.ir_stack_train(list(net), x2)
+    y1.sum().backward()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    y2.sum().backward()
+    g2 = [p.grad.clone() for p in net.parameters()]
+    assert any(not torch.equal(a, b) for a, b in zip(g1, g2))
+    assert all(torch.isfinite(a).all() for a in g1 + g2)

@@ -39,7 +39,7 @@ class ConvVoiceEncoder(nn.Module):
 
     def forward(self, embed: torch.Tensor) -> torch.Tensor:
         if self.training and not tracing():
-            F_.prepare_block_weights(self.layers)       # bf16 / transposed weight copies of all 9 blocks in one launch
+            return F_.ir_stack_train(self.layers, embed)      # the nine blocks through the stack executor: one host call per direction
         return self.layers(embed)
 
     def output_length(self, embed_len: torch.Tensor) -> torch.Tensor:

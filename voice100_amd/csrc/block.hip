@@ -429,3 +429,162 @@ extern "C" int v100_ir_prep_batched(const int* shapes, const void* const* w1s, c
     V100_GGL(weight_prep_batched_kernel, dim3((unsigned)gx, 2 * n), dim3(256), 0, (hipStream_t)stream, t);
     return v100_launch_status();
 }
+
+// =====================================================================================================================
+// Stack executor: ONE host call per direction for a run of consecutive InvertedResidual blocks (the encoder's nine, a decoder
+// segment's three or four): the per-block Python -> autograd -> ctypes crossings were 2/3 of the 3 ms a step took to ENQUEUE.
+// All activations the run keeps for backward live in ONE caller-allocated blob laid out by v100_ir_stack_plan; backward walks the
+// blocks in reverse with one shared workspace and two ping-pong gradient buffers.  Pure sequencing of v100_ir_fwd_train / v100_ir_bwd
+// (same kernels, same order, bit-identical results).
+//
+// desc (HOST ints): {n, B, T, bf16, act16_level, want_last_shadow} then n x {cin, hid, cout, k, stride, residual}
+// plan (HOST long long out, 8 per block + 6): per block byte offsets into the blob of a1, a2, a3, y, y16 (or -1), coef, prep, T_out;
+//   then {blob_bytes, bwd_ws_bytes, grad_floats, fwd_ws_offset, 0, 0}
+// params (HOST pointer table, 18 per block): w1 g1 b1 rm1 rv1 nbt1 | wd g2 b2 rm2 rv2 nbt2 | w3 g3 b3 rm3 rv3 nbt3
+enum { ST_N, ST_B, ST_T, ST_BF16, ST_LEVEL, ST_SHADOW, ST_HDR };
+namespace {
+struct StackBlock { int sh[IR_NSHAPE]; long long a1, a2, a3, y, y16, coef, prep; int Tout; size_t grad_floats; };
+inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
+// fills blocks[0..n) and the totals; returns 0 on a bad descriptor
+int stack_layout(const int* desc, StackBlock* blk, size_t& blob_bytes, size_t& bwd_ws, size_t& grad_floats, size_t& fwd_ws_off) {
+    const int n = desc[ST_N], B = desc[ST_B], bf = desc[ST_BF16], level = desc[ST_LEVEL];
+    if (n <= 0 || n > 32 || B <= 0 || desc[ST_T] <= 0 || (bf != 0 && bf != 1)) return 0;
+    int T = desc[ST_T];
+    size_t off = 0, fwd_ws = 0, bws = 0, dxmax = 0;
+    grad_floats = 0;
+    const bool shadows = bf == 1 && level >= 4;
+    for (int i = 0; i < n; ++i) {
+        const int* d = desc + ST_HDR + 6 * i;
+        StackBlock& b = blk[i];
+        const int cin = d[0], hid = d[1], cout = d[2], k = d[3], s = d[4], res = d[5];
+        if (cin <= 0 || hid <= 0 || cout <= 0 || k <= 0 || s <= 0) return 0;
+        int* sh = b.sh;
+        sh[IR_B] = B; sh[IR_CIN] = cin; sh[IR_HID] = hid; sh[IR_COUT] = cout; sh[IR_T] = T; sh[IR_K] = k; sh[IR_STRIDE] = s;
+        sh[IR_RES] = res; sh[IR_BF16] = bf; sh[IR_PREPPED] = 1 | (shadows ? 2 : 0); sh[IR_ACT16] = 0;
+        if (bf == 1 && level && v100_ir_act16_supported(sh)) sh[IR_ACT16] = level;
+        const int T2 = conv_out(T, k, s);
+        if (T2 <= 0) return 0;
+        b.Tout = T2;
+        const int lv = sh[IR_ACT16];
+        const size_t P = pitch16(T), P2 = pitch16(T2);
+        b.a1 = (long long)off; off = al256(off + (lv ? (size_t)B * hid * P * 2 : (size_t)B * hid * T * 4));
+        b.a2 = (long long)off; off = al256(off + (lv ? (size_t)B * hid * P * 2 : (size_t)B * hid * T2 * 4));   // (act16: stride 1, T2 == T)
+        b.a3 = (long long)off; off = al256(off + (lv >= 3 ? (size_t)B * cout * P * 2 : (size_t)B * cout * T2 * 4));
+        b.y = (long long)off; off = al256(off + (size_t)B * cout * T2 * 4);
+        b.y16 = -1;
+        if (shadows && (i + 1 < n || desc[ST_SHADOW])) { b.y16 = (long long)off; off = al256(off + (size_t)B * cout * P2 * 2); }
+        b.coef = (long long)off; off = al256(off + (size_t)12 * (hid > cout ? hid : cout) * 4);
+        b.prep = (long long)off; off = al256(off + (size_t)v100_ir_prep_bytes(sh));
+        const size_t fw = (size_t)v100_ir_fwd_workspace_bytes(sh), bw = (size_t)v100_ir_bwd_workspace_bytes(sh);
+        if (fw > fwd_ws) fwd_ws = fw;
+        if (bw > bws) bws = bw;
+        const size_t dxb = (size_t)B * cin * T * 4;
+        if (dxb > dxmax) dxmax = dxb;
+        b.grad_floats = (size_t)hid * cin + 2 * (size_t)hid + (size_t)hid * k + 2 * (size_t)hid + (size_t)cout * hid + 2 * (size_t)cout;
+        grad_floats += b.grad_floats;
+        T = T2;
+    }
+    fwd_ws_off = off;
+    blob_bytes = al256(off + fwd_ws) + 256;
+    bwd_ws = al256(bws) + 2 * al256(dxmax) + 256;
+    return 1;
+}
+}   // namespace
+
+extern "C" long long v100_ir_stack_plan(const int* desc, long long* plan) {
+    if (!desc || !plan) return -1;
+    StackBlock blk[32];
+    size_t blob, bws, gf, fwo;
+    if (!stack_layout(desc, blk, blob, bws, gf, fwo)) return -1;
+    const int n = desc[ST_N];
+    for (int i = 0; i < n; ++i) {
+        long long* o = plan + 8 * i;
+        o[0] = blk[i].a1; o[1] = blk[i].a2; o[2] = blk[i].a3; o[3] = blk[i].y; o[4] = blk[i].y16; o[5] = blk[i].coef; o[6] = blk[i].prep;
+        o[7] = blk[i].Tout;
+    }
+    long long* t = plan + 8 * n;
+    t[0] = (long long)blob; t[1] = (long long)bws; t[2] = (long long)gf; t[3] = (long long)fwo; t[4] = 0; t[5] = 0;
+    return (long long)blob;
+}
+
+// x16: bf16 shadow of x written by whatever produced x (NULL: the first expand GEMM reads the fp32 x)
+extern "C" int v100_ir_stack_fwd_train(const int* desc, const void* const* params, const void* x, const void* x16, void* blob,
+                                       void* stream) {
+    if (!desc || !params || !x || !blob) return V100_ERR_NULL;
+    StackBlock blk[32];
+    size_t blob_bytes, bws, gf, fwo;
+    if (!stack_layout(desc, blk, blob_bytes, bws, gf, fwo)) return V100_ERR_SHAPE;
+    const int n = desc[ST_N];
+    char* base = (char*)blob;
+    int rc;
+    {   // bf16 / transposed weight copies of every block: one launch
+        int shapes[32 * IR_NSHAPE];
+        const void* w1s[32]; const void* w3s[32]; void* preps[32];
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < IR_NSHAPE; ++j) shapes[i * IR_NSHAPE + j] = blk[i].sh[j];
+            w1s[i] = params[18 * i + 0]; w3s[i] = params[18 * i + 12]; preps[i] = base + blk[i].prep;
+        }
+        CK(v100_ir_prep_batched(shapes, w1s, w3s, preps, n, stream));
+    }
+    const void* xin = x;
+    const void* xin16 = x16;
+    for (int i = 0; i < n; ++i) {
+        const StackBlock& b = blk[i];
+        const void* P[28];
+        P[0] = xin;
+        for (int j = 0; j < 18; ++j) P[1 + j] = params[18 * i + j];
+        P[19] = base + b.a1; P[20] = base + b.a2; P[21] = base + b.a3; P[22] = base + b.y; P[23] = base + b.coef;
+        P[24] = base + fwo; P[25] = base + b.prep;
+        P[26] = xin16; P[27] = b.y16 >= 0 ? base + b.y16 : nullptr;
+        CK(v100_ir_fwd_train(b.sh, P, stream));
+        xin = base + b.y;
+        xin16 = b.y16 >= 0 ? base + b.y16 : nullptr;
+    }
+    return V100_OK;
+}
+
+// dy: gradient of the last block's output; dx: gradient of x (NULL = not needed); grads: grad_floats floats, per block
+// dW1 dg1 db1 dWd dg2 db2 dW3 dg3 db3; ws: bwd_ws_bytes (plan)
+extern "C" int v100_ir_stack_bwd(const int* desc, const void* const* params, const void* x, const void* x16, const void* blob,
+                                 const void* dy, void* dx, void* grads, void* ws, void* stream) {
+    if (!desc || !params || !x || !blob || !dy || !grads || !ws) return V100_ERR_NULL;
+    StackBlock blk[32];
+    size_t blob_bytes, bws, gf, fwo;
+    if (!stack_layout(desc, blk, blob_bytes, bws, gf, fwo)) return V100_ERR_SHAPE;
+    const int n = desc[ST_N];
+    const char* base = (const char*)blob;
+    size_t wsmax = 0, dxmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t bw = (size_t)v100_ir_bwd_workspace_bytes(blk[i].sh);
+        if (bw > wsmax) wsmax = bw;
+        const size_t dxb = (size_t)blk[i].sh[IR_B] * blk[i].sh[IR_CIN] * blk[i].sh[IR_T] * 4;
+        if (dxb > dxmax) dxmax = dxb;
+    }
+    char* w0 = (char*)ws;
+    char* pp[2] = {w0 + al256(wsmax), w0 + al256(wsmax) + al256(dxmax)};
+    size_t goff = gf;
+    const void* dyi = dy;
+    int rc;
+    for (int i = n - 1; i >= 0; --i) {
+        const StackBlock& b = blk[i];
+        goff -= b.grad_floats;
+        float* g = (float*)grads + goff;
+        const int cin = b.sh[IR_CIN], hid = b.sh[IR_HID], cout = b.sh[IR_COUT], k = b.sh[IR_K];
+        void* dxi = i > 0 ? (void*)pp[i & 1] : dx;
+        const void* P[25];
+        P[0] = i > 0 ? (const void*)(base + blk[i - 1].y) : x;
+        P[1] = base + b.a1; P[2] = base + b.a2; P[3] = base + b.a3;
+        P[4] = params[18 * i + 0]; P[5] = params[18 * i + 6]; P[6] = params[18 * i + 12];
+        P[7] = params[18 * i + 1]; P[8] = params[18 * i + 7]; P[9] = params[18 * i + 13];
+        P[10] = base + b.coef; P[11] = dyi; P[12] = dxi;
+        float* q = g;
+        P[13] = q; q += (size_t)hid * cin; P[14] = q; q += hid; P[15] = q; q += hid;
+        P[16] = q; q += (size_t)hid * k; P[17] = q; q += hid; P[18] = q; q += hid;
+        P[19] = q; q += (size_t)cout * hid; P[20] = q; q += cout; P[21] = q;
+        P[22] = w0; P[23] = base + b.prep;
+        P[24] = i > 0 ? (blk[i - 1].y16 >= 0 ? (const void*)(base + blk[i - 1].y16) : nullptr) : x16;
+        CK(v100_ir_bwd(b.sh, P, stream));
+        dyi = dxi;
+    }
+    return V100_OK;
+}

@@ -6,6 +6,7 @@
 #include "timing.h"
 #include <vector>
 #include <mutex>
+#include <stdlib.h>
 
 namespace {
 struct Pair { hipEvent_t a, b; int tag; double bytes; };
@@ -83,25 +84,40 @@ extern "C" int v100_timing_read(int tag, double* ms, long long* count, double* b
 // kernel launches issued by this library in this process so far (every launch site goes through V100_GGL / V100_EXT_GGL)
 extern "C" long long v100_launch_count(void) { return g_v100_launches.load(std::memory_order_relaxed); }
 
-// Device-copy yardstick for the HBM-bound kernels (bench.py `measured_copy_gbs`): dst[i] = src[i] in 16-byte pieces, four
-// independent loads in flight per thread before the first store, 2048 workgroups of 256 threads walking the buffer grid-stride.
+// Device-copy yardstick for the HBM-bound kernels (bench.py `copy_probe_gbs`): dst[i] = src[i] in 16-byte pieces, U independent
+// loads in flight per thread before the first store, workgroups of 256 threads walking the buffer grid-stride.
 // n16 = number of 16-byte pieces.  Same ABI conventions as every other entry point (device pointers, no sync).
+// V100_COPY_VARIANT (tuning only): digit 1 = unroll (1: 4, 2: 8, 3: 2), digit 2 = nontemporal (0 plain, 1 nt), digit 3 = workgroups per CU.
+template <int U, bool NT_>
 __global__ __launch_bounds__(256) void copy_probe_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long long n16) {
     const long long stride = (long long)gridDim.x * 256;
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        const f32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i);
-        __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride);
-        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT_ ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (NT_) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+            else dst[i + u * stride] = v[u];
+        }
     }
     for (; i < n16; i += stride) dst[i] = src[i];
 }
 extern "C" int v100_copy_probe(const void* src, void* dst, long long nbytes, void* stream) {
     if (!src || !dst) return V100_ERR_NULL;
     if (nbytes <= 0 || (nbytes & 15)) return V100_ERR_SHAPE;
-    V100_GGL(copy_probe_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, nbytes / 16);
+    static const int variant = [] { const char* e = getenv("V100_COPY_VARIANT"); return e ? atoi(e) : 801; }();
+    const int un = variant % 10, nt = (variant / 10) % 10, wpc = variant / 100 > 0 ? variant / 100 : 8;
+    const dim3 grid(256 * wpc), block(256);
+    const f32x4* s = (const f32x4*)src;
+    f32x4* d = (f32x4*)dst;
+    const long long n16 = nbytes / 16;
+    hipStream_t st = (hipStream_t)stream;
+#define CP(U_, N_) V100_GGL((copy_probe_kernel<U_, N_>), grid, block, 0, st, s, d, n16)
+    if (un == 2) { if (nt) CP(8, true); else CP(8, false); }
+    else if (un == 3) { if (nt) CP(2, true); else CP(2, false); }
+    else { if (nt) CP(4, true); else CP(4, false); }
+#undef CP
     return v100_launch_status();
 }

@@ -240,6 +240,124 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         return (dx, dW1.view_as(w1), dg1, db1, dWd.view_as(wd), dg2, db2, dW3.view_as(w3), dg3, db3) + (None,) * 16
 
 
+def _block_tensors(blk):
+    """The 18 parameter / buffer tensors of an InvertedResidual in the stack executor's order (include/voice100_hip.h)."""
+    pw, dw, pl, bn3 = blk.conv[0], blk.conv[1], blk.conv[2], blk.conv[3]
+    bn1, bn2 = pw[1], dw[1]
+    return (pw[0].weight, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.num_batches_tracked,
+            dw[0].weight, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked,
+            pl.weight, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked)
+
+
+_STACK_PLANS = {}
+
+
+def _stack_plan(cfgs, B, T, bf16, level, last_shadow):
+    """(desc ctypes array, per-block offsets, totals) of a run of blocks at this input shape: computed once per distinct key."""
+    key = (cfgs, B, T, bf16, level, last_shadow)
+    ent = _STACK_PLANS.get(key)
+    if ent is None:
+        n = len(cfgs)
+        desc = (ctypes.c_int * (6 + 6 * n))(n, B, T, bf16, level, int(last_shadow), *[v for c in cfgs for v in c])
+        plan = (ctypes.c_longlong * (8 * n + 6))()
+        if N.helper("v100_ir_stack_plan", desc, plan) < 0:
+            raise RuntimeError("InvertedResidual stack: invalid shape")
+        if len(_STACK_PLANS) > 256:                 # time-stretched lengths: at most ~100 distinct T per run
+            _STACK_PLANS.clear()
+        ent = _STACK_PLANS[key] = (desc, [tuple(plan[8 * i:8 * i + 8]) for i in range(n)], tuple(plan[8 * n:8 * n + 6]))
+    return ent
+
+
+class IRStackTrainFn(torch.autograd.Function):
+    """A run of consecutive training-mode InvertedResidual blocks (asr.py:67-76, tts.py:17-25, 72-76) as ONE autograd node:
+    one host call into the library's stack executor per direction (csrc/block.hip), every activation kept for backward in one
+    allocation.  Same kernels in the same order as the per-block InvertedResidualTrainFn: bit-identical results."""
+
+    @staticmethod
+    def forward(ctx, x, x16, meta, *params):
+        cfgs, precision, last_shadow = meta
+        _check(x, "InvertedResidual stack")
+        x = x.contiguous()
+        B, cin, T = x.shape
+        n = len(cfgs)
+        if len(params) != 18 * n or cfgs[0][0] != cin:
+            raise RuntimeError("InvertedResidual stack: parameter list / input width do not match the block configuration")
+        bf16 = _fmt(precision)
+        _no_fp16_training(bf16, "InvertedResidual (training mode)")
+        level = _ACT16 if bf16 == 1 else 0
+        desc, blocks, totals = _stack_plan(cfgs, B, T, bf16, level, bool(last_shadow))
+        for t in params:
+            if not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors")
+        if not (bf16 == 1 and level >= 4):
+            x16 = None
+        blob = torch.empty(totals[0], dtype=torch.uint8, device=x.device)
+        ptab = (ctypes.c_void_p * (18 * n))(*[t.data_ptr() for t in params])
+        N.call("v100_ir_stack_fwd_train", desc, ptab, x, x16, blob)
+        o = blocks[-1]
+        cout, T2 = cfgs[-1][2], o[7]
+        y = blob[o[3]:o[3] + 4 * B * cout * T2].view(torch.float32).view(B, cout, T2)
+        y16 = None
+        if o[4] >= 0:
+            P2 = (T2 + 7) & ~7
+            y16 = blob[o[4]:o[4] + 2 * B * cout * P2].view(torch.bfloat16).view(B, cout, P2)
+            ctx.mark_non_differentiable(y16)
+        ctx.set_materialize_grads(False)
+        # (plain attributes, not save_for_backward: y is a view of the blob, and the fused optimiser updates parameters through raw
+        # pointers anyway -- tensor version counters say nothing here)
+        ctx.blob, ctx.x, ctx.x16, ctx.params, ctx.desc, ctx.totals, ctx.cfgs = blob, x, x16, params, desc, totals, cfgs
+        ctx.y_shape = y.shape
+        return y, y16
+
+    @staticmethod
+    def backward(ctx, dy, _dy16=None):
+        x, params, cfgs, totals = ctx.x, ctx.params, ctx.cfgs, ctx.totals
+        n = len(cfgs)
+        if dy is None:
+            dy = torch.zeros(ctx.y_shape, dtype=torch.float32, device=x.device)
+        dy = dy.contiguous()
+        grads = _f32(totals[2], like=x)
+        ws = torch.empty(totals[1], dtype=torch.uint8, device=x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ptab = (ctypes.c_void_p * (18 * n))(*[t.data_ptr() for t in params])
+        N.call("v100_ir_stack_bwd", ctx.desc, ptab, x, ctx.x16, ctx.blob, dy, dx, grads, ws)
+        ctx.blob = None                                   # the activations are dead: free them before the rest of backward runs
+        out, off = [], 0
+        for i, (cin, hid, cout, k, _, _) in enumerate(cfgs):
+            p = params[18 * i:18 * i + 18]
+            blk = [None] * 18
+            for j, numel in ((0, hid * cin), (1, hid), (2, hid), (6, hid * k), (7, hid), (8, hid), (12, cout * hid), (13, cout), (14, cout)):
+                blk[j] = grads[off:off + numel].view_as(p[j])
+                off += numel
+            out.extend(blk)
+        return (dx, None, None) + tuple(out)
+
+
+def ir_stack_train(blocks, x, precision: Optional[str] = None, segment: Optional[int] = None):
+    """Training-mode forward of consecutive InvertedResidual modules through the stack executor.  `segment` = blocks per autograd
+    node: None -> the whole run as one node in a single-process job, three blocks per node under data parallelism (the gradient
+    buckets of the later blocks are then all-reduced while the earlier blocks' backward still runs, voice100_amd/dist.py)."""
+    blocks = list(blocks)
+    if segment is None:
+        import torch.distributed as dist
+        segment = 3 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else len(blocks)
+    precision = precision or _PRECISION
+    for s in range(0, len(blocks), segment):
+        seg = blocks[s:s + segment]
+        cfgs = tuple((b.conv[0][0].in_channels, b.conv[0][0].out_channels, b.conv[2].out_channels, int(b.kernel_size), int(b.stride),
+                      int(bool(b.use_residual))) for b in seg)
+        sh = getattr(x, "_v100_shadow", None)
+        x16 = sh[0] if (sh is not None and sh[1] == x._version and sh[0].shape[:2] == x.shape[:2]
+                        and sh[0].shape[2] == ((x.shape[2] + 7) & ~7)) else None
+        params = [t for b in seg for t in _block_tensors(b)]
+        last = s + segment >= len(blocks)
+        y, y16 = IRStackTrainFn.apply(x, x16, (cfgs, precision, not last), *params)
+        if y16 is not None:
+            y._v100_shadow = (y16, y._version)
+        x = y
+    return x
+
+
 def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
     """bf16 / transposed copies of the two 1x1 weights of every InvertedResidual in `blocks`, in ONE launch
     (v100_ir_prep_batched), into slices of ONE freshly allocated buffer that the blocks' next forward hands to the

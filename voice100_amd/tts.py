@@ -63,7 +63,11 @@ class VoiceDecoder(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training and not tracing():
-            F_.prepare_block_weights([m for m in self.layers if isinstance(m, InvertedResidual)])
+            # 4 blocks | transposed conv | 3 blocks | head: each run of blocks is one call into the stack executor
+            x = F_.ir_stack_train(self.layers[0:4], x)
+            x = self.layers[4](x)
+            x = F_.ir_stack_train(self.layers[5:8], x)
+            return self.layers[8](x)
         return self.layers(x)
 
 
@@ -166,8 +170,9 @@ class TextToAlignTextModel(Voice100ModelBase):
             return torch.transpose(self.layers(_stock.embedding_bct(x, self.embedding.weight)), 1, 2)
         x = F_.embedding_bct(x, self.embedding.weight)          # [B, H, L]
         if self.training:
-            F_.prepare_block_weights([m for m in self.layers if isinstance(m, InvertedResidual)])
-        x = self.layers(x)
+            x = self.layers[4](F_.ir_stack_train(self.layers[0:4], x))
+        else:
+            x = self.layers(x)
         return F_.transpose_last2(x)                             # [B, L, 2]
 
     def align(self, text: torch.Tensor, align: torch.Tensor, head=5, tail=5) -> torch.Tensor:
