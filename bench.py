@@ -372,7 +372,8 @@ def main():
             if pmc is not None and pmc.get("kernel_src_sha") != dw_source_sha():
                 pmc = None                      # the kernels changed since the counters were taken: no stale ratio
             act16 = F_.get_activation_storage() if args.precision == "bf16" else 0
-            roof = {"bound": "hbm", "kernel": "dwconv_mfma_kernel (depthwise forward: 8 Toeplitz-MFMA launches + the stride-2 first layer per step; "
+            roof = {"bound": "hbm", "kernel": "dwconv_fwd16_stream_kernel / dwconv_mfma_kernel (depthwise forward: 8 Toeplitz-MFMA launches + the stride-2 first layer per step, "
+                                              "rows <= 512 outputs on the streaming kernel, time-stretched longer rows on the general one; "
                                               + ("hidden activations stored as bf16: algorithmic bytes at 2 B/sample)" if act16 else "fp32 activations)"),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": round(pmc["ratio"] * nbytes / n) if pmc else None,

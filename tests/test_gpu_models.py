@@ -392,7 +392,7 @@ def test_fp16_inference_precision(cuda):
 
 
 # bars of the bf16 / act16-level-4 step (the numeric path bench.py runs) against the fp32 oracle; see the test body
-BF16_STEP_COSINE_MIN, BF16_STEP_NORM_DEV_MAX, BF16_STEP_LOSS_ERR_MAX = 0.97, 0.1, 1e-2
+BF16_STEP_COSINE_MIN, BF16_STEP_NORM_DEV_MAX, BF16_STEP_LOSS_ERR_MAX = 0.945, 0.01, 1e-4
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -424,38 +424,59 @@ def test_asr_metric_shape_ragged_lengths_vs_oracle(cuda, precision):
     ref_loss = cnn.audio_to_text_ctc_loss(((audio, audio_len), (text, text_len)), st, training=True, updates=updates)
     ref_grads = dict(zip(params, torch.autograd.grad(ref_loss, list(params.values()))))
     # HIP path
-    F_.set_matmul_precision(precision)
-    try:
-        m = m.to(cuda).train()
-        m.decoder.layers[0].p = 0.0
-        m.batch_augment.forward = lambda a, l: (a, l)
-        loss = m.training_step(((audio.to(cuda), audio_len.to(cuda)), (text.to(cuda), text_len.to(cuda))), 0)
-        loss.backward()
-    finally:
-        F_.set_matmul_precision("fp32")
+    def hip_step(level=None):
+        mm = AudioToTextCTC(audio_size=64, embed_size=512, vocab_size=29, hidden_size=512)
+        mm.load_state_dict(state)
+        keep = F_.get_activation_storage()
+        F_.set_matmul_precision(precision)
+        if level is not None:
+            F_.set_activation_storage(level)
+        try:
+            mm = mm.to(cuda).train()
+            mm.decoder.layers[0].p = 0.0
+            mm.batch_augment.forward = lambda a, l: (a, l)
+            ls = mm.training_step(((audio.to(cuda), audio_len.to(cuda)), (text.to(cuda), text_len.to(cuda))), 0)
+            ls.backward()
+        finally:
+            F_.set_matmul_precision("fp32")
+            F_.set_activation_storage(keep)
+        return mm, ls
+
     if precision == "bf16":
-        assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-2 * abs(float(ref_loss.detach()))
-        got = {k: p.grad.cpu() for k, p in m.named_parameters()}
         # The gradient of the untrained 9-block net is ill-conditioned: fp32 round-off (1e-7) already shows as 2e-3 below,
         # so bf16 operand rounding (4e-3) cannot be held to a small relative error.  What the throughput path must keep
-        # is the direction: cosine similarity with the fp32 oracle gradient over all parameters.
-        dot = sum(float((got[k].double() * ref_grads[k].double()).sum()) for k in ref_grads)
-        n1 = sum(float(got[k].double().pow(2).sum()) for k in ref_grads) ** 0.5
-        n2 = sum(float(ref_grads[k].double().pow(2).sum()) for k in ref_grads) ** 0.5
-        cos, ratio = dot / (n1 * n2), n1 / n2
-        loss_err = abs(float(loss.detach()) - float(ref_loss.detach())) / abs(float(ref_loss.detach()))
-        per = {k: float((got[k].double() * ref_grads[k].double()).sum() /
-                        (got[k].double().norm() * ref_grads[k].double().norm()).clamp_min(1e-30)) for k in ref_grads}
-        worst = min(per, key=per.get)
-        rec = {"activation_storage_level": F_.get_activation_storage(), "loss_rel_err": loss_err, "grad_cosine": cos,
-               "grad_norm_ratio": ratio, "worst_tensor": worst, "worst_tensor_cosine": per[worst]}
-        print("bf16 metric-shape step vs fp32 oracle:", rec)
+        # is the direction: cosine similarity with the fp32 oracle gradient over all parameters.  Measured at storage level 0
+        # (bf16 GEMM operands only -- what the reference's own bf16 autocast does) and at level 4 (what bench.py runs).
+        recs = {}
+        for level in (0, 4):
+            mm, ls = hip_step(level)
+            got = {k: p.grad.cpu() for k, p in mm.named_parameters()}
+            dot = sum(float((got[k].double() * ref_grads[k].double()).sum()) for k in ref_grads)
+            n1 = sum(float(got[k].double().pow(2).sum()) for k in ref_grads) ** 0.5
+            n2 = sum(float(ref_grads[k].double().pow(2).sum()) for k in ref_grads) ** 0.5
+            per = {k: float((got[k].double() * ref_grads[k].double()).sum() /
+                            (got[k].double().norm() * ref_grads[k].double().norm()).clamp_min(1e-30)) for k in ref_grads}
+            # tensors that carry the gradient (>= 1 % of the total norm): BatchNorm shifts in front of another training-mode
+            # BatchNorm have an analytically zero gradient, their "direction" is round-off on both sides
+            big = [k for k in ref_grads if float(ref_grads[k].double().norm()) >= 1e-2 * n2]
+            worst = min(big, key=per.get)
+            recs[level] = {"loss_rel_err": abs(float(ls.detach()) - float(ref_loss.detach())) / abs(float(ref_loss.detach())),
+                           "grad_cosine": dot / (n1 * n2), "grad_norm_ratio": n1 / n2, "worst_big_tensor": worst,
+                           "worst_big_tensor_cosine": per[worst], "n_big_tensors": len(big)}
+            del mm
+        print("bf16 metric-shape step vs fp32 oracle, by activation-storage level:", recs)
         import json, os
-        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
-        json.dump(rec, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_bf16_step.json"), "w"))
-        # measured on MI355X (profiles/r03_parity_bf16_step.json); asserted with a 2x margin on (1 - cosine), the loss error and |1 - ratio|
-        assert cos > BF16_STEP_COSINE_MIN and abs(ratio - 1.0) < BF16_STEP_NORM_DEV_MAX and loss_err < BF16_STEP_LOSS_ERR_MAX, rec
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        json.dump(recs, open(os.path.join(out, "parity_bf16_step.json"), "w"), indent=1)
+        # measured on MI355X (profiles/r03_parity_bf16_step.json: level 4 cosine 0.973, norm ratio 0.998, loss error 2e-6); asserted
+        # with a 2x margin on (1 - cosine), and bf16 STORAGE (level 4) may cost at most 0.02 of cosine over bf16 operands alone (level 0)
+        for level, r in recs.items():
+            assert r["grad_cosine"] > BF16_STEP_COSINE_MIN and abs(r["grad_norm_ratio"] - 1.0) < BF16_STEP_NORM_DEV_MAX \
+                and r["loss_rel_err"] < BF16_STEP_LOSS_ERR_MAX, (level, r)
+        assert recs[4]["grad_cosine"] > recs[0]["grad_cosine"] - 0.02, recs
         return
+    m, loss = hip_step()
     assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-4 * abs(float(ref_loss.detach()))
     got = {k: p.grad.cpu() for k, p in m.named_parameters()}
     num = sum(float((got[k].double() - ref_grads[k].double()).pow(2).sum()) for k in ref_grads)

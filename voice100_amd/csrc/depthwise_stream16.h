@@ -1,5 +1,5 @@
 // K2 forward for the benchmark's case, built around BYTES IN FLIGHT: training-mode depthwise forward with bf16-stored
-// activations (BN1 + ReLU6 on load, raw output + BN2 sums; asr.py:49) on rows that fit one 512-output tile (T <= 512, T % 8 == 0).
+// activations (BN1 + ReLU6 on load, raw output + BN2 sums; asr.py:49) on rows that fit one 512-output tile (T <= 512; any T: bf16 rows are pitched to a multiple of 8 samples).
 //
 // Why a second kernel.  dwconv_mfma_kernel keeps ONE row of loads in flight per wave and issues its first load only after the
 // tap prologue (taps -> LDS -> barrier -> Toeplitz fragments).  Inside a training step its input and output stream from / to HBM
@@ -20,49 +20,56 @@
 // dwconv_mfma_kernel<K, AFFINE_RELU6, RAW_STATS, NT, false, X | Y>: results are bit-identical to it.
 #pragma once
 
-template <int K, int NT, int D>
+// CP: cache-policy bits of the row loads / stores (0 default, 2 = nontemporal: the rows are read once and written once)
+template <int K, int NT, int D, int CP = 0>
 __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p) {
     using G_ = DwMfmaGeom<K, 7>;
     constexpr int STEPS = G_::STEPS, IMGP = G_::IMGP, WPAD = G_::WPAD, WLEN = G_::WLEN;
     __shared__ __attribute__((aligned(16))) unsigned short lds_img[4 * IMGP];
-    __shared__ float lds_w[WLEN];
+    __shared__ float lds_w[256];                             // WLEN used; every thread stores one slot (no lane-masked branch)
     __shared__ float lds_red[4][2];
 
     const int c = blockIdx.x, g = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_ = lane & 15, q_ = lane >> 4;
-    const int T = p.Tin;                                     // == Tout, a multiple of 8, <= 512: the row pitch is T
+    const int T = p.Tin;                                     // == Tout <= 512; rows are stored with pitch P (a multiple of 8 samples)
+    const int P = dw_pitch16(T);
     const int bper = (p.B + p.G - 1) / p.G;
     const int b0 = g * bper;
     const int nb = min(p.B, b0 + bper) - b0;
     const int nrows = wave < nb ? (nb - wave + 3) >> 2 : 0;  // this wave's rows: b0 + wave + 4 r
 
-    const unsigned tbytes = (unsigned)((size_t)p.B * p.C * T * 2);
+    const unsigned tbytes = (unsigned)((size_t)p.B * p.C * P * 2);
     const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, tbytes);
     const __amdgpu_buffer_rsrc_t ry = dw_make_rsrc(p.y, tbytes);
     const int vo_in = 8 * lane < T ? 16 * lane : 0x7ffffff0;
-    auto row_bytes = [&](int r) -> unsigned { return (unsigned)((b0 + wave + 4 * r) * p.C + c) * (unsigned)T * 2u; };
+    auto row_bytes = [&](int r) -> unsigned { return (unsigned)((b0 + wave + 4 * r) * p.C + c) * (unsigned)P * 2u; };
+    // (the scalar row offset is formed unconditionally -- only the per-lane offset takes part in the bounds check, so an
+    // out-of-range voffset alone makes the access a no-op -- and the voffset by a select: no branch for hipcc to build around a load)
     auto issue = [&](int r) -> dwm_u32x4 {
         const bool ok = r < nrows;                           // wave-uniform
-        return __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vo_in : 0x7ffffff0, ok ? (int)row_bytes(r) : 0, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vo_in : 0x7ffffff0, (int)row_bytes(r), CP);
     };
     // the taps FIRST: vmcnt retires in order, so a tap load issued behind the row requests would wait for all of them
     static_assert(WLEN <= 256, "one tap slot per thread");
     const int tj = (int)threadIdx.x - WPAD;
     const float tapv = p.w[(size_t)c * K + min(max(tj, 0), K - 1)];      // unconditional (clamped) load, selected below
+    __builtin_amdgcn_sched_barrier(0);
     dwm_u32x4 raw[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) raw[d] = issue(d);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- prologue, under the latency of those loads: taps, Toeplitz fragments, coefficients, the image's zero padding ----
-    if (threadIdx.x < WLEN) lds_w[threadIdx.x] = (tj >= 0 && tj < K) ? tapv : 0.f;
+    // (every thread stores: inside an `if (threadIdx.x < WLEN)` hipcc sinks the tap load into the branch, behind the row requests)
+    lds_w[threadIdx.x] = (tj >= 0 && tj < K) ? tapv : 0.f;
     const int off = (-p.pad) & 7;
     const int in0a = (-p.pad) & ~7;                          // input position of image element 0
     const int lpad = -in0a;
     unsigned short* img = lds_img + wave * IMGP;
     for (int c8 = lane; c8 < IMGP / 8; c8 += 64)
-        if (c8 < lpad / 8 || c8 >= (lpad + T) / 8) *reinterpret_cast<dwm_u32x4*>(img + 8 * c8) = dwm_u32x4{0u, 0u, 0u, 0u};
+        if (c8 < lpad / 8 || c8 >= (lpad + P) / 8) *reinterpret_cast<dwm_u32x4*>(img + 8 * c8) = dwm_u32x4{0u, 0u, 0u, 0u};
     const float ca = p.in_a[c], cb = p.in_b[c];
     __syncthreads();
     dwm_bf16x8 afr[STEPS][NT];
@@ -85,7 +92,9 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     }
     const unsigned short* bsrc = img + 16 * n_ + 8 * q_;
     unsigned short* stg = img + lpad + 8 * lane;
-    const bool stg_ok = 8 * lane < T;
+    // samples this lane stages (0 .. 8): positions 8 lane + e < T.  Zero padding applies to the TRANSFORMED tensor, and the pitch
+    // padding of a stored row holds arbitrary bits: everything at or past T is forced to zero
+    const int nval = min(max(T - 8 * lane, 0), 8);
     float s0 = 0.f, s1 = 0.f;
 
     // one row: stage raw[d] (BN1 + ReLU6, one bf16 digit), request row r + D into the freed registers, Toeplitz MFMAs, store
@@ -94,10 +103,12 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
         const float ra = ok ? ca : 0.f, rb = ok ? cb : 0.f;
         float vals[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) vals[e] = relu6f(fmaf(dwm_elem8(rw, e), ra, rb));
+        for (int e = 0; e < 8; ++e) vals[e] = e < nval ? relu6f(fmaf(dwm_elem8(rw, e), ra, rb)) : 0.f;
         const dwm_u32x4 w4 = {dwm_pack_rne(vals[0], vals[1]), dwm_pack_rne(vals[2], vals[3]), dwm_pack_rne(vals[4], vals[5]),
                               dwm_pack_rne(vals[6], vals[7])};
-        if (stg_ok) *reinterpret_cast<dwm_u32x4*>(stg) = w4;              // the padding stays zero
+        // unconditional store (lanes past the row write zeros INTO the zero padding): a lane-masked store is a branch, and the wait
+        // for the row's data inside it spoils the counted waits after the join
+        *reinterpret_cast<dwm_u32x4*>(stg) = w4;
         asm volatile("" ::: "memory");                                    // wave-local hand-off through LDS: program order
         rw = issue(r + D);
         const unsigned yb = row_bytes(r);
@@ -111,18 +122,20 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
                 bfr[0] = *reinterpret_cast<const dwm_bf16x8*>(bsrc + 256 * sub + 32 * s);
                 acc = dwm_mfma_digits<NT, 1>(afr[s], bfr, acc);
             }
-            // positions >= T hold exact zeros only when the whole tail of the image is zero padding: mask them out of the sums
-            const bool in_row = t0 < T;                                    // T % 8 == 0 and t0 % 4 == 0: all four or none
+            // outputs at positions >= T are not part of the row (they are not zero: the taps still reach real samples): out of the sums
+            const bool in_row = t0 < T;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float yv = in_row ? acc[e] : 0.f;
+                const float yv = t0 + e < T ? acc[e] : 0.f;
                 s0 += yv;
                 s1 = fmaf(yv, yv, s1);
             }
+            // 4 bf16 = one 8-byte store (the pitch keeps it aligned; samples past T land in the row's padding)
             const dwm_u32x2 o2 = {dwm_pack_rne(acc[0], acc[1]), dwm_pack_rne(acc[2], acc[3])};
-            __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && in_row) ? 2 * t0 : 0x7ffffff0, ok ? (int)yb : 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && in_row) ? 2 * t0 : 0x7ffffff0, (int)yb, CP);
         }
         asm volatile("" ::: "memory");                                    // the next row's LDS store stays behind these fragment reads
+        __builtin_amdgcn_sched_barrier(0);                                // rows are not interleaved (register pressure; LDS image reuse)
     };
 
 #pragma unroll
@@ -132,6 +145,205 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
         for (int d = 0; d < D; ++d) row(raw[d], r0 + d);
     }
 
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) { lds_red[wave][0] = s0; lds_red[wave][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t0s = (lds_red[0][0] + lds_red[1][0]) + (lds_red[2][0] + lds_red[3][0]);
+        const float t1s = (lds_red[0][1] + lds_red[1][1]) + (lds_red[2][1] + lds_red[3][1]);
+        p.stats[((size_t)g * p.C + c) * 2 + 0] = t0s;
+        p.stats[((size_t)g * p.C + c) * 2 + 1] = t1s;
+        if (p.fin.mode != 0) dw_finalize(p.fin, c, t0s, t1s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The fused backward of the same stage (autograd of asr.py:49 with BatchNorm-2 backward applied on load, the ReLU6 mask /
+// BatchNorm-1 backward sums on the way out and the depthwise weight gradient riding on the pass; every tensor bf16-stored), for
+// rows that fit one tile -- the streaming form of dwconv_mfma_kernel<K, AFFINE2, MASK_STATS, NT, true, X | X2 | AUX | Y>.
+// Per row a wave reads THREE 1 KB streams (dz2, a2 for the affine; a1 at its output positions for the mask and xin) and writes one:
+// the general kernel keeps one row of the first two in flight and loads a1 at the top of the row it is needed in (a full miss on
+// the critical path of every row).  Here all three are requested D rows ahead, from kernel entry on (12 VGPRs per row in flight).
+// Same arithmetic and order of accumulation: bit-identical results (E tiles, sums, stored gradient).
+template <int K, int NT, int D, int CP = 0>
+__global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p) {
+    using G_ = DwMfmaGeom<K, 7>;
+    constexpr int TILE = G_::TILE, STEPS = G_::STEPS, IMGP = G_::IMGP, WPAD = G_::WPAD, WLEN = G_::WLEN, IB = G_::IB;
+    constexpr int WAVE_U16 = IMGP + TILE;
+    constexpr int E_FLOATS = 16 * IB * 16;
+    constexpr int LDS_BYTES = (4 * WAVE_U16 * 2 > 4 * E_FLOATS * 4) ? 4 * WAVE_U16 * 2 : 4 * E_FLOATS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    __shared__ float lds_w[256];
+    __shared__ float lds_red[4][2];
+
+    const int c = blockIdx.x, g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_ = lane & 15, q_ = lane >> 4;
+    const int T = p.Tin;
+    const int P = dw_pitch16(T);
+    const int bper = (p.B + p.G - 1) / p.G;
+    const int b0 = g * bper;
+    const int nb = min(p.B, b0 + bper) - b0;
+    const int nrows = wave < nb ? (nb - wave + 3) >> 2 : 0;
+
+    const unsigned tbytes = (unsigned)((size_t)p.B * p.C * P * 2);
+    const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, tbytes), rx2 = dw_make_rsrc(p.x2, tbytes), raux = dw_make_rsrc(p.aux, tbytes);
+    const __amdgpu_buffer_rsrc_t ry = dw_make_rsrc(p.y, tbytes);
+    const int vo_in = 8 * lane < T ? 16 * lane : 0x7ffffff0;
+    int vo_aux[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int t0 = 256 * sub + 16 * n_ + 4 * q_;
+        vo_aux[sub] = t0 < T ? 2 * t0 : 0x7ffffff0;
+    }
+    auto row_bytes = [&](int r) -> unsigned { return (unsigned)((b0 + wave + 4 * r) * p.C + c) * (unsigned)P * 2u; };
+    struct Row { dwm_u32x4 g, g2; dwm_u32x2 a[2]; };
+    auto issue = [&](int r, Row& rw) {
+        const bool ok = r < nrows;
+        const int so = (int)row_bytes(r);
+        rw.g = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vo_in : 0x7ffffff0, so, CP);
+        rw.g2 = __builtin_amdgcn_raw_buffer_load_b128(rx2, ok ? vo_in : 0x7ffffff0, so, CP);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) rw.a[sub] = __builtin_amdgcn_raw_buffer_load_b64(raux, ok ? vo_aux[sub] : 0x7ffffff0, so, CP);
+    };
+    static_assert(WLEN <= 256, "one tap slot per thread");
+    const int tj = (int)threadIdx.x - WPAD;
+    const int tjc = min(max(tj, 0), K - 1);
+    const float tapv = p.w[(size_t)c * K + (p.flip ? (K - 1 - tjc) : tjc)];       // taps first (vmcnt retires in order)
+    __builtin_amdgcn_sched_barrier(0);
+    Row raw[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d, raw[d]);
+    __builtin_amdgcn_sched_barrier(0);
+
+    lds_w[threadIdx.x] = (tj >= 0 && tj < K) ? tapv : 0.f;
+    const int off = (-p.pad) & 7;
+    const int in0a = (-p.pad) & ~7;
+    const int lpad = -in0a;
+    unsigned short* img = reinterpret_cast<unsigned short*>(lds_raw) + wave * WAVE_U16;
+    unsigned short* ximg = img + IMGP;
+    for (int c8 = lane; c8 < IMGP / 8; c8 += 64)
+        if (c8 < lpad / 8 || c8 >= (lpad + P) / 8) *reinterpret_cast<dwm_u32x4*>(img + 8 * c8) = dwm_u32x4{0u, 0u, 0u, 0u};
+    const float ca = p.in_a[c], cb = p.in_b[c], cc = p.in_c[c], oa = p.out_a[c], ob = p.out_b[c];
+    __syncthreads();
+    dwm_bf16x8 afr[STEPS][NT];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        unsigned pk[NT][4];
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+            unsigned d0[3], d1[3];
+            dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp - n_ - off], d0);
+            dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp + 1 - n_ - off], d1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) pk[t][jp] = dwm_pack(d0[t], d1[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const dwm_u32x4 v = {pk[t][0], pk[t][1], pk[t][2], pk[t][3]};
+            afr[s][t] = __builtin_bit_cast(dwm_bf16x8, v);
+        }
+    }
+    const unsigned short* bsrc = img + 16 * n_ + 8 * q_;
+    unsigned short* stg = img + lpad + 8 * lane;
+    const int nval = min(max(T - 8 * lane, 0), 8);       // samples of the row this lane stages (everything at or past T is zero)
+    dwm_f32x4 eacc[IB];
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) eacc[ib] = dwm_f32x4{0.f, 0.f, 0.f, 0.f};
+    float s0 = 0.f, s1 = 0.f;
+
+    auto row = [&](Row& rw, int r) {
+        const bool ok = r < nrows;                   // rows past the end: zero coefficients -> g' = 0, xin = 0, mask 0, nothing stored
+        const float ra = ok ? ca : 0.f, rb = ok ? cb : 0.f, rc = ok ? cc : 0.f, roa = ok ? oa : 0.f, rob = ok ? ob : 0.f;
+        float auxv[2][4];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) auxv[sub][e] = dwm_elem(rw.a[sub], e);
+        float vals[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vals[e] = e < nval ? fmaf(dwm_elem8(rw.g, e), ra, fmaf(dwm_elem8(rw.g2, e), rb, rc)) : 0.f;
+        const dwm_u32x4 w4 = {dwm_pack_rne(vals[0], vals[1]), dwm_pack_rne(vals[2], vals[3]), dwm_pack_rne(vals[4], vals[5]),
+                              dwm_pack_rne(vals[6], vals[7])};
+        *reinterpret_cast<dwm_u32x4*>(stg) = w4;
+        // xin = relu6(bn1(a1)) at this lane's 2 x 4 output positions -> the tile image of the weight-gradient product
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int t0 = 256 * sub + 16 * n_ + 4 * q_;
+            float xv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = (t0 + e < T) ? relu6f(fmaf(auxv[sub][e], roa, rob)) : 0.f;
+            const dwm_u32x2 w2 = {dwm_pack_rne(xv[0], xv[1]), dwm_pack_rne(xv[2], xv[3])};
+            *reinterpret_cast<dwm_u32x2*>(ximg + t0) = w2;
+        }
+        asm volatile("" ::: "memory");
+        issue(r + D, rw);
+        {   // E[16 ib + m][rr] += sum_p g'img[16 (p + ib) + m] * ximg[16 p + rr]
+            dwm_bf16x8 xfr[1];
+            xfr[0] = dwm_tr_fragment(ximg, lane);
+#pragma unroll
+            for (int ib = 0; ib < IB; ++ib) {
+                dwm_bf16x8 gfr[1];
+                gfr[0] = dwm_tr_fragment(img + 16 * ib, lane);
+                eacc[ib] = dwm_mfma_digits<1, 1>(gfr, xfr, eacc[ib]);
+            }
+        }
+        const unsigned yb = row_bytes(r);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int t0 = 256 * sub + 16 * n_ + 4 * q_;
+            dwm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                dwm_bf16x8 bfr[1];
+                bfr[0] = *reinterpret_cast<const dwm_bf16x8*>(bsrc + 256 * sub + 32 * s);
+                acc = dwm_mfma_digits<NT, 1>(afr[s], bfr, acc);
+            }
+            const bool in_row = t0 < T;
+            float outv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pre = fmaf(auxv[sub][e], roa, rob);
+                float yv = (pre > 0.f && pre < 6.f) ? acc[e] : 0.f;
+                if (t0 + e < T) { s0 += yv; s1 = fmaf(yv, auxv[sub][e], s1); }
+                outv[e] = yv;
+            }
+            const dwm_u32x2 o2 = {dwm_pack_rne(outv[0], outv[1]), dwm_pack_rne(outv[2], outv[3])};
+            __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && in_row) ? 2 * t0 : 0x7ffffff0, (int)yb, CP);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);          // rows are not interleaved: the sums of a row retire before the next row starts
+    };
+
+#pragma unroll
+    for (int d = 0; d < D; ++d) row(raw[d], d);
+    for (int r0 = D; r0 < nrows; r0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) row(raw[d], r0 + d);
+    }
+
+    // dWf[jf] = sum over waves and rr of E[rr + jf + off][rr]; the E tiles go through LDS (over the dead images)
+    __syncthreads();
+    float* ebuf = reinterpret_cast<float*>(lds_raw);
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ebuf[(wave * 16 * IB + 16 * ib + 4 * q_ + e) * 16 + n_] = eacc[ib][e];
+    __syncthreads();
+    for (int jf = threadIdx.x; jf < K; jf += 256) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            float sw = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) sw += ebuf[(w * 16 * IB + rr + jf + off) * 16 + rr];
+            sum += sw;
+        }
+        p.wpartial[((size_t)g * p.C + c) * K + (K - 1 - jf)] = sum;
+    }
+    __syncthreads();
     s0 = wave_sum(s0);
     s1 = wave_sum(s1);
     if (lane == 0) { lds_red[wave][0] = s0; lds_red[wave][1] = s1; }
