@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void copy_probe_kernel(const f32x4* __restrict
 extern "C" int v100_copy_probe(const void* src, void* dst, long long nbytes, void* stream) {
     if (!src || !dst) return V100_ERR_NULL;
     if (nbytes <= 0 || (nbytes & 15)) return V100_ERR_SHAPE;
-    static const int variant = [] { const char* e = getenv("V100_COPY_VARIANT"); return e ? atoi(e) : 111;   // one workgroup per CU, nontemporal, 4 pieces in flight per lane: the fastest of profiles/r03_copy_probe_variants.txt }();
+    // default 111 = one workgroup per CU, nontemporal, 4 pieces in flight per lane: the fastest of profiles/r03_copy_probe_variants.txt
+    static const int variant = [] { const char* e = getenv("V100_COPY_VARIANT"); return e ? atoi(e) : 111; }();
     const int un = variant % 10, nt = (variant / 10) % 10, wpc = variant / 100 > 0 ? variant / 100 : 8;
     const dim3 grid(256 * wpc), block(256);
     const f32x4* s = (const f32x4*)src;
