@@ -17,7 +17,7 @@ static bool dws_bwd_enabled() {
 bool dw_launch_bwd_fused16g(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl) {
     // rows that fit one tile: the streaming kernel (V100_DW_STREAM_BWD=0: the general kernel, for A/B runs)
     if (dws_bwd_enabled() && p.stride == 1 && p.upsample == 1 && p.flip && p.Tin == p.Tout && p.Tin <= 512 &&
-        p.pre.f.mode == 0 && p.pad == p.K - 1 - (p.K - 1) / 2) {
+        p.pad == p.K - 1 - (p.K - 1) / 2) {
         const DwPathConfig cfg = dw_path_config();
         dim3 grid(p.C, p.G);
         static const int depth = [] { const char* e = getenv("V100_DW_STREAM_BWD_D"); return e ? atoi(e) : DWS_BWD_DEPTH; }();

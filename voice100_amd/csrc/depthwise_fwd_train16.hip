@@ -18,7 +18,7 @@ static bool dws_enabled() {
 
 bool dw_launch_fwd_train16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl) {
     if (dws_enabled() && p.stride == 1 && p.upsample == 1 && !p.flip && p.Tin == p.Tout && p.Tin <= 512 &&
-        p.pre.f.mode == 0 && p.pad == (p.K - 1) / 2) {
+        p.pad == (p.K - 1) / 2) {
         const DwPathConfig cfg = dw_path_config();
         dim3 grid(p.C, p.G);
         // tuning switches (A/B runs only): V100_DW_STREAM_D = rows in flight (1, 2, 4), V100_DW_STREAM_NT = nontemporal rows

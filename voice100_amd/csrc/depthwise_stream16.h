@@ -70,8 +70,13 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     unsigned short* img = lds_img + wave * IMGP;
     for (int c8 = lane; c8 < IMGP / 8; c8 += 64)
         if (c8 < lpad / 8 || c8 >= (lpad + P) / 8) *reinterpret_cast<dwm_u32x4*>(img + 8 * c8) = dwm_u32x4{0u, 0u, 0u, 0u};
-    const float ca = p.in_a[c], cb = p.in_b[c];
+    // BatchNorm 1 of this channel: coefficients from the finaliser launch -- or, with one group (this workgroup is then the only
+    // consumer of channel c), finalised HERE from the expand GEMM's slab of partial sums by the first wave (DwPre), under the latency
+    // of the row requests above: one dependent launch less per block
+    __shared__ float lds_coef[3];
+    if (p.pre.f.mode != 0 && wave == 0) dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
     __syncthreads();
+    const float ca = p.pre.f.mode != 0 ? lds_coef[0] : p.in_a[c], cb = p.pre.f.mode != 0 ? lds_coef[1] : p.in_b[c];
     dwm_bf16x8 afr[STEPS][NT];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
@@ -226,8 +231,14 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p)
     unsigned short* ximg = img + IMGP;
     for (int c8 = lane; c8 < IMGP / 8; c8 += 64)
         if (c8 < lpad / 8 || c8 >= (lpad + P) / 8) *reinterpret_cast<dwm_u32x4*>(img + 8 * c8) = dwm_u32x4{0u, 0u, 0u, 0u};
-    const float ca = p.in_a[c], cb = p.in_b[c], cc = p.in_c[c], oa = p.out_a[c], ob = p.out_b[c];
+    // BatchNorm-2 backward coefficients (p, q, r): from the finaliser launch, or finalised here from the project backward-data GEMM's
+    // slab by the first wave (DwPre; one group only), under the latency of the row requests
+    __shared__ float lds_coef[3];
+    if (p.pre.f.mode != 0 && wave == 0) dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
     __syncthreads();
+    const bool pre_on = p.pre.f.mode != 0;
+    const float ca = pre_on ? lds_coef[0] : p.in_a[c], cb = pre_on ? lds_coef[1] : p.in_b[c], cc = pre_on ? lds_coef[2] : p.in_c[c];
+    const float oa = p.out_a[c], ob = p.out_b[c];
     dwm_bf16x8 afr[STEPS][NT];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {

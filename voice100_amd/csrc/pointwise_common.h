@@ -228,6 +228,14 @@ __device__ __forceinline__ float half_wave_sum_dpp(float v) {
 // all 16 passes in flight before the accumulators go through LDS, statistics written once at the end.
 // PT: the tile's rows all lie inside the tensor but its last columns do not (t0 + 128 > T: the last t-tile of a time-stretched length):
 // same path with a per-lane column test -- lanes past T neither store nor count; a lane that straddles T masks per element.
+// cache policy of the epilogue's big streams (A/B: -DPW_EPI_CP_Y=2 / -DPW_EPI_CP_R=2 = nontemporal): Y is written once and read by
+// the NEXT kernel, R is read once
+#ifndef PW_EPI_CP_Y
+#define PW_EPI_CP_Y 0
+#endif
+#ifndef PW_EPI_CP_R
+#define PW_EPI_CP_R 0
+#endif
 template <int EPI_, int BM, int IO, bool PT = false>
 struct PwEpilogueFull {
     static constexpr bool YB = (IO & PW_IO_Y) != 0, RB = (IO & PW_IO_R) != 0;
@@ -265,8 +273,8 @@ struct PwEpilogueFull {
             if (use_r) {
 #pragma unroll
                 for (int pass = 0; pass < 16; ++pass) {
-                    if constexpr (RB) rpre[pass] = __builtin_amdgcn_raw_buffer_load_b64(rR, voR, pass * stepR, 0);
-                    else rpre[pass] = __builtin_amdgcn_raw_buffer_load_b128(rR, voR, pass * stepR, 0);
+                    if constexpr (RB) rpre[pass] = __builtin_amdgcn_raw_buffer_load_b64(rR, voR, pass * stepR, PW_EPI_CP_R);
+                    else rpre[pass] = __builtin_amdgcn_raw_buffer_load_b128(rR, voR, pass * stepR, PW_EPI_CP_R);
                 }
             }
         }
@@ -338,7 +346,7 @@ struct PwEpilogueFull {
                     // (PT: the pitch keeps a straddling lane's 8 bytes inside the row; columns past T are padding)
                     if (!PT || tcol < p.T) {
                         const epi_u32x2 o2 = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                        __builtin_amdgcn_raw_buffer_store_b64(o2, rY, voY, pass * stepY, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(o2, rY, voY, pass * stepY, PW_EPI_CP_Y);
                     }
                 } else if (PT && tcol + 3 >= p.T) {
                     float* yq = reinterpret_cast<float*>(reinterpret_cast<char*>(p.Y) + (size_t)pass * stepY + (unsigned)voY);
@@ -350,7 +358,9 @@ struct PwEpilogueFull {
                     // v99 stored the NEW v99 on gfx950 (sporadic wrong 4th elements) -- hipcc's hazard recognizer assumes that a
                     // > 64-bit MUBUF store with an SGPR soffset needs no wait states before its data registers are overwritten.
                     // For FLAT / global stores it pads.
-                    *reinterpret_cast<f32x4u*>(reinterpret_cast<char*>(p.Y) + (size_t)pass * stepY + (unsigned)voY) = v;
+                    f32x4u* yq = reinterpret_cast<f32x4u*>(reinterpret_cast<char*>(p.Y) + (size_t)pass * stepY + (unsigned)voY);
+                    if constexpr (PW_EPI_CP_Y != 0) __builtin_nontemporal_store((f32x4u)v, yq);
+                    else *yq = v;
                 }
             }
             if constexpr (do_stats) {
