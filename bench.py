@@ -227,6 +227,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--windows", type=int, default=5, help="extra timed windows of --steps steps after the reported one (spread only)")
+    ap.add_argument("--host-contention", type=int, default=8, help="after the timed region: the same steps beside N-1 busy host processes "
+                    "(what the enqueueing thread of one rank sees when 8 ranks share this host); 0/1 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -324,6 +326,28 @@ def main():
             step(batch)
         sync()
         windows.append((time.perf_counter() - tw) / args.steps * 1e3)
+    # Host side under contention: N-1 busy processes stand in for the other ranks' host threads on this box (each rank's Python is one
+    # enqueueing thread); same steps, same bracket.  Not part of `value`.
+    contended = None
+    if world == 1 and args.host_contention > 1:
+        import subprocess
+        burners = [subprocess.Popen([sys.executable, "-c", "while True: pass"]) for _ in range(args.host_contention - 1)]
+        try:
+            time.sleep(0.2)
+            sync()
+            tc = time.perf_counter()
+            for _ in range(args.steps):
+                step(batch)
+            host_c = time.perf_counter() - tc
+            sync()
+            total_c = time.perf_counter() - tc
+        finally:
+            for b_ in burners:                      # the exact processes started above, nothing else
+                b_.kill()
+            for b_ in burners:
+                b_.wait()
+        contended = {"busy_processes": args.host_contention - 1, "usable_cpus": usable_cpus(),
+                     "host_enqueue_ms_per_step": round(host_c / args.steps * 1e3, 3), "ms_per_step": round(total_c / args.steps * 1e3, 3)}
     kt, kt_all = {}, {}
     if not args.no_kernel_timing:
         kt = kt_main
@@ -402,6 +426,7 @@ def main():
             "loss": round(float(loss), 4),
             # host time to enqueue a step (the loop without the final synchronise): the step is GPU-bound while this stays below ms_per_step
             "host_enqueue_ms_per_step": round(host_loop / args.steps * 1e3, 3),
+            "host_under_contention": contended,
             "launches_per_step": {"value": round(launches, 1), "source": "v100_launch_count() over the timed steps of this run (library launches; the "
                                                                       "time-stretched steps of the seeded sequence take other kernel variants, not other counts)"},
             "windows_ms_per_step": ({"n": len(windows), "median": round(float(np.median(windows)), 3), "min": round(min(windows), 3),

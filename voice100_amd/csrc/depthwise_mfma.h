@@ -110,17 +110,23 @@ __device__ __forceinline__ float dwm_elem8(const dwm_u32x4& r, int e) {      // 
     const unsigned w = r[e >> 1];
     return __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
 }
+// DWM_CP: cache policy of the bf16-stored row streams of the act16 kernels (2 = nontemporal; in-step A/B of the general kernel: +-0, profiles/r03_ab_misc.txt; the streaming kernels take theirs as a template argument;
+// +16 % on the rotating-working-set micro-benchmark of the streaming kernels, profiles/r03_dw_stream_ab.txt)
+#ifndef DWM_CP
+#define DWM_CP 0
+#endif
+template <int CP = 0>
 __device__ __forceinline__ dwm_u32x4 dwm_load_run8(__amdgpu_buffer_rsrc_t r, int voff_elems, unsigned row_elems) {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, voff_elems < 0x20000000 ? voff_elems * 2 : 0x7ffffff0, (int)(row_elems * 2u), 0);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff_elems < 0x20000000 ? voff_elems * 2 : 0x7ffffff0, (int)(row_elems * 2u), CP);
 }
 template <bool B16>
 struct DwmRun { typedef f32x4 type; };
 template <>
 struct DwmRun<true> { typedef dwm_u32x2 type; };
-template <bool B16>
+template <bool B16, int CP = 0>
 __device__ __forceinline__ typename DwmRun<B16>::type dwm_load_run(__amdgpu_buffer_rsrc_t r, int voff_elems, unsigned row_elems) {
     // voff_elems: element offset inside the row, or a huge value for "out of range" (hardware returns zero)
-    if constexpr (B16) return __builtin_amdgcn_raw_buffer_load_b64(r, voff_elems < 0x20000000 ? voff_elems * 2 : 0x7ffffff0, (int)(row_elems * 2u), 0);
+    if constexpr (B16) return __builtin_amdgcn_raw_buffer_load_b64(r, voff_elems < 0x20000000 ? voff_elems * 2 : 0x7ffffff0, (int)(row_elems * 2u), CP);
     else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_elems < 0x20000000 ? voff_elems * 4 : 0x7ffffff0, (int)(row_elems * 4u), 0));
 }
 
@@ -262,8 +268,8 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
 #pragma unroll
             for (int v = 0; v < NVL; ++v) {
                 if constexpr (W8) {
-                    raw8[v] = dwm_load_run8(rx, vo[v], row * (unsigned)PinX);
-                    if constexpr (TWO) raw8b[v] = dwm_load_run8(rx2, vo[v], row * (unsigned)PinX2);
+                    raw8[v] = dwm_load_run8<DWM_CP>(rx, vo[v], row * (unsigned)PinX);
+                    if constexpr (TWO) raw8b[v] = dwm_load_run8<DWM_CP>(rx2, vo[v], row * (unsigned)PinX2);
                 } else {
                     rawx[v] = dwm_load_run<XB>(rx, vo[v], row * (unsigned)PinX);
                     if constexpr (TWO) rawx2[v] = dwm_load_run<X2B>(rx2, vo[v], row * (unsigned)PinX2);
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
                 for (int sub = 0; sub < SUBS; ++sub) {
                     const int t0 = out0 + 256 * sub + 16 * n_ + 4 * q_;
                     if constexpr (AUXB) {
-                        const dwm_u32x2 a2 = dwm_load_run<true>(raux, t0 < Tout ? t0 : 0x7ffffff0, (unsigned)(b * p.C + c) * (unsigned)PoutA);
+                        const dwm_u32x2 a2 = dwm_load_run<true, W8 ? DWM_CP : 0>(raux, t0 < Tout ? t0 : 0x7ffffff0, (unsigned)(b * p.C + c) * (unsigned)PoutA);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) auxv[sub][r] = (t0 + r < Tout) ? dwm_elem(a2, r) : 0.f;
                     } else {
@@ -433,7 +439,9 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
                     // 4 bf16 = one 8-byte store (the pitch keeps it aligned; samples past Tout land in the row's padding)
                     if (t0 < Tout) {
                         const dwm_u32x2 o2 = {dwm_pack_rne(outv[0], outv[1]), dwm_pack_rne(outv[2], outv[3])};
-                        *reinterpret_cast<dwm_u32x2*>(reinterpret_cast<unsigned short*>(p.y) + ((size_t)b * p.C + c) * PoutY + t0) = o2;
+                        dwm_u32x2* yq = reinterpret_cast<dwm_u32x2*>(reinterpret_cast<unsigned short*>(p.y) + ((size_t)b * p.C + c) * PoutY + t0);
+                        if constexpr (W8 && DWM_CP != 0) __builtin_nontemporal_store(o2, yq);
+                        else *yq = o2;
                     }
                 } else if (t0 + 3 < Tout) {
                     const f32x4 o = {outv[0], outv[1], outv[2], outv[3]};

@@ -333,6 +333,25 @@ class IRStackTrainFn(torch.autograd.Function):
         return (dx, None, None) + tuple(out)
 
 
+def _stack_segments(blocks, segment):
+    """[(cfgs, params tuple, blocks)] per segment: the static part of ir_stack_train's work, cached on the run's first block (it dies
+    with the module; module attributes and parameter objects are static -- a parameter that is REPLACED rather than updated in place is
+    caught by the identity check in ir_stack_train)."""
+    ent = blocks[0].__dict__.get("_v100_stack_meta")
+    if ent is None or len(ent[0]) != len(blocks) or any(a is not b for a, b in zip(ent[0], blocks)):
+        ent = blocks[0].__dict__["_v100_stack_meta"] = (tuple(blocks), {})
+    segs = ent[1].get(segment)
+    if segs is None:
+        segs = []
+        for s in range(0, len(blocks), segment):
+            seg = blocks[s:s + segment]
+            cfgs = tuple((b.conv[0][0].in_channels, b.conv[0][0].out_channels, b.conv[2].out_channels, int(b.kernel_size), int(b.stride),
+                          int(bool(b.use_residual))) for b in seg)
+            segs.append((cfgs, tuple(t for b in seg for t in _block_tensors(b)), seg))
+        ent[1][segment] = segs
+    return segs
+
+
 def ir_stack_train(blocks, x, precision: Optional[str] = None, segment: Optional[int] = None):
     """Training-mode forward of consecutive InvertedResidual modules through the stack executor.  `segment` = blocks per autograd
     node: None -> the whole run as one node in a single-process job, three blocks per node under data parallelism (the gradient
@@ -342,15 +361,17 @@ def ir_stack_train(blocks, x, precision: Optional[str] = None, segment: Optional
         import torch.distributed as dist
         segment = 3 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else len(blocks)
     precision = precision or _PRECISION
-    for s in range(0, len(blocks), segment):
-        seg = blocks[s:s + segment]
-        cfgs = tuple((b.conv[0][0].in_channels, b.conv[0][0].out_channels, b.conv[2].out_channels, int(b.kernel_size), int(b.stride),
-                      int(bool(b.use_residual))) for b in seg)
+    segs = _stack_segments(blocks, segment)
+    for i, (cfgs, params, seg) in enumerate(segs):
+        # a parameter object that was swapped out (module._parameters[...] = new) invalidates the cached tuple: re-read it
+        b0 = seg[0].conv[0][0].weight
+        if params[0] is not b0:
+            params = tuple(t for b in seg for t in _block_tensors(b))
+            segs[i] = (cfgs, params, seg)
         sh = getattr(x, "_v100_shadow", None)
         x16 = sh[0] if (sh is not None and sh[1] == x._version and sh[0].shape[:2] == x.shape[:2]
                         and sh[0].shape[2] == ((x.shape[2] + 7) & ~7)) else None
-        params = [t for b in seg for t in _block_tensors(b)]
-        last = s + segment >= len(blocks)
+        last = i + 1 == len(segs)
         y, y16 = IRStackTrainFn.apply(x, x16, (cfgs, precision, not last), *params)
         if y16 is not None:
             y._v100_shadow = (y16, y._version)
