@@ -1,30 +1,53 @@
-// K2 forward for the benchmark's case, built around BYTES IN FLIGHT: training-mode depthwise forward with bf16-stored
-// activations (BN1 + ReLU6 on load, raw output + BN2 sums; asr.py:49) on rows that fit one 512-output tile (T <= 512; any T: bf16 rows are pitched to a multiple of 8 samples).
+// K2 for the benchmark's case, built around how the rows reach HBM: training-mode depthwise forward and fused backward with
+// bf16-stored activations (asr.py:49 and its autograd) on rows that fit ONE wave item -- up to 512 outputs (NS = 2 sub-tiles of 256:
+// the nominal T' = 512 and every shorter time-stretched length) or up to 768 (NS = 3: the longer time-stretched lengths, <= 763).
 //
-// Why a second kernel.  dwconv_mfma_kernel keeps ONE row of loads in flight per wave and issues its first load only after the
-// tap prologue (taps -> LDS -> barrier -> Toeplitz fragments).  Inside a training step its input and output stream from / to HBM
-// (tools/bench_dw_regimes.py: the stand-alone number that round 2 quoted has both tensors resident in the 256 MB Infinity Cache), a
-// miss costs ~2 us under load, and a 2048-channel layer gives a wave only 8 rows: the kernel was latency-bound (PMC: 52-56 % of
-// wave cycles parked on s_waitcnt, MFMA 5-9 %, VALU active 21-28 %) at 16 KB of loads in flight per CU, where Little's law wants
-// >= 32 KB (MI355X_MICROARCH.md, "streaming").  Here a wave requests its first D rows at kernel entry -- the loads need nothing
-// but the row index -- so the whole prologue runs under the memory latency, and stays D rows (D x 16 B per lane = 4 VGPRs each)
-// ahead from then on: D = 4 gives 64 KB in flight per CU at 4 waves per SIMD.
+// Why a second set of kernels.  dwconv_mfma_kernel issues a row's first load only after the tap prologue (taps -> LDS -> barrier ->
+// Toeplitz fragments), re-derives the image's zero padding from out-of-range loads on every row, loads a1 (backward: mask / xin) at
+// the top of the row that needs it -- a full miss on the critical path of every row -- and walks rows longer than 512 outputs as two
+// tiles.  Inside a training step its input and output stream from / to HBM (tools/bench_dw_regimes.py: the stand-alone number that
+// round 2 quoted has both tensors resident in the 256 MB Infinity Cache), and what decides the rate there is measured in
+// profiles/r03_stream_pattern_probe.txt and profiles/r03_dw_stream_ab.txt:
+//   * a pure copy with this kernel's access pattern ([B][C][T] rows of 1 KB, one workgroup per channel) tops out at 4.5 - 5.1 TB/s --
+//     and goes DOWN with more rows in flight per wave (D = 4: 4.46, D = 1: 5.10 TB/s): a wave that requests rows b, b + 4, b + 8, ...
+//     at once spreads the chip's accesses over many 2 MB-apart regions, while all workgroups walking b in step sweep a few regions
+//     sequentially.  Little's law was the wrong model: DRAM locality is the limit.  So D = 1: the row after the current one;
+//   * the loads need nothing but the row index, so a wave requests its first rows at kernel entry and the whole prologue runs under
+//     their latency; all of a row's streams (backward: dz2, a2 AND a1) are requested together, one row ahead;
+//   * rows are read once and written once: nontemporal (CP = 2) is worth +9 % on a working set that rotates through HBM;
+//   * one (row) item per wave: no second tile for 513 .. 768 outputs, the zero padding of the LDS image is written once.
+// Measured, 8 layers, rotating working set: forward 189 -> 159 us, fused backward 391 -> 324 us; in the step forward 0.49 -> 0.54
+// of 8 TB/s on the same box.
 //
 // The main loop is branch-free (a conditional load or store makes hipcc's s_waitcnt insertion take the worst-case count at the
-// join, i.e. it waits for the prefetches just issued): rows past the wave's last row load through an out-of-range buffer offset
-// (the hardware returns zeros and moves no bytes), run with zeroed BatchNorm coefficients (so they add nothing to the sums) and
-// store through an out-of-range offset (dropped).  The first group of D rows is peeled so that the loop is entered in the same
-// queue state its back edge produces (otherwise the merged state again costs the prefetch depth).
+// join, i.e. it waits for the prefetch just issued): rows past the wave's last row load through an out-of-range buffer offset
+// (the hardware returns zeros and moves no bytes), run with zeroed coefficients (so they add nothing to the sums) and store
+// through an out-of-range offset (dropped).  The first group of D rows is peeled so that the loop is entered in the queue state
+// its back edge produces.
 //
 // Arithmetic, LDS image, fragment reads, statistics and the in-kernel BatchNorm finalisation (G == 1) are those of
-// dwconv_mfma_kernel<K, AFFINE_RELU6, RAW_STATS, NT, false, X | Y>: results are bit-identical to it.
+// dwconv_mfma_kernel<K, ..., NT, WG, IO>: the NS = 2 kernels are bit-identical to it; NS = 3 sums a row's outputs in one pass
+// instead of two tiles (same values, a different order of the fp32 partial sums).
 #pragma once
 
-// CP: cache-policy bits of the row loads / stores (0 default, 2 = nontemporal: the rows are read once and written once)
-template <int K, int NT, int D, int CP = 0>
-__global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p) {
+template <int K, int NS>
+struct DwStreamGeom {
     using G_ = DwMfmaGeom<K, 7>;
-    constexpr int STEPS = G_::STEPS, IMGP = G_::IMGP, WPAD = G_::WPAD, WLEN = G_::WLEN;
+    static constexpr int STEPS = G_::STEPS, WPAD = G_::WPAD, WLEN = G_::WLEN, IB = G_::IB;
+    static constexpr int TMAX = 256 * NS;                                   // outputs (= inputs) per row
+    static constexpr int NL = (TMAX + 511) / 512;                           // 16-byte loads per lane and stream
+    // image elements: B-fragment reads touch [0, 256 (NS-1) + 240 + 32 STEPS), the weight-gradient fragments [0, 512 NL + 16 (IB-1))
+    static constexpr int FWD_IMG = ((256 * (NS - 1) + 240 + 32 * STEPS + 7) / 8) * 8;
+    static constexpr int BWD_IMG = ((512 * NL + 16 * IB + 7) / 8) * 8;
+    static constexpr int XIMG = 512 * NL;                                   // xin image (weight gradient): whole 512-position steps
+};
+
+// CP: cache-policy bits of the row loads / stores (0 default, 2 = nontemporal: the rows are read once and written once)
+template <int K, int NT, int D, int CP = 0, int NS = 2>
+__global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p) {
+    using S_ = DwStreamGeom<K, NS>;
+    constexpr int STEPS = S_::STEPS, WPAD = S_::WPAD, WLEN = S_::WLEN, NL = S_::NL;
+    constexpr int IMGP = S_::FWD_IMG > 512 * NL + 64 ? S_::FWD_IMG : 512 * NL + 64;   // + the staged runs of lanes past the row
     __shared__ __attribute__((aligned(16))) unsigned short lds_img[4 * IMGP];
     __shared__ float lds_w[256];                             // WLEN used; every thread stores one slot (no lane-masked branch)
     __shared__ float lds_red[4][2];
@@ -33,7 +56,7 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_ = lane & 15, q_ = lane >> 4;
-    const int T = p.Tin;                                     // == Tout <= 512; rows are stored with pitch P (a multiple of 8 samples)
+    const int T = p.Tin;                                     // == Tout <= 256 NS; rows are stored with pitch P (a multiple of 8 samples)
     const int P = dw_pitch16(T);
     const int bper = (p.B + p.G - 1) / p.G;
     const int b0 = g * bper;
@@ -43,22 +66,26 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     const unsigned tbytes = (unsigned)((size_t)p.B * p.C * P * 2);
     const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, tbytes);
     const __amdgpu_buffer_rsrc_t ry = dw_make_rsrc(p.y, tbytes);
-    const int vo_in = 8 * lane < T ? 16 * lane : 0x7ffffff0;
+    int vo_in[NL];
+#pragma unroll
+    for (int v = 0; v < NL; ++v) vo_in[v] = 8 * (lane + 64 * v) < T ? 16 * (lane + 64 * v) : 0x7ffffff0;
     auto row_bytes = [&](int r) -> unsigned { return (unsigned)((b0 + wave + 4 * r) * p.C + c) * (unsigned)P * 2u; };
+    struct Row { dwm_u32x4 x[NL]; };
     // (the scalar row offset is formed unconditionally -- only the per-lane offset takes part in the bounds check, so an
     // out-of-range voffset alone makes the access a no-op -- and the voffset by a select: no branch for hipcc to build around a load)
-    auto issue = [&](int r) -> dwm_u32x4 {
+    auto issue = [&](int r, Row& rw) {
         const bool ok = r < nrows;                           // wave-uniform
-        return __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vo_in : 0x7ffffff0, (int)row_bytes(r), CP);
+#pragma unroll
+        for (int v = 0; v < NL; ++v) rw.x[v] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vo_in[v] : 0x7ffffff0, (int)row_bytes(r), CP);
     };
     // the taps FIRST: vmcnt retires in order, so a tap load issued behind the row requests would wait for all of them
     static_assert(WLEN <= 256, "one tap slot per thread");
     const int tj = (int)threadIdx.x - WPAD;
     const float tapv = p.w[(size_t)c * K + min(max(tj, 0), K - 1)];      // unconditional (clamped) load, selected below
     __builtin_amdgcn_sched_barrier(0);
-    dwm_u32x4 raw[D];
+    Row raw[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) raw[d] = issue(d);
+    for (int d = 0; d < D; ++d) issue(d, raw[d]);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- prologue, under the latency of those loads: taps, Toeplitz fragments, coefficients, the image's zero padding ----
@@ -96,29 +123,37 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
         }
     }
     const unsigned short* bsrc = img + 16 * n_ + 8 * q_;
-    unsigned short* stg = img + lpad + 8 * lane;
-    // samples this lane stages (0 .. 8): positions 8 lane + e < T.  Zero padding applies to the TRANSFORMED tensor, and the pitch
-    // padding of a stored row holds arbitrary bits: everything at or past T is forced to zero
-    const int nval = min(max(T - 8 * lane, 0), 8);
+    // samples this lane stages per load (0 .. 8): positions 8 (lane + 64 v) + e < T.  Zero padding applies to the TRANSFORMED tensor,
+    // and the pitch padding of a stored row holds arbitrary bits: everything at or past T is forced to zero.  A lane whose run lies
+    // wholly past the row writes its zeros INTO the zero padding (an unconditional store: a lane-masked store is a branch, and the
+    // wait for the row's data inside it spoils the counted waits after the join)
+    int nval[NL];
+    unsigned short* stg[NL];
+#pragma unroll
+    for (int v = 0; v < NL; ++v) {
+        nval[v] = min(max(T - 8 * (lane + 64 * v), 0), 8);
+        stg[v] = img + lpad + 8 * (lane + 64 * v);
+    }
     float s0 = 0.f, s1 = 0.f;
 
     // one row: stage raw[d] (BN1 + ReLU6, one bf16 digit), request row r + D into the freed registers, Toeplitz MFMAs, store
-    auto row = [&](dwm_u32x4& rw, int r) {
+    auto row = [&](Row& rw, int r) {
         const bool ok = r < nrows;                           // wave-uniform; rows past the end compute zeros and store nothing
         const float ra = ok ? ca : 0.f, rb = ok ? cb : 0.f;
-        float vals[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) vals[e] = e < nval ? relu6f(fmaf(dwm_elem8(rw, e), ra, rb)) : 0.f;
-        const dwm_u32x4 w4 = {dwm_pack_rne(vals[0], vals[1]), dwm_pack_rne(vals[2], vals[3]), dwm_pack_rne(vals[4], vals[5]),
-                              dwm_pack_rne(vals[6], vals[7])};
-        // unconditional store (lanes past the row write zeros INTO the zero padding): a lane-masked store is a branch, and the wait
-        // for the row's data inside it spoils the counted waits after the join
-        *reinterpret_cast<dwm_u32x4*>(stg) = w4;
+        for (int v = 0; v < NL; ++v) {
+            float vals[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vals[e] = e < nval[v] ? relu6f(fmaf(dwm_elem8(rw.x[v], e), ra, rb)) : 0.f;
+            const dwm_u32x4 w4 = {dwm_pack_rne(vals[0], vals[1]), dwm_pack_rne(vals[2], vals[3]), dwm_pack_rne(vals[4], vals[5]),
+                                  dwm_pack_rne(vals[6], vals[7])};
+            *reinterpret_cast<dwm_u32x4*>(stg[v]) = w4;
+        }
         asm volatile("" ::: "memory");                                    // wave-local hand-off through LDS: program order
-        rw = issue(r + D);
+        issue(r + D, rw);
         const unsigned yb = row_bytes(r);
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < NS; ++sub) {
             const int t0 = 256 * sub + 16 * n_ + 4 * q_;
             dwm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -171,11 +206,13 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
 // the general kernel keeps one row of the first two in flight and loads a1 at the top of the row it is needed in (a full miss on
 // the critical path of every row).  Here all three are requested D rows ahead, from kernel entry on (12 VGPRs per row in flight).
 // Same arithmetic and order of accumulation: bit-identical results (E tiles, sums, stored gradient).
-template <int K, int NT, int D, int CP = 0>
+template <int K, int NT, int D, int CP = 0, int NS = 2>
 __global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p) {
-    using G_ = DwMfmaGeom<K, 7>;
-    constexpr int TILE = G_::TILE, STEPS = G_::STEPS, IMGP = G_::IMGP, WPAD = G_::WPAD, WLEN = G_::WLEN, IB = G_::IB;
-    constexpr int WAVE_U16 = IMGP + TILE;
+    using S_ = DwStreamGeom<K, NS>;
+    constexpr int STEPS = S_::STEPS, WPAD = S_::WPAD, WLEN = S_::WLEN, IB = S_::IB, NL = S_::NL, XIMG = S_::XIMG;
+    constexpr int IMG0 = S_::FWD_IMG > S_::BWD_IMG ? S_::FWD_IMG : S_::BWD_IMG;
+    constexpr int IMGP = IMG0 > 512 * NL + 64 ? IMG0 : 512 * NL + 64;
+    constexpr int WAVE_U16 = IMGP + XIMG;
     constexpr int E_FLOATS = 16 * IB * 16;
     constexpr int LDS_BYTES = (4 * WAVE_U16 * 2 > 4 * E_FLOATS * 4) ? 4 * WAVE_U16 * 2 : 4 * E_FLOATS * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
@@ -196,22 +233,26 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p)
     const unsigned tbytes = (unsigned)((size_t)p.B * p.C * P * 2);
     const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, tbytes), rx2 = dw_make_rsrc(p.x2, tbytes), raux = dw_make_rsrc(p.aux, tbytes);
     const __amdgpu_buffer_rsrc_t ry = dw_make_rsrc(p.y, tbytes);
-    const int vo_in = 8 * lane < T ? 16 * lane : 0x7ffffff0;
-    int vo_aux[2];
+    int vo_in[NL], vo_aux[NS];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int v = 0; v < NL; ++v) vo_in[v] = 8 * (lane + 64 * v) < T ? 16 * (lane + 64 * v) : 0x7ffffff0;
+#pragma unroll
+    for (int sub = 0; sub < NS; ++sub) {
         const int t0 = 256 * sub + 16 * n_ + 4 * q_;
         vo_aux[sub] = t0 < T ? 2 * t0 : 0x7ffffff0;
     }
     auto row_bytes = [&](int r) -> unsigned { return (unsigned)((b0 + wave + 4 * r) * p.C + c) * (unsigned)P * 2u; };
-    struct Row { dwm_u32x4 g, g2; dwm_u32x2 a[2]; };
+    struct Row { dwm_u32x4 g[NL], g2[NL]; dwm_u32x2 a[NS]; };
     auto issue = [&](int r, Row& rw) {
         const bool ok = r < nrows;
         const int so = (int)row_bytes(r);
-        rw.g = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vo_in : 0x7ffffff0, so, CP);
-        rw.g2 = __builtin_amdgcn_raw_buffer_load_b128(rx2, ok ? vo_in : 0x7ffffff0, so, CP);
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) rw.a[sub] = __builtin_amdgcn_raw_buffer_load_b64(raux, ok ? vo_aux[sub] : 0x7ffffff0, so, CP);
+        for (int v = 0; v < NL; ++v) {
+            rw.g[v] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vo_in[v] : 0x7ffffff0, so, CP);
+            rw.g2[v] = __builtin_amdgcn_raw_buffer_load_b128(rx2, ok ? vo_in[v] : 0x7ffffff0, so, CP);
+        }
+#pragma unroll
+        for (int sub = 0; sub < NS; ++sub) rw.a[sub] = __builtin_amdgcn_raw_buffer_load_b64(raux, ok ? vo_aux[sub] : 0x7ffffff0, so, CP);
     };
     static_assert(WLEN <= 256, "one tap slot per thread");
     const int tj = (int)threadIdx.x - WPAD;
@@ -231,6 +272,8 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p)
     unsigned short* ximg = img + IMGP;
     for (int c8 = lane; c8 < IMGP / 8; c8 += 64)
         if (c8 < lpad / 8 || c8 >= (lpad + P) / 8) *reinterpret_cast<dwm_u32x4*>(img + 8 * c8) = dwm_u32x4{0u, 0u, 0u, 0u};
+    // the xin image past the last sub-tile (NS = 3: positions 768 .. 1023 of the second 512-position contraction step) stays zero
+    for (int c8 = 32 * NS + lane; c8 < XIMG / 8; c8 += 64) *reinterpret_cast<dwm_u32x4*>(ximg + 8 * c8) = dwm_u32x4{0u, 0u, 0u, 0u};
     // BatchNorm-2 backward coefficients (p, q, r): from the finaliser launch, or finalised here from the project backward-data GEMM's
     // slab by the first wave (DwPre; one group only), under the latency of the row requests
     __shared__ float lds_coef[3];
@@ -258,8 +301,13 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p)
         }
     }
     const unsigned short* bsrc = img + 16 * n_ + 8 * q_;
-    unsigned short* stg = img + lpad + 8 * lane;
-    const int nval = min(max(T - 8 * lane, 0), 8);       // samples of the row this lane stages (everything at or past T is zero)
+    int nval[NL];
+    unsigned short* stg[NL];
+#pragma unroll
+    for (int v = 0; v < NL; ++v) {
+        nval[v] = min(max(T - 8 * (lane + 64 * v), 0), 8);       // samples of the row this lane stages (everything at or past T is zero)
+        stg[v] = img + lpad + 8 * (lane + 64 * v);
+    }
     dwm_f32x4 eacc[IB];
 #pragma unroll
     for (int ib = 0; ib < IB; ++ib) eacc[ib] = dwm_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -268,20 +316,23 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p)
     auto row = [&](Row& rw, int r) {
         const bool ok = r < nrows;                   // rows past the end: zero coefficients -> g' = 0, xin = 0, mask 0, nothing stored
         const float ra = ok ? ca : 0.f, rb = ok ? cb : 0.f, rc = ok ? cc : 0.f, roa = ok ? oa : 0.f, rob = ok ? ob : 0.f;
-        float auxv[2][4];
+        float auxv[NS][4];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < NS; ++sub)
 #pragma unroll
             for (int e = 0; e < 4; ++e) auxv[sub][e] = dwm_elem(rw.a[sub], e);
-        float vals[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) vals[e] = e < nval ? fmaf(dwm_elem8(rw.g, e), ra, fmaf(dwm_elem8(rw.g2, e), rb, rc)) : 0.f;
-        const dwm_u32x4 w4 = {dwm_pack_rne(vals[0], vals[1]), dwm_pack_rne(vals[2], vals[3]), dwm_pack_rne(vals[4], vals[5]),
-                              dwm_pack_rne(vals[6], vals[7])};
-        *reinterpret_cast<dwm_u32x4*>(stg) = w4;
-        // xin = relu6(bn1(a1)) at this lane's 2 x 4 output positions -> the tile image of the weight-gradient product
+        for (int v = 0; v < NL; ++v) {
+            float vals[8];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+            for (int e = 0; e < 8; ++e) vals[e] = e < nval[v] ? fmaf(dwm_elem8(rw.g[v], e), ra, fmaf(dwm_elem8(rw.g2[v], e), rb, rc)) : 0.f;
+            const dwm_u32x4 w4 = {dwm_pack_rne(vals[0], vals[1]), dwm_pack_rne(vals[2], vals[3]), dwm_pack_rne(vals[4], vals[5]),
+                                  dwm_pack_rne(vals[6], vals[7])};
+            *reinterpret_cast<dwm_u32x4*>(stg[v]) = w4;
+        }
+        // xin = relu6(bn1(a1)) at this lane's NS x 4 output positions -> the tile image of the weight-gradient product
+#pragma unroll
+        for (int sub = 0; sub < NS; ++sub) {
             const int t0 = 256 * sub + 16 * n_ + 4 * q_;
             float xv[4];
 #pragma unroll
@@ -291,19 +342,21 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p)
         }
         asm volatile("" ::: "memory");
         issue(r + D, rw);
-        {   // E[16 ib + m][rr] += sum_p g'img[16 (p + ib) + m] * ximg[16 p + rr]
+        // E[16 ib + m][rr] += sum_p g'img[16 (p + ib) + m] * ximg[16 p + rr], 32 blocks p (512 positions) per contraction step
+#pragma unroll
+        for (int h = 0; h < NL; ++h) {
             dwm_bf16x8 xfr[1];
-            xfr[0] = dwm_tr_fragment(ximg, lane);
+            xfr[0] = dwm_tr_fragment(ximg + 512 * h, lane);
 #pragma unroll
             for (int ib = 0; ib < IB; ++ib) {
                 dwm_bf16x8 gfr[1];
-                gfr[0] = dwm_tr_fragment(img + 16 * ib, lane);
+                gfr[0] = dwm_tr_fragment(img + 512 * h + 16 * ib, lane);
                 eacc[ib] = dwm_mfma_digits<1, 1>(gfr, xfr, eacc[ib]);
             }
         }
         const unsigned yb = row_bytes(r);
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < NS; ++sub) {
             const int t0 = 256 * sub + 16 * n_ + 4 * q_;
             dwm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
