@@ -150,6 +150,16 @@ int v100_stft_frames(const float* x, float* frames, int B, int N, int T, int hop
 int v100_power_spectrum(const float* spec, float* pw, int B, int F, int T, void* stream);
 /* out[b][t][c] = log(in[b][c][t] + offset)   (data_modules.py:290-291) */
 int v100_log_transpose(const float* in, float* out, int B, int C, int T, float offset, void* stream);
+/* The whole of MelSpectrogramAudioTransform.forward's arithmetic (voice100/data_modules.py:276-291) in ONE launch: x [B][N] waveform ->
+ * out [B][T][n_mels] = log(mel + log_offset), T = 1 + N / hop, torchaudio-0.13.1 MelSpectrogram defaults (center, reflect padding,
+ * power 2).  One wave per frame: windowed load, 256-point complex radix-4 FFT of the 512 real samples, real-input split, power,
+ * triangular filters, log (csrc/mel.hip).  n_fft = 512 and n_mels <= 64 only (the reference's configuration; 1 otherwise -- the
+ * caller then uses the framing / DFT-GEMM / filterbank-GEMM kernels above).  Tables (device, built by the caller in double):
+ * window [512] (the win_length Hann window centred in n_fft zeros), tw256 [256][2] / tw512 [257][2] = (cos, -sin)(2 pi k / 256 | 512),
+ * mel_start / mel_count [n_mels] = first bin and number of bins (<= 32) of each filter, mel_w [n_mels][32] its weights. */
+int v100_log_mel_fused(const float* x, float* out, const float* window, const float* tw256, const float* tw512, const int* mel_start,
+                       const int* mel_count, const float* mel_w, int B, int N, int T, int hop, int n_fft, int n_mels, float log_offset,
+                       void* stream);
 /* AlignTextToAudioModel.predict epilogue (tts.py:197-200, _layers_v1.py:132-138): x [B][T][2+S+Cap] ->
  * f0 = gate(x0 < 0 ? 0 : x1*std+mean), logspc, codeap un-normalised */
 int v100_world_unnormalize(const float* x, float* f0, float* logspc, float* codeap, const float* f0_mean, const float* f0_std,

@@ -104,12 +104,17 @@ def test_log_mel_vs_oracle_and_torch_stft(cuda):
     from oracle import mel as O
     tr = MelSpectrogramAudioTransform().to(cuda)
     g = torch.Generator().manual_seed(11)
-    for n in (16000, 4321, 800):
+    assert tr.fused                                   # the reference's configuration runs as ONE launch (csrc/mel.hip)
+    for n in (16000, 4321, 800, 300):
         wav = (torch.rand(n, generator=g) * 2 - 1)
         got = tr(wav.to(cuda)).cpu()
         ref = O.log_mel(wav.numpy())
         assert got.shape == ref.shape == (1 + n // 160, 64)
         assert rel_err(got, ref) < 1e-4
+        # ... and the five-launch form (framing, DFT GEMM, power, filterbank GEMM, log) that other configurations take
+        assert rel_err(tr.transform(wav.to(cuda), fused=False).cpu(), ref) < 1e-4
+        if n < 16000:
+            continue
         spec = torch.stft(wav, 512, hop_length=160, win_length=400, window=torch.hann_window(400), center=True,
                           pad_mode="reflect", return_complex=True).abs() ** 2
         fb = torch.from_numpy(O.melscale_fbanks())

@@ -52,6 +52,32 @@ class MelSpectrogramAudioTransform(nn.Module):
         self.register_buffer("dft_basis", torch.from_numpy(basis.astype(np.float32)), persistent=False)      # [2*nf, win]
         fb = _melscale_fbanks(nf, 0.0, sample_rate / 2.0, n_mels, sample_rate)
         self.register_buffer("mel_fb_t", torch.from_numpy(np.ascontiguousarray(fb.T)), persistent=False)      # [n_mels, nf]
+        # tables of the one-launch kernel (csrc/mel.hip): n_fft = 512, <= 64 filters, each a contiguous run of <= 32 bins
+        self.fused = False
+        if n_fft == 512 and n_mels <= 64:
+            starts, counts, wts, ok = np.zeros(n_mels, np.int32), np.zeros(n_mels, np.int32), np.zeros((n_mels, 32), np.float32), True
+            for m in range(n_mels):
+                nz = np.nonzero(fb[:, m])[0]
+                if nz.size == 0:
+                    continue
+                lo, hi = int(nz[0]), int(nz[-1]) + 1
+                if hi - lo > 32:
+                    ok = False
+                    break
+                starts[m], counts[m] = lo, hi - lo
+                wts[m, :hi - lo] = fb[lo:hi, m]                     # zeros inside the run (none for triangles) stay zero weights
+            if ok:
+                win512 = np.zeros(n_fft, dtype=np.float64)
+                win512[left:left + win_length] = window
+                k256, k512 = np.arange(256, dtype=np.float64), np.arange(257, dtype=np.float64)
+                tw = lambda k, n_: np.stack([np.cos(2.0 * np.pi * k / n_), -np.sin(2.0 * np.pi * k / n_)], axis=1).astype(np.float32)
+                self.register_buffer("_win512", torch.from_numpy(win512.astype(np.float32)), persistent=False)
+                self.register_buffer("_tw256", torch.from_numpy(tw(k256, 256.0)), persistent=False)
+                self.register_buffer("_tw512", torch.from_numpy(tw(k512, 512.0)), persistent=False)
+                self.register_buffer("_mel_start", torch.from_numpy(starts), persistent=False)
+                self.register_buffer("_mel_count", torch.from_numpy(counts), persistent=False)
+                self.register_buffer("_mel_w", torch.from_numpy(wts), persistent=False)
+                self.fused = True
 
     @property
     def audio_size(self) -> int:
@@ -61,8 +87,10 @@ class MelSpectrogramAudioTransform(nn.Module):
         return 1 + n_samples // self.hop_length
 
     @torch.no_grad()
-    def transform(self, waveform: torch.Tensor) -> torch.Tensor:
-        """waveform [N] or [B, N] fp32 on the GPU -> log-mel [T, n_mels] or [B, T, n_mels]."""
+    def transform(self, waveform: torch.Tensor, fused: bool = None) -> torch.Tensor:
+        """waveform [N] or [B, N] fp32 on the GPU -> log-mel [T, n_mels] or [B, T, n_mels].  One launch (csrc/mel.hip: FFT per wave)
+        for the reference's configuration; `fused=False` (or any other n_fft / filter count) takes the framing + DFT-GEMM +
+        filterbank-GEMM kernels."""
         squeeze = waveform.dim() == 1
         x = waveform[None] if squeeze else waveform
         F_._check(x, "MelSpectrogramAudioTransform")
@@ -70,6 +98,11 @@ class MelSpectrogramAudioTransform(nn.Module):
         B, n = x.shape
         T = self.num_frames(n)
         nf = self.n_fft // 2 + 1
+        if self.fused if fused is None else (fused and self.fused):
+            out = torch.empty((B, T, self.n_mels), dtype=torch.float32, device=x.device)
+            N.call("v100_log_mel_fused", x, out, self._win512, self._tw256, self._tw512, self._mel_start, self._mel_count, self._mel_w,
+                   B, n, T, self.hop_length, self.n_fft, self.n_mels, float(self.log_offset))
+            return out[0] if squeeze else out
         frames = torch.empty((B, self.win_length, T), dtype=torch.float32, device=x.device)
         N.call("v100_stft_frames", x, frames, B, n, T, self.hop_length, self.win_length, self.n_fft)
         spec = torch.empty((B, 2 * nf, T), dtype=torch.float32, device=x.device)
