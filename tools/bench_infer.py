@@ -78,6 +78,8 @@ def main():
         tts = AlignTextToAudioModel(vocab_size=29, hidden_size=512, use_mcep=False).to(dev).eval()
         tts_mcep = AlignTextToAudioModel(vocab_size=29, hidden_size=512, use_mcep=True).to(dev).eval()
         align_model = TextToAlignTextModel(vocab_size=29, hidden_size=512).to(dev).eval()
+        # an untrained head predicts ~0 frames per token: bias it to gap ~ 1, length ~ 3 so 128 tokens become ~500 aligned frames
+        align_model.layers[4].bias.copy_(torch.tensor([0.6931, 1.3863], device=dev))
         mel = MelSpectrogramAudioTransform().to(dev)
         voc = WORLDVocoder(use_mcep=True).to(dev)
         chain = TTSPipeline(align_model, tts_mcep, voc)

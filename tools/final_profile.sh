@@ -1,16 +1,22 @@
 #!/bin/bash
-# Round-end evidence: rocprofv3 --kernel-trace --stats of the bench command, the bench line itself (unprofiled), PMC passes of the
-# depthwise micro-benchmark (traffic ratio for bench.py) -> gpurun_out/final/
-tag=${1:-r02k}
+# Round-end evidence -> gpurun_out/final/ (copy what is to be judged into profiles/):
+#   rocprofv3 --kernel-trace --stats of the bench command (per-kernel table + per-step breakdown), PMC passes of the depthwise
+#   micro-benchmark (HBM traffic ratio for bench.py's `roofline.traffic`, tagged with the kernel sources' hash), kernel tables of
+#   config 3 (tts predict + chain) and config 5 (log-mel -> encoder -> greedy decode), and the unprofiled bench line.
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/final; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs > $out/${tag}_bench_line_under_rocprof.json 2> $out/prof_err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python3 bench.py --steps 30 --warmup 5 --windows 0 --host-contention 0 --no-cpu-baseline --no-other-configs > $out/${tag}_bench_line_under_rocprof.json 2> $out/prof_err.txt
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1)
 cp "$f" $out/${tag}_bench_bf16_kernel_stats.csv
-python3 tools/prof_summary.py "$f" 35 60 > $out/${tag}_bench_bf16_summary.txt
-python3 tools/trace_step.py "$(find $out/prof -name '*kernel_trace.csv' | head -1)" 60 > $out/${tag}_step_breakdown.txt
+python3 tools/prof_summary.py "$f" 36 60 > $out/${tag}_bench_bf16_summary.txt
+python3 tools/trace_step.py "$(find $out/prof -name '*kernel_trace.csv' | head -1)" 70 > $out/${tag}_step_breakdown.txt
+rm -rf $out/prof
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python3 tools/bench_infer.py --iters 20 > $out/${tag}_infer_line_under_rocprof.json 2>> $out/prof_err.txt
+f=$(find $out/prof -name "*kernel_stats.csv" | head -1)
+python3 tools/prof_summary.py "$f" 1 40 > $out/${tag}_infer_configs_kernel_summary.txt
 rm -rf $out/prof
 tools/pmc_passes.sh $out/pmc --what dw16,dw > /dev/null 2>&1
-python3 tools/pmc_table.py $out/pmc --json $out/r02_dw_fwd_pmc.json > $out/${tag}_pmc_counters.txt 2>&1
+python3 tools/pmc_table.py $out/pmc --json $out/dw_fwd_pmc.json > $out/${tag}_pmc_counters.txt 2>&1
 python3 bench.py > $out/${tag}_bench_line.json 2> $out/bench_err.txt
-tail -c 400 $out/${tag}_bench_line.json
+tail -c 600 $out/${tag}_bench_line.json

@@ -49,8 +49,8 @@ for hid, k, s in SPECS:
     P16 = (t + 7) & ~7
     for kind, pat, rd, wrb in (("fwd", rf"dwconv(_mfma)?_kernel<{k}, (1, 0, 3, false, 0|{s}, 8, 1, 0, true, false)>", 4.0 * B * hid * t, 4.0 * B * hid * tout),
                                ("bwd fused", rf"dwconv(_mfma)?_kernel<{k}, 2, 2, 3, true, 0>", 4.0 * B * hid * (2 * tout + t), 4.0 * B * hid * t),
-                               ("fwd16", rf"dwconv_mfma_kernel<{k}, 1, 0, 2, false, 9>", 2.0 * B * hid * P16, 2.0 * B * hid * P16),
-                               ("bwd16 fused", rf"dwconv_mfma_kernel<{k}, 2, 2, 2, true, 15>", 2.0 * B * hid * 3 * P16, 2.0 * B * hid * P16)):
+                               ("fwd16", rf"(dwconv_mfma_kernel<{k}, 1, 0, 2, false, 9>|dwconv_fwd16_stream_kernel<{k}, 2, \d+, \d+, \d+>)", 2.0 * B * hid * P16, 2.0 * B * hid * P16),
+                               ("bwd16 fused", rf"(dwconv_mfma_kernel<{k}, 2, 2, 2, true, 15>|dwconv_bwd16_stream_kernel<{k}, 2, \d+, \d+, \d+>)", 2.0 * B * hid * 3 * P16, 2.0 * B * hid * P16)):
         names = [n for n in fe if re.search(pat, n)]
         if not names:
             continue
@@ -59,7 +59,7 @@ for hid, k, s in SPECS:
         w_mb = wr.get(n, {}).get("WRITE_SIZE", 0.0) * 1024 / 1e6
         ratio = (r_mb + w_mb) / ((rd + wrb) / 1e6)
         print(f"{n[:78]:78s} {r_mb:8.1f} {w_mb:8.1f} {rd / 1e6:8.1f} {wrb / 1e6:8.1f} {ratio:6.3f}")
-        want = "fwd16" if any("false, 9>" in q for q in fe) else "fwd"      # the act16 kernels when the run exercised them
+        want = "fwd16" if any(("false, 9>" in q or "fwd16_stream" in q) for q in fe) else "fwd"      # the act16 kernels when the run exercised them
         if kind == want or (kind == "fwd" and s != 1):
             tot_meas += r_mb + w_mb
             tot_algo += (rd + wrb) / 1e6
@@ -81,7 +81,7 @@ print("SQ counters per kernel (fractions of SQ_WAVE_CYCLES; WAIT_ANY = parked on
 print("mfma_busy/sq_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, the raw ratio of the two counters as in profiles/r01k_pmc_counters.txt: for comparing builds)")
 for n, c in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
     wc = c.get("SQ_WAVE_CYCLES", 0)
-    if wc <= 0 or not any(s in n for s in ("dwconv", "pw_gemm", "pw_wgrad")):
+    if wc <= 0 or not any(s in n for s in ("dwconv", "pw_gemm", "pw_wgrad", "log_mel")):
         continue
     busy = c.get("SQ_BUSY_CYCLES", 0)
     print(f"{n[:86]:86s} wait_any {100 * c.get('SQ_WAIT_ANY', 0) / wc:5.1f}%  wait_inst {100 * c.get('SQ_WAIT_INST_ANY', 0) / wc:5.1f}%  "

@@ -447,17 +447,15 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
 
 #include "depthwise_mfma.h"
 
-// Which stride-1 path runs: the Toeplitz-MFMA kernel (default) or the register-window VALU kernel (V100_DW_PATH=valu, kept
-// for A/B measurements and as the path for shapes the MFMA kernel does not cover); V100_DW_DIGITS = 2 | 3 bf16 digits per
-// fp32 operand (default 3: fp32-exact products).  Read once.
-// With 16-bit activation storage the taps default to TWO digits (16 mantissa bits against data rounded to 8): V100_DW_DIGITS=3
-// restores the third.
-struct DwPathConfig { bool mfma; int digits; bool digits3; };
+// Stride-1 layers with a specialised kernel size run on the Toeplitz-MFMA kernels (round 3: the register-window VALU kernels they
+// replaced are no longer instantiated for those sizes -- they remain for the stride-2 opener and, as dwconv_generic_kernel, for
+// everything else).  Precision knob, read once: V100_DW_DIGITS = 2 | 3 bf16 digits per fp32 tap / sample (default 3: fp32-exact
+// products).  With 16-bit activation storage the taps default to TWO digits (16 mantissa bits against data rounded to 8):
+// V100_DW_DIGITS=3 restores the third.
+struct DwPathConfig { int digits; bool digits3; };
 static inline DwPathConfig dw_path_config() {
     static const DwPathConfig cfg = [] {
-        DwPathConfig c{true, 3, false};
-        const char* e = getenv("V100_DW_PATH");
-        if (e && e[0] == 'v') c.mfma = false;
+        DwPathConfig c{3, false};
         const char* d = getenv("V100_DW_DIGITS");
         if (d && d[0] == '2') c.digits = 2;
         if (d && d[0] == '3') c.digits3 = true;
@@ -479,7 +477,7 @@ static bool dw_launch_specialised(const DwParams& p, hipStream_t st, const V100T
     dim3 grid(p.C, p.G);
     {
         const DwPathConfig cfg = dw_path_config();
-        if ((cfg.mfma || IO != 0) && p.stride == 1 && p.upsample == 1) {
+        if (p.stride == 1 && p.upsample == 1) {
 #define X(KK)                                                                                                           \
     if (p.K == KK) {                                                                                                    \
         if (cfg.digits == 2 || (IO != 0 && !cfg.digits3)) V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 2, WG, IO>), grid, dim3(256), 0, st, p); \
@@ -500,9 +498,6 @@ static bool dw_launch_specialised(const DwParams& p, hipStream_t st, const V100T
         else V100_LAUNCH(tl, (dwconv_kernel<KK, SS, 4, IM, OM, true, WG>), grid, dim3(256), 0, st, p);            \
         return true;                                                                                              \
     } while (0)
-#define X(KK) if (p.K == KK && p.stride == 1) DW_GO(KK, 1);
-    V100_DW_SPECIALISED(X)
-#undef X
     if constexpr (!WG) {
         if (p.K == 11 && p.stride == 2) DW_GO(11, 2);
     }

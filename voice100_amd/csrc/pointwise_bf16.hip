@@ -514,139 +514,6 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// NN GEMM for the two training GEMMs whose operands need NO transform (X stored as bf16: the expand forward GEMM on the bf16 shadow of
-// the block input, the project backward-data GEMM on da3): both operands go global -> LDS by DMA (`buffer_load_dwordx4 ... lds`,
-// no staging registers, no conversion / pack VALU work, no ds_write), three LDS stages, one raw barrier per k-tile with a counted
-// vmcnt.  In the register-staged kernel above the staging transforms + LDS stores are 30 % of the main loop of exactly these GEMMs
-// (profiles/r02j_gemm_ablation.txt).  A keeps the [row][64 k] XOR-swizzled image (the swizzle moves to the SOURCE address: a DMA
-// writes LDS lane-linearly); X cannot be transposed by a DMA, so it stays [k][128 t] (256-byte rows, 16-byte chunks XOR-ed with
-// ((k & 3) << 2) | ((k >> 2) & 3)) and the B fragments are transposed reads (`ds_read_b64_tr_b16`, cdna_hip_programming.md T10).
-// Same 256 x 128 block tile, wave tiling, accumulator layout and epilogue as pw_gemm_bf16_fast_kernel<.., 256, ..>.
-typedef short pw_s16x4 __attribute__((ext_vector_type(4)));
-template <int EPI, int IO>
-__global__ __launch_bounds__(512) void pw_gemm_bf16_dma_kernel(PwParams p) {
-    static_assert((IO & PW_IO_X) != 0, "X must be a bf16 (pitched) tensor");
-    constexpr int BM = 256;
-    constexpr int A_BYTES = BM * 128;               // [256][64] bf16
-    constexpr int X_BYTES = 64 * 256;               // [64][128] bf16
-    constexpr int STAGE = A_BYTES + X_BYTES;        // 48 KB
-    constexpr int SMEM = 3 * STAGE;                 // 144 KB (the epilogue's [256][128] fp32 tile, 128 KB, reuses it)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
-    typedef __attribute__((address_space(3))) pw_s16x4 lds_s16x4;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int b, tt, mt;
-    pw_work(p, b, tt, mt);
-    const int m0 = mt * BM, t0 = tt * PW_BN;
-    const int M = p.M, K = p.K;
-    const int P16 = pw_pitch16(p.T);
-    // The DMAs are INLINE ASM: beside a `buffer_load ... lds` it knows about, hipcc puts `s_waitcnt vmcnt(0)` in front of the first LDS
-    // read of every k-tile (it cannot tell which ring slot the read aliases), which drains the two tiles in flight; the waits here
-    // are counted by hand (vmcnt(6): the six DMAs of the next tile may still fly).  Descriptors as plain SGPR quads, LDS base in M0.
-    typedef int pw_i32x4 __attribute__((ext_vector_type(4)));
-    auto mk = [](const void* base, unsigned bytes) {
-        const unsigned long long a = (unsigned long long)base;
-        return pw_i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-    };
-    const pw_i32x4 rA = mk(p.Abf, (unsigned)M * K * 2u);
-    const pw_i32x4 rX = mk(reinterpret_cast<const char*>(p.X) + (size_t)b * K * P16 * 2, (unsigned)K * P16 * 2u);
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-
-    // DMA source offsets (bytes).  A: instruction i of wave w fills LDS bytes (4w + i) * 1024 ... + 1023 of the A image = rows
-    // 8 (4w + i) ... + 7; lane l -> row + l / 8, LDS slot l % 8 holds global chunk slot ^ ((row >> 1) & 7).
-    int voA[4], voX[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 8 * (4 * wave + i) + (lane >> 3), slot = lane & 7;
-        voA[i] = ((m0 + row) * K + ((slot ^ ((row >> 1) & 7)) << 3)) * 2;
-    }
-    // X: instruction j of wave w fills k-rows 4 (2w + j) ... + 3 (256 B each); lane l -> row + l / 16, slot l % 16 holds chunk
-    // slot ^ (((row & 3) << 2) | ((row >> 2) & 3))
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 4 * (2 * wave + j) + (lane >> 4), slot = lane & 15;
-        voX[j] = (row * P16 + t0 + ((slot ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 3)) * 2;
-    }
-    auto issue = [&](int kt, int buf) {
-        const unsigned st = lds0 + buf * STAGE;
-        const int soA = kt * 128, soX = kt * 64 * P16 * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned dst = st + (4 * wave + i) * 1024;
-            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voA[i]), "s"(rA), "s"(soA), "s"(dst) : "memory", "m0");
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned dst = st + A_BYTES + (2 * wave + j) * 1024;
-            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voX[j]), "s"(rX), "s"(soX), "s"(dst) : "memory", "m0");
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // fragment addresses.  A: as the register-staged kernel.  B: lane l of a 16-lane group g = l >> 4 takes column 16 (g & 1) + (l & 15)
-    // of the wave's 32-column block and k = 8 (g >> 1) ... + 7 as two transposed reads of 4 k-rows x 16 columns; lane 4q + pp of the
-    // group addresses row r0 + q, chunk c0 + (pp >> 1), + 8 (pp & 1) bytes.
-    const int lr = lane & 31, lh = lane >> 5;
-    const int sw = (lr >> 1) & 7;
-    const int rdA0 = (wm * 64 + lr) * 128;
-    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    int trB[2][4][2];                   // [j][ks][half]: byte offset inside the X image
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = 16 * ks + 8 * (g >> 1) + 4 * h + q;
-                const int ch = ((wn * 64 + j * 32 + 16 * (g & 1)) >> 3) + (pp >> 1);
-                trB[j][ks][h] = 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (pp & 1);
-            }
-
-    const int nk = K / 64;
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    for (int kt = 0; kt < nk; ++kt) {
-        // own DMAs of tile kt are complete (those of tile kt + 1 may still fly), then every wave's are
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // buffer (kt + 2) % 3 was read in iteration kt - 1: every wave is past those reads (it has arrived at this barrier)
-        if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
-        const unsigned char* Ab = smem + (kt % 3) * STAGE;
-        const unsigned char* Xb = Ab + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int co = ((ks * 2 + lh) ^ sw) << 4;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + co);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + 32 * 128 + co);
-            bf16x8 bfr[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const pw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Xb + trB[j][ks][0]));
-                const pw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Xb + trB[j][ks][1]));
-                bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr[0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr[1], acc[1][1], 0, 0, 0);
-        }
-    }
-    asm volatile("" ::: "memory");
-    __syncthreads();                       // every wave is done reading the stages: the epilogue parks the accumulators there
-    pw_epilogue_lds<EPI, BM, IO>(p, acc, reinterpret_cast<float*>(smem), b, m0, t0, tt, wm, wn, tid);
-}
-
 // Backward-weight, bf16: contraction index is t; both operands are read as 8 consecutive t
 // (two float4), transformed, rounded and written as one 16-byte chunk of a [row][t] image.
 template <int GM_, int XM_, bool TV>
@@ -1383,18 +1250,6 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
         else V100_GGL((pw_gemm_bf16_fast_kernel<XM, EP, 128, false, false, (IOV)>), grid, dim3(256), 0, st, pb);      \
         return true;                                                                                                            \
     }
-#if PW_DMA
-    // both operands by LDS-DMA (pw_gemm_bf16_dma_kernel): the two GEMMs with a plain bf16 X, whole k-tiles
-#define XD(EP, IOV)                                                                                                             \
-    if (big && p.x_mode == 0 && p.epi_mode == EP && p.io16 == (IOV) && (p.K & 63) == 0 && p.K >= PW_DMA_MINK &&                   \
-        ((PW_DMA >> (EP == 1 ? 0 : 1)) & 1)) {                                                                                   \
-        V100_GGL((pw_gemm_bf16_dma_kernel<EP, (IOV)>), grid, dim3(512), 0, st, pb);                                   \
-        return true;                                                                                                            \
-    }
-    XD(1, PW_IO_X | PW_IO_Y)
-    XD(4, PW_IO_X | PW_IO_R | PW_IO_Y)
-#undef XD
-#endif
 #if PW_PERSIST
     // short-K GEMMs with several tiles per CU: persistent workgroups (grid = tiles / 2 or / 4 when that divides evenly)
 #define XP(XM, EP, IOV)                                                                                                         \

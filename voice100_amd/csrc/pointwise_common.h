@@ -34,12 +34,6 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #ifndef PW_EPI_FAST
 #define PW_EPI_FAST 2      /* 1: lean epilogue for interior tiles; 2: also for the partial last t-tile (PT) */
 #endif
-#ifndef PW_DMA
-#define PW_DMA 0             /* bit 0: expand forward (on the bf16 shadow), bit 1: project backward-data, by the LDS-DMA kernel: measured +-0 in the step, off */
-#endif
-#ifndef PW_DMA_MINK
-#define PW_DMA_MINK 512
-#endif
 #ifndef PW_PERSIST
 #define PW_PERSIST 1         /* persistent workgroups with cross-tile prefetch for the short-K training GEMMs */
 #endif
