@@ -274,21 +274,20 @@ class IRStackTrainFn(torch.autograd.Function):
     allocation.  Same kernels in the same order as the per-block InvertedResidualTrainFn: bit-identical results."""
 
     @staticmethod
-    def forward(ctx, x, x16, meta, *params):
-        cfgs, precision, last_shadow = meta
+    def forward(ctx, x, x16, meta, *weights):
+        # weights: the 9 trainable tensors of each block (w1 g1 b1 wd g2 b2 w3 g3 b3) -- the autograd inputs; meta carries the full
+        # 18-tensor table per block (running statistics included: buffers, no gradient, so not autograd inputs -- half the arguments)
+        cfgs, precision, last_shadow, params = meta
         _check(x, "InvertedResidual stack")
         x = x.contiguous()
         B, cin, T = x.shape
         n = len(cfgs)
-        if len(params) != 18 * n or cfgs[0][0] != cin:
+        if len(params) != 18 * n or len(weights) != 9 * n or cfgs[0][0] != cin:
             raise RuntimeError("InvertedResidual stack: parameter list / input width do not match the block configuration")
         bf16 = _fmt(precision)
         _no_fp16_training(bf16, "InvertedResidual (training mode)")
         level = _ACT16 if bf16 == 1 else 0
         desc, blocks, totals = _stack_plan(cfgs, B, T, bf16, level, bool(last_shadow))
-        for t in params:
-            if not t.is_cuda or not t.is_contiguous():
-                raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors")
         if not (bf16 == 1 and level >= 4):
             x16 = None
         blob = torch.empty(totals[0], dtype=torch.uint8, device=x.device)
@@ -325,11 +324,9 @@ class IRStackTrainFn(torch.autograd.Function):
         out, off = [], 0
         for i, (cin, hid, cout, k, _, _) in enumerate(cfgs):
             p = params[18 * i:18 * i + 18]
-            blk = [None] * 18
             for j, numel in ((0, hid * cin), (1, hid), (2, hid), (6, hid * k), (7, hid), (8, hid), (12, cout * hid), (13, cout), (14, cout)):
-                blk[j] = grads[off:off + numel].view_as(p[j])
+                out.append(grads[off:off + numel].view_as(p[j]))
                 off += numel
-            out.extend(blk)
         return (dx, None, None) + tuple(out)
 
 
@@ -347,7 +344,11 @@ def _stack_segments(blocks, segment):
             seg = blocks[s:s + segment]
             cfgs = tuple((b.conv[0][0].in_channels, b.conv[0][0].out_channels, b.conv[2].out_channels, int(b.kernel_size), int(b.stride),
                           int(bool(b.use_residual))) for b in seg)
-            segs.append((cfgs, tuple(t for b in seg for t in _block_tensors(b)), seg))
+            params = tuple(t for b in seg for t in _block_tensors(b))
+            for t in params:
+                if not t.is_cuda or not t.is_contiguous():
+                    raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors (no CPU fallback)")
+            segs.append((cfgs, params, seg))
         ent[1][segment] = segs
     return segs
 
@@ -372,7 +373,8 @@ def ir_stack_train(blocks, x, precision: Optional[str] = None, segment: Optional
         x16 = sh[0] if (sh is not None and sh[1] == x._version and sh[0].shape[:2] == x.shape[:2]
                         and sh[0].shape[2] == ((x.shape[2] + 7) & ~7)) else None
         last = i + 1 == len(segs)
-        y, y16 = IRStackTrainFn.apply(x, x16, (cfgs, precision, not last), *params)
+        weights = [params[18 * b + j] for b in range(len(cfgs)) for j in (0, 1, 2, 6, 7, 8, 12, 13, 14)]
+        y, y16 = IRStackTrainFn.apply(x, x16, (cfgs, precision, not last, params), *weights)
         if y16 is not None:
             y._v100_shadow = (y16, y._version)
         x = y
