@@ -35,6 +35,29 @@ __global__ __launch_bounds__(256, MINB) void rows_copy(const u32x4* __restrict__
     }
 }
 
+// GEMM-epilogue-shaped stores / X-operand-shaped loads: a 512-thread workgroup owns a [256 rows x 128 columns] bf16 tile of a
+// [B][M][512] (batch-major) or [M][B][512] (channel-major) tensor and writes (or reads) it as 16 passes of 16 rows x 256 B (one row
+// per half-wave, 8 B per lane) -- what PwEpilogueFull does after its LDS transposition.  Tiles are dealt (b, tt, mt)-major like the
+// GEMM's grid.  Answers: would channel-major hidden tensors (which the depthwise kernels like) cost the GEMMs their store rate?
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <bool CMAJOR, bool LOAD>
+__global__ __launch_bounds__(512) void tile_rows(u32x2* __restrict__ y, int B, int M, unsigned* sink) {
+    const int ntt = 4, nmt = M / 256;
+    const int v = blockIdx.x;
+    const int mt = v % nmt, tt = (v / nmt) % ntt, b = v / (nmt * ntt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    unsigned acc = 0;
+#pragma unroll
+    for (int pass = 0; pass < 16; ++pass) {
+        const int m = mt * 256 + pass * 16 + wave * 2 + half;
+        const size_t row = CMAJOR ? ((size_t)m * B + b) : ((size_t)b * M + m);
+        u32x2* q = y + (row * 512 + tt * 128) / 4 + col;          // 4 bf16 per u32x2
+        if (LOAD) { const u32x2 t = *q; acc += t[0] ^ t[1]; }
+        else *q = u32x2{(unsigned)v, (unsigned)pass};
+    }
+    if (LOAD && acc == 0x12345678u) *sink = acc;
+}
+
 int main() {
     const int B = 32, C = 2048, SETS = 10;
     const size_t n16 = (size_t)B * C * 64;          // 16-byte pieces per tensor (64 MB)
@@ -61,5 +84,24 @@ int main() {
     run("[C][B][T] rows, D=8 nt", rows_copy<8, true, true, 1>, 256);
     run("[B][C][T] rows, D=1 plain (general kernel)", rows_copy<1, false, false, 1>, 2048);
     run("[B][C][T] rows, D=2 plain", rows_copy<2, false, false, 1>, 2048);
+    {
+        const int M = 2048;
+        unsigned* sink; hipMalloc(&sink, 4);
+        auto runt = [&](const char* name, auto kern) {
+            const int grid = (M / 256) * 4 * B;
+            for (int i = 0; i < SETS; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, 0, (u32x2*)ys[i], B, M, sink);
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            const int iters = 40;
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, 0, (u32x2*)ys[i % SETS], B, M, sink);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%-60s: %6.1f us  %5.0f GB/s\n", name, ms / iters * 1e3, 1.0 * n16 * 16 / (ms / iters * 1e-3) / 1e9);
+        };
+        runt("GEMM-epilogue stores, [B][M][T] (batch-major) 67 MB", tile_rows<false, false>);
+        runt("GEMM-epilogue stores, [M][B][T] (channel-major)", tile_rows<true, false>);
+        runt("tile-row loads,       [B][M][T]", tile_rows<false, true>);
+        runt("tile-row loads,       [M][B][T]", tile_rows<true, true>);
+    }
     return 0;
 }
