@@ -338,7 +338,8 @@ int v100_ctc_greedy_decode(const float* logits, const int* lens, long long* out,
 int v100_ctc_best_path(const float* logp, const long long* labels, const int* in_len, const int* lab_len, void* back_ws, int* path,
                        float* score, int B, int T, int V, int Lmax, int max_move, void* stream);
 /* TextToAlignTextModel.align (voice100/models/tts.py:89-110) batched: text [B][Lmax] int64, align [B][Lmax][2] float64
- * (gap, length), out [B][Tmax] int64, out_len [B]. */
+ * (gap, length), out [B][Tmax] int64 (zero padded; rows longer than Tmax are cut), out_len [B].  out == NULL: only out_len is
+ * written (head + int(sum(align)) + tail per utterance), so the caller can size `out` with one read-back. */
 int v100_align_expand(const long long* text, const double* align, const int* text_len, long long* out, int* out_len, int B, int Lmax,
                       int Tmax, int head, int tail, void* stream);
 

@@ -116,29 +116,50 @@ __global__ __launch_bounds__(256) void ctc_best_path_kernel(const float* __restr
     }
 }
 
-// one thread per utterance (L is a few hundred at most; the work is a serial double-precision prefix sum)
-__global__ void align_expand_kernel(const long long* __restrict__ text, const double* __restrict__ align, const int* __restrict__ text_len,
-                                    long long* __restrict__ out, int* __restrict__ out_len, int B, int Lmax, int Tmax, int head, int tail) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// one workgroup per utterance: thread 0 walks the serial double-precision prefix sum (L is a few hundred at most) and leaves each
+// token's [s, e) span in LDS / global scratch-free form: spans are written to the output row by ALL threads afterwards.  Exactly the
+// reference's loop: later tokens overwrite earlier ones where spans overlap (they can, through rounding), so the fill walks tokens in
+// order per output position: position j takes the LAST token i whose span covers it.
+__global__ __launch_bounds__(256) void align_expand_kernel(const long long* __restrict__ text, const double* __restrict__ align,
+                                                           const int* __restrict__ text_len, long long* __restrict__ out,
+                                                           int* __restrict__ out_len, int Lmax, int Tmax, int head, int tail) {
+    extern __shared__ int spans[];                 // [2 * Lmax]: s_i, e_i
+    __shared__ int n_sh;
+    const int b = blockIdx.x;
     const int L = text_len ? min(text_len[b], Lmax) : Lmax;
-    long long* o = out + (size_t)b * Tmax;
-    for (int t = 0; t < Tmax; ++t) o[t] = 0;
-    double total = 0.0;
-    for (int i = 0; i < L; ++i) total += align[((size_t)b * Lmax + i) * 2] + align[((size_t)b * Lmax + i) * 2 + 1];
-    int n = head + (int)total + tail;            // int(torch.sum(align)) truncates toward zero
-    if (n > Tmax) n = Tmax;
-    double t = (double)head;
-    for (int i = 0; i < L; ++i) {
-        t += align[((size_t)b * Lmax + i) * 2];
-        int s = (int)rint(t);                    // Python round(): half to even on the double
-        t += align[((size_t)b * Lmax + i) * 2 + 1];
-        int e = (int)rint(t);
-        if (s == e) e = e + 1 > 0 ? e + 1 : 0;
-        if (s < 0) s = 0;                        // python range(s, e) with negative s would index from the end; never happens with head >= 0 and gaps >= 0
-        for (int j = s; j < e && j < n; ++j) o[j] = text[(size_t)b * Lmax + i];
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+        for (int i = 0; i < L; ++i) total += align[((size_t)b * Lmax + i) * 2] + align[((size_t)b * Lmax + i) * 2 + 1];
+        int n = head + (int)total + tail;            // int(torch.sum(align)) truncates toward zero
+        if (out && n > Tmax) n = Tmax;
+        double t = (double)head;
+        for (int i = 0; i < L; ++i) {
+            t += align[((size_t)b * Lmax + i) * 2];
+            int s = (int)rint(t);                    // Python round(): half to even on the double
+            t += align[((size_t)b * Lmax + i) * 2 + 1];
+            int e = (int)rint(t);
+            if (s == e) e = e + 1 > 0 ? e + 1 : 0;
+            if (s < 0) s = 0;                        // python range(s, e) with negative s would index from the end; never happens with head >= 0 and gaps >= 0
+            spans[2 * i] = s;
+            spans[2 * i + 1] = e < n ? e : n;
+        }
+        n_sh = n;
+        out_len[b] = n;
     }
-    out_len[b] = n;
+    __syncthreads();
+    if (!out) return;                                // length query only
+    const int n = n_sh;
+    long long* o = out + (size_t)b * Tmax;
+    for (int j = threadIdx.x; j < Tmax; j += blockDim.x) {
+        long long v = 0;
+        if (j < n) {
+            // spans are (nearly) sorted: scan backwards from the end for the last covering token -- L is small, and the loop is
+            // uniform enough (every thread scans the same list)
+            for (int i = L - 1; i >= 0; --i)
+                if (j >= spans[2 * i] && j < spans[2 * i + 1]) { v = text[(size_t)b * Lmax + i]; break; }
+        }
+        o[j] = v;
+    }
 }
 
 extern "C" int v100_ctc_greedy_decode(const float* logits, const int* lens, long long* out, int* out_len, int B, int T, int V, int blank, void* stream) {
@@ -160,9 +181,9 @@ extern "C" int v100_ctc_best_path(const float* logp, const long long* labels, co
 
 extern "C" int v100_align_expand(const long long* text, const double* align, const int* text_len, long long* out, int* out_len, int B, int Lmax,
                                  int Tmax, int head, int tail, void* stream) {
-    if (!text || !align || !out || !out_len) return V100_ERR_NULL;
-    if (B <= 0 || Lmax <= 0 || Tmax <= 0 || head < 0 || tail < 0) return V100_ERR_SHAPE;
-    V100_GGL(align_expand_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, text, align, text_len, out, out_len, B, Lmax,
+    if (!text || !align || !out_len) return V100_ERR_NULL;            // out == NULL: only the lengths are written (the caller sizes `out` from them)
+    if (B <= 0 || Lmax <= 0 || Lmax > 8192 || (out && Tmax <= 0) || head < 0 || tail < 0) return V100_ERR_SHAPE;
+    V100_GGL(align_expand_kernel, dim3(B), dim3(256), 2 * Lmax * sizeof(int), (hipStream_t)stream, text, align, text_len, out, out_len, Lmax,
                        Tmax, head, tail);
     return v100_launch_status();
 }

@@ -45,9 +45,12 @@ def align_expand(text: torch.Tensor, align: torch.Tensor, text_len=None, head: i
     text = text.to(torch.int64).contiguous()
     al = align.to(device=text.device, dtype=torch.float64).contiguous()
     B, L = text.shape
-    tmax = int(head + tail + float(al.sum(dim=(1, 2)).max()) + 2)
     tl = text_len.to(device=text.device, dtype=torch.int32).contiguous() if text_len is not None else None
-    out = torch.empty((B, tmax), dtype=torch.int64, device=text.device)
     out_len = torch.empty((B,), dtype=torch.int32, device=text.device)
+    # pass 1: the lengths only (the output's width depends on the data: ONE read-back), pass 2: the expansion, exactly that wide
+    # (pad_sequence semantics: the longest utterance ends at the tensor's edge)
+    N.call("v100_align_expand", text, al, tl, None, out_len, B, L, 0, int(head), int(tail))
+    tmax = max(int(out_len.max()), 1)
+    out = torch.empty((B, tmax), dtype=torch.int64, device=text.device)
     N.call("v100_align_expand", text, al, tl, out, out_len, B, L, tmax, int(head), int(tail))
     return out, out_len

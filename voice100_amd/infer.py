@@ -118,9 +118,8 @@ class TTSPipeline:
         pred = self.align_model(text)                                        # [B, L, 2]
         align = torch.clamp_min(torch.exp(pred) - 1.0, 0.0)
         aligntext, at_len = align_expand(text, align, text_len, self.head, self.tail)
-        # pad_sequence semantics (update_samples.py:66): the batch is exactly as wide as its longest utterance, so that one ends
-        # at the convolutions' zero padding, not at extra blank tokens
-        aligntext = aligntext[:, :max(int(at_len.max()), 1)].contiguous()
+        # (align_expand sizes the batch exactly as wide as its longest utterance -- pad_sequence semantics, update_samples.py:66 --
+        # so that one ends at the convolutions' zero padding, not at extra blank tokens)
         f0, feat, codeap = self.audio_model.predict(aligntext)               # 2 * La - 1 frames
         v = self.vocoder
         if v is not None and v.use_mcep:
