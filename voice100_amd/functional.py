@@ -311,6 +311,9 @@ class IRStackTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dy16=None):
         x, params, cfgs, totals = ctx.x, ctx.params, ctx.cfgs, ctx.totals
+        if ctx.blob is None:
+            raise RuntimeError("InvertedResidual stack: backward ran already for this forward (its activations are freed as soon as "
+                               "they are consumed; retain_graph / a second backward needs a second forward)")
         n = len(cfgs)
         if dy is None:
             dy = torch.zeros(ctx.y_shape, dtype=torch.float32, device=x.device)
