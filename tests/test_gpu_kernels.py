@@ -102,7 +102,8 @@ def test_dwconv_backward_data_and_weight(cuda, B, C, T, K, stride):
 
 
 GEMM_CASES = [(2, 40, 24, 200), (3, 128, 64, 256), (1, 29, 512, 130), (2, 260, 256, 1023), (2, 256, 1024, 512), (1, 2, 8, 33),
-              (2, 512, 320, 128), (1, 128, 192, 256)]     # odd k-tile counts on both block-tile heights
+              (2, 512, 320, 128), (1, 128, 192, 256),     # odd k-tile counts on both block-tile heights
+              (2, 512, 29, 512), (3, 130, 7, 64)]         # K <= 32: plain / bias stores take the small-K VALU kernel (vocabulary-head data gradient)
 
 
 @pytest.mark.parametrize("B,M,K,T", GEMM_CASES)

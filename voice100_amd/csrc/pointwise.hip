@@ -105,6 +105,64 @@ extern "C" int v100_weight_prep_f16(const float* w, int rows, int cols, void* w1
     return v100_launch_status();
 }
 
+// Small-K GEMM on the VALU: Y[b][m][t] = sum_{k < K} A[m][k] * X[b][k][t] (+ bias[m]) for K <= 32 -- the data gradient of the
+// vocabulary head (asr.py:91: dx[512 x T'] = W^T[512 x 29] dy[29 x T']), which the MFMA kernels ran through their generic
+// (scalar-safe, K padded to 64) path at 34 us per step for 1 GFLOP.  29 FMAs per output are nothing; the kernel is the 33 MB store.
+// A workgroup owns a [64 m x 128 t] tile: A tile in LDS, a thread holds 8 m x 4 t accumulators.  fmt 0: fp32 operands (exact fp32,
+// fmaf chain in k order); fmt 1: operands rounded to bf16 like the MFMA path, fp32 accumulate.  T % 4 == 0.
+__global__ __launch_bounds__(256) void pw_smallk_kernel(PwParams p) {
+    __shared__ float As[64][33];
+    const int K = p.K, M = p.M, T = p.T;
+    const int nmt = (M + 63) >> 6, ntt = (T + 127) >> 7;
+    int v = blockIdx.x;
+    const int mt = v % nmt; v /= nmt;
+    const int tt = v % ntt;
+    const int b = v / ntt;
+    const int m0 = mt * 64, t0 = tt * 128;
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {          // columns K .. 31 are zero: the k loop below runs in whole groups of 8
+        const int r = i >> 5, k = i & 31;
+        float a = 0.f;
+        if (m0 + r < M && k < K) a = p.fmt ? __builtin_bit_cast(float, (unsigned)p.Abf[(size_t)(m0 + r) * K + k] << 16) : p.A[(size_t)(m0 + r) * K + k];
+        As[r][k] = a;
+    }
+    __syncthreads();
+    const int tq = threadIdx.x & 31, mi = threadIdx.x >> 5;
+    const int t = t0 + 4 * tq;
+    if (t >= T) return;
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xb = p.X + (size_t)b * K * T + t;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        f32x4 xs[8];                                  // eight rows requested before the first is used (rows past K: row K-1 again, times zero)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xs[u] = *reinterpret_cast<const f32x4*>(xb + (size_t)min(k0 + u, K - 1) * T);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            f32x4 x = xs[u];
+            if (p.fmt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = __builtin_bit_cast(float, (unsigned)f2bf(x[e]) << 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = As[8 * mi + j][k0 + u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(a, x[e], acc[j][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = m0 + 8 * mi + j;
+        if (m < M) {
+            f32x4 o = acc[j];
+            if (p.bias) { const float bs = p.bias[m]; o += f32x4{bs, bs, bs, bs}; }
+            *reinterpret_cast<f32x4*>(p.Y + ((size_t)b * M + m) * T + t) = o;
+        }
+    }
+}
+
 extern "C" int v100_pw_gemm(const float* A, const void* A_bf16, const float* X, const float* X2, const float* xa,
                             const float* xb, const float* xc, int x_mode, float* Y, const float* bias, const float* ea,
                             const float* eb, const float* R, int epi_mode, float* stats, int B, int M, int K, int T,
@@ -126,6 +184,12 @@ extern "C" int v100_pw_gemm(const float* A, const void* A_bf16, const float* X, 
     dim3 grid((unsigned)nwg);
     hipStream_t st = (hipStream_t)stream;
     V100TimedRegion timed(V100_T_PW_GEMM, st);
+    if (K <= 32 && use_bf16 != 2 && x_mode == PW_X_NONE && epi_mode == PW_EPI_STORE && (T & 3) == 0 && M >= 64 &&
+        (size_t)B * K * T * 4 < 0x7fffff00ull) {                                             // see pw_smallk_kernel
+        const long nw = (long)((M + 63) >> 6) * ((T + 127) >> 7) * B;
+        V100_GGL(pw_smallk_kernel, dim3((unsigned)nw), dim3(256), 0, st, p);
+        return v100_launch_status();
+    }
     if (use_bf16 == 2) { if (!pw_launch_gemm_f16(p, grid, st)) return V100_ERR_SHAPE; }     // fp16: inference combinations only
     else if (use_bf16) pw_launch_gemm_bf16(p, grid, st);
     else pw_launch_gemm_f32(p, grid, st);
