@@ -379,3 +379,37 @@ def test_block_act16_wide_shapes(cuda, cin, k, B, T):
     finally:
         F_.set_activation_storage(keep)
         F_.set_matmul_precision("fp32")
+
+
+@pytest.mark.parametrize("cin,k,B,T", [(64, 19, 2, 133), (256, 51, 3, 512), (512, 83, 2, 640), (256, 35, 2, 1023), (128, 7, 4, 77)])
+def test_eval_block_bf16_storage(cuda, cin, k, B, T):
+    """Inference at precision "bf16": the hidden tensors of an eval-mode block stored as bf16 (activation storage >= 1) against fp32
+    storage (level 0; both with bf16 GEMM operands) and against the block in exact fp32 -- rows of <= 512, <= 768 (one wave item)
+    and longer (general kernel), odd lengths."""
+    from voice100_amd import functional as F_
+    from voice100_amd.layers import InvertedResidual
+    keep = F_.get_activation_storage()
+    try:
+        torch.manual_seed(cin + k)
+        blk = InvertedResidual(cin, cin, kernel_size=k).to(cuda).eval()
+        g = torch.Generator().manual_seed(T)
+        with torch.no_grad():
+            for m in blk.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g).to(cuda) * 0.2)
+                    m.running_var.copy_((torch.rand(m.running_var.shape, generator=g) + 0.5).to(cuda))
+        x = torch.randn(B, cin, T, generator=g).to(cuda)
+        outs = {}
+        with torch.no_grad():
+            F_.set_matmul_precision("fp32")
+            outs["fp32"] = blk(x)
+            F_.set_matmul_precision("bf16")
+            for lv in (0, 4):
+                F_.set_activation_storage(lv)
+                outs[lv] = blk(x)
+        assert torch.isfinite(outs[4]).all()
+        assert rel_err(outs[4], outs[0]) < 1.5e-2          # one extra bf16 rounding of each hidden tensor
+        assert rel_err(outs[4], outs["fp32"]) < 3e-2 and rel_err(outs[0], outs["fp32"]) < 3e-2
+    finally:
+        F_.set_activation_storage(keep)
+        F_.set_matmul_precision("fp32")

@@ -355,6 +355,16 @@ extern "C" int v100_ir_fwd_eval(const int* sh, const void* const* P, void* strea
     ir_eval_carve(sh, const_cast<void*>(P[4]), c);
     float *h1 = (float*)P[5], *h2 = (float*)P[6], *y = (float*)P[7];
     int rc;
+    if (sh[IR_ACT16]) {
+        // inference at precision "bf16": the two hidden tensors (each 4x the block's width, already BatchNorm'ed and clamped to [0, 6])
+        // are stored as bf16 [B][hid][pitch16(T)] -- half the bytes of the three kernels' big streams; the GEMMs round them to bf16 as
+        // operands anyway.  Same three launches.
+        if (bf != 1 || !v100_ir_act16_supported(sh)) return V100_ERR_SHAPE;
+        CK(v100_pw_gemm_io(c.w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, h1, c.s1, c.t1, nullptr, 2, nullptr, B, hid, cin, T, PW_IO_Y, stream));
+        CK(dw_fwd_eval_io(h1, (const float*)P[2], c.s2, c.t2, h2, B, hid, T, K, stream));
+        CK(v100_pw_gemm_io(c.w3bf, h2, nullptr, nullptr, nullptr, nullptr, 0, y, c.s3, c.t3, res ? x : nullptr, 3, nullptr, B, cout, hid, T2, PW_IO_X, stream));
+        return V100_OK;
+    }
     CK(v100_pw_gemm((const float*)P[1], c.w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, h1, nullptr, c.s1, c.t1, nullptr, 2, nullptr, B, hid, cin, T, bf, stream));
     CK(v100_dwconv(h1, nullptr, (const float*)P[2], nullptr, nullptr, nullptr, 0, h2, nullptr, c.s2, c.t2, 1, nullptr, v100_dw_num_groups(B, hid),
                    B, hid, T, T2, K, S, pad, 0, 1, 0, stream));

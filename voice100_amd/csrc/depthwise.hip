@@ -439,6 +439,21 @@ int dw_fwd_train_io_fin(const void* a1, const float* w, const float* in_a, const
     return v100_launch_status();
 }
 
+// eval-mode depthwise stage on bf16-stored hidden tensors (block executor, inference at precision "bf16"): h2 = relu6(conv(h1) * out_a
+// + out_b), rows pitched to a multiple of 8 samples
+int dw_fwd_eval_io(const void* h1, const float* w, const float* out_a, const float* out_b, void* h2, int B, int C, int T, int K, void* stream) {
+    if (!h1 || !w || !out_a || !out_b || !h2) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || (K & 1) == 0) return V100_ERR_SHAPE;
+    if ((size_t)B * C * dw_pitch16(T) * 4 >= 0x7fffff00ull) return V100_ERR_SHAPE;
+    const int G = v100_dw_num_groups(B, C);
+    DwParams p{(const float*)h1, nullptr, w, nullptr, nullptr, nullptr, (float*)h2, nullptr, out_a, out_b, nullptr,
+               B, C, T, T, K, 1, (K - 1) / 2, 0, 1, G, DW_IN_NONE, DW_OUT_AFFINE_RELU6, nullptr, DW_IO_X | DW_IO_Y, DwFin{}, DwPre{}};
+    hipStream_t st = (hipStream_t)stream;
+    V100TimedLaunch timed(V100_T_DW_FWD, 2.0 * B * C * 2.0 * T + 4.0 * C * K + 8.0 * C);
+    if (!dw_launch_fwd_eval16(p, st, timed)) return V100_ERR_SHAPE;
+    return v100_launch_status();
+}
+
 extern "C" int v100_dwconv_bwd_io(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc,
                                   const void* xpre, const float* xa, const float* xb, void* dxin, float* stats, float* wpartial,
                                   float* dw, int G, int B, int C, int T, int K, int io16, void* stream) {

@@ -126,6 +126,7 @@ int chan_reduce2_io_fin(const void* u, const void* v, float* partial, int B, int
 // the act16 entry points with in-kernel BatchNorm finalisation (block executor; fin.mode != 0 requires G == 1)
 int dw_fwd_train_io_fin(const void* a1, const float* w, const float* in_a, const float* in_b, void* a2, float* stats, int G, int B, int C,
                         int T, int K, int io16, const DwFin& fin, const DwPre& pre, void* stream);
+int dw_fwd_eval_io(const void* h1, const float* w, const float* out_a, const float* out_b, void* h2, int B, int C, int T, int K, void* stream);
 int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc, const void* xpre,
                   const float* xa, const float* xb, void* dxin, float* stats, float* wpartial, float* dw, int G, int B, int C, int T, int K,
                   int io16, const DwFin& fin, const DwPre& pre, void* stream);
@@ -507,6 +508,7 @@ static bool dw_launch_specialised(const DwParams& p, hipStream_t st, const V100T
 }
 
 bool dw_launch_fwd_train16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);     // a1 in, a2 out stored as bf16
+bool dw_launch_fwd_eval16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);      // eval: h1 in, h2 = relu6(bn2(conv)) out, bf16
 bool dw_launch_bwd_fused16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);     // a2 (x2) and a1 (aux) stored as bf16
 bool dw_launch_bwd_fused16g(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);    // ... and dz2 in, dz1 out too
 bool dw_launch_fwd_train(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);   // in AFFINE_RELU6, out RAW_STATS

@@ -43,7 +43,9 @@ struct DwStreamGeom {
 };
 
 // CP: cache-policy bits of the row loads / stores (0 default, 2 = nontemporal: the rows are read once and written once)
-template <int K, int NT, int D, int CP = 0, int NS = 2>
+// EV (eval mode, inference): the input is the already-activated h1 (no transform on load), the output relu6(acc * out_a + out_b)
+// with the folded BatchNorm-2 coefficients, no statistics -- ConvBNActivate's "dw" stage with frozen statistics (asr.py:27-37, 49)
+template <int K, int NT, int D, int CP = 0, int NS = 2, bool EV = false>
 __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p) {
     using S_ = DwStreamGeom<K, NS>;
     constexpr int STEPS = S_::STEPS, WPAD = S_::WPAD, WLEN = S_::WLEN, NL = S_::NL;
@@ -101,9 +103,11 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     // consumer of channel c), finalised HERE from the expand GEMM's slab of partial sums by the first wave (DwPre), under the latency
     // of the row requests above: one dependent launch less per block
     __shared__ float lds_coef[3];
-    if (p.pre.f.mode != 0 && wave == 0) dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
+    if (!EV && p.pre.f.mode != 0 && wave == 0) dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
     __syncthreads();
-    const float ca = p.pre.f.mode != 0 ? lds_coef[0] : p.in_a[c], cb = p.pre.f.mode != 0 ? lds_coef[1] : p.in_b[c];
+    float ca = 1.f, cb = 0.f, oa = 1.f, ob = 0.f;
+    if constexpr (EV) { oa = p.out_a[c]; ob = p.out_b[c]; }
+    else { ca = p.pre.f.mode != 0 ? lds_coef[0] : p.in_a[c]; cb = p.pre.f.mode != 0 ? lds_coef[1] : p.in_b[c]; }
     dwm_bf16x8 afr[STEPS][NT];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
@@ -140,11 +144,15 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     auto row = [&](Row& rw, int r) {
         const bool ok = r < nrows;                           // wave-uniform; rows past the end compute zeros and store nothing
         const float ra = ok ? ca : 0.f, rb = ok ? cb : 0.f;
+        (void)ra; (void)rb;
 #pragma unroll
         for (int v = 0; v < NL; ++v) {
             float vals[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) vals[e] = e < nval[v] ? relu6f(fmaf(dwm_elem8(rw.x[v], e), ra, rb)) : 0.f;
+            for (int e = 0; e < 8; ++e) {
+                const float xin = EV ? dwm_elem8(rw.x[v], e) : relu6f(fmaf(dwm_elem8(rw.x[v], e), ra, rb));
+                vals[e] = e < nval[v] ? xin : 0.f;
+            }
             const dwm_u32x4 w4 = {dwm_pack_rne(vals[0], vals[1]), dwm_pack_rne(vals[2], vals[3]), dwm_pack_rne(vals[4], vals[5]),
                                   dwm_pack_rne(vals[6], vals[7])};
             *reinterpret_cast<dwm_u32x4*>(stg[v]) = w4;
@@ -164,11 +172,16 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
             }
             // outputs at positions >= T are not part of the row (they are not zero: the taps still reach real samples): out of the sums
             const bool in_row = t0 < T;
+            if constexpr (EV) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float yv = t0 + e < T ? acc[e] : 0.f;
-                s0 += yv;
-                s1 = fmaf(yv, yv, s1);
+                for (int e = 0; e < 4; ++e) acc[e] = relu6f(fmaf(acc[e], oa, ob));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float yv = t0 + e < T ? acc[e] : 0.f;
+                    s0 += yv;
+                    s1 = fmaf(yv, yv, s1);
+                }
             }
             // 4 bf16 = one 8-byte store (the pitch keeps it aligned; samples past T land in the row's padding)
             const dwm_u32x2 o2 = {dwm_pack_rne(acc[0], acc[1]), dwm_pack_rne(acc[2], acc[3])};
@@ -185,6 +198,7 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
         for (int d = 0; d < D; ++d) row(raw[d], r0 + d);
     }
 
+    if constexpr (EV) return;
     s0 = wave_sum(s0);
     s1 = wave_sum(s1);
     if (lane == 0) { lds_red[wave][0] = s0; lds_red[wave][1] = s1; }

@@ -1365,6 +1365,8 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     X(2, 5, PW_IO_X | PW_IO_X2) X(2, 0, PW_IO_X | PW_IO_X2)
     X(1, 1, PW_IO_X | PW_IO_Y)            // ... and the project output a3 / its gradient da3
     X(0, 4, PW_IO_X | PW_IO_R | PW_IO_Y)
+    X(0, 2, PW_IO_Y)                      // eval-mode expand: h1 = relu6(bn1(W1 x)) stored as bf16 (inference, block executor)
+    X(0, 3, PW_IO_X)                      // eval-mode project: y = bn3(W3 h2) (+ x), h2 bf16 in
 #undef X
     return false;
 }

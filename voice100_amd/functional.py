@@ -452,7 +452,16 @@ def inverted_residual_eval_cached(blk, x, precision: Optional[str] = None):
         cache = torch.empty(N.helper("v100_ir_eval_cache_bytes", shape), dtype=torch.uint8, device=x.device)
         N.call("v100_ir_eval_prep", shape, _ptr_table(tuple(t.detach() for t in params) + (cache,)))
         blk._eval_cache, blk._eval_key = cache, key
-    h1, h2, y = _f32(B, hid, T, like=x), _f32(B, hid, T2, like=x), _f32(B, cout, T2, like=x)
+    y = _f32(B, cout, T2, like=x)
+    if bf16 == 1 and _ACT16 and N.helper("v100_ir_act16_supported", shape):
+        # precision "bf16": the two hidden tensors (4x the block's width, values in [0, 6] after BatchNorm + ReLU6) stored as bf16 with
+        # pitched rows -- half the bytes of the big streams of all three kernels (the GEMMs round them to bf16 as operands anyway)
+        shape[10] = 1
+        pitch = (T + 7) & ~7
+        h1 = torch.empty((B, hid, pitch), dtype=torch.bfloat16, device=x.device)
+        h2 = torch.empty((B, hid, pitch), dtype=torch.bfloat16, device=x.device)
+    else:
+        h1, h2 = _f32(B, hid, T, like=x), _f32(B, hid, T2, like=x)
     N.call("v100_ir_fwd_eval", shape, _ptr_table((x, w1.detach(), wd.detach(), w3.detach(), blk._eval_cache, h1, h2, y)))
     return y
 
