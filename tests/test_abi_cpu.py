@@ -118,3 +118,41 @@ def test_augment_draw_consumes_rng_like_the_reference():
             assert d.noise[:3] == (-5.0 + 5.0 * random.random(), -5.0 + 5.0 * random.random(), 5.0 * random.random())
         assert d.mix == (random.random() < 0.2)
         assert after == random.random()                       # same number of draws consumed
+
+
+def test_stack_plan_layout(lib):
+    """v100_ir_stack_plan (host arithmetic only): the encoder's nine blocks at the benchmark shape and at a time-stretched odd length --
+    every tensor 256-byte aligned inside the blob, no two overlapping, sized for its storage format, and the totals consistent with
+    the per-block helpers."""
+    from voice100_amd import functional as F_
+    cfgs = ((64, 256, 256, 11, 2, 0), (256, 1024, 256, 19, 1, 1), (256, 1024, 256, 27, 1, 1), (256, 1024, 256, 35, 1, 1),
+            (256, 1024, 512, 51, 1, 0), (512, 2048, 512, 59, 1, 1), (512, 2048, 512, 67, 1, 1), (512, 2048, 512, 75, 1, 1),
+            (512, 2048, 512, 83, 1, 0))
+    for T in (1024, 759):
+        for bf16, level in ((0, 0), (1, 0), (1, 2), (1, 4)):
+            desc, blocks, totals = F_._stack_plan(cfgs, 32, T, bf16, level, False)
+            B, t = 32, T
+            spans = []
+            for (cin, hid, cout, k, s, res), o in zip(cfgs, blocks):
+                t2 = (t + 2 * ((k - 1) // 2) - k) // s + 1
+                assert o[7] == t2
+                act = bf16 == 1 and level and s == 1
+                P, P2 = (t + 7) & ~7, (t2 + 7) & ~7
+                sizes = {0: B * hid * (P * 2 if act else t * 4), 1: B * hid * (P * 2 if act else t2 * 4),
+                         2: B * cout * (P * 2 if (act and level >= 3) else t2 * 4), 3: B * cout * t2 * 4,
+                         5: 12 * max(hid, cout) * 4}
+                if o[4] >= 0:
+                    sizes[4] = B * cout * P2 * 2
+                for j, n in sizes.items():
+                    assert o[j] % 256 == 0 and o[j] >= 0
+                    spans.append((o[j], o[j] + n))
+                spans.append((o[6], o[6] + 1))
+                assert (o[4] >= 0) == (bf16 == 1 and level >= 4 and (cin, k) != (512, 83))      # every block but the last writes a shadow
+                t = t2
+            spans.sort()
+            for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                assert a1 <= b0, (T, bf16, level, a0, a1, b0, b1)
+            assert totals[0] >= spans[-1][1] and totals[1] > 0
+            assert totals[2] == sum(hid * cin + 2 * hid + hid * k + 2 * hid + cout * hid + 2 * cout for cin, hid, cout, k, _, _ in cfgs)
+    bad = (ctypes.c_int * 12)(1, 32, 0, 1, 4, 0, 64, 256, 256, 11, 2, 0)
+    assert lib.v100_ir_stack_plan(bad, (ctypes.c_longlong * 14)()) < 0
