@@ -212,7 +212,8 @@ def test_chan_passes_io_vs_float64(cuda, B, C, T):
 
 
 @pytest.mark.parametrize("B,C,T,K", [(2, 8, 48, 19), (3, 6, 133, 83), (2, 4, 700, 51), (2, 4, 1100, 35), (32, 64, 512, 59), (32, 64, 512, 27),
-                                     (3, 8, 763, 83), (5, 4, 768, 19), (2, 4, 520, 59), (6, 4, 513, 67), (9, 3, 379, 75)])
+                                     (3, 8, 763, 83), (5, 4, 768, 19), (2, 4, 520, 59), (6, 4, 513, 67), (9, 3, 379, 75),
+                                     (1, 1, 5, 7), (2, 3, 8, 5), (4, 2, 1, 5), (7, 5, 257, 11), (33, 2, 40, 17)])      # tiny / degenerate rows, B > 32
 def test_dwconv_io_vs_float64(cuda, B, C, T, K):
     """Depthwise forward / fused backward with 16-bit storage (asr.py:49 and its autograd), elementwise against float64 on the
     operands as the kernels define them (transformed data operand rounded once to bf16, fp32 taps)."""
