@@ -55,6 +55,8 @@ def main():
         cases = [
             ("expand fwd   <0,1,Y>", lambda: N.call("v100_pw_gemm_io", W1, x, None, None, None, None, 0, a1, None, None, None, 1, st_h, B, hid, C, T, 4),
              B * T * (4 * C + 2 * hid)),
+            ("expand fwd   <0,1,X|Y>", lambda: N.call("v100_pw_gemm_io", W1, a3, None, None, None, None, 0, a1, None, None, None, 1, st_h, B, hid, C, T, 5),
+             B * T * (2 * C + 2 * hid)),
             ("project fwd  <1,1,X|Y>", lambda: N.call("v100_pw_gemm_io", W2, a2, None, ch[0], ch[1], None, 1, a3, None, None, None, 1, st_c, B, C, hid, T, 5),
              B * T * (2 * hid + 2 * C)),
             ("project bwdd <0,4,X|Y|R>", lambda: N.call("v100_pw_gemm_io", W2t, da3, None, None, None, None, 0, dz2, ch[0], ch[1], a2, 4, st_h, B, hid, C, T, 13),

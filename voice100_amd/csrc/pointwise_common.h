@@ -43,6 +43,19 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #ifndef PW_WG_WIDE
 #define PW_WG_WIDE 1         /* 256 x 128 backward-weight tiles for the act16 combinations (0: the 128 x 128 kernel everywhere) */
 #endif
+#ifndef PW_WS
+#define PW_WS 6              /* wave-specialised NN GEMM (pw_gemm_bf16_ws_kernel): bit x_mode set = that prologue family uses it (7 = all;
+                                6 = the two with a transform on load, whose K is the hidden width: project forward, expand backward-data) */
+#endif
+#ifndef PW_WS_PRIO
+#define PW_WS_PRIO 0         /* s_setprio experiment: 1 / 2 staging waves at priority 1 / 3, 3 matrix waves at priority 1 */
+#endif
+#ifndef PW_WS_ABL
+#define PW_WS_ABL 0
+#endif
+#ifndef PW_WS_MINK
+#define PW_WS_MINK 1024      /* ... at K >= this (shorter K: the persistent / 128-row forms of the 8-wave kernel win, profiles/r03_ws_gemm.txt) */
+#endif
 #ifndef PW_BM128_MAXK
 #define PW_BM128_MAXK 0      /* A/B knob: 128-row tiles (two workgroups per CU) for GEMMs with K <= this */
 #endif
