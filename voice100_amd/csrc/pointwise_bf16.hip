@@ -1460,6 +1460,267 @@ __global__ __launch_bounds__(512) void pw_wgrad_bf16_wide_kernel(WgParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wave-specialised backward-weight (round 3): pw_gemm_bf16_ws_kernel's division of labour on pw_wgrad_bf16_wide_kernel's tile.
+// Twelve waves: waves 0-7 (64 x 64 each of the GR x XR tile) copy the PLAIN operand's 256 x 64 bf16 tile to LDS as loaded (4 pieces
+// per lane, two register stages, one ds_write_b128 + the request two steps ahead behind each k-step's MFMAs) and run the MFMAs;
+// waves 8-11 stage the TRANSFORMED operand's 128 x 64 tile (BatchNorm-backward affine of two bf16 tensors, or BatchNorm + ReLU6):
+// NSQ register stages of loads, transform, bf16 pack, 4 ds_write_b128 per lane and step.  One barrier per step.  Full tiles only
+// (M % GR == 0, K % XR == 0); TAIL: T % 64 != 0, contraction indices past T are zeroed in BOTH operands (masks on the plain one).
+template <int GM, int XM, bool TAIL, int IO, int GR, int XR, int NSW>
+__global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgParams p) {
+    static_assert((GM == PW_X_NONE) != (XM == PW_X_NONE), "one plain operand (256 rows), one transformed (128 rows)");
+    static_assert((IO & WG_IO_G) && (IO & WG_IO_X) && (GM != PW_X_AFFINE2 || (IO & WG_IO_G2)), "bf16-stored operands only");
+    constexpr bool PG = GM == PW_X_NONE;                    // the plain operand is G
+    static_assert((PG ? GR : XR) == 256 && (PG ? XR : GR) == 128, "tile shape");
+    constexpr int QM = PG ? XM : GM;                        // the transform
+    constexpr int NX = XR / 64;
+    static_assert(NSW == 4 || NSW == 8, "staging waves: one or two per SIMD");
+    constexpr int NSQ = (QM == PW_X_AFFINE2 && NSW == 4) ? 3 : 4;    // register stages of the transformed operand
+    constexpr int NQP = 16 / NSW;                           // 16-byte pieces per staging lane and step
+    constexpr int QRS = 8 * NSW;                            // rows between a lane's pieces
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][GR * 128];   // [m][t] bf16
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][XR * 128];   // [k][t] bf16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int s, mt, ktile;
+    wg_work(p, s, mt, ktile);
+    const int m0 = mt * GR, n0 = ktile * XR;
+    const int M = p.M, K = p.K, T = p.T;
+    const int bper = (p.B + p.S - 1) / p.S;
+    const int b_lo = s * bper, b_hi = min(p.B, b_lo + bper);
+    const int P16 = pw_pitch16(T);
+    const int nt = (T + BF_BK - 1) / BF_BK;
+    const int nsteps = (b_hi > b_lo) ? (b_hi - b_lo) * nt : 0;
+    // step -> (batch element, t offset); steps past the end are clamped to the last (an unconditional, redundant load: a
+    // conditional one would make hipcc wait for the YOUNGER stage at the join)
+    auto step_bt = [&](int step, int& b, int& t0) {
+        const int q = min(step, nsteps - 1);
+        const int bi = q / nt;
+        b = b_lo + bi;
+        t0 = (q - bi * nt) * BF_BK;
+    };
+    // contraction indices t0 + 8 ch + e >= T of a 16-byte piece -> zero
+    auto tail_mask = [&](u32x4 v, int tb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] &= (tb + 2 * j < T ? 0xffffu : 0u) | (tb + 2 * j + 1 < T ? 0xffff0000u : 0u);
+        return v;
+    };
+    if (nsteps == 0) {                                      // (no work for this split: the partial tile is zeros)
+        if (wave < 8) {
+            const int wm = wave / NX, wn = wave % NX, col = lane & 31, half = lane >> 5;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, k = n0 + wn * 64 + j * 32 + col;
+                        if (m < M && k < K) p.partial[((size_t)s * M + m) * K + k] = 0.f;
+                    }
+        }
+        return;
+    }
+
+    if (wave >= 8) {
+        // ------------------------------------------------ staging waves: the transformed operand ------------------------------------------------
+        const int pt = tid - 512;
+        const int qrow = pt >> 3, ch = pt & 7;              // piece i: row qrow + QRS i (same swizzle key), chunk ch
+        const int row0 = PG ? n0 : m0, rows = PG ? K : M;
+        const float* q1 = PG ? p.X : p.G;
+        const float* q2 = PG ? p.X : p.G2;
+        const float* pa = PG ? p.xa : p.ga;
+        const float* pb = PG ? p.xb : p.gb;
+        unsigned char (*Qs)[128 * 128] = PG ? reinterpret_cast<unsigned char (*)[128 * 128]>(Bs) : reinterpret_cast<unsigned char (*)[128 * 128]>(As);
+        float ca[NQP], cb[NQP], cc[NQP];
+#pragma unroll
+        for (int i = 0; i < NQP; ++i) {
+            const int r = row0 + qrow + QRS * i;
+            ca[i] = pa[r]; cb[i] = pb[r];
+            cc[i] = QM == PW_X_AFFINE2 ? p.gc[r] : 0.f;
+        }
+        const int voQ = ((row0 + qrow) * P16 + ch * 8) * 2;
+        const int stepQ = QRS * P16 * 2;
+        const int ldsQ = bf_off(qrow, ch);
+        u32x4 rq[NSQ][NQP], rq2[NSQ][QM == PW_X_AFFINE2 ? NQP : 1];
+#define WS_SB() __builtin_amdgcn_sched_barrier(0)
+        auto load_q = [&](int step, auto stg, int i) {
+            constexpr int SG = decltype(stg)::value;
+            int b, t0;
+            step_bt(step, b, t0);
+            const __amdgpu_buffer_rsrc_t r1 = make_rsrc(reinterpret_cast<const u16*>(q1) + (size_t)b * rows * P16, (unsigned)rows * P16 * 2u);
+            rq[SG][i] = __builtin_amdgcn_raw_buffer_load_b128(r1, voQ, t0 * 2 + i * stepQ, 0);
+            if constexpr (QM == PW_X_AFFINE2) {
+                const __amdgpu_buffer_rsrc_t r2 = make_rsrc(reinterpret_cast<const u16*>(q2) + (size_t)b * rows * P16, (unsigned)rows * P16 * 2u);
+                rq2[SG][i] = __builtin_amdgcn_raw_buffer_load_b128(r2, voQ, t0 * 2 + i * stepQ, 0);
+            }
+        };
+        // step st (registers of stage SG) -> LDS slot st & 1; step st + NSQ requested into the same registers
+        auto stage = [&](int st, auto stg) {
+            constexpr int SG = decltype(stg)::value;
+            unsigned char* Qd = Qs[st & 1] + ldsQ;
+            int tb = 0;
+            bool tail = false;
+            if constexpr (TAIL) {
+                int b, t0;
+                step_bt(st, b, t0);
+                tail = t0 + BF_BK > T;
+                tb = t0 + ch * 8;
+            }
+            u32x4 o[NQP];
+#pragma unroll
+            for (int i = 0; i < NQP; ++i) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = pw_bf16_at(rq[SG][i], e);
+                    if constexpr (QM == PW_X_AFFINE2) v[e] = fmaf(x, ca[i], fmaf(pw_bf16_at(rq2[SG][i], e), cb[i], cc[i]));
+                    else v[e] = relu6f(fmaf(x, ca[i], cb[i]));
+                }
+                o[i][0] = pack_bf16(v[0], v[1]); o[i][1] = pack_bf16(v[2], v[3]); o[i][2] = pack_bf16(v[4], v[5]); o[i][3] = pack_bf16(v[6], v[7]);
+                if constexpr (TAIL) { if (tail) o[i] = tail_mask(o[i], tb); }
+            }
+            WS_SB();
+#pragma unroll
+            for (int i = 0; i < NQP; ++i) {                 // stores and the next requests interleaved
+                *reinterpret_cast<u32x4*>(Qd + i * (QRS * 128)) = o[i];
+                load_q(st + NSQ, stg, i);
+                WS_SB();
+            }
+        };
+        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+#pragma unroll
+        for (int i = 0; i < NQP; ++i) load_q(0, S0{}, i);
+        WS_SB();
+#pragma unroll
+        for (int i = 0; i < NQP; ++i) load_q(1, S1{}, i);
+        WS_SB();
+#pragma unroll
+        for (int i = 0; i < NQP; ++i) load_q(2, S2{}, i);
+        WS_SB();
+        if constexpr (NSQ == 4) {
+#pragma unroll
+            for (int i = 0; i < NQP; ++i) load_q(3, S3{}, i);
+            WS_SB();
+        }
+        stage(0, S0{});
+        __syncthreads();                                   // step 0 is in LDS
+        // NSQ steps per trip with EXITS, not skipped bodies (pw_gemm_bf16_ws_kernel); the stores are unconditional (a step past the
+        // last re-stages the last tile into the slot nobody reads)
+        for (int st = 0;; st += NSQ) {
+            if (st >= nsteps) break;
+            stage(st + 1, S1{});
+            __syncthreads();
+            if (st + 1 >= nsteps) break;
+            stage(st + 2, S2{});
+            __syncthreads();
+            if (st + 2 >= nsteps) break;
+            if constexpr (NSQ == 4) {
+                stage(st + 3, S3{});
+                __syncthreads();
+                if (st + 3 >= nsteps) break;
+            }
+            stage(st + NSQ, S0{});
+            __syncthreads();
+        }
+#undef WS_SB
+        return;
+    }
+
+    // ---------------------------------------------------- matrix waves: the plain operand + MFMA ----------------------------------------------------
+    const int wm = wave / NX, wn = wave % NX;
+    const int prow = tid >> 3, pch = tid & 7;               // piece i: row prow + 64 i (same swizzle key), chunk pch
+    const int prow0 = PG ? m0 : n0, prows = PG ? M : K;
+    const float* pp = PG ? p.G : p.X;
+    unsigned char (*Ps)[256 * 128] = PG ? reinterpret_cast<unsigned char (*)[256 * 128]>(As) : reinterpret_cast<unsigned char (*)[256 * 128]>(Bs);
+    const int voP = ((prow0 + prow) * P16 + pch * 8) * 2;
+    const int stepP = 64 * P16 * 2;
+    const int ldsP = bf_off(prow, pch);
+    u32x4 rp[2][4];
+    auto load_p = [&](int step, auto stg, int i) {
+        constexpr int SG = decltype(stg)::value;
+        int b, t0;
+        step_bt(step, b, t0);
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(reinterpret_cast<const u16*>(pp) + (size_t)b * prows * P16, (unsigned)prows * P16 * 2u);
+        rp[SG][i] = __builtin_amdgcn_raw_buffer_load_b128(r, voP, t0 * 2 + i * stepP, 0);
+    };
+    auto piece_out = [&](int step, u32x4 v) {
+        if constexpr (TAIL) {
+            int b, t0;
+            step_bt(step, b, t0);
+            if (t0 + BF_BK > T) v = tail_mask(v, t0 + pch * 8);
+        }
+        return v;
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int sw = (lr >> 1) & 7;
+    const int rdA0 = (wm * 64 + lr) * 128, rdB0 = (wn * 64 + lr) * 128;
+    // step st: fragments from slot st & 1; the plain tile of step st + 1 (registers of stage SG) -> slot (st + 1) & 1, step st + 3 requested
+    auto block = [&](int st, auto stg) {
+        constexpr int SG = decltype(stg)::value;
+        const unsigned char* Ab = As[st & 1];
+        const unsigned char* Bb = Bs[st & 1];
+        unsigned char* Pd = Ps[(st + 1) & 1] + ldsP;
+#pragma unroll
+        for (int ks = 0; ks < BF_BK / 16; ++ks) {
+            const int co = ((ks * 2 + lh) ^ sw) << 4;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + co);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + 32 * 128 + co);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + co);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + 32 * 128 + co);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            *reinterpret_cast<u32x4*>(Pd + ks * 8192) = piece_out(st + 1, rp[SG][ks]);
+            load_p(st + 3, stg, ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_p(0, S0{}, i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_p(1, S1{}, i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { *reinterpret_cast<u32x4*>(Ps[0] + ldsP + i * 8192) = piece_out(0, rp[0][i]); load_p(2, S0{}, i); }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                       // step 0 is in LDS
+    int st = 0;
+    for (; st + 1 < nsteps; st += 2) {                     // pairs, then the odd step
+        block(st, S1{});
+        __syncthreads();
+        block(st + 1, S0{});
+        __syncthreads();
+    }
+    if (st < nsteps) {
+        block(st, S1{});
+        __syncthreads();
+    }
+    const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int k = n0 + wn * 64 + j * 32 + col;
+                if (m < M && k < K) p.partial[((size_t)s * M + m) * K + k] = acc[i][j][r];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dispatch: fast kernels (modes fixed at compile time, aligned K) for the combinations the networks
 // use; everything else goes to the generic instantiation (run-time modes, scalar-safe loads).
 #define PW_NN_COMBOS(X) X(0, 0) X(0, 1) X(1, 1) X(0, 2) X(0, 3) X(0, 4) X(2, 0) X(2, 5)
@@ -1643,6 +1904,24 @@ bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
         else V100_GGL((pw_wgrad_bf16_wide_kernel<GM, XM, true, (IOV), GR, XR, NS>), gw, dim3(512), 0, st, pw);                \
         return true;                                                                                                                \
     }
+#if PW_WG_WS
+    // wave-specialised form: full tiles, every operand bf16-stored
+#define XS(GM, XM, IOV, GR, XR, NSW)                                                                                                  \
+    if (p.g_mode == GM && p.x_mode == XM && p.io16 == (IOV) && p.M % GR == 0 && p.K % XR == 0) {                                    \
+        WgParams pw = p;                                                                                                            \
+        pw.n_mtiles = p.M / GR;                                                                                                     \
+        pw.n_ktiles = p.K / XR;                                                                                                     \
+        const dim3 gw((unsigned)(pw.n_mtiles * pw.n_ktiles * p.S));                                                                 \
+        if (p.T % BF_BK == 0) V100_GGL((pw_wgrad_bf16_ws_kernel<GM, XM, false, (IOV), GR, XR, NSW>), gw, dim3(512 + 64 * NSW), 0, st, pw); \
+        else V100_GGL((pw_wgrad_bf16_ws_kernel<GM, XM, true, (IOV), GR, XR, NSW>), gw, dim3(512 + 64 * NSW), 0, st, pw);        \
+        return true;                                                                                                                \
+    }
+    // (measured, profiles/r03_ws_gemm.txt: the project gradient -13 % at 512 channels; the expand gradient, whose staging waves
+    //  transform TWO tensors, +-0 with four or eight staging waves -- it keeps the 8-wave kernel)
+    if constexpr (PW_WG_WS & 2) { XS(2, 0, WG_IO_G | WG_IO_G2 | WG_IO_X, 128, 256, (PW_WG_WS & 8 ? 8 : 4)) }
+    if constexpr (PW_WG_WS & 1) { XS(0, 1, WG_IO_G | WG_IO_X, 256, 128, (PW_WG_WS & 4 ? 8 : 4)) }
+#undef XS
+#endif
     XW(2, 0, WG_IO_G | WG_IO_G2 | WG_IO_X, 128, 256, 2)      // ... X = bf16 shadow of the block input: copied as loaded, 32 registers a stage
     XW(2, 0, WG_IO_G | WG_IO_G2, 128, 256, PW_WG_EXPAND_NST)      // expand: G = affine2(dz1, a1), X = block input (plain fp32)
     XW(0, 1, WG_IO_G | WG_IO_X, 256, 128, 2)       // project: G = da3 (plain bf16, copied), X = relu6(bn2(a2))
