@@ -71,7 +71,10 @@ def affine2(x, x2, a, b, c):         # fmaf(x, a, fmaf(x2, b, c))
 
 
 GEMM_SHAPES = [(2, 32, 8, 48), (3, 200, 64, 100), (2, 72, 256, 133), (1, 512, 128, 700),
-               (32, 1024, 256, 512), (8, 2048, 512, 512), (8, 512, 2048, 512)]      # the last three: the benchmark's block shapes
+               (32, 1024, 256, 512), (8, 2048, 512, 512), (8, 512, 2048, 512),      # these three: the benchmark's block shapes
+               # the wave-specialised kernel (K >= 1024 with a transform on load, M % 256 == 0): odd / even k-tile counts that are
+               # not multiples of its 3 or 4 register stages, a t-tile tail, a row pitch that is not T, one m-tile, K at its cap
+               (2, 256, 1088, 200), (3, 512, 1024, 133), (1, 768, 1152, 64), (2, 256, 2048, 90), (1, 256, 1216, 128)]
 
 
 @pytest.mark.parametrize("B,M,K,T", GEMM_SHAPES)
@@ -142,7 +145,10 @@ def test_pw_gemm_io_vs_float64(cuda, B, M, K, T):
 
 
 @pytest.mark.parametrize("B,M,K,T", [(2, 32, 8, 48), (4, 200, 64, 100), (3, 64, 256, 133), (3, 300, 260, 133), (5, 640, 384, 77),
-                                     (32, 1024, 256, 512), (16, 2048, 512, 512), (16, 512, 2048, 512)])
+                                     (32, 1024, 256, 512), (16, 2048, 512, 512), (16, 512, 2048, 512),
+                                     # the wave-specialised project gradient (M % 256 == 0, K % 128 == 0): T % 64 != 0 with a
+                                     # pitch that is not T, a single step per split, odd step counts, more splits than steps allow
+                                     (3, 256, 384, 133), (5, 256, 128, 77), (2, 512, 256, 64), (7, 256, 1024, 192), (1, 256, 128, 40)])
 def test_pw_wgrad_io_vs_float64(cuda, B, M, K, T):
     N = _native()
     g = torch.Generator().manual_seed(M * 3 + T + K)
