@@ -244,6 +244,9 @@ __device__ __forceinline__ float half_wave_sum_dpp(float v) {
 #ifndef PW_EPI_CP_Y
 #define PW_EPI_CP_Y 0
 #endif
+#ifndef PW_EPI_STATS_LDS
+#define PW_EPI_STATS_LDS 1    /* lean epilogue: BatchNorm partial sums reduced through the parked tile's LDS rows, not by DPP per pass */
+#endif
 #ifndef PW_EPI_CP_R
 #define PW_EPI_CP_R 0
 #endif
@@ -375,14 +378,39 @@ struct PwEpilogueFull {
                 }
             }
             if constexpr (do_stats) {
-                sv0[pass] = half_wave_sum_dpp(s0);
-                sv1[pass] = half_wave_sum_dpp(s1);
+                if constexpr (PW_EPI_STATS_LDS) {
+                    // this lane's partial sums -> the (consumed) first two floats of its own slot in the row just read
+                    *reinterpret_cast<float2*>(const_cast<float*>(crow) + pass * RPP * 128) = make_float2(s0, s1);
+                } else {
+                    sv0[pass] = half_wave_sum_dpp(s0);
+                    sv1[pass] = half_wave_sum_dpp(s1);
+                }
             }
         }
         if constexpr (do_stats) {
-            if (col == 31) {
-                const size_t part = (size_t)b * p.n_ttiles + tt;
-                float* sp = p.stats + (part * p.M + mrow) * 2;
+            const size_t part = (size_t)b * p.n_ttiles + tt;
+            float* sp = p.stats + (part * p.M + mrow) * 2;
+            if constexpr (PW_EPI_STATS_LDS) {
+                // Row sums WITHOUT a cross-lane reduction per pass (14 DPP instructions a pass = 224 of a wave's ~800 epilogue
+                // instructions, and the epilogue is bound by VALU issue): the 32 lanes of a half-wave parked their partials in the
+                // half-wave's own 16 rows; now lane l sums 16 of the 32 partials of row (l & 15) -- a rotated start per row keeps
+                // the 16 rows' reads on 16 different bank groups --, the two halves meet with one exchange, lanes 0-15 store one
+                // row's statistics each.  Fixed order: deterministic.
+                const int c = col & 15, base = col & 16;
+                const float* rp = ct + (wave * 2 + half + c * RPP) * 128;
+                float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float2 v2 = *reinterpret_cast<const float2*>(rp + (base + ((i + c) & 15)) * 4);
+                    t0 += v2.x; t1 += v2.y;
+                }
+                t0 += __shfl_xor(t0, 16, 64);
+                t1 += __shfl_xor(t1, 16, 64);
+                if (col < 16) {
+                    const epi_u32x2 o2 = {__builtin_bit_cast(unsigned, t0), __builtin_bit_cast(unsigned, t1)};
+                    *reinterpret_cast<epi_u32x2*>(sp + c * RPP * 2) = o2;
+                }
+            } else if (col == 31) {
 #pragma unroll
                 for (int pass = 0; pass < 16; ++pass) {
                     const epi_u32x2 o2 = {__builtin_bit_cast(unsigned, sv0[pass]), __builtin_bit_cast(unsigned, sv1[pass])};
