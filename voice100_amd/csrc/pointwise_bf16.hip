@@ -293,6 +293,24 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         constexpr int q = decltype(slc)::value;
         if constexpr (PW_ABLATE & 32) return;          // timing-only: no transform / LDS stores
         *reinterpret_cast<u32x4*>(As + buf * A_BYTES + ldsA[q]) = ra[SG][q];
+        if constexpr (XM == PW_X_NONE && XB && !F16) {
+            // plain bf16 X: the [k][t] -> [t][k] transposition is a byte shuffle of the loaded words (column q of rows 2j, 2j + 1
+            // -> word j), one v_perm_b32 per two elements instead of unpack + unpack + v_cvt_pk
+            constexpr unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;
+            unsigned char* dst = Bs + buf * (128 * 128) + ldsB[q];
+            if constexpr (KPT == 8) {
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_perm(rb[SG][2 * j + 1][q >> 1], rb[SG][2 * j][q >> 1], sel);
+                *reinterpret_cast<u32x4*>(dst) = o;
+            } else {
+                uint2 o;
+                o.x = __builtin_amdgcn_perm(rb[SG][1][q >> 1], rb[SG][0][q >> 1], sel);
+                o.y = __builtin_amdgcn_perm(rb[SG][3][q >> 1], rb[SG][2][q >> 1], sel);
+                *reinterpret_cast<uint2*>(dst) = o;
+            }
+            return;
+        }
         float v[KPT];
 #pragma unroll
         for (int e = 0; e < KPT; ++e) {
