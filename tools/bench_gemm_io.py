@@ -65,6 +65,8 @@ def main():
              B * T * (4 * hid + 8 * C)),
             ("expand wgrad <2,0,G|G2>", lambda: N.call("v100_pw_wgrad_io", dz1, a1, ch[0], ch[1], ch[2], 2, x, None, None, 0, p1, dW1, S1, B, hid, C, T, 3),
              B * T * (4 * hid + 4 * C)),
+            ("expand wgrad <2,0,G|G2|X>", lambda: N.call("v100_pw_wgrad_io", dz1, a1, ch[0], ch[1], ch[2], 2, a3, None, None, 0, p1, dW1, S1, B, hid, C, T, 7),
+             B * T * (4 * hid + 2 * C)),
             ("project wgrad<0,1,G|X>", lambda: N.call("v100_pw_wgrad_io", da3, None, None, None, None, 0, a2, ch[0], ch[1], 1, p2, dW2, S2, B, C, hid, T, 5),
              B * T * (2 * hid + 2 * C)),
         ]

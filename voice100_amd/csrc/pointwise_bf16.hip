@@ -1513,6 +1513,7 @@ __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgPara
     // conditional one would make hipcc wait for the YOUNGER stage at the join)
     auto step_bt = [&](int step, int& b, int& t0) {
         const int q = min(step, nsteps - 1);
+        (void)q;
         const int bi = q / nt;
         b = b_lo + bi;
         t0 = (q - bi * nt) * BF_BK;
@@ -1564,7 +1565,7 @@ __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgPara
         auto load_q = [&](int step, auto stg, int i) {
             constexpr int SG = decltype(stg)::value;
             int b, t0;
-            step_bt(step, b, t0);
+            step_bt((PW_WG_ABL & 2) ? 0 : step, b, t0);           // (timing-only bit 1: every step re-reads the first tile)
             const __amdgpu_buffer_rsrc_t r1 = make_rsrc(reinterpret_cast<const u16*>(q1) + (size_t)b * rows * P16, (unsigned)rows * P16 * 2u);
             rq[SG][i] = __builtin_amdgcn_raw_buffer_load_b128(r1, voQ, t0 * 2 + i * stepQ, 0);
             if constexpr (QM == PW_X_AFFINE2) {
@@ -1585,8 +1586,22 @@ __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgPara
                 tb = t0 + ch * 8;
             }
             u32x4 o[NQP];
+            if constexpr (PW_WG_ABL & 8) {                  // timing-only: loads kept, nothing else
+#pragma unroll
+                for (int i = 0; i < NQP; ++i) {
+                    asm volatile("" :: "v"(rq[SG][i]));
+                    if constexpr (QM == PW_X_AFFINE2) asm volatile("" :: "v"(rq2[SG][i]));
+                    load_q(st + NSQ, stg, i);
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NQP; ++i) {
+                if constexpr (PW_WG_ABL & 4) {              // timing-only: raw copy, no transform
+                    o[i] = rq[SG][i];
+                    if constexpr (QM == PW_X_AFFINE2) o[i][0] ^= rq2[SG][i][0];
+                    continue;
+                }
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -1658,7 +1673,7 @@ __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgPara
     auto load_p = [&](int step, auto stg, int i) {
         constexpr int SG = decltype(stg)::value;
         int b, t0;
-        step_bt(step, b, t0);
+        step_bt((PW_WG_ABL & 1) ? 0 : step, b, t0);               // (timing-only bit 0)
         const __amdgpu_buffer_rsrc_t r = make_rsrc(reinterpret_cast<const u16*>(pp) + (size_t)b * prows * P16, (unsigned)prows * P16 * 2u);
         rp[SG][i] = __builtin_amdgcn_raw_buffer_load_b128(r, voP, t0 * 2 + i * stepP, 0);
     };
@@ -1693,10 +1708,12 @@ __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgPara
             const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + 32 * 128 + co);
             const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + co);
             const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + 32 * 128 + co);
+            if constexpr (!(PW_WG_ABL & 16)) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             *reinterpret_cast<u32x4*>(Pd + ks * 8192) = piece_out(st + 1, rp[SG][ks]);
             load_p(st + 3, stg, ks);
@@ -1934,8 +1951,8 @@ bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
         else V100_GGL((pw_wgrad_bf16_ws_kernel<GM, XM, true, (IOV), GR, XR, NSW>), gw, dim3(512 + 64 * NSW), 0, st, pw);        \
         return true;                                                                                                                \
     }
-    // (measured, profiles/r03_ws_gemm.txt: the project gradient -13 % at 512 channels; the expand gradient, whose staging waves
-    //  transform TWO tensors, +-0 with four or eight staging waves -- it keeps the 8-wave kernel)
+    // (measured, profiles/r03_ws_gemm.txt: the project gradient -13 % at 512 channels, the expand gradient -12 %; eight staging
+    //  waves instead of four: slower)
     if constexpr (PW_WG_WS & 2) { XS(2, 0, WG_IO_G | WG_IO_G2 | WG_IO_X, 128, 256, (PW_WG_WS & 8 ? 8 : 4)) }
     if constexpr (PW_WG_WS & 1) { XS(0, 1, WG_IO_G | WG_IO_X, 256, 128, (PW_WG_WS & 4 ? 8 : 4)) }
 #undef XS

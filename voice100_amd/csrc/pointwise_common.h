@@ -47,8 +47,12 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #define PW_WS 6              /* wave-specialised NN GEMM (pw_gemm_bf16_ws_kernel): bit x_mode set = that prologue family uses it (7 = all;
                                 6 = the two with a transform on load, whose K is the hidden width: project forward, expand backward-data) */
 #endif
+#ifndef PW_WG_ABL
+#define PW_WG_ABL 0          /* timing-only builds of pw_wgrad_bf16_ws_kernel: 1 / 2 every plain / transformed load re-reads the first tile, 4 no
+                                transform, 8 staging waves: loads only, 16 no MFMA */
+#endif
 #ifndef PW_WG_WS
-#define PW_WG_WS 1           /* wave-specialised backward-weight kernel (pw_wgrad_bf16_ws_kernel), all-bf16 act16 combinations: bit 0 the project
+#define PW_WG_WS 3           /* wave-specialised backward-weight kernel (pw_wgrad_bf16_ws_kernel), all-bf16 act16 combinations: bit 0 the project
                                 gradient, bit 1 the expand gradient; bits 2 / 3: eight staging waves instead of four for the former / latter */
 #endif
 #ifndef PW_WS_PRIO
