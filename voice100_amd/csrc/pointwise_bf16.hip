@@ -1879,6 +1879,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     XS(2, 5, PW_IO_X | PW_IO_X2) XS(2, 0, PW_IO_X | PW_IO_X2)           // expand backward-data
     XS(0, 4, PW_IO_X | PW_IO_R | PW_IO_Y)                               // project backward-data
     XS(0, 1, PW_IO_X | PW_IO_Y)                                         // expand forward on the bf16 shadow
+    XS(0, 3, PW_IO_X)                                                   // eval-mode project (K = the hidden width): y = bn3(W3 h2) (+ x)
 #undef XS
 #endif
 #if PW_PERSIST

@@ -44,8 +44,9 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #define PW_WG_WIDE 1         /* 256 x 128 backward-weight tiles for the act16 combinations (0: the 128 x 128 kernel everywhere) */
 #endif
 #ifndef PW_WS
-#define PW_WS 6              /* wave-specialised NN GEMM (pw_gemm_bf16_ws_kernel): bit x_mode set = that prologue family uses it (7 = all;
-                                6 = the two with a transform on load, whose K is the hidden width: project forward, expand backward-data) */
+#define PW_WS 7              /* wave-specialised NN GEMM (pw_gemm_bf16_ws_kernel): bit x_mode set = that prologue family uses it.  With
+                                PW_WS_MINK = 1024 that is: project forward and expand backward-data (transform on load, K = the hidden
+                                width) in training, the eval-mode project GEMM (plain bf16 h2, K = the hidden width) in inference */
 #endif
 #ifndef PW_WG_ABL
 #define PW_WG_ABL 0          /* timing-only builds of pw_wgrad_bf16_ws_kernel: 1 / 2 every plain / transformed load re-reads the first tile, 4 no
