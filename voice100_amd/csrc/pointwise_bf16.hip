@@ -1534,7 +1534,7 @@ __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgPara
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, k = n0 + wn * 64 + j * 32 + col;
-                        if (m < M && k < K) p.partial[((size_t)s * M + m) * K + k] = 0.f;
+                        p.partial[((size_t)s * M + m) * K + k] = 0.f;
                     }
         }
         return;
@@ -1751,7 +1751,7 @@ __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgPara
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int k = n0 + wn * 64 + j * 32 + col;
-                if (m < M && k < K) p.partial[((size_t)s * M + m) * K + k] = acc[i][j][r];
+                p.partial[((size_t)s * M + m) * K + k] = acc[i][j][r];      // (full tiles only: no bounds tests, no exec-mask branches)
             }
 }
 
