@@ -74,7 +74,10 @@ GEMM_SHAPES = [(2, 32, 8, 48), (3, 200, 64, 100), (2, 72, 256, 133), (1, 512, 12
                (32, 1024, 256, 512), (8, 2048, 512, 512), (8, 512, 2048, 512),      # these three: the benchmark's block shapes
                # the wave-specialised kernel (K >= 1024 with a transform on load, M % 256 == 0): odd / even k-tile counts that are
                # not multiples of its 3 or 4 register stages, a t-tile tail, a row pitch that is not T, one m-tile, K at its cap
-               (2, 256, 1088, 200), (3, 512, 1024, 133), (1, 768, 1152, 64), (2, 256, 2048, 90), (1, 256, 1216, 128)]
+               (2, 256, 1088, 200), (3, 512, 1024, 133), (1, 768, 1152, 64), (2, 256, 2048, 90), (1, 256, 1216, 128),
+               # the overlapped-epilogue kernel (plain bf16 X, K = 256 / 512, >= 512 tiles): partial last t-tiles with T % 4 != 0 and
+               # T % 8 == 0, an uneven number of tiles per workgroup (768 / 256 and 640 / 256)
+               (32, 2048, 512, 379), (32, 2048, 256, 250), (20, 2048, 512, 512), (32, 1280, 256, 512)]
 
 
 @pytest.mark.parametrize("B,M,K,T", GEMM_SHAPES)

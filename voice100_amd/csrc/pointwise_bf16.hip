@@ -1478,6 +1478,361 @@ __global__ __launch_bounds__(512) void pw_wgrad_bf16_wide_kernel(WgParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Short-K GEMM with the epilogue of tile i UNDER the main loop of tile i + 1 (plain bf16 X, bf16 Y, whole tiles; K = 256 or 512).
+// The short-K GEMMs (expand forward, project backward-data: 4-8 k-tiles) spend more of a tile in their epilogue than in their main
+// loop, and the two add up: the epilogue is bound by vector-instruction issue and LDS round trips with the matrix pipe idle, the
+// main loop by the matrix pipe with little else to issue (profiles/r03_ws_gemm.txt: a persistent form that only prefetches across
+// the epilogue, a staggered start, an early R request and a re-spaced k-tile all measured +-0).  Here a persistent workgroup keeps
+// TWO accumulator sets: when tile i's k-loop ends its accumulators are set aside and the k-loop of tile i + 1 starts at once; the
+// epilogue of tile i is cut into wave-LOCAL units -- park one 32 x 32 block in the wave's own 4 KB of LDS, four row passes over it
+// (ds_read_b128, partial sums, bf16 pack, 8-byte stores of 64-byte row segments), a per-row reduction of the partial sums -- that
+// need no workgroup barrier and are issued one or three at a time behind the MFMAs of each k-step.  Only the last step (the two
+// column halves of a row meet: waves wn = 1 hand their row sums to waves wn = 0 through LDS) leans on the k-loop's own barriers.
+// Staging as in the wave-specialised kernels' matrix waves (A pieces and X columns behind each k-step's MFMAs).
+template <int EPI, int IO, int NK>
+__global__ __launch_bounds__(512) void pw_gemm_bf16_ov_kernel(PwParams p) {
+    static_assert((EPI == PW_EPI_STATS && IO == (PW_IO_X | PW_IO_Y)) || (EPI == PW_EPI_MASK_STATS && IO == (PW_IO_X | PW_IO_R | PW_IO_Y)),
+                  "expand forward on the bf16 shadow / project backward-data");
+    constexpr bool MASK = EPI == PW_EPI_MASK_STATS;
+    static_assert(NK == 4 || NK == 8, "K = 256 or 512");
+    constexpr int BM = 256;
+    constexpr int A_BYTES = BM * 128, X_BYTES = 128 * 128;
+    constexpr int STAGES = 2 * A_BYTES + 2 * X_BYTES;   // 96 KB
+    constexpr int SCR = 8 * 4096;                       // a 32 x 32 fp32 block per wave
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES + SCR + 4 * 32 * 16 + 512 * 8];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + 2 * A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* scr = reinterpret_cast<float*>(smem + STAGES + wave * 4096);
+    float* cfe = reinterpret_cast<float*>(smem + STAGES + SCR + 4 * 32 * 16);       // MASK: (ea, eb) of the previous tile's 256 rows
+    const int M = p.M, K = p.K;
+    const int P16 = pw_pitch16(p.T);
+    const int total = p.n_mtiles * p.n_ttiles * p.B;
+    int v = blockIdx.x;
+    int b, tt, mt;
+    pw_work_v(p, v, total, b, tt, mt);
+#define OV_SB() __builtin_amdgcn_sched_barrier(0)
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.Abf, (unsigned)M * K * 2u);
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.X, (unsigned)p.B * K * P16 * 2u);
+    const __amdgpu_buffer_rsrc_t rY = make_rsrc(p.Y, (unsigned)p.B * M * P16 * 2u);
+    const int arow = 32 * wave + (lane >> 3);
+    int ldsA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ldsA[i] = bf_off(arow + 8 * i, lane & 7);
+    const int stepA = 16 * K, stepX = P16 * 2;
+    const int b_tq = (tid & 31) * 4, b_kg = tid >> 5;
+    int ldsB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ldsB[q] = bf_off(b_tq + q, b_kg >> 1) + (b_kg & 1) * 8;
+    auto vo_a = [&](int mt_) { return ((mt_ * BM + arow) * K + (lane & 7) * 8) * 2; };
+    auto vo_x = [&](int b_, int tt_) { return ((b_ * K + 4 * b_kg) * P16 + tt_ * PW_BN + b_tq) * 2; };
+    int voA = vo_a(mt), voX = vo_x(b, tt), voAn, voXn;
+    int t_lim = p.T - tt * PW_BN - b_tq;                // this lane's X columns q < t_lim exist
+    auto aim_next = [&]() {
+        const int vn = v + (int)gridDim.x < total ? v + (int)gridDim.x : v;
+        int b_, tt_, mt_;
+        pw_work_v(p, vn, total, b_, tt_, mt_);
+        voAn = vo_a(mt_); voXn = vo_x(b_, tt_);
+    };
+    aim_next();
+    // MASK: ONE register stage for A (weights: L2 hits, a k-tile of lead) and one set of R pieces -- the mask epilogue's registers
+    constexpr bool A1 = true;
+    constexpr int AL = A1 ? 2 : 3;                      // A k-tile requested behind the store of k-tile kt + 1: kt + AL
+    u32x4 ra[A1 ? 1 : 2][4];
+    u32x2 rb[2][4];
+    auto load_a = [&](int kt, auto stg, int i) {        // kt >= NK: k-tile kt - NK of the next tile
+        constexpr int SG = A1 ? 0 : decltype(stg)::value;
+        const bool nx = kt >= NK;
+        ra[SG][i] = __builtin_amdgcn_raw_buffer_load_b128(rA, nx ? voAn : voA, (nx ? kt - NK : kt) * (BF_BK * 2) + i * stepA, 0);
+    };
+    auto load_x = [&](int kt, auto stg, int e) {
+        constexpr int SG = decltype(stg)::value;
+        const bool nx = kt >= NK;
+        rb[SG][e] = __builtin_amdgcn_raw_buffer_load_b64(rX, nx ? voXn : voX, ((nx ? kt - NK : kt) * BF_BK + e) * stepX, 0);
+    };
+    auto store_x_col = [&](int buf, auto stg, auto qc) {
+        constexpr int SG = decltype(stg)::value;
+        constexpr int q = decltype(qc)::value;
+        constexpr unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;
+        uint2 o;
+        // columns past T (partial last t-tile) are staged as ZEROS: their accumulators are exactly 0, so they add nothing to the
+        // statistics and the epilogue needs no per-element column tests
+        const unsigned keep = q < t_lim ? 0xffffffffu : 0u;
+        o.x = __builtin_amdgcn_perm(rb[SG][1][q >> 1], rb[SG][0][q >> 1], sel) & keep;
+        o.y = __builtin_amdgcn_perm(rb[SG][3][q >> 1], rb[SG][2][q >> 1], sel) & keep;
+        *reinterpret_cast<uint2*>(Bs + buf * X_BYTES + ldsB[q]) = o;
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2], accp[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+    const int lr = lane & 31, lh = lane >> 5;
+    const int sw = (lr >> 1) & 7;
+    const int rdA0 = (wm * 64 + lr) * 128, rdB0 = (wn * 64 + lr) * 128;
+
+    // ---- the previous tile's epilogue, in units ----
+    int pb = 0, ptt = 0, pmt = 0;                         // its coordinates
+    int ep_vo = 0, ep_tl = 0;                             // this lane's byte offset into Y / R at block (0, 0), pass 0; columns left before T
+    float rs0[2] = {0.f, 0.f}, rs1[2] = {0.f, 0.f};       // lanes 0-31: row sums (y, y^2) of rows i * 32 + lane over this wave's 64 columns
+    float* xarea = reinterpret_cast<float*>(smem + STAGES + SCR);      // [4 wm][32 lanes][4]
+    // 25 units: block blk = u / 6 (i = blk / 2, j = blk % 2), stage w = u % 6, software-pipelined so that every LDS read is issued
+    // one unit (= one k-step: four MFMAs) before its data are used -- an in-order wave that waits for an LDS round trip inside a
+    // unit also holds back its next MFMA:
+    //   w 0: park block blk (16 ds_write_b32)   [+ blk > 0: add up the previous block's partial sums, read in its w 5]
+    //   w 1: read row pass 0      w 2-4: finish pass w - 2 (sums, pack, store, partials -> LDS), read pass w - 1
+    //   w 5: finish pass 3, read this lane's four partial pairs of row (lane & 31)
+    //   u 24: add up block 3's partial sums
+    // MASK (project backward-data): x = (0 < ea * R + eb < 6) ? x : 0, sums (x, x * R); a block's four R pieces (a2, bf16) and row
+    // coefficients are requested a whole block (six units) ahead of their row passes
+    const __amdgpu_buffer_rsrc_t rR = make_rsrc(MASK ? p.R : p.X, MASK ? (unsigned)p.B * M * P16 * 2u : 0u);
+    const __amdgpu_buffer_rsrc_t rEa = make_rsrc(MASK ? p.ea : p.X, MASK ? (unsigned)M * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rEb = make_rsrc(MASK ? p.eb : p.X, MASK ? (unsigned)M * 4u : 0u);
+    u32x2 ep_rr[1][MASK ? 4 : 1];
+    float2 ep_c[2];                                     // (ea, eb) of the row of the pass in flight, read with its data
+    auto ep_r_req = [&](auto bc) {                      // block blk's R pieces (requested when the previous block's last pass is done)
+        constexpr int blk = decltype(bc)::value, i = blk >> 1, j = blk & 1;
+        if constexpr (MASK) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+                ep_rr[0][ps] = __builtin_amdgcn_raw_buffer_load_b64(rR, ep_vo, ((i * 32 + 8 * ps) * P16 + j * 32) * 2, 0);
+        }
+    };
+    auto ep_coef_tile = [&]() {                         // the tile's row coefficients -> LDS (each wave: its own 64 rows, read back only by itself)
+        if constexpr (MASK) {
+            const int row = pmt * BM + wm * 64 + lane;
+            const float a_ = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rEa, row * 4, 0, 0));
+            const float b_ = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rEb, row * 4, 0, 0));
+            *reinterpret_cast<float2*>(cfe + (wave * 64 + lane) * 2) = make_float2(a_, b_);      // (its own copy: no cross-wave order needed)
+        }
+    };
+    f32x4 ep_d[2];
+    float2 ep_r[4];
+    auto ep_read = [&](auto psc) {
+        constexpr int ps = decltype(psc)::value;
+        ep_d[ps & 1] = *reinterpret_cast<const f32x4*>(scr + (8 * ps + (lane >> 3)) * 32 + (lane & 7) * 4);
+    };
+    auto ep_read_c = [&](auto psc, auto ic) {           // MASK: the pass's row coefficients
+        constexpr int ps = decltype(psc)::value, i = decltype(ic)::value;
+        if constexpr (MASK) ep_c[ps & 1] = *reinterpret_cast<const float2*>(cfe + (wave * 64 + i * 32 + 8 * ps + (lane >> 3)) * 2);
+    };
+    auto ep_finish = [&](auto psc, auto ic, auto jc) {
+        constexpr int ps = decltype(psc)::value, i = decltype(ic)::value, j = decltype(jc)::value;
+        f32x4 a = ep_d[ps & 1];
+        float s0 = 0.f, s1 = 0.f;
+        if constexpr (MASK) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // (columns past T of a partial last t-tile: their accumulators are exactly 0 -- zero X --, but R's row padding is
+                //  whatever the allocation held; the median maps a NaN / Inf there to a finite value and leaves every bf16 number as
+                //  it is, so 0 * R stays 0)
+                const float r = __builtin_amdgcn_fmed3f(pw_bf16_at(ep_rr[0][ps], e), -3.3895314e38f, 3.3895314e38f);
+                const float pre = fmaf(r, ep_c[ps & 1].x, ep_c[ps & 1].y);
+                const float x = (pre > 0.f && pre < 6.f) ? a[e] : 0.f;
+                a[e] = x;
+                s0 += x; s1 = fmaf(x, r, s1);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s0 += a[e]; s1 = fmaf(a[e], a[e], s1); }
+        }
+        const u32x2 o2 = {pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3])};
+        // (a straddling lane's 8 bytes stay inside the pitched row; a lane wholly past T aims outside the descriptor: dropped)
+        __builtin_amdgcn_raw_buffer_store_b64(o2, rY, j * 32 < ep_tl ? ep_vo : 0x7ffffff0, ((i * 32 + 8 * ps) * P16 + j * 32) * 2, 0);
+        *reinterpret_cast<float2*>(scr + (8 * ps + (lane >> 3)) * 32 + (lane & 7) * 4) = make_float2(s0, s1);
+    };
+    auto ep_red_read = [&]() {       // (start rotated by the row: 2-way bank conflicts, not 16)
+        const int row = lane & 31, h4 = (lane >> 5) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ep_r[q] = *reinterpret_cast<const float2*>(scr + row * 32 + ((h4 + q + row) & 7) * 4);
+    };
+    auto ep_red_sum = [&](auto ic) { // this half-wave's four of the row's eight partial pairs; the halves meet in epi_xchg
+        constexpr int i = decltype(ic)::value;
+        rs0[i] += (ep_r[0].x + ep_r[1].x) + (ep_r[2].x + ep_r[3].x);
+        rs1[i] += (ep_r[0].y + ep_r[1].y) + (ep_r[2].y + ep_r[3].y);
+    };
+    auto epi_unit = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (u == 24) { ep_red_sum(std::integral_constant<int, 1>{}); return; }
+        constexpr int blk = (u / 6) & 3, i = blk >> 1, j = blk & 1, w = u % 6;
+        using IC = std::integral_constant<int, i>; using JC = std::integral_constant<int, j>;
+        if constexpr (w == 0) {
+            if constexpr (blk > 0) ep_red_sum(std::integral_constant<int, ((blk - 1) >> 1)>{});
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = accp[i][j][r];
+        } else if constexpr (w == 1) {
+            ep_read(std::integral_constant<int, 0>{});
+            ep_read_c(std::integral_constant<int, 0>{}, IC{});
+        } else if constexpr (w <= 4) {
+            ep_finish(std::integral_constant<int, w - 2>{}, IC{}, JC{});
+            ep_read(std::integral_constant<int, w - 1>{});
+            ep_read_c(std::integral_constant<int, w - 1>{}, IC{});
+        } else {
+            ep_finish(std::integral_constant<int, 3>{}, IC{}, JC{});
+            if constexpr (blk < 3) ep_r_req(std::integral_constant<int, (blk + 1) & 3>{});
+            ep_red_read();
+        }
+    };
+    auto epi_xchg = [&]() {                              // half-waves meet; column half 1 -> LDS
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { rs0[i] += __shfl_xor(rs0[i], 32, 64); rs1[i] += __shfl_xor(rs1[i], 32, 64); }
+        if (wn == 1 && lane < 32) *reinterpret_cast<f32x4*>(xarea + (wm * 32 + lane) * 4) = (f32x4){rs0[0], rs1[0], rs0[1], rs1[1]};
+    };
+    auto epi_final = [&]() {                             // column half 0 adds it and stores the tile's statistics (a barrier after xchg)
+        if (wn == 0 && lane < 32) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(xarea + (wm * 32 + lane) * 4);
+            const size_t part = (size_t)pb * p.n_ttiles + ptt;
+            float* sp = p.stats + (part * M + pmt * BM + wm * 64 + lane) * 2;
+            *reinterpret_cast<float2*>(sp) = make_float2(rs0[0] + o[0], rs1[0] + o[1]);
+            *reinterpret_cast<float2*>(sp + 64) = make_float2(rs0[1] + o[2], rs1[1] + o[3]);
+        }
+        rs0[0] = rs0[1] = rs1[0] = rs1[1] = 0.f;
+    };
+    // units of k-step `slot` of a k-loop that carries an epilogue: 25 data units over slots 0 .. S - 6, xchg in the last slot of k-tile
+    // NK - 2, final in the last slot of all (one barrier between them)
+    constexpr int NU = 25, SLOTS = 4 * NK, DSL = SLOTS - 5, UPS = (NU + DSL - 1) / DSL;
+    auto epi_slot = [&](auto sc) {
+        constexpr int slot = decltype(sc)::value;
+#define OV_U(k_) if constexpr (slot * UPS + (k_) < NU && (k_) < UPS) epi_unit(std::integral_constant<int, (slot * UPS + (k_) < NU ? slot * UPS + (k_) : 0)>{});
+        OV_U(0) OV_U(1) OV_U(2)
+#undef OV_U
+        if constexpr (slot == SLOTS - 5) epi_xchg();
+        if constexpr (slot == SLOTS - 1) epi_final();
+    };
+
+    auto mfma_step = [&](int kt, int ks) {
+        const unsigned char* Ab = As + (kt & 1) * A_BYTES;
+        const unsigned char* Bb = Bs + (kt & 1) * X_BYTES;
+        const int co = ((ks * 2 + lh) ^ sw) << 4;
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + co);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + 32 * 128 + co);
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + co);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + 32 * 128 + co);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    };
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+    // k-tile kt (static): fragments from slot kt & 1; k-tile kt + 1 (registers of stage (kt + 1) & 1) -> LDS, k-tile kt + 3 requested
+    // (none of it in the last k-tile); EP: the previous tile's epilogue units of these four k-steps
+    auto ktile = [&](auto ktc, auto epc) {
+        constexpr int kt = decltype(ktc)::value;
+        constexpr bool EP = decltype(epc)::value;
+        constexpr bool STAGE = kt < NK - 1;
+        using SG = std::integral_constant<int, (kt + 1) & 1>;
+        constexpr int nb = (kt + 1) & 1;
+        unsigned char* Ad = As + nb * A_BYTES;
+        auto a_piece = [&](int i) {
+            if constexpr (STAGE) { *reinterpret_cast<u32x4*>(Ad + ldsA[i]) = ra[A1 ? 0 : SG::value][i]; load_a(kt + AL, SG{}, i); }
+        };
+        // no fence between a k-step's MFMAs and its other work; the scheduler is asked for the pipeline
+        // reads, MFMA, 8 others, MFMA, 8 others, MFMA, 8 others, MFMA, rest -- an in-order wave issues nothing else while it waits for
+        // the matrix pipe to take its next MFMA, and its SIMD partner is in the same phase (fenced instead: 51.2 -> 53.7 us)
+#define OV_MID() do { } while (0)
+#define OV_PIPE() do {                                                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x296, PW_OV_GAP, 0); \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x296, PW_OV_GAP, 0); \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x296, PW_OV_GAP, 0); \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); } while (0)
+        mfma_step(kt, 0); OV_MID();
+        a_piece(0); if constexpr (STAGE) store_x_col(nb, SG{}, Q0{});
+        if constexpr (EP) epi_slot(std::integral_constant<int, kt * 4 + 0>{});
+        OV_PIPE(); OV_SB();
+        mfma_step(kt, 1); OV_MID();
+        a_piece(1); if constexpr (STAGE) store_x_col(nb, SG{}, Q1{});
+        if constexpr (EP) epi_slot(std::integral_constant<int, kt * 4 + 1>{});
+        OV_PIPE(); OV_SB();
+        mfma_step(kt, 2); OV_MID();
+        a_piece(2); if constexpr (STAGE) store_x_col(nb, SG{}, Q2{});
+        if constexpr (EP) epi_slot(std::integral_constant<int, kt * 4 + 2>{});
+        OV_PIPE(); OV_SB();
+        mfma_step(kt, 3); OV_MID();
+        a_piece(3);
+        if constexpr (STAGE) {
+            store_x_col(nb, SG{}, Q3{});
+#pragma unroll
+            for (int e = 0; e < 4; ++e) load_x(kt + 3, SG{}, e);
+        }
+        if constexpr (EP) epi_slot(std::integral_constant<int, kt * 4 + 3>{});
+        OV_PIPE(); OV_SB();
+#undef OV_MID
+#undef OV_PIPE
+        __syncthreads();
+    };
+    auto kloop = [&](auto epc) {
+        // k-tile 0 -> LDS slot 0 (registers of stage 0), k-tile 2 requested
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { *reinterpret_cast<u32x4*>(As + ldsA[i]) = ra[0][i]; load_a(AL - 1, S0{}, i); }
+        store_x_col(0, S0{}, Q0{}); store_x_col(0, S0{}, Q1{}); store_x_col(0, S0{}, Q2{}); store_x_col(0, S0{}, Q3{});
+#pragma unroll
+        for (int e = 0; e < 4; ++e) load_x(2, S0{}, e);
+        OV_SB();
+        __syncthreads();
+        ktile(std::integral_constant<int, 0>{}, epc); ktile(std::integral_constant<int, 1>{}, epc);
+        ktile(std::integral_constant<int, 2>{}, epc); ktile(std::integral_constant<int, 3>{}, epc);
+        if constexpr (NK == 8) {
+            ktile(std::integral_constant<int, 4>{}, epc); ktile(std::integral_constant<int, 5>{}, epc);
+            ktile(std::integral_constant<int, 6>{}, epc); ktile(std::integral_constant<int, 7>{}, epc);
+        }
+    };
+    // (loads past the last k-tile of a k-loop aim at the next tile: after it, stage 0 holds that tile's k-tile 0, stage 1 its k-tile 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_a(0, S0{}, i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) load_x(0, S0{}, e);
+    OV_SB();
+    if constexpr (!A1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_a(1, S1{}, i);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) load_x(1, S1{}, e);
+    OV_SB();
+    kloop(std::false_type{});
+    for (;;) {
+        // the tile just finished becomes "previous": its accumulators are set aside, its epilogue rides on the next k-loop
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) accp[i][j] = acc[i][j];
+        pb = b; ptt = tt; pmt = mt;
+        ep_tl = p.T - (tt * PW_BN + wn * 64 + (lane & 7) * 4);
+        ep_vo = ((b * M + mt * BM + wm * 64 + (lane >> 3)) * P16 + tt * PW_BN + wn * 64 + (lane & 7) * 4) * 2;
+        ep_r_req(std::integral_constant<int, 0>{});
+        ep_coef_tile();
+        const int vn = v + (int)gridDim.x;
+        if (vn >= total) break;
+        v = vn;
+        pw_work_v(p, v, total, b, tt, mt);
+        voA = voAn; voX = voXn;
+        t_lim = p.T - tt * PW_BN - b_tq;
+        aim_next();
+        zero_acc();
+        kloop(std::true_type{});
+    }
+    // the last tile's epilogue on its own
+#define OV_D(u_) epi_unit(std::integral_constant<int, u_>{});
+    OV_D(0) OV_D(1) OV_D(2) OV_D(3) OV_D(4) OV_D(5) OV_D(6) OV_D(7) OV_D(8) OV_D(9) OV_D(10) OV_D(11)
+    OV_D(12) OV_D(13) OV_D(14) OV_D(15) OV_D(16) OV_D(17) OV_D(18) OV_D(19) OV_D(20) OV_D(21) OV_D(22) OV_D(23) OV_D(24)
+#undef OV_D
+    epi_xchg();
+    __syncthreads();
+    epi_final();
+#undef OV_SB
+}
+
+// ---------------------------------------------------------------------------------------------
 // Wave-specialised backward-weight (round 3): pw_gemm_bf16_ws_kernel's division of labour on pw_wgrad_bf16_wide_kernel's tile.
 // Twelve waves: waves 0-7 (64 x 64 each of the GR x XR tile) copy the PLAIN operand's 256 x 64 bf16 tile to LDS as loaded (4 pieces
 // per lane, two register stages, one ds_write_b128 + the request two steps ahead behind each k-step's MFMAs) and run the MFMAs;
@@ -1868,6 +2223,26 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
         else V100_GGL((pw_gemm_bf16_fast_kernel<XM, EP, 128, false, false, (IOV)>), grid, dim3(256), 0, st, pb);      \
         return true;                                                                                                            \
     }
+#if PW_OV
+    // epilogue under the next tile's main loop: plain bf16 X, bf16 Y, whole 256-row tiles, K = 256 / 512, >= 2 tiles per workgroup
+    if (big && p.x_mode == 0 && (p.K == 256 || p.K == 512) && (p.M & 255) == 0 && !p.bias && (long)p.B * p.K * P * 2 < 0x7fffffffL &&
+        (long)p.B * p.M * P * 2 < 0x7ffffff0L) {
+        const long nt_ = (long)pb.n_mtiles * p.n_ttiles * p.B;
+        const unsigned gridp = 256;                    // one workgroup per CU walks tiles v = blockIdx.x, + 256, ... (any count)
+        if (nt_ >= 2 * gridp) {
+            if (p.epi_mode == 1 && p.io16 == (PW_IO_X | PW_IO_Y)) {
+                if (p.K == 512) V100_GGL((pw_gemm_bf16_ov_kernel<1, (PW_IO_X | PW_IO_Y), 8>), dim3(gridp), dim3(512), 0, st, pb);
+                else V100_GGL((pw_gemm_bf16_ov_kernel<1, (PW_IO_X | PW_IO_Y), 4>), dim3(gridp), dim3(512), 0, st, pb);
+                return true;
+            }
+            if (PW_OV_MASK && p.epi_mode == 4 && p.io16 == (PW_IO_X | PW_IO_R | PW_IO_Y)) {
+                if (p.K == 512) V100_GGL((pw_gemm_bf16_ov_kernel<4, (PW_IO_X | PW_IO_R | PW_IO_Y), 8>), dim3(gridp), dim3(512), 0, st, pb);
+                else V100_GGL((pw_gemm_bf16_ov_kernel<4, (PW_IO_X | PW_IO_R | PW_IO_Y), 4>), dim3(gridp), dim3(512), 0, st, pb);
+                return true;
+            }
+        }
+    }
+#endif
 #if PW_WS
     // wave-specialised kernel: bf16-stored X operands, 256-row tiles, whole tiles in M (rows past M are handled by the epilogue)
 #define XS(XM, EP, IOV)                                                                                                         \

@@ -48,6 +48,15 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
                                 PW_WS_MINK = 1024 that is: project forward and expand backward-data (transform on load, K = the hidden
                                 width) in training, the eval-mode project GEMM (plain bf16 h2, K = the hidden width) in inference */
 #endif
+#ifndef PW_OV
+#define PW_OV 1              /* short-K GEMMs with the epilogue under the next tile's main loop (pw_gemm_bf16_ov_kernel): expand forward */
+#endif
+#ifndef PW_OV_MASK
+#define PW_OV_MASK 1         /* ... and project backward-data (mask epilogue) */
+#endif
+#ifndef PW_OV_GAP
+#define PW_OV_GAP 8
+#endif
 #ifndef PW_WG_ABL
 #define PW_WG_ABL 0          /* timing-only builds of pw_wgrad_bf16_ws_kernel: 1 / 2 every plain / transformed load re-reads the first tile, 4 no
                                 transform, 8 staging waves: loads only, 16 no MFMA */
