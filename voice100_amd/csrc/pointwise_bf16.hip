@@ -11,9 +11,6 @@
 // ^ ((row >> 4) & 1) and a lane remap was measured: no gain, so the simpler form stays.)
 // =============================================================================================
 #define BF_BK 64
-#ifndef PW_FRAG_AHEAD
-#define PW_FRAG_AHEAD 0      /* measured: 533 vs 525 us over the GEMM set, pw_gemm 1.745 vs 1.72 ms in the step (profiles/r03_ab_misc.txt): off */
-#endif
 
 __device__ __forceinline__ int bf_off(int row, int chunk) {          // byte offset inside a [128][64] bf16 tile
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -387,24 +384,6 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
 #pragma unroll
         for (int ks = 0; ks < BF_BK / 16; ++ks) mfma_step(cur, ks);
     };
-    struct PwFrag { bf16x8 a0, a1, b0, b1; };
-    auto read_frag = [&](int cur, int ks) -> PwFrag {
-        const int co = ((ks * 2 + lh) ^ sw) << 4;
-        const unsigned char* Ab = As + cur * A_BYTES;
-        const unsigned char* Bb = Bs + cur * (128 * 128);
-        PwFrag f;
-        f.a0 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + co);
-        f.b0 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + co);
-        f.a1 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + 32 * 128 + co);
-        f.b1 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + 32 * 128 + co);
-        return f;
-    };
-    auto mfma_frag = [&](const PwFrag& f) {
-        acc[0][0] = mfma16<F16>(f.a0, f.b0, acc[0][0]);
-        acc[0][1] = mfma16<F16>(f.a0, f.b1, acc[0][1]);
-        acc[1][0] = mfma16<F16>(f.a1, f.b0, acc[1][0]);
-        acc[1][1] = mfma16<F16>(f.a1, f.b1, acc[1][1]);
-    };
     // pin: the registers of stage SG are first USED after this point.
     // (a macro, not a lambda: clang rejects captured arrays as inline-asm operands inside a generic lambda)
 #define PW_LOOP_SYNC() do { if constexpr (!(PW_ABLATE & 128)) __syncthreads(); } while (0)   /* bit 7: timing-only */
@@ -454,62 +433,6 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         // Main loop: both prefetches are unconditional.  (A conditional load makes hipcc's waitcnt insertion assume
         // the not-taken count at the join, so the wait for the OLDER stage degenerates into a wait for the prefetch
         // just issued -- the whole point of the second register stage.)
-#if PW_FRAG_AHEAD
-        // Round 3: fragment reads pinned AHEAD of their MFMAs.  hipcc placed each step's four ds_read_b128 directly in front of the
-        // MFMAs that use them (ds_read x4; s_waitcnt lgkmcnt(2); v_mfma ...), so every k-tile opened with a bare LDS round trip and
-        // every later step waited for reads issued a few instructions earlier -- with both waves of a SIMD in the same phase (one
-        // barrier per k-tile) nobody fills those gaps.  Now the first TWO steps' fragments are requested right after the barrier, the
-        // 14 global loads of the prefetch are issued under their latency, and each later step's reads go out one MFMA step (128
-        // matrix-pipe cycles) before use.
-        for (; kt + 3 < nk; kt += 2) {
-            {
-                const PwFrag f0 = read_frag(0, 0), f1 = read_frag(0, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                load_coefs((kt + 1) * BF_BK);
-                __builtin_amdgcn_sched_barrier(0);
-                load_tiles((kt + 2) * BF_BK, S0{});
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_frag(f0);
-                const PwFrag f2 = read_frag(0, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_frag(f1);
-                __builtin_amdgcn_sched_barrier(0);
-                PW_PIN(NST - 1);
-                store_slice(1, S1{}, Q0{});
-                const PwFrag f3 = read_frag(0, 3);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_frag(f2);
-                store_slice(1, S1{}, Q1{});
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_frag(f3);
-                store_slice(1, S1{}, Q2{}); store_slice(1, S1{}, Q3{});
-                PW_LOOP_SYNC();
-            }
-            {
-                const PwFrag f0 = read_frag(1, 0), f1 = read_frag(1, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                load_coefs((kt + 2) * BF_BK);
-                __builtin_amdgcn_sched_barrier(0);
-                load_tiles((kt + 3) * BF_BK, S1{});
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_frag(f0);
-                const PwFrag f2 = read_frag(1, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_frag(f1);
-                __builtin_amdgcn_sched_barrier(0);
-                PW_PIN(0);
-                store_slice(0, S0{}, Q0{});
-                const PwFrag f3 = read_frag(1, 3);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_frag(f2);
-                store_slice(0, S0{}, Q1{});
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_frag(f3);
-                store_slice(0, S0{}, Q2{}); store_slice(0, S0{}, Q3{});
-                PW_LOOP_SYNC();
-            }
-        }
-#else
         for (; kt + 3 < nk; kt += 2) {
             // even tile kt: compute LDS 0; stage 1 holds tile kt+1; stage 0 is free -> tile kt+2.
             // vmcnt retires in order: the coefficient loads needed first are issued BEFORE the tile prefetch
@@ -537,7 +460,6 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
             store_slice(0, S0{}, Q2{}); store_slice(0, S0{}, Q3{});
             PW_LOOP_SYNC();
         }
-#endif
         // Tail: the last two or three tiles (at most one pass), prefetches guarded
         for (; kt + 1 < nk; kt += 2) {
             const bool more = kt + 2 < nk;          // wave-uniform; MFMAs stay outside the branches (one accumulator chain)
@@ -652,8 +574,6 @@ __global__ __launch_bounds__(768) void pw_gemm_bf16_ws_kernel(PwParams p) {
     if (wave >= 8) {
         // ------------------------------------------------ staging waves: 256 threads ------------------------------------------------
         const int pt = tid - 512;
-        if constexpr (PW_WS_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-        if constexpr (PW_WS_PRIO == 2) __builtin_amdgcn_s_setprio(3);
         const __amdgpu_buffer_rsrc_t rX = make_rsrc(reinterpret_cast<const char*>(p.X) + (size_t)b * K * P16 * 2, (unsigned)K * P16 * 2u);
         const __amdgpu_buffer_rsrc_t rX2 = make_rsrc(reinterpret_cast<const char*>(XM == PW_X_AFFINE2 ? p.X2 : p.X) + (size_t)b * K * P16 * 2,
                                                      (unsigned)K * P16 * 2u);
@@ -776,7 +696,6 @@ __global__ __launch_bounds__(768) void pw_gemm_bf16_ws_kernel(PwParams p) {
     // ---------------------------------------------------- matrix waves: 0-7 ----------------------------------------------------
     // A: wave w stages rows 32 w ... + 31 of the tile (4 pieces of 8 rows x 128 B: lane l -> row + l / 8, chunk l % 8), two register
     // stages, one piece stored and the piece two tiles ahead requested behind each k-step's MFMAs
-    if constexpr (PW_WS_PRIO == 3) __builtin_amdgcn_s_setprio(1);
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.Abf, (unsigned)M * K * 2u);
     const int arow = 32 * wave + (lane >> 3);
     const int voA0 = ((m0 + arow) * K + (lane & 7) * 8) * 2;

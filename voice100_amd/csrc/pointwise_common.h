@@ -65,9 +65,6 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #define PW_WG_WS 3           /* wave-specialised backward-weight kernel (pw_wgrad_bf16_ws_kernel), all-bf16 act16 combinations: bit 0 the project
                                 gradient, bit 1 the expand gradient; bits 2 / 3: eight staging waves instead of four for the former / latter */
 #endif
-#ifndef PW_WS_PRIO
-#define PW_WS_PRIO 0         /* s_setprio experiment: 1 / 2 staging waves at priority 1 / 3, 3 matrix waves at priority 1 */
-#endif
 #ifndef PW_WS_ABL
 #define PW_WS_ABL 0
 #endif
