@@ -38,6 +38,7 @@ def make_fn(net):
 
 def main():
     outdir, n_items = sys.argv[1], int(sys.argv[2])
+    subgroup = len(sys.argv) > 3 and sys.argv[3] == "subgroup"
     rank, _, world = init_distributed()
     assert dist.is_initialized() and dist.get_world_size() == world
     g = torch.Generator().manual_seed(11)
@@ -46,6 +47,26 @@ def main():
     lens[0] = 24                                      # the global maximum sits in rank 0's shard: other shards are narrower
     fn = make_fn(build())
     res = {}
+    if subgroup:
+        # a sub-group that does NOT contain global rank 0: its rank 0 is global rank 1, which must receive the result
+        grp = dist.new_group(ranks=[1, 2])
+        if rank in (1, 2):
+            out = scatter_run(fn, (x, lens), mode="round_robin", group=grp)
+            assert (out is None) == (rank != 1)
+            if rank == 1:
+                res["round_robin"] = out
+                # fixed-size outputs with the shapes given up front: no agreement round
+                fix = lambda a, b: (a.sum((1, 2)), b.to(torch.int32))          # noqa: E731
+                res["fixed"] = scatter_run(fix, (x, lens), group=grp, out_specs=[((), torch.float32), ((), torch.int32)])
+                res["fixed_single"] = list(fix(x, lens))
+                res["single"] = list(fn(x, lens))
+                torch.save(res, os.path.join(outdir, "infer.pt"))
+            else:
+                fix = lambda a, b: (a.sum((1, 2)), b.to(torch.int32))          # noqa: E731
+                assert scatter_run(fix, (x, lens), group=grp, out_specs=[((), torch.float32), ((), torch.int32)]) is None
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     for mode in ("contiguous", "round_robin"):
         out = scatter_run(fn, (x, lens), mode=mode)
         assert (out is None) == (rank != 0)

@@ -67,3 +67,72 @@ def test_stack_no_input_grad_and_reuse(cuda):
     g2 = [p.grad.clone() for p in net.parameters()]
     assert any(not torch.equal(a, b) for a, b in zip(g1, g2))
     assert all(torch.isfinite(a).all() for a in g1 + g2)
+
+
+def test_frozen_block_and_hooks_take_per_module_dispatch(cuda):
+    """nn.Sequential semantics (asr.py:76): a block the user froze with block.eval() inside a training-mode encoder keeps its running
+    statistics and USES them; forward hooks on inner blocks fire.  The stack executor must step aside for both."""
+    from voice100_amd import functional as F_
+    from voice100_amd.asr import ConvVoiceEncoder
+    torch.manual_seed(5)
+    enc = ConvVoiceEncoder(8, 16, 16).to(cuda).train()
+    for p in enc.layers[0].parameters():
+        p.requires_grad_(False)
+    enc.layers[0].eval()                                   # frozen opener: its input (the mel) needs no gradient either
+    with torch.no_grad():
+        enc.layers[0].conv[0][1].running_mean.normal_()
+        enc.layers[0].conv[0][1].running_var.uniform_(0.5, 2.0)
+    before = {k: v.clone() for k, v in enc.layers[0].named_buffers()}
+    other = {k: v.clone() for k, v in enc.layers[1].named_buffers()}
+    x = torch.randn(2, 8, 64, device=cuda)
+    y = enc(x)
+    y.sum().backward()
+    for k, v in enc.layers[0].named_buffers():
+        assert torch.equal(v, before[k]), k               # running_mean / running_var / num_batches_tracked untouched
+    assert any(not torch.equal(v, other[k]) for k, v in enc.layers[1].named_buffers())   # the training blocks still track
+    # the frozen block really ran on its running statistics: same as its own eval forward
+    with torch.no_grad():
+        h = enc.layers[0](x)
+    enc2 = ConvVoiceEncoder(8, 16, 16).to(cuda).train()
+    enc2.load_state_dict(enc.state_dict())
+    enc2.layers[0].eval()
+    for p in enc2.layers[0].parameters():
+        p.requires_grad_(False)
+    y_rest = F_.ir_stack_train(list(enc2.layers)[1:], h)
+    assert torch.allclose(y_rest, y, rtol=0, atol=0)
+    assert all(p.grad is not None for p in enc.layers[1].parameters())
+    # a frozen block that would need a gradient is refused instead of silently detached
+    enc.layers[3].eval()
+    with pytest.raises(RuntimeError, match="frozen-BatchNorm"):
+        enc(x)
+    enc.layers[3].train()
+    # forward hooks on an inner block fire (the stack path bypasses Module.__call__)
+    seen = []
+    hnd = enc.layers[2].register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+    enc(x)
+    hnd.remove()
+    assert seen == [(2, 8, 32)]
+    enc(x)
+    assert len(seen) == 1
+
+
+def test_stack_sees_replaced_buffers(cuda):
+    """Module._apply REPLACES BatchNorm buffers (.double().float() round trip) and load_state_dict(assign=True) replaces parameters:
+    the cached 18-tensor table must follow, or running statistics go to dead buffers and stale weights are read."""
+    from voice100_amd import functional as F_
+    from voice100_amd.layers import InvertedResidual
+    torch.manual_seed(9)
+    net = torch.nn.Sequential(InvertedResidual(8, 8, kernel_size=7), InvertedResidual(8, 8, kernel_size=5)).to(cuda).train()
+    x = torch.randn(2, 8, 40, device=cuda)
+    F_.ir_stack_train(list(net), x)
+    net.double().float()                                    # new buffer AND parameter objects
+    rm_before = net[1].conv[1][1].running_mean.clone()
+    F_.ir_stack_train(list(net), x)
+    assert not torch.equal(net[1].conv[1][1].running_mean, rm_before)          # the LIVE buffer was updated
+    ref = copy.deepcopy(net)
+    sd = {k: (torch.randn_like(v) if v.dtype.is_floating_point and "running_var" not in k else v.clone()) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, assign=True)
+    ref.load_state_dict(sd)
+    y = F_.ir_stack_train(list(net), x)
+    y_ref = ref[1](ref[0](x))
+    assert torch.equal(y, y_ref)

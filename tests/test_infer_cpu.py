@@ -44,3 +44,17 @@ def test_scatter_gather_gloo_world2_equals_single_process(tmp_path, n_items):
         assert ids.dtype == torch.int64 and n.dtype == torch.int32
         assert torch.equal(n, n1) and torch.equal(sc, sc1)            # bit for bit
         assert ids.shape == ids1.shape and torch.equal(ids, ids1)
+
+
+def test_scatter_gather_subgroup_without_global_rank0(tmp_path):
+    """world 3, group = ranks {1, 2}: the group's rank 0 is global rank 1 (dist.gather's dst is a global rank), and the
+    out_specs form (no object all-gather) returns the same values."""
+    from voice100_amd.trainer import launch_ranks
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_infer_worker.py")
+    rc = launch_ranks(worker, [str(tmp_path), "5", "subgroup"], 3, timeout=300)
+    assert rc == 0
+    res = torch.load(tmp_path / "infer.pt")
+    for got, want in zip(res["round_robin"], res["single"]):
+        assert torch.equal(got, want)
+    for got, want in zip(res["fixed"], res["fixed_single"]):
+        assert got.dtype == want.dtype and torch.equal(got, want)

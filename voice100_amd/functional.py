@@ -356,21 +356,55 @@ def _stack_segments(blocks, segment):
     return segs
 
 
+def _stack_eligible(blocks) -> bool:
+    """The stack executor runs every block of a run in training mode and bypasses Module.__call__: it may only stand in for
+    `nn.Sequential` dispatch (asr.py:76, tts.py:25) when that is what per-module dispatch would have done -- every block in training
+    mode (a block the user froze with block.eval() keeps its running statistics and uses them) and no forward / pre-forward hook
+    registered on any block (the hooks would be skipped).  Global module hooks count as hooks on every block."""
+    import torch.nn.modules.module as _m
+    if _m._global_forward_hooks or _m._global_forward_pre_hooks:
+        return False
+    for b in blocks:
+        if not b.training or b._forward_hooks or b._forward_pre_hooks:
+            return False
+        # a frozen sub-module (block.conv[1][1].eval(): one BatchNorm on running statistics) is not expressible by the fused block
+        # either way; the per-block path sees the same block.training flag, so it is no reason to leave the stack
+    return True
+
+
 def ir_stack_train(blocks, x, precision: Optional[str] = None, segment: Optional[int] = None):
     """Training-mode forward of consecutive InvertedResidual modules through the stack executor.  `segment` = blocks per autograd
     node: None -> the whole run as one node in a single-process job, three blocks per node under data parallelism (the gradient
-    buckets of the later blocks are then all-reduced while the earlier blocks' backward still runs, voice100_amd/dist.py)."""
+    buckets of the later blocks are then all-reduced while the earlier blocks' backward still runs, voice100_amd/dist.py).
+    Falls back to calling the modules one by one (what the reference's nn.Sequential does) when any block is in eval mode or
+    carries forward hooks."""
     blocks = list(blocks)
+    if not _stack_eligible(blocks):
+        for b in blocks:
+            if not b.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in b.parameters())):
+                # a frozen (eval-mode) block inside a training run: the reference back-propagates through its frozen BatchNorm; the
+                # eval-mode kernels here are inference-only, and handing back a detached result would silently cut every gradient
+                # upstream of the block (or the block's own, if its parameters still require grad)
+                raise RuntimeError("InvertedResidual in eval mode inside a training-mode stack needs a gradient (its input or its "
+                                   "parameters require grad): frozen-BatchNorm fine-tuning is not built.  Freeze it completely "
+                                   "(requires_grad_(False) on the block and on everything upstream), or keep it in train() mode")
+            x = b(x)
+        return x
     if segment is None:
         import torch.distributed as dist
         segment = 3 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else len(blocks)
     precision = precision or _PRECISION
     segs = _stack_segments(blocks, segment)
     for i, (cfgs, params, seg) in enumerate(segs):
-        # a parameter object that was swapped out (module._parameters[...] = new) invalidates the cached tuple: re-read it
-        b0 = seg[0].conv[0][0].weight
-        if params[0] is not b0:
-            params = tuple(t for b in seg for t in _block_tensors(b))
+        # any parameter / buffer object that was swapped out since the tuple was cached (Module._apply replaces BatchNorm buffers on
+        # .to() / .float(); load_state_dict(assign=True) and module._parameters[...] = new replace parameters) invalidates it: the
+        # executor would otherwise read dead weights and write running statistics into dead buffers.  18 identity checks per block.
+        current = tuple(t for b in seg for t in _block_tensors(b))
+        if any(a is not c for a, c in zip(params, current)):
+            for t in current:
+                if not t.is_cuda or not t.is_contiguous():
+                    raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors (no CPU fallback)")
+            params = current
             segs[i] = (cfgs, params, seg)
         sh = getattr(x, "_v100_shadow", None)
         x16 = sh[0] if (sh is not None and sh[1] == x._version and sh[0].shape[:2] == x.shape[:2]

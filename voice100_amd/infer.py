@@ -43,14 +43,17 @@ def _world(group=None) -> Tuple[int, int]:
 
 
 def scatter_run(fn: Callable[..., Sequence[torch.Tensor]], inputs: Sequence[torch.Tensor], mode: str = "contiguous",
-                group=None, pad_value=0) -> Optional[List[torch.Tensor]]:
+                group=None, pad_value=0, out_specs=None) -> Optional[List[torch.Tensor]]:
     """Run `fn` data-parallel over dim 0 of `inputs` and gather its outputs on rank 0.
 
     Every rank holds (or can index) the full `inputs`; rank r calls fn(*[x[idx_r] for x in inputs]) on its shard -- no
     collective touches the data path -- and gets back a sequence of tensors whose dim 0 is the shard.  Outputs may be
     ragged in dim 1 across ranks (aligned-text / WORLD-frame counts differ): they are padded with `pad_value` to the
-    global maximum before the gather.  Returns the outputs in the ORIGINAL item order on rank 0 and None elsewhere.
-    With no process group (or a group of one) it is just fn(*inputs)."""
+    global maximum before the gather.  Returns the outputs in the ORIGINAL item order on the group's rank 0 (whatever its
+    global rank is) and None elsewhere.  With no process group (or a group of one) it is just fn(*inputs).
+    `out_specs` = [(trailing shape, dtype), ...] per output when the caller knows them (fixed-size outputs: token-id
+    matrices, per-chunk features): the shapes then need no agreement round, i.e. no object all-gather and no host
+    synchronisation per call -- what a timed streaming loop wants."""
     rank, world = _world(group)
     n = inputs[0].shape[0]
     if any(x.shape[0] != n for x in inputs):
@@ -65,11 +68,19 @@ def scatter_run(fn: Callable[..., Sequence[torch.Tensor]], inputs: Sequence[torc
         outs = None
     # Shapes and dtypes are agreed through rank 0's view of a rank that has work; ranks without items (n < world) build
     # zero-sized placeholders after learning the trailing shapes.
-    meta = [None] * world
-    dist.all_gather_object(meta, None if outs is None else [(tuple(o.shape[1:]), str(o.dtype)) for o in outs], group=group)
+    if out_specs is not None:
+        specs = [(tuple(sh), str(dt)) for sh, dt in out_specs]
+        if outs is not None and any(tuple(o.shape[1:]) != sp[0] or str(o.dtype) != sp[1] for o, sp in zip(outs, specs)):
+            raise ValueError("scatter_run: fn's outputs do not match out_specs")
+        meta = [specs] * world
+    else:
+        meta = [None] * world
+        dist.all_gather_object(meta, None if outs is None else [(tuple(o.shape[1:]), str(o.dtype)) for o in outs], group=group)
     ref = next((m for m in meta if m is not None), None)
     if ref is None:
         return [] if rank == 0 else None
+    # dist.gather's dst is a GLOBAL rank: the group's rank 0 may be any process of the job
+    dst = dist.get_global_rank(group, 0) if group is not None else 0
     dev = outs[0].device if outs is not None else inputs[0].device
     result = []
     for k, (_, dtname) in enumerate(ref):
@@ -82,7 +93,7 @@ def scatter_run(fn: Callable[..., Sequence[torch.Tensor]], inputs: Sequence[torc
             o = outs[k]
             buf[(slice(0, o.shape[0]),) + tuple(slice(0, s) for s in o.shape[1:])] = o
         gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-        dist.gather(buf, gathered, dst=0, group=group)
+        dist.gather(buf, gathered, dst=dst, group=group)
         if rank == 0:
             merged = torch.full((n,) + full, pad_value, dtype=dt, device=dev)
             for r in range(world):

@@ -17,8 +17,6 @@ from . import functional as F_
 from ._base import tracing
 
 
-_warned_eval_detach = False
-
 
 class ConvBNActivate(nn.ModuleList):
     """Conv1d(bias=False) + BatchNorm1d + ReLU6 parameter group (asr.py:27-37).
@@ -99,11 +97,10 @@ class InvertedResidual(nn.Module):
             if x.is_leaf:
                 raise RuntimeError("InvertedResidual in eval mode is inference-only (frozen-BatchNorm fine-tuning is not "
                                    "built): call it under torch.no_grad(), or switch the block to train()")
-            global _warned_eval_detach
-            if not _warned_eval_detach:
-                _warned_eval_detach = True
-                warnings.warn("voice100_amd: eval-mode InvertedResidual called with autograd on; its output is detached "
-                              "(inference only). Wrap inference in torch.no_grad() to silence this.", stacklevel=2)
+            # (python's default warning filter shows this once per call site; every call warns so that a filter of "always" sees all)
+            warnings.warn("voice100_amd: eval-mode InvertedResidual called with autograd on; its output is DETACHED "
+                          "(inference only: nothing upstream of this block receives a gradient). Wrap inference in "
+                          "torch.no_grad() to silence this.", stacklevel=2)
         with torch.no_grad():
             return F_.inverted_residual_eval_cached(self, x.detach(), prec)
 
