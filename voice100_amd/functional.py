@@ -250,6 +250,16 @@ def _block_tensors(blk):
 
 
 _STACK_PLANS = {}
+_STACK_SEGMENT = None          # blocks per autograd node of a stack; None = automatic (ir_stack_train)
+
+
+def set_stack_segment(n: Optional[int]) -> None:
+    """Blocks per autograd node of the stack executor: None = automatic (the whole run in a single-process job, three under data
+    parallelism); an int forces it (bench.py measures the data-parallel form, 3, on one GPU)."""
+    global _STACK_SEGMENT
+    if n is not None and n < 1:
+        raise ValueError("segment must be >= 1 or None")
+    _STACK_SEGMENT = n
 
 
 def _stack_plan(cfgs, B, T, bf16, level, last_shadow):
@@ -390,6 +400,8 @@ def ir_stack_train(blocks, x, precision: Optional[str] = None, segment: Optional
                                    "(requires_grad_(False) on the block and on everything upstream), or keep it in train() mode")
             x = b(x)
         return x
+    if segment is None:
+        segment = _STACK_SEGMENT
     if segment is None:
         import torch.distributed as dist
         segment = 3 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else len(blocks)

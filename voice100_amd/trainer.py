@@ -63,7 +63,9 @@ class TrainStep:
     With more than one rank the constructor first copies rank 0's parameters and buffers to every rank (DDP's
     construction-time broadcast), so replicas cannot start from different weights."""
 
-    def __init__(self, model: torch.nn.Module, bucket_bytes: int = 16 << 20):
+    def __init__(self, model: torch.nn.Module, bucket_bytes: int = 16 << 20, force_exchange: bool = False):
+        # force_exchange: run the bucketed all-reduce machinery even in a process group of ONE rank (bench.py's
+        # `dp_path_single_rank`: what the data-parallel path costs at full size, measurable without a node)
         self.model = model
         broadcast_module_state(model)
         cfg = model.configure_optimizers()
@@ -71,7 +73,7 @@ class TrainStep:
             self.optimizer, self.scheduler = cfg["optimizer"], cfg.get("lr_scheduler")
         else:
             self.optimizer, self.scheduler = cfg, None
-        self.buckets = FlatGradBuckets(model.parameters(), bucket_bytes)
+        self.buckets = FlatGradBuckets(model.parameters(), bucket_bytes, force_exchange=force_exchange)
         self.step_idx = 0
 
     def __call__(self, batch) -> torch.Tensor:
