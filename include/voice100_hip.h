@@ -184,6 +184,26 @@ int v100_world_loss_bwd(const float* unit, const float* gout, float* dpred, int 
 /* y = max(exp(x) - offset, 0)   (WORLDVocoder.decode, voice100/vocoder.py:99) */
 int v100_exp_clip(const float* x, float* y, float offset, long long n, void* stream);
 
+/* ---- WORLD synthesis (csrc/world.hip; SURVEY.md 8f rank 4, first half) -- PARITY UNPINNED -----------------------
+ * pyworld.decode_aperiodicity + pyworld.synthesize as WORLDVocoder.decode calls them (voice100/vocoder.py:100-101).
+ * pyworld 0.3.2 (C++ WORLD) is not in the reference tree: the kernels follow the published algorithm as restated in
+ * oracle/world_synth.py.  fft_size 512 (16 kHz) only.
+ *   v100_world_randn_host    HOST function, HOST pointer: the first n values of WORLD's randn() after randn_reseed() (every
+ *                            Synthesis call reseeds: one fixed sequence for all utterances; callers upload it once)
+ *   v100_world_decode_aperiodicity   coded [rows][nb] dB -> ap [rows][fft_size/2+1]
+ *   v100_world_synthesize    f0 [B][T], sp / ap [B][T][257], frames [B] int32 (NULL: every utterance has T frames),
+ *                            randn_table [table_len >= samples per utterance], tw256 [256][2] / tw512 [257][2] = cos, -sin
+ *                            of 2 pi k / 256 and / 512, dc_remover [512] (oracle.world_synth.dc_remover), all built in double
+ *                            by the caller -> y [B][Ymax] fp32, Ymax = (int)(T * frame_period_ms * fs / 1000), zero beyond
+ *                            an utterance's own length; n_pulses [B] (-1 and a NaN row: more than max_pulses pulses). */
+int v100_world_randn_host(float* host_out, long long n);
+int v100_world_decode_aperiodicity(const float* coded, float* ap, long long rows, int nb, int fs, int fft_size, void* stream);
+long long v100_world_synth_workspace_bytes(int B, int T, int fs, double frame_period_ms, int fft_size, int max_pulses);
+int v100_world_synthesize(const float* f0, const float* sp, const float* ap, const int* frames, const float* randn_table,
+                          long long table_len, const float* tw256, const float* tw512, const float* dc_remover, float* y,
+                          int* n_pulses, void* workspace, int B, int T, int fs, double frame_period_ms, int fft_size,
+                          int max_pulses, void* stream);
+
 /* ---- K11 dense k-tap conv blocks of the v2 models (csrc/layernorm.hip) -------------------
  * ConvLayerBlock / ConvTransposeLayerBlock, voice100/models/_layers_v2.py:29-89: conv -> LayerNorm over channels
  * -> exact GELU.  The dense convolution runs on the K1 GEMM over an im2col copy (rows tap-major: j*Cin + c);

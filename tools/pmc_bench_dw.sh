@@ -9,7 +9,7 @@ set -e
 out=$1
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-COMMON="--steps 4 --warmup 2 --windows 0 --host-contention 0 --sustained-seconds 0 --no-extras --no-cpu-baseline --no-other-configs --no-kernel-timing"
+COMMON="--no-presize --steps 4 --warmup 2 --windows 0 --host-contention 0 --sustained-seconds 0 --no-extras --no-cpu-baseline --no-other-configs --no-kernel-timing"
 run() {  # name counter bench-args...
   name=$1; ctr=$2; shift 2
   rm -rf "$out/raw_$name"

@@ -43,6 +43,8 @@ def table(tag, t_in):
     for hid, k, s in SPECS:
         tout = (t - 1) // s + 1
         names = [n for n in fe if (m := FWD.search(n)) and int(next(g for g in m.groups() if g)) == k]
+        # (several variants of one layer can only appear when the run mixed lengths: keep the one the run dispatched most)
+        names = sorted(names, key=lambda q: -fe[q][1])[:1]
         for n in names:
             bf16 = "fwd16_stream" in n or re.search(r"false, 9>", n) is not None
             if bf16:

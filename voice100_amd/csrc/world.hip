@@ -1,0 +1,550 @@
+// WORLD synthesis on the device: pyworld.decode_aperiodicity + pyworld.synthesize as the reference calls them
+// (voice100/vocoder.py:100-101), the last step of BASELINE configs[2] ("... -> WORLD features + vocoder").
+//
+// PARITY UNPINNED: the arithmetic lives in pyworld 0.3.2 (C++ WORLD), which is neither in the reference tree nor in the build
+// image.  These kernels follow the published algorithm as restated in oracle/world_synth.py (Morise et al. 2016; D4C 2016) and
+// are held to that restatement (<= 1e-4 of the waveform's peak, pulse instants bit-exact).
+//
+// Three launches per call, every utterance of the batch at once:
+//   1. world_timebase_kernel   one workgroup per utterance.  F0 contour -> per-sample phase increment (linear interpolation over the
+//                              frame grid, in DOUBLE and with contraction off: it must round like the C / numpy reference), then the
+//                              running phase as ONE sequential double accumulation (lane 0: the unvoiced default of 500 Hz at
+//                              16 kHz puts every crossing exactly on a sample, so which side of 2 pi a sample lands on is decided by
+//                              the rounding of that particular summation order -- a parallel scan would move pulses by one sample),
+//                              wrap + crossing detection + ordered compaction in parallel -> pulse sample index, fractional shift.
+//   2. world_pulse_kernel      one WAVE per pulse: envelope / aperiodicity interpolated between the two frames, minimum-phase
+//                              spectra (log -> real cepstrum -> fold -> spectrum: two 512-point real FFTs each, run as 256-point
+//                              radix-4 complex FFTs through 2 KB of wave-local LDS), fractional delay, inverse FFT, DC removal for
+//                              the periodic part; a zero-mean noise burst (WORLD's own xorshift sequence, a fixed table) coloured by
+//                              the aperiodic minimum-phase spectrum -> a 512-sample response per pulse.
+//   3. world_overlap_add_kernel  one thread per output sample gathers the responses that cover it, in pulse order (deterministic; no
+//                              float atomics).
+// fp32 except the time base.  fft_size 512 (16 kHz) only: 22.05 kHz / 1024 returns V100_ERR_SHAPE (the oracle restates both).
+#include "common.h"
+#include "../../include/voice100_hip.h"
+
+namespace {
+constexpr int NF = 512, NH = 256, NB = 257;          // fft size, half, bins
+constexpr double kPi = 3.1415926535897932384626433832795;
+constexpr double kDefaultF0 = 500.0;
+
+struct WorldParams {
+    const float* f0; const float* sp; const float* ap; const int* frames;
+    const float* randn; long long table_len;
+    float* y; int* n_pulses;
+    double* total; unsigned char* vuv; int* idx; float* xshift; float* resp;
+    int B, T, fs, Ymax, Pcap;
+    double frame_period;      // seconds
+    double frame_period_ms;
+    const float* tw256; const float* tw512; const float* dcr;
+};
+
+// everything up to the matching "contract(fast)" must round like the C / numpy reference: no fused multiply-adds
+#pragma clang fp contract(off)
+__device__ __forceinline__ int world_ylen(int frames, double frame_period_ms, int fs) {
+    return (int)((double)frames * frame_period_ms * (double)fs / 1000.0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 1. time base
+__global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int T = p.frames ? p.frames[b] : p.T;
+    const int ylen = T > 0 ? world_ylen(T, p.frame_period_ms, p.fs) : 0;
+    const float* f0 = p.f0 + (size_t)b * p.T;
+    double* total = p.total + (size_t)b * p.Ymax;
+    unsigned char* vuv = p.vuv + (size_t)b * p.Ymax;
+    int* idx = p.idx + (size_t)b * p.Pcap;
+    float* xs = p.xshift + (size_t)b * p.Pcap;
+    const double fp = p.frame_period, fs = (double)p.fs;
+    const double lowest = fs / (double)NF + 1.0;
+    __shared__ int s_cnt[4];
+    __shared__ int s_base;
+    if (T < 2 || ylen < 2) {              // the reference extrapolates the contour from its last two frames: fewer is undefined there
+        if (tid == 0) p.n_pulses[b] = 0;
+        return;
+    }
+    // coarse contour value at frame j (j <= T: the extra point extrapolates linearly), unvoiced (below fs / fft + 1) = 0
+    auto cf0 = [&](int j) -> double {
+        if (j < T) { const double v = (double)f0[j]; return v < lowest ? 0.0 : v; }
+        const double a = (double)f0[T - 1], c = (double)f0[T - 2];
+        return (a < lowest ? 0.0 : a) * 2 - (c < lowest ? 0.0 : c);
+    };
+    auto cvuv = [&](int j) -> double {
+        if (j < T) return ((double)f0[j] < lowest) ? 0.0 : 1.0;
+        return (((double)f0[T - 1] < lowest) ? 0.0 : 1.0) * 2 - (((double)f0[T - 2] < lowest) ? 0.0 : 1.0);
+    };
+    for (int i = tid; i < ylen; i += 256) {
+        const double t = (double)i / fs;
+        int k = (int)(t / fp) + 1;                       // x[k-1] <= t < x[k] with x[j] = j * fp, fixed up against the products themselves
+        if (k < 1) k = 1;
+        if (k > T) k = T;
+        while (k > 1 && t < (double)(k - 1) * fp) --k;
+        while (k < T && t >= (double)k * fp) ++k;
+        const double x0 = (double)(k - 1) * fp, x1 = (double)k * fp;
+        const double s = (t - x0) / (x1 - x0);
+        const double fa = cf0(k - 1), fb = cf0(k), va = cvuv(k - 1), vb = cvuv(k);
+        double fi = fa + s * (fb - fa);
+        const double vi = va + s * (vb - va);
+        const bool voiced = vi > 0.5;
+        if (!voiced) fi = kDefaultF0;
+        vuv[i] = voiced ? 1 : 0;
+        total[i] = 2.0 * kPi * fi / fs;                  // the increment; accumulated in place below
+    }
+    __syncthreads();
+    if (tid == 0) {                                      // ONE summation order (see the header)
+        double acc = 0.0;
+        int i = 0;
+        for (; i + 8 <= ylen; i += 8) {
+            double v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = total[i + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { acc += v[e]; total[i + e] = acc; }
+        }
+        for (; i < ylen; ++i) { acc += total[i]; total[i] = acc; }
+        s_base = 0;
+    }
+    __syncthreads();
+    // crossings: |wrap[i + 1] - wrap[i]| > pi, i < ylen - 1; ordered compaction, 256 samples per round
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i0 = 0; i0 < ylen - 1; i0 += 256) {
+        const int i = i0 + tid;
+        bool hit = false;
+        double w0 = 0.0, w1 = 0.0;
+        if (i < ylen - 1) {
+            w0 = fmod(total[i], 2.0 * kPi);
+            w1 = fmod(total[i + 1], 2.0 * kPi);
+            hit = fabs(w1 - w0) > kPi;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; ++w) before += s_cnt[w];
+        if (hit) {
+            const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
+            if (slot < p.Pcap) {
+                idx[slot] = i;
+                const double y1 = w0 - 2.0 * kPi;
+                xs[slot] = (float)(-y1 / (w1 - y1));      // fraction of a sample to the exact crossing, in [0, 1)
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) p.n_pulses[b] = s_base <= p.Pcap ? s_base : -1;       // -1: more pulses than the caller made room for
+}
+
+// frame pair and interpolation weight of the pulse at sample `id` (GetSpectralEnvelope / GetAperiodicRatio: floor / ceil of the frame
+// position in double)
+__device__ __forceinline__ void world_frame_mix(int id, int fs, double frame_period, int T, int& fl, int& ce, float& mix) {
+    const double pos = ((double)id / (double)fs) / frame_period;
+    const int f0_ = (int)floor(pos), c0_ = (int)ceil(pos);
+    fl = f0_ < T - 1 ? f0_ : T - 1;
+    ce = c0_ < T - 1 ? c0_ : T - 1;
+    mix = fl == ce ? 0.f : (float)(pos - (double)fl);
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 2. one response per pulse
+struct cplx { float re, im; };
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cplx mul_mi(cplx a) { return {a.im, -a.re}; }          // a * (-i)
+__device__ __forceinline__ void radix4(cplx (&a)[4]) {
+    const cplx s0 = cadd(a[0], a[2]), s1 = csub(a[0], a[2]), s2 = cadd(a[1], a[3]), s3 = mul_mi(csub(a[1], a[3]));
+    a[0] = cadd(s0, s2); a[2] = csub(s0, s2); a[1] = cadd(s1, s3); a[3] = csub(s1, s3);
+}
+__device__ __forceinline__ int rev4x4(int k) {
+    return ((k & 3) << 6) | (((k >> 2) & 3) << 4) | (((k >> 4) & 3) << 2) | ((k >> 6) & 3);
+}
+#define WAVE_LDS_FENCE() asm volatile("" ::: "memory")     /* wave-local exchange through LDS: program order is enough */
+
+// 256-point forward complex FFT of a[q] = input[lane + 64 q]; on return Z[k] sits at z[rev4x4(k)]  (mel.hip's transform)
+__device__ __forceinline__ void fft256(cplx (&a)[4], float2* z, int lane, const cplx (&tw)[3][3]) {
+    radix4(a);
+#pragma unroll
+    for (int qq = 1; qq < 4; ++qq) a[qq] = cmul(a[qq], tw[0][qq - 1]);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) z[lane + 64 * qq] = make_float2(a[qq].re, a[qq].im);
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+        const int quarter = 64 >> (2 * s);
+        const int g = (lane / quarter) * (4 * quarter), j = lane & (quarter - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float2 v = z[g + j + q * quarter]; a[q] = {v.x, v.y}; }
+        WAVE_LDS_FENCE();
+        radix4(a);
+        if (s < 3) {
+#pragma unroll
+            for (int qq = 1; qq < 4; ++qq) a[qq] = cmul(a[qq], tw[s][qq - 1]);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) z[g + j + qq * quarter] = make_float2(a[qq].re, a[qq].im);
+        WAVE_LDS_FENCE();
+    }
+}
+
+// Real FFT of the 512 real samples held as r[0..511] in LDS: X[k], k = lane + 64 q (q = 0..3) into x[q], X[256] into x256 (all lanes).
+// Forward transform, unnormalised.  Clobbers z.
+__device__ __forceinline__ void rfft512(const float* r, float2* z, int lane, const cplx (&tw)[3][3], const cplx (&w512)[4], cplx (&x)[4],
+                                        cplx& x256) {
+    cplx a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float2 v = *reinterpret_cast<const float2*>(r + 2 * (lane + 64 * q)); a[q] = {v.x, v.y}; }
+    WAVE_LDS_FENCE();
+    fft256(a, z, lane, tw);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        const float2 zk = z[rev4x4(k)], zm = z[rev4x4((256 - k) & 255)];
+        const cplx e = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
+        const cplx d = {0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y)};
+        x[q] = cadd(e, cmul(w512[q], mul_mi(d)));
+    }
+    const float2 z0 = z[0];
+    x256 = {z0.x - z0.y, 0.f};                           // X[N/2] = E[0] - O[0] = Re Z[0] - Im Z[0]
+    WAVE_LDS_FENCE();
+}
+
+// Inverse (backward, unnormalised: x[n] = sum_k X[k] e^{+2 pi i k n / 512} over the Hermitian extension) real FFT.  X[k] for k = lane + 64 q
+// in x[q], X[256] in x256 (real).  The spectrum is first parked in LDS (sre / sim, 257 floats each) because bin 256 - k belongs to another
+// lane; the 512 real samples come back in r[0..511].
+__device__ __forceinline__ void irfft512(const cplx (&x)[4], cplx x256, float* sre, float* sim, float2* z, float* r, int lane,
+                                         const cplx (&tw)[3][3], const cplx (&w512)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sre[lane + 64 * q] = x[q].re; sim[lane + 64 * q] = x[q].im; }
+    if (lane == 0) { sre[256] = x256.re; sim[256] = 0.f; }
+    WAVE_LDS_FENCE();
+    cplx a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        const cplx xk = {sre[k], sim[k]}, xm = {sre[256 - k], -sim[256 - k]};           // X[k], conj X[256 - k]
+        const cplx e = {0.5f * (xk.re + xm.re), 0.5f * (xk.im + xm.im)};                 // spectrum of the even samples
+        const cplx d = {0.5f * (xk.re - xm.re), 0.5f * (xk.im - xm.im)};
+        const cplx o = cmul(d, cplx{w512[q].re, -w512[q].im});                           // ... of the odd samples: (X[k] - conj X[256-k]) / 2 * W^-k
+        // Z[k] = E[k] + i O[k]; the inverse transform is conj(FFT(conj Z))
+        a[q] = {e.re - o.im, -(e.im + o.re)};
+    }
+    WAVE_LDS_FENCE();
+    fft256(a, z, lane, tw);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = lane + 64 * q;
+        const float2 v = z[rev4x4(n)];
+        *reinterpret_cast<float2*>(r + 2 * n) = make_float2(2.f * v.x, -2.f * v.y);      // x[2n], x[2n+1]; factor 2: 512-point sum from a 256-point one
+    }
+    WAVE_LDS_FENCE();
+}
+
+// minimum-phase spectrum exp(FFT(fold(IFFT(mirror(L))))) of the log-amplitude L[k] (k = lane + 64 q in l[q], L[256] in l256)
+__device__ __forceinline__ void min_phase(const float (&l)[4], float l256, float* r, float2* z, int lane, const cplx (&tw)[3][3],
+                                          const cplx (&w512)[4], cplx (&h)[4], cplx& h256) {
+    // mirrored real sequence of 512: r[j] = L[j] (j <= 256), L[512 - j] beyond
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        r[k] = l[q];
+        if (k > 0) r[512 - k] = l[q];
+    }
+    if (lane == 0) r[256] = l256;
+    WAVE_LDS_FENCE();
+    cplx c[4], c256;
+    rfft512(r, z, lane, tw, w512, c, c256);             // real cepstrum x 512 (imaginary parts are round-off: the input is even)
+    // fold: c[0], 2 c[1..255], c[256], zeros beyond
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        r[k] = c[q].re * (k == 0 ? (1.f / 512.f) : (2.f / 512.f));
+        r[256 + k] = (k == 0) ? c256.re * (1.f / 512.f) : 0.f;
+    }
+    WAVE_LDS_FENCE();
+    cplx m[4], m256;
+    rfft512(r, z, lane, tw, w512, m, m256);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float e = expf(m[q].re);
+        float sn, cs;
+        sincosf(m[q].im, &sn, &cs);
+        h[q] = {e * cs, e * sn};
+    }
+    h256 = {expf(m256.re), 0.f};                       // the folded cepstrum is real: bin 256 of its spectrum is real
+}
+
+__global__ __launch_bounds__(256) void world_pulse_kernel(WorldParams p) {
+    __shared__ float2 zbuf[4][256];
+    __shared__ float rbuf[4][512];
+    __shared__ float sbuf[4][2][260];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int P = p.n_pulses[b];
+    if (P <= 0) return;
+    float2* z = zbuf[wave];
+    float* r = rbuf[wave];
+    float* sre = sbuf[wave][0];
+    float* sim = sbuf[wave][1];
+    cplx tw[3][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int quarter = 64 >> (2 * s);
+        const int j = lane & (quarter - 1);
+        const int mult = 1 << (2 * s);
+#pragma unroll
+        for (int qq = 1; qq < 4; ++qq) {
+            const int k = (mult * j * qq) & 255;
+            tw[s][qq - 1] = {p.tw256[2 * k], p.tw256[2 * k + 1]};
+        }
+    }
+    cplx w512[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int k = lane + 64 * q; w512[q] = {p.tw512[2 * k], p.tw512[2 * k + 1]}; }
+    const int T = p.frames ? p.frames[b] : p.T;
+    const int* idx = p.idx + (size_t)b * p.Pcap;
+    const float* xs = p.xshift + (size_t)b * p.Pcap;
+    const unsigned char* vuv = p.vuv + (size_t)b * p.Ymax;
+    const float* spb = p.sp + (size_t)b * p.T * NB;
+    const float* apb = p.ap + (size_t)b * p.T * NB;
+    float* respb = p.resp + (size_t)b * p.Pcap * NF;
+    const int idx0 = idx[0];
+    for (int pi = blockIdx.x * 4 + wave; pi < P; pi += gridDim.x * 4) {
+        const int id = idx[pi];
+        const int ns = idx[pi + 1 < P ? pi + 1 : P - 1] - id;           // samples to the next pulse (0 for the last one)
+        const bool cur_v = vuv[id] != 0;
+        int fl, ce;
+        float mix;
+        world_frame_mix(id, p.fs, p.frame_period, T, fl, ce, mix);
+        float env[4], rat[4], env256, rat256;
+        {
+            const float* s0 = spb + (size_t)fl * NB;
+            const float* s1 = spb + (size_t)ce * NB;
+            const float* a0 = apb + (size_t)fl * NB;
+            const float* a1 = apb + (size_t)ce * NB;
+            auto safe = [](float v) { return fminf(fmaxf(v, 0.001f), 1.0f); };          // (0.999999999999 is 1 in fp32)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = lane + 64 * q;
+                env[q] = (1.f - mix) * fabsf(s0[k]) + mix * fabsf(s1[k]);
+                const float a = (1.f - mix) * safe(a0[k]) + mix * safe(a1[k]);
+                rat[q] = a * a;
+            }
+            env256 = (1.f - mix) * fabsf(s0[256]) + mix * fabsf(s1[256]);
+            const float a = (1.f - mix) * safe(a0[256]) + mix * safe(a1[256]);
+            rat256 = a * a;
+        }
+        const float rat0 = __shfl(rat[0], 0, 64);
+        const bool periodic = cur_v && !(rat0 > 0.999f);
+        // ---- periodic part ----
+        float per[8];                                    // this lane's 8 samples of the (fftshifted) periodic response: n = 2 (lane + 64 q) + e
+        if (periodic) {
+            float l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) l[q] = 0.5f * logf(env[q] * (1.f - rat[q]) + 1e-12f);
+            const float l256 = 0.5f * logf(env256 * (1.f - rat256) + 1e-12f);
+            cplx h[4], h256;
+            min_phase(l, l256, r, z, lane, tw, w512, h, h256);
+            // fractional delay of xs samples: multiply by cos - i |sin| of 2 pi x k / 512
+            const float coef = 6.283185307179586f * xs[pi] / 512.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float sn, cs;
+                sincosf(coef * (float)(lane + 64 * q), &sn, &cs);
+                h[q] = cmul(h[q], cplx{cs, -fabsf(sn)});
+            }
+            {
+                float sn, cs;
+                sincosf(coef * 256.f, &sn, &cs);
+                h256 = {h256.re * cs, 0.f};              // the c2r transform ignores the imaginary part of bin N/2
+            }
+            irfft512(h, h256, sre, sim, z, r, lane, tw, w512);
+            // fftshift + DC removal: dc = sum of the causal half (unshifted samples 0..255)
+            float part = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { const float2 v = *reinterpret_cast<const float2*>(r + 2 * (lane + 64 * q)); part += v.x + v.y; }
+            const float dc = wave_sum(part);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 2 * (lane + 64 * q);       // position in the shifted response
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = n + e;
+                    const float w = p.dcr[i];
+                    per[2 * q + e] = i < NH ? -dc * w : r[i - NH] - dc * w;
+                }
+            }
+            WAVE_LDS_FENCE();
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) per[e] = 0.f;
+        }
+        // ---- aperiodic part: zero-mean noise burst of ns samples, coloured ----
+        cplx nz[4], nz256;
+        {
+            const long base = (long)id - idx0;
+            const int nuse = ns < NF ? ns : NF;
+            float sum = 0.f;
+            for (int i = lane; i < ns; i += 64) sum += (base + i < p.table_len) ? p.randn[base + i] : 0.f;
+            const float mean = ns > 0 ? wave_sum(sum) / (float)ns : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = lane + 64 * q;
+                r[i] = (i < nuse && base + i < p.table_len) ? p.randn[base + i] - mean : 0.f;
+            }
+            WAVE_LDS_FENCE();
+            rfft512(r, z, lane, tw, w512, nz, nz256);
+        }
+        {
+            float l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) l[q] = 0.5f * logf(cur_v ? env[q] * rat[q] : env[q]);
+            const float l256 = 0.5f * logf(cur_v ? env256 * rat256 : env256);
+            cplx h[4], h256;
+            min_phase(l, l256, r, z, lane, tw, w512, h, h256);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h[q] = cmul(h[q], nz[q]);
+            h256 = {h256.re * nz256.re, 0.f};
+            irfft512(h, h256, sre, sim, z, r, lane, tw, w512);
+        }
+        const float sq = sqrtf((float)ns);
+        float* out = respb + (size_t)pi * NF;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = 2 * (lane + 64 * q);
+            const int src = n < NH ? n + NH : n - NH;    // fftshift of the aperiodic response
+            const float2 a = *reinterpret_cast<const float2*>(r + src);
+            *reinterpret_cast<float2*>(out + n) = make_float2((per[2 * q] * sq + a.x) * (1.f / 512.f), (per[2 * q + 1] * sq + a.y) * (1.f / 512.f));
+        }
+        WAVE_LDS_FENCE();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3. overlap-add: y[n] = sum over pulses with idx in [n - 256, n + 255] of resp[pulse][n - idx + 255], pulse order
+__global__ __launch_bounds__(256) void world_overlap_add_kernel(WorldParams p) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int T = p.frames ? p.frames[b] : p.T;
+    const int ylen = T > 0 ? world_ylen(T, p.frame_period_ms, p.fs) : 0;
+    if (n >= p.Ymax) return;
+    float* y = p.y + (size_t)b * p.Ymax;
+    const int P = p.n_pulses[b];
+    if (n >= ylen) { y[n] = 0.f; return; }
+    if (P < 0) { y[n] = __builtin_nanf(""); return; }   // pulse list overflowed: fail loudly
+    const int* idx = p.idx + (size_t)b * p.Pcap;
+    const float* resp = p.resp + (size_t)b * p.Pcap * NF;
+    int lo = 0, hi = P;                                  // first pulse with idx >= n - 256
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (idx[mid] < n - NH) lo = mid + 1; else hi = mid;
+    }
+    float acc = 0.f;
+    for (int q = lo; q < P; ++q) {
+        const int id = idx[q];
+        if (id > n + NH - 1) break;
+        acc += resp[(size_t)q * NF + (n - id + NH - 1)];
+    }
+    y[n] = acc;
+}
+
+// decode_aperiodicity: coded [rows][nb] dB -> ap [rows][257]
+__global__ void world_decode_ap_kernel(const float* __restrict__ coded, float* __restrict__ ap, long long rows, int nb, int fs, int nbins, int fft_size) {
+    const long long row = blockIdx.x;
+    if (row >= rows) return;
+    const float* c = coded + row * nb;
+    float mean = 0.f;
+    for (int i = 0; i < nb; ++i) mean += c[i];
+    mean /= (float)nb;
+    float* o = ap + row * nbins;
+    if (mean > -0.5f) {
+        for (int k = threadIdx.x; k < nbins; k += blockDim.x) o[k] = 1.0f;               // 1 - 1e-12 rounds to 1 in fp32
+        return;
+    }
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
+        const float f = (float)fs / (float)fft_size * (float)k;
+        // coarse grid: 0 Hz (-60 dB), 3 kHz steps (coded values), fs / 2 (-1e-12 dB)
+        int seg = (int)(f / 3000.f);
+        if (seg > nb) seg = nb;
+        const float x0 = 3000.f * seg, x1 = seg == nb ? 0.5f * fs : 3000.f * (seg + 1);
+        const float y0 = seg == 0 ? -60.f : c[seg - 1], y1 = seg == nb ? -1e-12f : c[seg];
+        const float db = y0 + (f - x0) / (x1 - x0) * (y1 - y0);
+        o[k] = exp2f(db * (3.321928094887362f / 20.f));
+    }
+}
+}   // namespace
+
+// WORLD's randn() after randn_reseed(): sum of twelve xorshift128 draws (>> 4, x 2^-28) minus 6.  HOST function on a HOST buffer (the one
+// entry point of the library that is not a launch): the sequence is the same for every utterance and call, so callers fill it once.
+extern "C" int v100_world_randn_host(float* host_out, long long n) {
+    if (!host_out) return V100_ERR_NULL;
+    if (n < 0) return V100_ERR_SHAPE;
+    uint32_t x = 123456789u, y = 362436069u, z = 521288629u, w = 88675123u;
+    for (long long i = 0; i < n; ++i) {
+        uint32_t tmp = 0;
+        for (int j = 0; j < 12; ++j) {
+            const uint32_t t = x ^ (x << 11);
+            x = y; y = z; z = w;
+            w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+            tmp += w >> 4;
+        }
+        host_out[i] = (float)(tmp / 268435456.0 - 6.0);
+    }
+    return V100_OK;
+}
+
+extern "C" int v100_world_decode_aperiodicity(const float* coded, float* ap, long long rows, int nb, int fs, int fft_size, void* stream) {
+    if (!coded || !ap) return V100_ERR_NULL;
+    if (rows <= 0 || fs <= 0 || fft_size < 2) return V100_ERR_SHAPE;
+    const double lim = (fs / 2.0 - 3000.0) < 15000.0 ? (fs / 2.0 - 3000.0) : 15000.0;
+    if (nb < 1 || nb != (int)(lim / 3000.0) || rows > 0x7fffffffL) return V100_ERR_SHAPE;
+    V100_GGL(world_decode_ap_kernel, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, coded, ap, rows, nb, fs, fft_size / 2 + 1, fft_size);
+    return v100_launch_status();
+}
+
+static int world_ymax(int T, int fs, double frame_period_ms) { return (int)((double)T * frame_period_ms * (double)fs / 1000.0); }
+
+// bytes of the `workspace` argument of v100_world_synthesize
+extern "C" long long v100_world_synth_workspace_bytes(int B, int T, int fs, double frame_period_ms, int fft_size, int max_pulses) {
+    if (B <= 0 || T <= 0 || fs <= 0 || fft_size != NF || max_pulses <= 0 || frame_period_ms <= 0) return -1;
+    const long long Y = (world_ymax(T, fs, frame_period_ms) + 63) & ~63LL;
+    const long long Pc = (max_pulses + 63) & ~63LL;
+    return (long long)B * (Y * 8 + Y + Pc * 4 + Pc * 4 + Pc * NF * 4) + 256;
+}
+
+extern "C" int v100_world_synthesize(const float* f0, const float* sp, const float* ap, const int* frames, const float* randn_table,
+                                     long long table_len, const float* tw256, const float* tw512, const float* dc_remover, float* y,
+                                     int* n_pulses, void* workspace, int B, int T, int fs, double frame_period_ms, int fft_size,
+                                     int max_pulses, void* stream) {
+    if (!f0 || !sp || !ap || !randn_table || !tw256 || !tw512 || !dc_remover || !y || !n_pulses || !workspace) return V100_ERR_NULL;
+    if (B <= 0 || T < 2 || fs <= 0 || fft_size != NF || max_pulses <= 0 || frame_period_ms <= 0) return V100_ERR_SHAPE;
+    const int Ymax = world_ymax(T, fs, frame_period_ms);
+    if (Ymax < 2 || table_len < Ymax || B > 65535) return V100_ERR_SHAPE;
+    const long long Y = (Ymax + 63) & ~63LL, Pc = (max_pulses + 63) & ~63LL;
+    char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    WorldParams p{};
+    p.f0 = f0; p.sp = sp; p.ap = ap; p.frames = frames; p.randn = randn_table; p.table_len = table_len; p.y = y; p.n_pulses = n_pulses;
+    p.total = (double*)w;               w += (size_t)B * Y * 8;
+    p.idx = (int*)w;                    w += (size_t)B * Pc * 4;
+    p.xshift = (float*)w;               w += (size_t)B * Pc * 4;
+    p.resp = (float*)w;                 w += (size_t)B * Pc * NF * 4;
+    p.vuv = (unsigned char*)w;
+    p.B = B; p.T = T; p.fs = fs; p.Ymax = Ymax; p.Pcap = (int)Pc;
+    p.frame_period = frame_period_ms / 1000.0; p.frame_period_ms = frame_period_ms;
+    p.tw256 = tw256; p.tw512 = tw512; p.dcr = dc_remover;
+    // (Ymax as the row pitch of total / vuv would leave rows of `total` 8-byte aligned only when Ymax is even: use the padded Y)
+    p.Ymax = Ymax;
+    hipStream_t st = (hipStream_t)stream;
+    WorldParams pt = p;
+    pt.Ymax = (int)Y;                   // workspace rows are Y long; y rows are Ymax long (kernels 1 and 2 only touch the workspace)
+    V100_GGL(world_timebase_kernel, dim3((unsigned)B), dim3(256), 0, st, pt);
+    int gx = (max_pulses + 3) / 4;
+    if (gx > 2048) gx = 2048;
+    V100_GGL(world_pulse_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, st, pt);
+    // overlap-add reads idx / resp (pitch Pcap) and writes y (pitch Ymax)
+    V100_GGL(world_overlap_add_kernel, dim3((unsigned)((Ymax + 255) / 256), (unsigned)B), dim3(256), 0, st, p);
+    return v100_launch_status();
+}

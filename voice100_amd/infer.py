@@ -116,12 +116,16 @@ class TTSPipeline:
           -> AlignTextToAudioModel.predict                f0 [B, 2La-1], logspc|mcep, codeap           (tts.py:192-201)
           -> (use_mcep) logspc = mcep @ mc2sp             one fp32 MFMA GEMM over all B x T frames      (vocoder.py:95)
           -> spc = max(exp(logspc) - 1e-15, 0)                                                         (vocoder.py:99)
+          -> ap = decode_aperiodicity(codeap); waveform = synthesize(f0, spc, ap)                      (vocoder.py:100-101; round 4,
+                                                           csrc/world.hip -- parity unpinned, see voice100_amd/vocoder.py)
 
-    What remains on the CPU in the reference after this is pyworld.decode_aperiodicity + pyworld.synthesize."""
+    configs[2] therefore ends in a waveform [B, samples] on the device ("wave", zero beyond each utterance's "wave_len")."""
 
-    def __init__(self, align_model, audio_model, vocoder=None, head: int = 5, tail: int = 5):
+    def __init__(self, align_model, audio_model, vocoder=None, head: int = 5, tail: int = 5, synthesize: bool = True,
+                 f0_ceil: float = 1000.0):
         self.align_model, self.audio_model, self.vocoder = align_model, audio_model, vocoder
         self.head, self.tail = head, tail
+        self.synthesize, self.f0_ceil = synthesize, f0_ceil
 
     @torch.no_grad()
     def __call__(self, text: torch.Tensor, text_len: torch.Tensor):
@@ -141,8 +145,14 @@ class TTSPipeline:
         spc = v.logspc_to_spc(logspc) if v is not None else None
         # valid WORLD frames per utterance: 2 * len - 1 (update_samples.py:81 slices 2 * len, which yields the same)
         frames = torch.clamp_min(2 * at_len - 1, 0)
-        return {"align": align, "aligntext": aligntext, "aligntext_len": at_len, "f0": f0, "logspc": logspc, "spc": spc,
-                "codeap": codeap, "frames": frames}
+        out = {"align": align, "aligntext": aligntext, "aligntext_len": at_len, "f0": f0, "logspc": logspc, "spc": spc,
+               "codeap": codeap, "frames": frames}
+        if v is not None and self.synthesize and v.n_fft == 512 and f0.shape[1] >= 2:
+            ap = v.decode_aperiodicity(codeap)
+            wave, npulses = v.synthesize(f0, spc, ap, frames=frames, f0_ceil=self.f0_ceil)
+            out["wave"], out["n_pulses"] = wave, npulses
+            out["wave_len"] = (frames.to(torch.float64) * v.frame_period * v.sample_rate / 1000).to(torch.int64)
+        return out
 
 
 class ASRPipeline:

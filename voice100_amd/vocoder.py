@@ -1,7 +1,10 @@
 """WORLD vocoder glue (voice100/vocoder.py:14-141): the reference-owned arithmetic -- mel-cepstrum <-> log
 spectrum matrices (host, float64, built once), their application and the log/exp/clip steps -- with the
-per-frame products on the GPU.  DIO / CheapTrick / D4C / synthesis live in pyworld (C++ WORLD), which is not
-part of this hot path: encode()/decode() call it when installed and raise otherwise.
+per-frame products on the GPU.  Round 4: decode() -- pyworld.decode_aperiodicity + pyworld.synthesize, vocoder.py:100-101 --
+runs on the device too (csrc/world.hip: pulse instants from the F0 contour, one minimum-phase response per pulse, deterministic
+overlap-add).  PARITY UNPINNED: pyworld's C++ is not in the reference tree; the kernels follow the published algorithm as restated
+in oracle/world_synth.py and are tested against that restatement and its properties.  DIO / CheapTrick / D4C (encode) stay in
+pyworld: encode() calls it when installed and raises otherwise.
 """
 from typing import Tuple
 
@@ -109,7 +112,83 @@ class WORLDVocoder(nn.Module):
         N.call("v100_exp_clip", x, y, float(self.log_offset), x.numel())
         return y
 
-    # ---- pyworld-owned analysis / synthesis ---------------------------------------------------------
+    # ---- WORLD synthesis on the device (first half; parity unpinned) -------------------------------
+    _randn_cache = {}          # device -> float32 tensor: WORLD's randn() sequence (one fixed sequence, see csrc/world.hip)
+
+    @classmethod
+    def _randn_table(cls, n: int, device) -> torch.Tensor:
+        t = cls._randn_cache.get(device)
+        if t is None or t.numel() < n:
+            import ctypes
+            m = max(n, 1 << 18, 0 if t is None else 2 * t.numel())
+            host = torch.empty(m, dtype=torch.float32)
+            rc = N.load().v100_world_randn_host(ctypes.c_void_p(host.data_ptr()), m)
+            if rc != 0:
+                raise RuntimeError(f"v100_world_randn_host failed (status {rc})")
+            t = cls._randn_cache[device] = host.to(device)
+        return t
+
+    def _synth_tables(self, device):
+        tabs = getattr(self, "_synth_tabs", None)
+        if tabs is None or tabs[0].device != device:
+            n = self.n_fft
+            k = np.arange(n // 2, dtype=np.float64)
+            tw_h = np.stack([np.cos(2 * np.pi * k / (n // 2)), -np.sin(2 * np.pi * k / (n // 2))], axis=1)
+            k = np.arange(n // 2 + 1, dtype=np.float64)
+            tw_f = np.stack([np.cos(2 * np.pi * k / n), -np.sin(2 * np.pi * k / n)], axis=1)
+            i = np.arange(n // 2, dtype=np.float64)
+            half = 0.5 - 0.5 * np.cos(2.0 * np.pi * (i + 1.0) / (1.0 + n))            # WORLD GetDCRemover: a Hann window of unit sum
+            dcr = np.concatenate([half, half[::-1]]) / (2.0 * half.sum())
+            tabs = self._synth_tabs = tuple(torch.from_numpy(a.astype(np.float32)).contiguous().to(device) for a in (tw_h, tw_f, dcr))
+        return tabs
+
+    @torch.no_grad()
+    def decode_aperiodicity(self, codeap: torch.Tensor) -> torch.Tensor:
+        """pyworld.decode_aperiodicity(codeap, fs, n_fft) on the device (vocoder.py:100): [..., nb] dB -> [..., n_fft/2+1]."""
+        F_._check(codeap, "WORLDVocoder.decode_aperiodicity")
+        c = codeap.contiguous()
+        rows = c.numel() // c.shape[-1]
+        ap = torch.empty(c.shape[:-1] + (self.n_fft // 2 + 1,), dtype=torch.float32, device=c.device)
+        N.call("v100_world_decode_aperiodicity", c, ap, rows, int(c.shape[-1]), int(self.sample_rate), int(self.n_fft))
+        return ap
+
+    @torch.no_grad()
+    def synthesize(self, f0: torch.Tensor, spc: torch.Tensor, ap: torch.Tensor, frames: torch.Tensor = None, f0_ceil: float = 1000.0):
+        """pyworld.synthesize(f0, spc, ap, fs, frame_period) for a batch, on the device (vocoder.py:101).
+
+        f0 [B, T], spc / ap [B, T, n_fft/2+1] fp32 CUDA; frames [B] int32 = valid frames per utterance (None: all T).
+        Returns (waveform [B, int(T * frame_period * fs / 1000)] fp32, zero beyond an utterance's own length; n_pulses [B] int32).
+        Room is made for f0_ceil / fs pulses per sample (unvoiced frames pulse at 500 Hz); an utterance that needs more comes
+        back as NaN with n_pulses = -1 -- raise f0_ceil."""
+        for t, nm in ((f0, "f0"), (spc, "spc"), (ap, "ap")):
+            F_._check(t, "WORLDVocoder.synthesize " + nm)
+        if self.n_fft != 512:
+            raise RuntimeError("WORLDVocoder.synthesize: the device kernels are built for n_fft = 512 (16 kHz)")
+        f0, spc, ap = f0.contiguous(), spc.contiguous(), ap.contiguous()
+        B, T = f0.shape
+        nb = self.n_fft // 2 + 1
+        if spc.shape != (B, T, nb) or ap.shape != (B, T, nb):
+            raise ValueError("synthesize: spc / ap must be [B, T, n_fft/2+1]")
+        if T < 2:
+            raise ValueError("synthesize needs at least two frames (WORLD extrapolates the contour from its last two)")
+        ymax = int(T * self.frame_period * self.sample_rate / 1000)
+        cap = int(ymax * max(float(f0_ceil), 500.0) / self.sample_rate) + 2
+        dev = f0.device
+        tw_h, tw_f, dcr = self._synth_tables(dev)
+        table = self._randn_table(ymax, dev)
+        if frames is not None:
+            frames = frames.to(device=dev, dtype=torch.int32).contiguous()
+        y = torch.empty((B, ymax), dtype=torch.float32, device=dev)
+        npulses = torch.empty((B,), dtype=torch.int32, device=dev)
+        nbytes = N.helper("v100_world_synth_workspace_bytes", B, T, int(self.sample_rate), float(self.frame_period), int(self.n_fft), cap)
+        if nbytes < 0:
+            raise RuntimeError("v100_world_synth_workspace_bytes: unsupported shape")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        N.call("v100_world_synthesize", f0, spc, ap, frames, table, table.numel(), tw_h, tw_f, dcr, y, npulses, ws,
+               B, T, int(self.sample_rate), float(self.frame_period), int(self.n_fft), cap)
+        return y, npulses
+
+    # ---- pyworld-owned analysis ----------------------------------------------------------------------
     @staticmethod
     def _pyworld():
         try:
@@ -135,11 +214,25 @@ class WORLDVocoder(nn.Module):
                 torch.from_numpy(codeap.astype(np.float32)))
 
     def decode(self, f0: torch.Tensor, logspc_or_mcep: torch.Tensor, codeap: torch.Tensor) -> np.ndarray:
-        pyworld = self._pyworld()
-        f0 = f0.cpu().numpy().astype(np.double, order="C")
-        feat = logspc_or_mcep.cpu().numpy().astype(np.double)
-        logspc = feat @ self.mc2sp_matrix if self.use_mcep else feat
-        codeap = codeap.cpu().numpy().astype(np.double, order="C")
-        spc = np.maximum(np.exp(logspc) - self.log_offset, 0).copy(order="C")
-        ap = pyworld.decode_aperiodicity(codeap, self.sample_rate, self.n_fft)
-        return pyworld.synthesize(f0, spc, ap, self.sample_rate, frame_period=self.frame_period)
+        """vocoder.py:89-102 for one utterance (f0 [T], features [T, D], codeap [T, nb]) -> waveform, float64 numpy as the reference
+        returns it.  Everything runs on the GPU (mcep -> log spectrum GEMM, exp / clip, aperiodicity decoding, synthesis); CPU
+        tensors are moved to the current CUDA device -- there is no CPU fallback."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("WORLDVocoder.decode runs on the GPU only (no CPU fallback; see oracle/world_synth.py for the checker)")
+        dev = f0.device if f0.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        f0 = f0.to(dev, torch.float32).reshape(1, -1)
+        feat = logspc_or_mcep.to(dev, torch.float32)
+        if self.use_mcep:
+            if self._mc2sp_t.device != dev:
+                self.to(dev)
+            logspc = self.mcep_to_logspc(feat)
+        else:
+            logspc = feat
+        spc = self.logspc_to_spc(logspc)[None]
+        ap = self.decode_aperiodicity(codeap.to(dev, torch.float32))[None]
+        # pulses per sample are bounded by the largest interpolated F0 (the extrapolated end point can reach twice the maximum)
+        ceil = max(500.0, 2.0 * float(f0.max())) + 1.0
+        y, n = self.synthesize(f0, spc, ap, f0_ceil=ceil)
+        if int(n[0]) < 0:
+            raise RuntimeError("WORLDVocoder.decode: pulse list overflow")
+        return y[0].double().cpu().numpy()
