@@ -196,6 +196,15 @@ int v100_exp_clip(const float* x, float* y, float offset, long long n, void* str
  *                            of 2 pi k / 256 and / 512, dc_remover [512] (oracle.world_synth.dc_remover), all built in double
  *                            by the caller -> y [B][Ymax] fp32, Ymax = (int)(T * frame_period_ms * fs / 1000), zero beyond
  *                            an utterance's own length; n_pulses [B] (-1 and a NaN row: more than max_pulses pulses). */
+/* ---- channel-major inference layout (round 4; csrc/block.hip v100_ir_fwd_eval with shape[10] == 2) --------------------------
+ * Activations [C][B][P], P = (T + 7) & ~7: one [C x (B P)] matrix with every utterance's (padded) row back to back, so a 1x1
+ * convolution is ONE GEMM over all B P columns (asr.py:47,51 on 1-second chunks: full 128-column tiles instead of 51 of 128) and a
+ * channel's rows are contiguous for the depthwise kernel.  Block inputs / outputs fp32, hidden tensors in the GEMM operand format
+ * (bf16, or fp16 at precision "fp16").  v100_bct_to_cm: [B][C][T] fp32 -> [C][B][P] (padding zeroed); v100_cm_to_btc: [C][B][P] ->
+ * [B][T][C] (the model-edge transpose of the logits, asr.py:114). */
+int v100_bct_to_cm(const float* in, float* out, int B, int C, int T, void* stream);
+int v100_cm_to_btc(const float* in, float* out, int B, int C, int T, void* stream);
+
 int v100_world_randn_host(float* host_out, long long n);
 int v100_world_decode_aperiodicity(const float* coded, float* ap, long long rows, int nb, int fs, int fft_size, void* stream);
 long long v100_world_synth_workspace_bytes(int B, int T, int fs, double frame_period_ms, int fft_size, int max_pulses);

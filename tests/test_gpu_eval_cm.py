@@ -1,0 +1,134 @@
+"""Channel-major inference path (round 4: functional.inverted_residual_eval_cm, AudioToTextCTC._forward_eval_cm; asr.py:40-59,
+62-94, 110-116 in eval mode): activations [C][B][P], one GEMM over all utterances' columns per 1x1 convolution, short rows packed
+several to a depthwise wave item, hidden tensors in the GEMM operand format (bf16 / fp16).  Held to the per-module batch-major path
+-- itself held to the oracle by test_gpu_models / test_gpu_kernels -- element for element, and to the fp32 path at the precision's bar."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _block(cuda, cin, cout, k, res, seed):
+    from voice100_amd.layers import InvertedResidual
+    torch.manual_seed(seed)
+    blk = InvertedResidual(cin, cout, kernel_size=k, use_residual=res).to(cuda)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_((torch.randn(m.running_mean.shape, generator=g) * 0.2).to(cuda))
+                m.running_var.copy_((torch.rand(m.running_var.shape, generator=g) + 0.5).to(cuda))
+                m.weight.copy_((torch.rand(m.weight.shape, generator=g) + 0.5).to(cuda))
+                m.bias.copy_((torch.randn(m.bias.shape, generator=g) * 0.2).to(cuda))
+    return blk.eval()
+
+
+def _cm_block(blk, x, precision):
+    from voice100_amd import functional as F_
+    B, _, T = x.shape
+    F_.set_matmul_precision(precision)
+    try:
+        yc = F_.inverted_residual_eval_cm(blk, F_.bct_to_cm(x), B, T)
+        y = F_.cm_to_btc(yc, B, T).transpose(1, 2).contiguous()
+    finally:
+        F_.set_matmul_precision("fp32")
+    return y
+
+
+@pytest.mark.parametrize("k", [19, 51, 83])
+def test_block_channel_major_equals_batch_major(cuda, k):
+    """bf16: the same kernels on the same values in another layout -- every valid element identical, whatever the row length
+    (packed short rows, one row per item, the 513 .. 768 form) and batch size (last item partly filled)."""
+    from voice100_amd import functional as F_
+    blk = _block(cuda, 64, 64, k, True, 10 + k)
+    for B, T in ((1, 5), (3, 51), (7, 56), (33, 51), (5, 100), (2, 200), (3, 301), (2, 512), (3, 600), (2, 768)):
+        g = torch.Generator().manual_seed(B * 1000 + T)
+        x = torch.randn(B, 64, T, generator=g).to(cuda)
+        F_.set_matmul_precision("bf16")
+        try:
+            with torch.no_grad():
+                ref = blk(x)
+        finally:
+            F_.set_matmul_precision("fp32")
+        got = _cm_block(blk, x, "bf16")
+        assert got.shape == ref.shape
+        assert torch.equal(got, ref), (k, B, T, float((got - ref).abs().max()))
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16", 3e-2), ("fp16", 4e-3)])
+def test_block_channel_major_vs_fp32(cuda, precision, tol):
+    """Against the exact-fp32 eval path (the parity path, held to the oracle at 1e-4): bf16 at the bf16 bar; fp16 -- fp16 operands,
+    fp16-stored hidden tensors, two fp16 digits per depthwise tap -- at 4e-3."""
+    for (cin, cout, k, res, B, T) in ((256, 256, 35, True, 9, 51), (256, 512, 51, False, 4, 128), (512, 512, 83, True, 16, 51), (512, 512, 59, True, 3, 400)):
+        blk = _block(cuda, cin, cout, k, res, k + B)
+        x = torch.randn(B, cin, T, generator=torch.Generator().manual_seed(T)).to(cuda)
+        with torch.no_grad():
+            ref = blk(x)                                       # fp32
+        got = _cm_block(blk, x, precision)
+        assert rel_err(got, ref) < tol, (precision, cin, k, B, T, rel_err(got, ref))
+
+
+def test_asr_eval_channel_major_model(cuda):
+    """AudioToTextCTC.forward in eval mode: the channel-major path is taken for the 16-bit precisions and reproduces the per-module
+    path (bf16: identical logits; fp16: at the fp16 bar, same greedy tokens where the margins allow), steps aside for hooks, for
+    fp32 and for rows longer than a wave item."""
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd import functional as F_
+    from voice100_amd.decode import ctc_greedy_decode
+    torch.manual_seed(5)
+    m = AudioToTextCTC(audio_size=64, embed_size=128, vocab_size=29, hidden_size=128).to(cuda).eval()
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_((torch.randn(mod.running_mean.shape, generator=g) * 0.1).to(cuda))
+                mod.running_var.copy_((torch.rand(mod.running_var.shape, generator=g) + 0.5).to(cuda))
+    for B, T in ((37, 101), (2, 256), (3, 1024)):
+        audio = (torch.randn(B, T, 64, generator=g) * 2 - 4).to(cuda)
+        with torch.no_grad():
+            ref32 = m(audio)
+        outs = {}
+        for prec in ("bf16", "fp16"):
+            F_.set_matmul_precision(prec)
+            try:
+                with torch.no_grad():
+                    F_.EVAL_CM = True
+                    calls = []
+                    orig = F_.inverted_residual_eval_cm
+                    F_.inverted_residual_eval_cm = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+                    try:
+                        outs[prec, True] = m(audio)
+                    finally:
+                        F_.inverted_residual_eval_cm = orig
+                    assert len(calls) == 8, "the channel-major path was not taken"
+                    F_.EVAL_CM = False
+                    outs[prec, False] = m(audio)
+            finally:
+                F_.EVAL_CM = True
+                F_.set_matmul_precision("fp32")
+        assert outs["bf16", True].shape == ref32.shape == (B, (T + 1) // 2, 29)
+        assert torch.equal(outs["bf16", True], outs["bf16", False])
+        assert rel_err(outs["fp16", True], ref32) < 1e-2 and rel_err(outs["fp16", False], ref32) < 1e-2
+        assert rel_err(outs["bf16", True], ref32) < 6e-2
+    # fp32: never channel-major; a forward hook on an inner block: the per-module path (the hook must fire)
+    audio = (torch.randn(4, 101, 64, generator=g) * 2 - 4).to(cuda)
+    F_.set_matmul_precision("bf16")
+    try:
+        seen = []
+        h = m.encoder.layers[3].register_forward_hook(lambda mod, i, o: seen.append(tuple(o.shape)))
+        with torch.no_grad():
+            a = m(audio)
+        h.remove()
+        assert seen == [(4, 64, 51)]
+        with torch.no_grad():
+            b = m(audio)
+        assert torch.equal(a, b)
+        # rows longer than 768 outputs: per-module path, still correct
+        long = (torch.randn(1, 1700, 64, generator=g) * 2 - 4).to(cuda)
+        with torch.no_grad():
+            assert m(long).shape == (1, 850, 29)
+    finally:
+        F_.set_matmul_precision("fp32")

@@ -89,7 +89,7 @@ def test_synthesize_batch_ragged_frames_equals_single(cuda):
     assert y.shape == (4, int(T * 10.0 * FS / 1000))
     for b, L in enumerate(lens):
         yl = int(L * 10.0 * FS / 1000)
-        y1, n1 = v.synthesize(_dev(f0[b:b + 1, :L], cuda), _dev(sp[b:b + 1, :L], cuda), ap[b:b + 1, :L].contiguous())
+        y1, n1 = v.synthesize(_dev(f0[b:b + 1, :L], cuda), _dev(sp[b:b + 1, :L], cuda), ap[b:b + 1, :L].clone())
         assert int(n1[0]) == int(n[b])
         assert torch.equal(y[b, :yl], y1[0]) and float(y[b, yl:].abs().max() if yl < y.shape[1] else 0.0) == 0.0
         ref = W.synthesize(f0[b, :L].astype(np.float64), sp[b, :L].astype(np.float64), ap[b, :L].cpu().numpy().astype(np.float64), FS, 10.0)

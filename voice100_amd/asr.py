@@ -79,9 +79,38 @@ class AudioToTextCTC(Voice100ModelBase):
         if tracing():                            # torch.jit.trace / torch.onnx.export: plain aten ops (_stock.py)
             return torch.transpose(self.decoder(self.encoder(torch.transpose(audio, 1, 2))), 1, 2)
         x = F_.transpose_last2(audio)            # [B,T,C] -> [B,C,T]
+        if not self.training and not (torch.is_grad_enabled() and audio.requires_grad):
+            y = self._forward_eval_cm(x)
+            if y is not None:
+                return y
         x = self.encoder(x)
         x = self.decoder(x)
         return F_.transpose_last2(x)             # [B,V,T'] -> [B,T',V]
+
+    def _forward_eval_cm(self, x: torch.Tensor):
+        """Inference at the 16-bit precisions: after the stride-2 opener the eight stride-1 blocks and the vocabulary head run on
+        CHANNEL-MAJOR activations (functional.inverted_residual_eval_cm): one GEMM over the whole batch's columns per 1x1 convolution
+        -- 1-second chunks (51 output frames) fill the 128-column tiles -- and packed short rows in the depthwise stage.  Same
+        arithmetic per element as the per-module path (asr.py:62-94); None when the path does not apply (fp32, hooks, long rows ...)."""
+        enc, dec = self.encoder, self.decoder
+        layers = list(enc.layers)
+        drop, conv = dec.layers[0], dec.layers[1]
+        mods = (enc, enc.layers, dec, dec.layers, drop, conv)
+        if enc.training or dec.training or any(m._forward_hooks or m._forward_pre_hooks for m in mods):
+            return None
+        B, _, T = x.shape
+        T1 = int(enc.output_length(torch.tensor(T)))
+        if layers[0].stride != 2 or T1 != F_.conv_out_len(T, int(layers[0].kernel_size), 2):
+            return None
+        if not F_.eval_cm_supported(layers[1:], T1):
+            return None
+        with torch.no_grad():
+            y = layers[0](x)                     # the stride-2 opener: batch-major (its depthwise kernel is the register-window one)
+            xc = F_.bct_to_cm(y)
+            for blk in layers[1:]:
+                xc = F_.inverted_residual_eval_cm(blk, xc, B, T1)
+            logits = F_.pointwise_conv1d_cm(xc, conv.weight, conv.bias)
+            return F_.cm_to_btc(logits, B, T1)
 
     def output_length(self, audio_len: torch.Tensor) -> torch.Tensor:
         return self.encoder.output_length(audio_len)

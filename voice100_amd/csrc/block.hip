@@ -42,7 +42,7 @@ const float kMom = 0.1f, kEps = 1e-5f;
 // and its BatchNorm-backward gradient da3 (workspace).  Statistics and every accumulation stay fp32; only the stored copies are rounded.
 enum { IR_B, IR_CIN, IR_HID, IR_COUT, IR_T, IR_K, IR_STRIDE, IR_RES, IR_BF16, IR_PREPPED, IR_ACT16, IR_NSHAPE };
 static inline int pitch16(int T) { return (T + 7) & ~7; }
-enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8, WG_IO_G = 1, WG_IO_G2 = 2, WG_IO_X = 4 };   // DW_IO_*: depthwise_common.h
+enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8, PW_IO_F16 = 16, WG_IO_G = 1, WG_IO_G2 = 2, WG_IO_X = 4 };   // DW_IO_*: depthwise_common.h
 
 // 1 when a block of this shape can run with act16 != 0 (stride 1, a depthwise kernel size with an MFMA kernel, bf16 operands,
 // tensors addressable by the buffer-descriptor kernels)
@@ -355,6 +355,25 @@ extern "C" int v100_ir_fwd_eval(const int* sh, const void* const* P, void* strea
     ir_eval_carve(sh, const_cast<void*>(P[4]), c);
     float *h1 = (float*)P[5], *h2 = (float*)P[6], *y = (float*)P[7];
     int rc;
+    if (sh[IR_ACT16] == 2) {
+        // CHANNEL-MAJOR inference (round 4): x [cin][B P] fp32, h1 / h2 [hid][B P] 16-bit, y [cout][B P] fp32, P = pitch16(T) -- every
+        // utterance of the batch back to back in ONE [C x (B P)] matrix.  The two 1x1 convolutions are then ONE GEMM over all B P columns
+        // (1-second chunks, T' = 51: 128-column tiles are full instead of 40 % full), a channel's rows are contiguous for the depthwise
+        // kernel (the order it walks them in), short rows are packed several to a wave item.  The columns T .. P-1 of an utterance are
+        // padding: finite garbage that no valid column ever reads (GEMM columns are independent; the depthwise kernel masks them).
+        // Hidden tensors in the GEMMs' operand format: bf16, or fp16 at precision "fp16".
+        int shb[IR_NSHAPE];
+        for (int i = 0; i < IR_NSHAPE; ++i) shb[i] = sh[i];
+        shb[IR_BF16] = 1;
+        if ((bf != 1 && bf != 2) || S != 1 || T > 768 || !v100_ir_act16_supported(shb)) return V100_ERR_SHAPE;
+        const long long N = (long long)B * pitch16(T);
+        if (N > 0x7fffff00LL) return V100_ERR_SHAPE;
+        const int f16 = bf == 2 ? PW_IO_F16 : 0;
+        CK(v100_pw_gemm_io(c.w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, h1, c.s1, c.t1, nullptr, 2, nullptr, 1, hid, cin, (int)N, PW_IO_Y | f16, stream));
+        CK(dw_fwd_eval_io(h1, (const float*)P[2], c.s2, c.t2, h2, B, hid, T, K, stream, 1, bf == 2));
+        CK(v100_pw_gemm_io(c.w3bf, h2, nullptr, nullptr, nullptr, nullptr, 0, y, c.s3, c.t3, res ? x : nullptr, 3, nullptr, 1, cout, hid, (int)N, PW_IO_X | f16, stream));
+        return V100_OK;
+    }
     if (sh[IR_ACT16]) {
         // inference at precision "bf16": the two hidden tensors (each 4x the block's width, already BatchNorm'ed and clamped to [0, 6])
         // are stored as bf16 [B][hid][pitch16(T)] -- half the bytes of the three kernels' big streams; the GEMMs round them to bf16 as

@@ -494,6 +494,32 @@ __global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __res
     }
 }
 
+// Channel-major inference layout (block.hip, v100_ir_fwd_eval with shape[10] == 2): [B][C][T] -> [C][B][P], P = (T + 7) & ~7, the padding
+// columns zeroed; and back out of it at the model's edge: [C][B][P] -> [B][T][C]  (asr.py:114: transpose(1, 2) of the logits)
+__global__ __launch_bounds__(256) void bct_to_cm_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int T, int P) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* src = in + ((size_t)b * C + c) * T;
+    float* dst = out + ((size_t)c * B + b) * P;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < P; t += gridDim.x * 256) dst[t] = t < T ? src[t] : 0.f;
+}
+__global__ __launch_bounds__(256) void cm_to_btc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int T, int P) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, t = t0 + tx;
+        if (c < C && t < T) tile[ty + 8 * i][tx] = in[((size_t)c * B + b) * P + t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + 8 * i, c = c0 + tx;
+        if (c < C && t < T) out[((size_t)b * T + t) * C + c] = tile[tx][ty + 8 * i];
+    }
+}
+
 // K6: out[b][c][t] = table[idx[b][t]][c]   (nn.Embedding + transpose(1,2): tts.py:81-83, 176-177)
 __global__ __launch_bounds__(256) void embedding_bct_kernel(const long long* __restrict__ idx, const float* __restrict__ table,
                                                             float* __restrict__ out, int V, int C, int T) {
@@ -697,6 +723,23 @@ extern "C" int v100_transpose_last2(const float* in, float* out, int B, int R, i
     if (!in || !out) return V100_ERR_NULL;
     if (B <= 0 || R <= 0 || Cc <= 0) return V100_ERR_SHAPE;
     V100_GGL(transpose_last2_kernel, dim3(ceil_div(Cc, 32), ceil_div(R, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, R, Cc);
+    return v100_launch_status();
+}
+
+extern "C" int v100_bct_to_cm(const float* in, float* out, int B, int C, int T, void* stream) {
+    if (!in || !out) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || B > 65535 || C > 65535) return V100_ERR_SHAPE;
+    const int P = (T + 7) & ~7;
+    V100_GGL(bct_to_cm_kernel, dim3(ceil_div(P, 256) < 4 ? ceil_div(P, 256) : 4, (unsigned)C, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+             in, out, B, C, T, P);
+    return v100_launch_status();
+}
+
+extern "C" int v100_cm_to_btc(const float* in, float* out, int B, int C, int T, void* stream) {
+    if (!in || !out) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || T <= 0 || B > 65535) return V100_ERR_SHAPE;
+    const int P = (T + 7) & ~7;
+    V100_GGL(cm_to_btc_kernel, dim3(ceil_div(C, 32), ceil_div(T, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, B, C, T, P);
     return v100_launch_status();
 }
 

@@ -441,16 +441,28 @@ int dw_fwd_train_io_fin(const void* a1, const float* w, const float* in_a, const
 
 // eval-mode depthwise stage on bf16-stored hidden tensors (block executor, inference at precision "bf16"): h2 = relu6(conv(h1) * out_a
 // + out_b), rows pitched to a multiple of 8 samples
-int dw_fwd_eval_io(const void* h1, const float* w, const float* out_a, const float* out_b, void* h2, int B, int C, int T, int K, void* stream) {
+int dw_fwd_eval_io(const void* h1, const float* w, const float* out_a, const float* out_b, void* h2, int B, int C, int T, int K, void* stream,
+                   int cm, int f16) {
     if (!h1 || !w || !out_a || !out_b || !h2) return V100_ERR_NULL;
     if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || (K & 1) == 0) return V100_ERR_SHAPE;
     if ((size_t)B * C * dw_pitch16(T) * 4 >= 0x7fffff00ull) return V100_ERR_SHAPE;
     const int G = v100_dw_num_groups(B, C);
     DwParams p{(const float*)h1, nullptr, w, nullptr, nullptr, nullptr, (float*)h2, nullptr, out_a, out_b, nullptr,
                B, C, T, T, K, 1, (K - 1) / 2, 0, 1, G, DW_IN_NONE, DW_OUT_AFFINE_RELU6, nullptr, DW_IO_X | DW_IO_Y, DwFin{}, DwPre{}};
+    p.cm = cm;
+    // rows much shorter than a wave item (1-second chunks: 51 outputs against 512 positions): several utterances side by side in one
+    // item, each followed by >= pad zeros (its own right padding = the next one's left padding)
+    const int P = dw_pitch16(T), pad = (K - 1) / 2;
+    // a multiple of 16: an output then keeps its row (t mod 16) inside the 16 x 16 Toeplitz block whatever its segment, so the packed
+    // form sums exactly what the one-row form sums
+    const int ss = (P + pad + 15) & ~15;
+    const int room = T <= 512 ? 512 : 768;
+    int segn = T <= 512 ? (room - P) / ss + 1 : 1;
+    if (segn > 1 && (segn - 1) * ss + P > room) --segn;
+    if (segn > 1) { p.segn = segn; p.segs = ss; }
     hipStream_t st = (hipStream_t)stream;
     V100TimedLaunch timed(V100_T_DW_FWD, 2.0 * B * C * 2.0 * T + 4.0 * C * K + 8.0 * C);
-    if (!dw_launch_fwd_eval16(p, st, timed)) return V100_ERR_SHAPE;
+    if (!dw_launch_fwd_eval16(p, st, timed, f16 != 0)) return V100_ERR_SHAPE;
     return v100_launch_status();
 }
 

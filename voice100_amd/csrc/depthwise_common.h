@@ -65,7 +65,18 @@ struct DwParams {
     DwFin fin;           // mode 0 unless the caller asked for in-kernel finalisation (G == 1)
     DwPre pre;           // f.mode 0 unless the kernel also finalises the BatchNorm whose coefficients it applies on load (G == 1): then
                          // in_a / in_b / in_c are ignored and the coefficients come from pre (and are written to pre.f.o0 .. o2)
+    // Channel-major storage ("cm", streaming kernels only): the tensors are [C][B][P] -- a channel's B rows contiguous, which is the
+    // order this kernel walks them in (one workgroup per channel) and, seen from the 1x1 GEMMs, ONE [C x (B P)] matrix whose columns
+    // are all utterances back to back -- instead of [B][C][P].  Row (b, c) then starts at (c B + b) P.
+    int cm;
+    // Segment packing (eval-mode streaming kernel only): rows much shorter than a wave item's 256 NS positions (1-second chunks: 51
+    // outputs) are laid side by side in ONE LDS image, `segn` utterances per item, `segs` image positions apart (a multiple of 16, >= P +
+    // pad so that the zeros between two rows are each row's own zero padding).  0 / 1: one row per item.
+    int segn, segs;
 };
+__device__ __forceinline__ unsigned dw_row_index(const DwParams& p, int b, int c) {
+    return p.cm ? (unsigned)(c * p.B + b) : (unsigned)(b * p.C + c);
+}
 enum { DW_IO_X = 1, DW_IO_X2 = 2, DW_IO_AUX = 4, DW_IO_Y = 8 };
 
 // one lane, with the channel's complete sums in double: the arithmetic of bn_finalize_train_kernel / bn_bwd_finalize_kernel.
@@ -126,7 +137,8 @@ int chan_reduce2_io_fin(const void* u, const void* v, float* partial, int B, int
 // the act16 entry points with in-kernel BatchNorm finalisation (block executor; fin.mode != 0 requires G == 1)
 int dw_fwd_train_io_fin(const void* a1, const float* w, const float* in_a, const float* in_b, void* a2, float* stats, int G, int B, int C,
                         int T, int K, int io16, const DwFin& fin, const DwPre& pre, void* stream);
-int dw_fwd_eval_io(const void* h1, const float* w, const float* out_a, const float* out_b, void* h2, int B, int C, int T, int K, void* stream);
+int dw_fwd_eval_io(const void* h1, const float* w, const float* out_a, const float* out_b, void* h2, int B, int C, int T, int K, void* stream,
+                   int cm = 0, int f16 = 0);
 int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc, const void* xpre,
                   const float* xa, const float* xb, void* dxin, float* stats, float* wpartial, float* dw, int G, int B, int C, int T, int K,
                   int io16, const DwFin& fin, const DwPre& pre, void* stream);
@@ -508,7 +520,7 @@ static bool dw_launch_specialised(const DwParams& p, hipStream_t st, const V100T
 }
 
 bool dw_launch_fwd_train16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);     // a1 in, a2 out stored as bf16
-bool dw_launch_fwd_eval16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);      // eval: h1 in, h2 = relu6(bn2(conv)) out, bf16
+bool dw_launch_fwd_eval16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl, bool f16 = false);      // eval: h1 in, h2 = relu6(bn2(conv)) out, bf16
 bool dw_launch_bwd_fused16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);     // a2 (x2) and a1 (aux) stored as bf16
 bool dw_launch_bwd_fused16g(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);    // ... and dz2 in, dz1 out too
 bool dw_launch_fwd_train(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl);   // in AFFINE_RELU6, out RAW_STATS

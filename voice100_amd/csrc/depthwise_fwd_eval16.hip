@@ -11,7 +11,22 @@
 #define DWS_NT 1
 #endif
 
-bool dw_launch_fwd_eval16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl) {
+// f16: the tensors hold fp16 (streaming kernel only: rows of up to 768 outputs); p.cm: channel-major storage (streaming kernel only)
+bool dw_launch_fwd_eval16(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl, bool f16) {
+    if (f16) {
+        if (!(p.stride == 1 && p.upsample == 1 && !p.flip && p.Tin == p.Tout && p.Tin <= 768 && p.pad == (p.K - 1) / 2)) return false;
+        dim3 grid(p.C, p.G);
+        // two fp16 digits per tap: 22 mantissa bits, far below the fp16 rounding of the stored activations
+#define X(KK)                                                                                                                           \
+    if (p.K == KK) {                                                                                                                    \
+        if (p.Tin <= 512) V100_LAUNCH(tl, (dwconv_fwd16_stream_kernel<KK, 2, DWS_DEPTH, DWS_NT * 2, 2, true, true>), grid, dim3(256), 0, st, p);  \
+        else V100_LAUNCH(tl, (dwconv_fwd16_stream_kernel<KK, 2, DWS_DEPTH, DWS_NT * 2, 3, true, true>), grid, dim3(256), 0, st, p);         \
+        return true;                                                                                                                    \
+    }
+        V100_DW_SPECIALISED(X)
+#undef X
+        return false;
+    }
     if (p.stride == 1 && p.upsample == 1 && !p.flip && p.Tin == p.Tout && p.Tin <= 768 && p.pad == (p.K - 1) / 2) {
         const DwPathConfig cfg = dw_path_config();
         dim3 grid(p.C, p.G);
@@ -29,5 +44,6 @@ bool dw_launch_fwd_eval16(const DwParams& p, hipStream_t st, const V100TimedLaun
 #undef X
 #undef GO
     }
+    if (p.cm) return false;               // the general kernel addresses [B][C][P] only
     return dw_launch_specialised<DW_IN_NONE, DW_OUT_AFFINE_RELU6, false, DW_IO_X | DW_IO_Y>(p, st, tl);
 }

@@ -48,7 +48,8 @@ __device__ __forceinline__ dwm_bf16x8 dwm_tr_fragment(const unsigned short* tile
 
 // acc += sum over the digit pairs (i, j), i < NA, j < NB, i + j <= max(NA, NB) - 1, of a[i] x b[j], smallest terms first
 // (3 x 3 digits: six products, fp32-exact; 3 x 1: three products, exact for a bf16-valued b)
-template <int NA, int NB>
+// F16: the fragments hold IEEE fp16 digits (inference at precision "fp16": fp16-stored activations against fp16 digits of the taps)
+template <int NA, int NB, bool F16 = false>
 __device__ __forceinline__ dwm_f32x4 dwm_mfma_digits(const dwm_bf16x8 (&a)[NA], const dwm_bf16x8 (&b)[NB], dwm_f32x4 acc) {
     constexpr int LIM = (NA > NB ? NA : NB) - 1;
 #pragma unroll
@@ -56,9 +57,23 @@ __device__ __forceinline__ dwm_f32x4 dwm_mfma_digits(const dwm_bf16x8 (&a)[NA], 
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int j = s - i;
-            if (j >= 0 && j < NB) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc, 0, 0, 0);
+            if (j >= 0 && j < NB) {
+                if constexpr (F16) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b[j]), acc, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc, 0, 0, 0);
+            }
         }
     return acc;
+}
+// fp16 digits of an fp32 value (round to nearest): v ~ d0 + d1 + d2, 11 + 11 (+ what fp16's range leaves) mantissa bits; as 16-bit patterns
+__device__ __forceinline__ void dwm_split_f16(float v, unsigned (&d)[3]) {
+    const _Float16 h0 = (_Float16)v;
+    const float r1 = v - (float)h0;
+    const _Float16 h1 = (_Float16)r1;
+    const float r2 = r1 - (float)h1;
+    const _Float16 h2 = (_Float16)r2;
+    d[0] = __builtin_bit_cast(unsigned short, h0);
+    d[1] = __builtin_bit_cast(unsigned short, h1);
+    d[2] = __builtin_bit_cast(unsigned short, h2);
 }
 
 // OFFMAX = 3: image element 0 sits at a position that is a multiple of 4 (4-sample loads); 7: a multiple of 8 (8-sample, 16-byte

@@ -45,8 +45,11 @@ struct DwStreamGeom {
 // CP: cache-policy bits of the row loads / stores (0 default, 2 = nontemporal: the rows are read once and written once)
 // EV (eval mode, inference): the input is the already-activated h1 (no transform on load), the output relu6(acc * out_a + out_b)
 // with the folded BatchNorm-2 coefficients, no statistics -- ConvBNActivate's "dw" stage with frozen statistics (asr.py:27-37, 49)
-template <int K, int NT, int D, int CP = 0, int NS = 2, bool EV = false>
+// F16 (EV only): the stored tensors hold IEEE fp16 (inference at precision "fp16"): the loaded words ARE the matrix operand -- no
+// conversion while staging --, the taps are split into fp16 digits, the output is rounded to fp16
+template <int K, int NT, int D, int CP = 0, int NS = 2, bool EV = false, bool F16 = false>
 __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p) {
+    static_assert(!F16 || EV, "fp16 storage: inference only");
     using S_ = DwStreamGeom<K, NS>;
     constexpr int STEPS = S_::STEPS, WPAD = S_::WPAD, WLEN = S_::WLEN, NL = S_::NL;
     constexpr int IMGP = S_::FWD_IMG > 512 * NL + 64 ? S_::FWD_IMG : 512 * NL + 64;   // + the staged runs of lanes past the row
@@ -63,22 +66,33 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     const int bper = (p.B + p.G - 1) / p.G;
     const int b0 = g * bper;
     const int nb = min(p.B, b0 + bper) - b0;
-    const int nrows = wave < nb ? (nb - wave + 3) >> 2 : 0;  // this wave's rows: b0 + wave + 4 r
+    // segment packing (EV only): SEGN utterances side by side in one item, SS image positions apart; SEGN = 1: one row per item
+    const int SEGN = (EV && p.segn > 1) ? p.segn : 1, SS = (EV && p.segn > 1) ? p.segs : 0;
+    const int nitems = (nb + SEGN - 1) / SEGN;
+    const int nrows = wave < nitems ? (nitems - wave + 3) >> 2 : 0;  // this wave's items: utterances b0 + (wave + 4 r) SEGN ...
 
     const unsigned tbytes = (unsigned)((size_t)p.B * p.C * P * 2);
     const __amdgpu_buffer_rsrc_t rx = dw_make_rsrc(p.x, tbytes);
     const __amdgpu_buffer_rsrc_t ry = dw_make_rsrc(p.y, tbytes);
-    int vo_in[NL];
+    const int seg_bytes = (p.cm ? P : p.C * P) * 2;          // byte distance between the rows of consecutive utterances of this channel
+    int vo_in[NL], seg_in[NL], w_in[NL];
 #pragma unroll
-    for (int v = 0; v < NL; ++v) vo_in[v] = 8 * (lane + 64 * v) < T ? 16 * (lane + 64 * v) : 0x7ffffff0;
-    auto row_bytes = [&](int r) -> unsigned { return (unsigned)((b0 + wave + 4 * r) * p.C + c) * (unsigned)P * 2u; };
+    for (int v = 0; v < NL; ++v) {
+        const int rp = 8 * (lane + 64 * v);                  // image position of this lane's run
+        seg_in[v] = SEGN > 1 ? rp / SS : 0;
+        w_in[v] = rp - seg_in[v] * SS;                       // position inside the segment's row
+        vo_in[v] = (seg_in[v] < SEGN && w_in[v] < T) ? seg_in[v] * seg_bytes + 2 * w_in[v] : 0x7ffffff0;
+    }
+    auto row_bytes = [&](int r) -> unsigned { return dw_row_index(p, b0 + (wave + 4 * r) * SEGN, c) * (unsigned)P * 2u; };
     struct Row { dwm_u32x4 x[NL]; };
     // (the scalar row offset is formed unconditionally -- only the per-lane offset takes part in the bounds check, so an
     // out-of-range voffset alone makes the access a no-op -- and the voffset by a select: no branch for hipcc to build around a load)
     auto issue = [&](int r, Row& rw) {
         const bool ok = r < nrows;                           // wave-uniform
+        const int left = nb - (wave + 4 * r) * SEGN;         // utterances left from this item's first one (the last item may be short)
 #pragma unroll
-        for (int v = 0; v < NL; ++v) rw.x[v] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vo_in[v] : 0x7ffffff0, (int)row_bytes(r), CP);
+        for (int v = 0; v < NL; ++v)
+            rw.x[v] = __builtin_amdgcn_raw_buffer_load_b128(rx, (ok && seg_in[v] < left) ? vo_in[v] : 0x7ffffff0, (int)row_bytes(r), CP);
     };
     // the taps FIRST: vmcnt retires in order, so a tap load issued behind the row requests would wait for all of them
     static_assert(WLEN <= 256, "one tap slot per thread");
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     const int lpad = -in0a;
     unsigned short* img = lds_img + wave * IMGP;
     for (int c8 = lane; c8 < IMGP / 8; c8 += 64)
-        if (c8 < lpad / 8 || c8 >= (lpad + P) / 8) *reinterpret_cast<dwm_u32x4*>(img + 8 * c8) = dwm_u32x4{0u, 0u, 0u, 0u};
+        if (SEGN > 1 || c8 < lpad / 8 || c8 >= (lpad + P) / 8) *reinterpret_cast<dwm_u32x4*>(img + 8 * c8) = dwm_u32x4{0u, 0u, 0u, 0u};
     // BatchNorm 1 of this channel: coefficients from the finaliser launch -- or, with one group (this workgroup is then the only
     // consumer of channel c), finalised HERE from the expand GEMM's slab of partial sums by the first wave (DwPre), under the latency
     // of the row requests above: one dependent launch less per block
@@ -115,10 +129,17 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
             unsigned d0[3], d1[3];
-            dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp - n_ - off], d0);
-            dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp + 1 - n_ - off], d1);
+            if constexpr (F16) {
+                dwm_split_f16(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp - n_ - off], d0);
+                dwm_split_f16(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp + 1 - n_ - off], d1);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) pk[t][jp] = dwm_pack(d0[t], d1[t]);
+                for (int t = 0; t < NT; ++t) pk[t][jp] = d0[t] | (d1[t] << 16);
+            } else {
+                dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp - n_ - off], d0);
+                dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp + 1 - n_ - off], d1);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) pk[t][jp] = dwm_pack(d0[t], d1[t]);
+            }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     unsigned short* stg[NL];
 #pragma unroll
     for (int v = 0; v < NL; ++v) {
-        nval[v] = min(max(T - 8 * (lane + 64 * v), 0), 8);
+        nval[v] = seg_in[v] < SEGN ? min(max(T - w_in[v], 0), 8) : 0;      // (runs between two segments: zeros, the rows' padding)
         stg[v] = img + lpad + 8 * (lane + 64 * v);
     }
     float s0 = 0.f, s1 = 0.f;
@@ -147,6 +168,17 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
         (void)ra; (void)rb;
 #pragma unroll
         for (int v = 0; v < NL; ++v) {
+            if constexpr (F16) {
+                // the stored fp16 words are the operand: only the positions at or past T are cleared (by halfword)
+                dwm_u32x4 w4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned m = (2 * j < nval[v] ? 0x0000ffffu : 0u) | (2 * j + 1 < nval[v] ? 0xffff0000u : 0u);
+                    w4[j] = rw.x[v][j] & m;
+                }
+                *reinterpret_cast<dwm_u32x4*>(stg[v]) = w4;
+                continue;
+            }
             float vals[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -162,16 +194,18 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
         const unsigned yb = row_bytes(r);
 #pragma unroll
         for (int sub = 0; sub < NS; ++sub) {
-            const int t0 = 256 * sub + 16 * n_ + 4 * q_;
+            const int o0 = 256 * sub + 16 * n_ + 4 * q_;     // output position in the image; its segment and position in that row:
+            const int oseg = SEGN > 1 ? o0 / SS : 0;
+            const int t0 = o0 - oseg * SS;
             dwm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 dwm_bf16x8 bfr[1];
                 bfr[0] = *reinterpret_cast<const dwm_bf16x8*>(bsrc + 256 * sub + 32 * s);
-                acc = dwm_mfma_digits<NT, 1>(afr[s], bfr, acc);
+                acc = dwm_mfma_digits<NT, 1, F16>(afr[s], bfr, acc);
             }
             // outputs at positions >= T are not part of the row (they are not zero: the taps still reach real samples): out of the sums
-            const bool in_row = t0 < T;
+            const bool in_row = t0 < T && oseg < SEGN && oseg < nb - (wave + 4 * r) * SEGN;
             if constexpr (EV) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = relu6f(fmaf(acc[e], oa, ob));
@@ -184,8 +218,9 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
                 }
             }
             // 4 bf16 = one 8-byte store (the pitch keeps it aligned; samples past T land in the row's padding)
-            const dwm_u32x2 o2 = {dwm_pack_rne(acc[0], acc[1]), dwm_pack_rne(acc[2], acc[3])};
-            __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && in_row) ? 2 * t0 : 0x7ffffff0, (int)yb, CP);
+            const dwm_u32x2 o2 = {F16 ? pack16<true>(acc[0], acc[1]) : dwm_pack_rne(acc[0], acc[1]),
+                                  F16 ? pack16<true>(acc[2], acc[3]) : dwm_pack_rne(acc[2], acc[3])};
+            __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && in_row) ? oseg * seg_bytes + 2 * t0 : 0x7ffffff0, (int)yb, CP);
         }
         asm volatile("" ::: "memory");                                    // the next row's LDS store stays behind these fragment reads
         __builtin_amdgcn_sched_barrier(0);                                // rows are not interleaved (register pressure; LDS image reuse)
@@ -255,7 +290,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p)
         const int t0 = 256 * sub + 16 * n_ + 4 * q_;
         vo_aux[sub] = t0 < T ? 2 * t0 : 0x7ffffff0;
     }
-    auto row_bytes = [&](int r) -> unsigned { return (unsigned)((b0 + wave + 4 * r) * p.C + c) * (unsigned)P * 2u; };
+    auto row_bytes = [&](int r) -> unsigned { return dw_row_index(p, b0 + wave + 4 * r, c) * (unsigned)P * 2u; };
     struct Row { dwm_u32x4 g[NL], g2[NL]; dwm_u32x2 a[NS]; };
     auto issue = [&](int r, Row& rw) {
         const bool ok = r < nrows;

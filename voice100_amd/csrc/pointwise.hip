@@ -225,14 +225,14 @@ extern "C" int v100_pw_gemm_io(const void* A_bf16, const void* X, const void* X2
                                int x_mode, void* Y, const float* ea, const float* eb, const void* R, int epi_mode, float* stats,
                                int B, int M, int K, int T, int io16, void* stream) {
     if (!A_bf16 || !X || !Y) return V100_ERR_NULL;
-    if (B <= 0 || M <= 0 || K <= 0 || T <= 0 || io16 <= 0 || io16 > 15) return V100_ERR_SHAPE;
+    if (B <= 0 || M <= 0 || K <= 0 || T <= 0 || io16 <= 0 || io16 > 31 || io16 == PW_IO_F16) return V100_ERR_SHAPE;
     if (x_mode != PW_X_NONE && (!xa || !xb)) return V100_ERR_NULL;
     if (x_mode == PW_X_AFFINE2 && (!X2 || !xc)) return V100_ERR_NULL;
     if (epi_mode == PW_EPI_MASK_STATS && (!ea || !eb)) return V100_ERR_NULL;
     if ((epi_mode == PW_EPI_MASK_STATS || epi_mode == PW_EPI_ADD) && !R) return V100_ERR_NULL;
     if ((epi_mode == PW_EPI_STATS || epi_mode == PW_EPI_MASK_STATS) && !stats) return V100_ERR_NULL;
     PwParams p{nullptr, (const u16*)A_bf16, (const float*)X, (const float*)X2, xa, xb, xc, (float*)Y, nullptr, ea, eb, (const float*)R, stats,
-               B, M, K, T, x_mode, epi_mode, ceil_div(M, PW_BM), ceil_div(T, PW_BN), 1, 0, 0, 0, 0u, io16};
+               B, M, K, T, x_mode, epi_mode, ceil_div(M, PW_BM), ceil_div(T, PW_BN), (io16 & PW_IO_F16) ? 2 : 1, 0, 0, 0, 0u, io16};
     hipStream_t st = (hipStream_t)stream;
     V100TimedRegion timed(V100_T_PW_GEMM, st);
     if (!pw_launch_gemm_bf16_io(p, st)) return V100_ERR_SHAPE;

@@ -170,7 +170,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <int XM, int EPI, int BM, bool F16 = false, bool TAPS = false, int IO = 0, bool PERSIST = false>
 __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     static_assert(!TAPS || XM == PW_X_NONE, "tap-addressed X has no prologue");
-    static_assert(!(IO != 0 && (TAPS || F16)), "16-bit activation storage: bf16 training combinations only");
+    static_assert(!(IO != 0 && TAPS), "16-bit activation storage: no tap-addressed form");
+    static_assert(((IO & PW_IO_F16) != 0) == (F16 && IO != 0), "fp16-stored tensors go with fp16 operands (PW_IO_F16), bf16-stored ones with bf16");
+    static_assert(!(F16 && IO != 0 && XM != PW_X_NONE), "fp16 storage: plain X operand only (inference)");
     // PERSIST: the grid is a divisor of the tile count and a workgroup walks tiles v = blockIdx.x, + gridDim.x, ...; the first two
     // k-tiles of the NEXT tile are requested into the (idle) staging registers before the epilogue of the current one, so a
     // tile's start does not wait a memory latency (2.5 us of the ~15 us a 256 x 128 x 512 tile takes) and the epilogue's
@@ -290,8 +292,8 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
         constexpr int q = decltype(slc)::value;
         if constexpr (PW_ABLATE & 32) return;          // timing-only: no transform / LDS stores
         *reinterpret_cast<u32x4*>(As + buf * A_BYTES + ldsA[q]) = ra[SG][q];
-        if constexpr (XM == PW_X_NONE && XB && !F16) {
-            // plain bf16 X: the [k][t] -> [t][k] transposition is a byte shuffle of the loaded words (column q of rows 2j, 2j + 1
+        if constexpr (XM == PW_X_NONE && XB) {
+            // plain 16-bit X (bf16, or fp16 under F16: the stored format IS the operand format): the [k][t] -> [t][k] transposition is a byte shuffle of the loaded words (column q of rows 2j, 2j + 1
             // -> word j), one v_perm_b32 per two elements instead of unpack + unpack + v_cvt_pk
             constexpr unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;
             unsigned char* dst = Bs + buf * (128 * 128) + ldsB[q];
@@ -2129,6 +2131,23 @@ void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
 // false = no instantiation for this (modes, mask) or the shape does not fit the buffer-addressed kernels.
 bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     const int P = pw_pitch16(p.T);
+    if (p.io16 & PW_IO_F16) {
+        // inference at precision "fp16" with fp16-stored hidden tensors: the two eval-mode GEMMs of a block, 256-row tiles
+        if (!((p.K & 1) == 0 && (long)(p.K + 64) * P * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL &&
+              (long)p.B * p.M * P * 4 < 0x7fffff00L && p.M >= 256 && p.x_mode == 0)) return false;
+        PwParams pb = p;
+        pb.n_mtiles = (p.M + 255) / 256;
+        const dim3 grid((unsigned)((long)pb.n_mtiles * p.n_ttiles * p.B));
+        if (p.epi_mode == 2 && p.io16 == (PW_IO_Y | PW_IO_F16)) {
+            V100_GGL((pw_gemm_bf16_fast_kernel<0, 2, 256, true, false, (PW_IO_Y | PW_IO_F16)>), grid, dim3(512), 0, st, pb);
+            return true;
+        }
+        if (p.epi_mode == 3 && p.io16 == (PW_IO_X | PW_IO_F16)) {
+            V100_GGL((pw_gemm_bf16_fast_kernel<0, 3, 256, true, false, (PW_IO_X | PW_IO_F16)>), grid, dim3(512), 0, st, pb);
+            return true;
+        }
+        return false;
+    }
     const bool full = (p.K & 1) == 0 && (long)(p.K + 64) * P * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL &&
                       (long)p.B * p.M * P * 4 < 0x7fffff00L;
     if (!full) return false;

@@ -98,7 +98,9 @@ struct PwParams {
     // whatever T is); X / X2 / Y / R then point at bf16 data.  0 = everything fp32 (pitch T).
     int io16;
 };
-enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8 };
+// PW_IO_F16: the 16-bit tensors named by the other bits hold IEEE fp16, not bf16 (inference at precision "fp16": the hidden activations
+// are stored in the operand format of the GEMMs that read them)
+enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8, PW_IO_F16 = 16 };
 enum { WG_IO_G = 1, WG_IO_G2 = 2, WG_IO_X = 4 };
 __host__ __device__ __forceinline__ int pw_pitch16(int T) { return (T + 7) & ~7; }
 // element q of a run of bf16 values held as dwords (two per dword, low half first)
@@ -263,7 +265,8 @@ __device__ __forceinline__ float half_wave_sum_dpp(float v) {
 #endif
 template <int EPI_, int BM, int IO, bool PT = false>
 struct PwEpilogueFull {
-    static constexpr bool YB = (IO & PW_IO_Y) != 0, RB = (IO & PW_IO_R) != 0;
+    static constexpr bool YB = (IO & PW_IO_Y) != 0, RB = (IO & PW_IO_R) != 0, YF16 = (IO & PW_IO_F16) != 0;
+    static_assert(!(YF16 && RB), "fp16 storage: inference combinations only (no R tensor in 16 bits)");
     typedef unsigned int epi_u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int epi_u32x4 __attribute__((ext_vector_type(4)));
     static constexpr int epi = EPI_;
@@ -370,7 +373,7 @@ struct PwEpilogueFull {
                 if constexpr (YB) {
                     // (PT: the pitch keeps a straddling lane's 8 bytes inside the row; columns past T are padding)
                     if (!PT || tcol < p.T) {
-                        const epi_u32x2 o2 = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                        const epi_u32x2 o2 = {pack16<YF16>(v[0], v[1]), pack16<YF16>(v[2], v[3])};
                         __builtin_amdgcn_raw_buffer_store_b64(o2, rY, voY, pass * stepY, PW_EPI_CP_Y);
                     }
                 } else if (PT && tcol + 3 >= p.T) {
@@ -447,7 +450,7 @@ __device__ __forceinline__ bool pw_tile_rows_full(const PwParams& p, int BM, int
 template <int EPI_, int BM, int IO = 0>
 __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)[2][2], float* ct, int b, int m0, int t0, int tt,
                                                 int wm, int wn, int tid) {
-    constexpr bool YB = (IO & PW_IO_Y) != 0, RB = (IO & PW_IO_R) != 0;
+    constexpr bool YB = (IO & PW_IO_Y) != 0, RB = (IO & PW_IO_R) != 0, YF16 = (IO & PW_IO_F16) != 0;
     typedef unsigned int epi_u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int epi_u32x4 __attribute__((ext_vector_type(4)));
     const int P16 = pw_pitch16(p.T);
@@ -532,7 +535,7 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
             if constexpr (YB) {
                 // 4 bf16 = one 8-byte store; the pitch keeps it aligned, columns past T inside the pitch are padding
                 if (t < p.T) {
-                    const epi_u32x2 o2 = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                    const epi_u32x2 o2 = {pack16<YF16>(v[0], v[1]), pack16<YF16>(v[2], v[3])};
                     *reinterpret_cast<epi_u32x2*>(reinterpret_cast<u16*>(p.Y) + o16) = o2;
                 }
             } else if (t + 3 < p.T) *reinterpret_cast<f32x4u*>(p.Y + o) = v;

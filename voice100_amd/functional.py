@@ -512,6 +512,91 @@ def inverted_residual_eval_cached(blk, x, precision: Optional[str] = None):
     return y
 
 
+# ---- channel-major inference (round 4) ------------------------------------------------------------------------------
+# Activations [C][B][P] (P = (T + 7) & ~7): one [C x (B P)] matrix per tensor, the utterances' rows back to back.  Each 1x1
+# convolution of a block is then ONE GEMM over all B P columns, the depthwise kernel walks a channel's rows contiguously and packs
+# short rows several to a wave item (include/voice100_hip.h).  Used by the models' eval-mode forwards at the 16-bit precisions.
+EVAL_CM = os.environ.get("VOICE100_EVAL_CM", "1") not in ("", "0")
+
+
+def eval_cm_supported(blocks, T: int, precision: Optional[str] = None) -> bool:
+    """True when a run of eval-mode InvertedResidual blocks can run channel-major: 16-bit precision, stride 1, kernel sizes with a
+    matrix-pipe depthwise kernel, rows that fit one wave item, nothing that Module.__call__ would have to do (hooks)."""
+    import torch.nn.modules.module as _m
+    if not EVAL_CM or _fmt(precision) == 0 or T > 768 or T < 1:
+        return False
+    if _m._global_forward_hooks or _m._global_forward_pre_hooks:
+        return False
+    for b in blocks:
+        if b.training or b.stride != 1 or b._forward_hooks or b._forward_pre_hooks:
+            return False
+        if not N.helper("v100_dw_mfma_supported", int(b.kernel_size), 1):
+            return False
+        w1 = b.conv[0][0].weight
+        if not w1.is_cuda or (w1.shape[0] % 2) or (w1.shape[1] % 2) or (b.conv[2].weight.shape[0] % 2):
+            return False
+    return True
+
+
+def bct_to_cm(x: torch.Tensor) -> torch.Tensor:
+    """[B, C, T] fp32 -> channel-major [C, B * P] fp32 (padding columns zeroed)."""
+    _check(x, "bct_to_cm")
+    x = x.contiguous()
+    B, C, T = x.shape
+    P = (T + 7) & ~7
+    y = _f32(C, B * P, like=x)
+    N.call("v100_bct_to_cm", x, y, B, C, T)
+    return y
+
+
+def cm_to_btc(x: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    """channel-major [C, B * P] fp32 -> [B, T, C] (the model-edge transpose, asr.py:114)."""
+    C = x.shape[0]
+    y = _f32(B, T, C, like=x)
+    N.call("v100_cm_to_btc", x, y, B, C, T)
+    return y
+
+
+def inverted_residual_eval_cm(blk, x: torch.Tensor, B: int, T: int, precision: Optional[str] = None) -> torch.Tensor:
+    """Eval-mode InvertedResidual (stride 1) on a channel-major activation x [cin, B * P]: three launches (one GEMM over all
+    columns, the depthwise stage, one GEMM), hidden tensors stored in the GEMMs' 16-bit operand format.  Inference only."""
+    pw, dw, pl, bn3 = blk.conv[0], blk.conv[1], blk.conv[2], blk.conv[3]
+    bn1, bn2 = pw[1], dw[1]
+    w1, wd, w3 = pw[0].weight, dw[0].weight, pl.weight
+    fmt = _fmt(precision)
+    hid, cin, cout, k = w1.shape[0], w1.shape[1], w3.shape[0], int(blk.kernel_size)
+    P = (T + 7) & ~7
+    if x.shape != (cin, B * P):
+        raise RuntimeError("inverted_residual_eval_cm: x must be [cin, B * pitch(T)]")
+    shape = (ctypes.c_int * 11)(B, cin, hid, cout, T, k, 1, int(bool(blk.use_residual)), int(fmt), 0, 0)
+    params = (w1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
+              w3, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var)
+    key = (fmt,) + tuple((t.data_ptr(), t._version) for t in params) + (wd.data_ptr(), wd._version)
+    if getattr(blk, "_eval_key", None) != key:
+        for t in params + (wd,):
+            if not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors (no CPU fallback)")
+        cache = torch.empty(N.helper("v100_ir_eval_cache_bytes", shape), dtype=torch.uint8, device=x.device)
+        N.call("v100_ir_eval_prep", shape, _ptr_table(tuple(t.detach() for t in params) + (cache,)))
+        blk._eval_cache, blk._eval_key = cache, key
+    shape[10] = 2
+    h = torch.empty((2, hid, B * P), dtype=torch.float16 if fmt == 2 else torch.bfloat16, device=x.device)
+    y = _f32(cout, B * P, like=x)
+    N.call("v100_ir_fwd_eval", shape, _ptr_table((x, w1.detach(), wd.detach(), w3.detach(), blk._eval_cache, h[0], h[1], y)))
+    return y
+
+
+def pointwise_conv1d_cm(x: torch.Tensor, w: torch.Tensor, bias, precision: Optional[str] = None) -> torch.Tensor:
+    """nn.Conv1d(kernel_size=1) on a channel-major activation [cin, N] -> [cout, N] (inference): one GEMM over all columns."""
+    cout, cin = w.shape[0], w.shape[1]
+    n = x.shape[1]
+    fmt = _fmt(precision)
+    W = _Weights(w.detach().reshape(cout, cin), fmt, False)
+    y = _f32(cout, n, like=x)
+    _pw_gemm(W.w, W.w_bf, x, y, cout, cin, n, 1, fmt, bias=bias.detach() if bias is not None else None, epi=0)
+    return y
+
+
 def inverted_residual_eval(x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3,
                            kernel_size, stride, use_residual, precision):
     """Eval-mode InvertedResidual: BatchNorm folded to per-channel scale/shift inside the three kernels."""
