@@ -259,6 +259,8 @@ def main():
                     "(what the enqueueing thread of one rank sees when 8 ranks share this host); 0/1 = skip")
     ap.add_argument("--sustained-seconds", type=float, default=10.0, help="after the contract window: back-to-back steps for at least this "
                     "long (steady-state clocks; reported as `sustained`, never as `value`); 0 = skip")
+    ap.add_argument("--graph-diag", action="store_true", help="also time a hipGraph replay of the step (timing diagnostic; a failed capture can "
+                    "poison the context, so it is not part of the default run)")
     ap.add_argument("--no-extras", action="store_true", help="skip fp32_ms_per_step and dp_path_single_rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -479,6 +481,52 @@ def main():
                     dist.destroy_process_group()
         except Exception as e:                                       # noqa: BLE001
             dp_line = {"error": f"{type(e).__name__}: {e}"}
+    # hipGraph replay of the step (review round 3, item 5) -- a TIMING DIAGNOSTIC, not a training mode: the captured step re-uses the
+    # augmentation decisions, the dropout seed and the Adam bias-correction scalars of the capture (they are host-drawn kernel arguments),
+    # so replays are not valid optimisation steps; what the replay shows is what a launch graph could buy: host time per step and whether
+    # the GPU time per step moves at all once the ~150 launches arrive without host gaps.  Nominal length only (time-stretch off).
+    graph_diag = None
+    if world == 1 and args.graph_diag:
+        keep_ts = aug.do_timestretch if aug is not None else None
+        try:
+            if aug is not None:
+                aug.do_timestretch = False
+            gstep = TrainStep(model)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    gstep(batch)
+            torch.cuda.current_stream().wait_stream(side)
+            sync()
+            te = time.perf_counter()
+            for _ in range(args.steps):
+                gstep(batch)
+            host_e = time.perf_counter() - te
+            sync()
+            tot_e = time.perf_counter() - te
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gstep(batch)
+            for _ in range(3):
+                graph.replay()
+            sync()
+            tg = time.perf_counter()
+            for _ in range(args.steps):
+                graph.replay()
+            host_g = time.perf_counter() - tg
+            sync()
+            tot_g = time.perf_counter() - tg
+            graph_diag = {"eager_nominal_T": {"ms_per_step": round(tot_e / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(host_e / args.steps * 1e3, 3)},
+                          "graph_replay": {"ms_per_step": round(tot_g / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(host_g / args.steps * 1e3, 3)},
+                          "note": "timing diagnostic only: replays repeat the captured step's host-drawn arguments (augmentation decisions, dropout seed, "
+                                  "Adam scalars); time-stretch off in both arms"}
+            del graph
+        except Exception as e:                                       # noqa: BLE001
+            graph_diag = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        finally:
+            if aug is not None and keep_ts is not None:
+                aug.do_timestretch = keep_ts
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -569,6 +617,7 @@ def main():
             "sustained": sustained,
             "fp32_ms_per_step": fp32_line,
             "dp_path_single_rank": dp_line,
+            "launch_graph_diagnostic": graph_diag,
         }
         # the extras must never cost the primary line: any failure in them is reported inside the JSON instead
         if world == 1 and not args.no_other_configs and args.precision == "bf16":

@@ -2132,25 +2132,23 @@ void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
 bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     const int P = pw_pitch16(p.T);
     if (p.io16 & PW_IO_F16) {
-        // inference at precision "fp16" with fp16-stored hidden tensors: the two eval-mode GEMMs of a block, 256-row tiles
+        // inference at precision "fp16" with fp16-stored hidden tensors: the two eval-mode GEMMs of a block (256-row tiles; 128 for M < 256)
         if (!((p.K & 1) == 0 && (long)(p.K + 64) * P * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL &&
-              (long)p.B * p.M * P * 4 < 0x7fffff00L && p.M >= 256 && p.x_mode == 0)) return false;
+              (long)p.B * p.M * P * 4 < 0x7fffff00L && p.x_mode == 0)) return false;
+        const bool big16 = p.M >= 256;
         PwParams pb = p;
-        pb.n_mtiles = (p.M + 255) / 256;
+        pb.n_mtiles = (p.M + (big16 ? 255 : 127)) / (big16 ? 256 : 128);
         const dim3 grid((unsigned)((long)pb.n_mtiles * p.n_ttiles * p.B));
-        if (p.epi_mode == 2 && p.io16 == (PW_IO_Y | PW_IO_F16)) {
-            V100_GGL((pw_gemm_bf16_fast_kernel<0, 2, 256, true, false, (PW_IO_Y | PW_IO_F16)>), grid, dim3(512), 0, st, pb);
-            return true;
+#define XF(EP, IOV)                                                                                                                  \
+        if (p.epi_mode == EP && p.io16 == (IOV)) {                                                                                  \
+            if (big16) V100_GGL((pw_gemm_bf16_fast_kernel<0, EP, 256, true, false, (IOV)>), grid, dim3(512), 0, st, pb);            \
+            else V100_GGL((pw_gemm_bf16_fast_kernel<0, EP, 128, true, false, (IOV)>), grid, dim3(256), 0, st, pb);                  \
+            return true;                                                                                                            \
         }
-        if (p.epi_mode == 3 && p.io16 == (PW_IO_X | PW_IO_F16)) {
-            V100_GGL((pw_gemm_bf16_fast_kernel<0, 3, 256, true, false, (PW_IO_X | PW_IO_F16)>), grid, dim3(512), 0, st, pb);
-            return true;
-        }
+        XF(2, PW_IO_Y | PW_IO_F16) XF(3, PW_IO_X | PW_IO_F16)
+#undef XF
         return false;
     }
-    const bool full = (p.K & 1) == 0 && (long)(p.K + 64) * P * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL &&
-                      (long)p.B * p.M * P * 4 < 0x7fffff00L;
-    if (!full) return false;
     const bool big = p.M >= 256 && p.K > PW_BM128_MAXK;
     PwParams pb = p;
     pb.n_mtiles = (p.M + (big ? 255 : 127)) / (big ? 256 : 128);

@@ -32,7 +32,7 @@ struct WorldParams {
     const float* f0; const float* sp; const float* ap; const int* frames;
     const float* randn; long long table_len;
     float* y; int* n_pulses;
-    double* total; unsigned char* vuv; int* idx; float* xshift; float* resp;
+    unsigned char* vuv; int* idx; float* xshift; float* resp;
     int B, T, fs, Ymax, Pcap;
     double frame_period;      // seconds
     double frame_period_ms;
@@ -48,18 +48,23 @@ __device__ __forceinline__ int world_ylen(int frames, double frame_period_ms, in
 // ---------------------------------------------------------------------------------------------------------------------------
 // 1. time base
 __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
+    // Chunks of CH samples through LDS: (1) all threads interpolate the contour -> phase increments, (2) thread 0 accumulates them IN
+    // ORDER (the one summation order, see the header; ~10 cycles a sample: the increments come from LDS, unrolled so the reads run ahead of
+    // the dependent adds), (3) all threads wrap, detect the 2 pi crossings and compact them in order.  The running phase never goes to
+    // HBM; only the per-sample voicing flag (1 byte) and the pulse list do.
+    constexpr int CH = 2048;
+    __shared__ double s_tot[CH + 1];                     // [0] = the last total of the previous chunk
+    __shared__ int s_cnt[4];
+    __shared__ int s_base;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int T = p.frames ? p.frames[b] : p.T;
     const int ylen = T > 0 ? world_ylen(T, p.frame_period_ms, p.fs) : 0;
     const float* f0 = p.f0 + (size_t)b * p.T;
-    double* total = p.total + (size_t)b * p.Ymax;
     unsigned char* vuv = p.vuv + (size_t)b * p.Ymax;
     int* idx = p.idx + (size_t)b * p.Pcap;
     float* xs = p.xshift + (size_t)b * p.Pcap;
     const double fp = p.frame_period, fs = (double)p.fs;
     const double lowest = fs / (double)NF + 1.0;
-    __shared__ int s_cnt[4];
-    __shared__ int s_base;
     if (T < 2 || ylen < 2) {              // the reference extrapolates the contour from its last two frames: fewer is undefined there
         if (tid == 0) p.n_pulses[b] = 0;
         return;
@@ -74,65 +79,74 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
         if (j < T) return ((double)f0[j] < lowest) ? 0.0 : 1.0;
         return (((double)f0[T - 1] < lowest) ? 0.0 : 1.0) * 2 - (((double)f0[T - 2] < lowest) ? 0.0 : 1.0);
     };
-    for (int i = tid; i < ylen; i += 256) {
-        const double t = (double)i / fs;
-        int k = (int)(t / fp) + 1;                       // x[k-1] <= t < x[k] with x[j] = j * fp, fixed up against the products themselves
-        if (k < 1) k = 1;
-        if (k > T) k = T;
-        while (k > 1 && t < (double)(k - 1) * fp) --k;
-        while (k < T && t >= (double)k * fp) ++k;
-        const double x0 = (double)(k - 1) * fp, x1 = (double)k * fp;
-        const double s = (t - x0) / (x1 - x0);
-        const double fa = cf0(k - 1), fb = cf0(k), va = cvuv(k - 1), vb = cvuv(k);
-        double fi = fa + s * (fb - fa);
-        const double vi = va + s * (vb - va);
-        const bool voiced = vi > 0.5;
-        if (!voiced) fi = kDefaultF0;
-        vuv[i] = voiced ? 1 : 0;
-        total[i] = 2.0 * kPi * fi / fs;                  // the increment; accumulated in place below
-    }
-    __syncthreads();
-    if (tid == 0) {                                      // ONE summation order (see the header)
-        double acc = 0.0;
-        int i = 0;
-        for (; i + 8 <= ylen; i += 8) {
-            double v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = total[i + e];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { acc += v[e]; total[i + e] = acc; }
-        }
-        for (; i < ylen; ++i) { acc += total[i]; total[i] = acc; }
-        s_base = 0;
-    }
-    __syncthreads();
-    // crossings: |wrap[i + 1] - wrap[i]| > pi, i < ylen - 1; ordered compaction, 256 samples per round
     const int lane = tid & 63, wave = tid >> 6;
-    for (int i0 = 0; i0 < ylen - 1; i0 += 256) {
-        const int i = i0 + tid;
-        bool hit = false;
-        double w0 = 0.0, w1 = 0.0;
-        if (i < ylen - 1) {
-            w0 = fmod(total[i], 2.0 * kPi);
-            w1 = fmod(total[i + 1], 2.0 * kPi);
-            hit = fabs(w1 - w0) > kPi;
+    if (tid == 0) { s_base = 0; s_tot[0] = 0.0; }
+    double carry = 0.0;                                   // thread 0: the running phase
+    for (int c0 = 0; c0 < ylen; c0 += CH) {
+        const int n = min(CH, ylen - c0);
+        __syncthreads();                                  // the previous chunk's detection has read s_tot
+        for (int j = tid; j < n; j += 256) {
+            const int i = c0 + j;
+            const double t = (double)i / fs;
+            int k = (int)(t / fp) + 1;                   // x[k-1] <= t < x[k] with x[j] = j * fp, fixed up against the products themselves
+            if (k < 1) k = 1;
+            if (k > T) k = T;
+            while (k > 1 && t < (double)(k - 1) * fp) --k;
+            while (k < T && t >= (double)k * fp) ++k;
+            const double x0 = (double)(k - 1) * fp, x1 = (double)k * fp;
+            const double s = (t - x0) / (x1 - x0);
+            const double fa = cf0(k - 1), fb = cf0(k), va = cvuv(k - 1), vb = cvuv(k);
+            double fi = fa + s * (fb - fa);
+            const double vi = va + s * (vb - va);
+            const bool voiced = vi > 0.5;
+            if (!voiced) fi = kDefaultF0;
+            vuv[i] = voiced ? 1 : 0;
+            s_tot[1 + j] = 2.0 * kPi * fi / fs;          // the increment; accumulated in place below
         }
-        const unsigned long long m = __ballot(hit);
-        if (lane == 0) s_cnt[wave] = __popcll(m);
         __syncthreads();
-        int before = s_base;
-        for (int w = 0; w < wave; ++w) before += s_cnt[w];
-        if (hit) {
-            const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
-            if (slot < p.Pcap) {
-                idx[slot] = i;
-                const double y1 = w0 - 2.0 * kPi;
-                xs[slot] = (float)(-y1 / (w1 - y1));      // fraction of a sample to the exact crossing, in [0, 1)
+        if (tid == 0) {
+            s_tot[0] = carry;                             // total of sample c0 - 1 (0 before the first sample: never read there)
+            double acc = carry;
+            int j = 0;
+            for (; j + 16 <= n; j += 16) {
+                double v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = s_tot[1 + j + e];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc += v[e]; s_tot[1 + j + e] = acc; }
             }
+            for (; j < n; ++j) { acc += s_tot[1 + j]; s_tot[1 + j] = acc; }
+            carry = acc;
         }
         __syncthreads();
-        if (tid == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        __syncthreads();
+        // crossings between samples i and i + 1, i = c0 - 1 + j for j = 0 .. n - 1 (i >= 0): |wrap[i + 1] - wrap[i]| > pi
+        for (int j0 = 0; j0 < n; j0 += 256) {
+            const int j = j0 + tid;
+            const int i = c0 - 1 + j;
+            bool hit = false;
+            double w0 = 0.0, w1 = 0.0;
+            if (j < n && i >= 0) {
+                w0 = fmod(s_tot[j], 2.0 * kPi);
+                w1 = fmod(s_tot[j + 1], 2.0 * kPi);
+                hit = fabs(w1 - w0) > kPi;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) s_cnt[wave] = __popcll(m);
+            __syncthreads();
+            int before = s_base;
+            for (int w = 0; w < wave; ++w) before += s_cnt[w];
+            if (hit) {
+                const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < p.Pcap) {
+                    idx[slot] = i;
+                    const double y1 = w0 - 2.0 * kPi;
+                    xs[slot] = (float)(-y1 / (w1 - y1));  // fraction of a sample to the exact crossing, in [0, 1)
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            __syncthreads();
+        }
     }
     if (tid == 0) p.n_pulses[b] = s_base <= p.Pcap ? s_base : -1;       // -1: more pulses than the caller made room for
 }
@@ -512,7 +526,7 @@ extern "C" long long v100_world_synth_workspace_bytes(int B, int T, int fs, doub
     if (B <= 0 || T <= 0 || fs <= 0 || fft_size != NF || max_pulses <= 0 || frame_period_ms <= 0) return -1;
     const long long Y = (world_ymax(T, fs, frame_period_ms) + 63) & ~63LL;
     const long long Pc = (max_pulses + 63) & ~63LL;
-    return (long long)B * (Y * 8 + Y + Pc * 4 + Pc * 4 + Pc * NF * 4) + 256;
+    return (long long)B * (Y + Pc * 4 + Pc * 4 + Pc * NF * 4) + 256;
 }
 
 extern "C" int v100_world_synthesize(const float* f0, const float* sp, const float* ap, const int* frames, const float* randn_table,
@@ -527,7 +541,6 @@ extern "C" int v100_world_synthesize(const float* f0, const float* sp, const flo
     char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     WorldParams p{};
     p.f0 = f0; p.sp = sp; p.ap = ap; p.frames = frames; p.randn = randn_table; p.table_len = table_len; p.y = y; p.n_pulses = n_pulses;
-    p.total = (double*)w;               w += (size_t)B * Y * 8;
     p.idx = (int*)w;                    w += (size_t)B * Pc * 4;
     p.xshift = (float*)w;               w += (size_t)B * Pc * 4;
     p.resp = (float*)w;                 w += (size_t)B * Pc * NF * 4;
