@@ -267,7 +267,8 @@ int v100_timing_read(int tag, double* ms, long long* count, double* bytes);
  * output for the next block's X operand, v100_chan_affine2_shadow) are stored as bf16 [B][C][P], P = (T + 7) & ~7 (pitched rows: every 4- / 8-sample access stays 8 / 16-byte aligned for any
  * T).  Accumulators, BatchNorm statistics and reductions stay fp32.  io16 masks select which operands are such tensors:
  *   v100_pw_gemm_io:   1 X, 2 X2, 4 Y, 8 R        v100_pw_wgrad_io: 1 G, 2 G2, 4 X
- *   v100_dwconv_*_io:  1 x (first stream), 2 x2, 4 aux (a1), 8 y
+ *   v100_dwconv_*_io:  1 x (first stream), 2 x2, 4 aux (a1), 8 y; 16 = the tensors are CHANNEL-MAJOR [C][B][P] (rows of up to 768
+ *                      outputs; the layout probe of round 4: tools/bench_dw_regimes.py --cm, tests/test_gpu_act16.py)
  * Same arithmetic as v100_pw_gemm / v100_pw_wgrad / v100_dwconv / v100_dwconv_bwd (bf16 operands); only the combinations the
  * block executor issues exist, anything else returns 1 (no fallback). */
 int v100_pw_gemm_io(const void* A_bf16, const void* X, const void* X2, const float* xa, const float* xb, const float* xc,

@@ -9,7 +9,10 @@ matter, to explain the stand-alone -> in-step gap of the graded kernel (round-2 
   produced   rotating, and the input is written by the expand GEMM (v100_pw_gemm_io) launched right before -- the step's own
              order: the depthwise input was just stored (dirty lines in L2 / MALL), its BatchNorm statistics finalised between.
 
-python tools/bench_dw_regimes.py [--iters 40] [--sets 10] [--lib other.so] [--bwd]"""
+--cm (round 4, review item 3): the same launches on CHANNEL-MAJOR tensors [C][B][P] (io16 bit 16) -- the layout the depthwise access
+pattern wants (profiles/r03_stream_pattern_probe.txt) -- with the producing GEMM run as ONE GEMM over all B P columns (B = 1, T = B P).
+
+python tools/bench_dw_regimes.py [--iters 40] [--sets 10] [--lib other.so] [--bwd] [--cm]"""
 import argparse
 import os
 import sys
@@ -30,6 +33,7 @@ def main():
     ap.add_argument("--lib", default=None)
     ap.add_argument("--bwd", action="store_true", help="also the fused backward kernel")
     ap.add_argument("--layers", default="", help="comma list of kernel sizes (default all)")
+    ap.add_argument("--cm", action="store_true", help="channel-major tensors [C][B][P]")
     args = ap.parse_args()
     if args.lib:
         N.LIB_PATH = os.path.abspath(args.lib)
@@ -54,15 +58,20 @@ def main():
         dwg = torch.empty(hid, k, device=dev)
         nb_f, nb_b = 2 * B * hid * 2 * T, 2 * B * hid * 4 * T
 
+        cmb = 16 if args.cm else 0                      # (the buffers are just bytes: the same allocations serve both layouts)
+
         def fwd(i):
-            N.call("v100_dwconv_fwd_train_io", xs[i], w, a, b, ys[i], st, G, B, hid, T, k, 9)
+            N.call("v100_dwconv_fwd_train_io", xs[i], w, a, b, ys[i], st, G, B, hid, T, k, 9 | cmb)
 
         def bwd(i):
             j = (i + S // 2) % S
-            N.call("v100_dwconv_bwd_io", ys[i], ys[j], w, a, b, c, xs[i], a, b, xs[j], st, part, dwg, G, B, hid, T, k, 15)
+            N.call("v100_dwconv_bwd_io", ys[i], ys[j], w, a, b, c, xs[i], a, b, xs[j], st, part, dwg, G, B, hid, T, k, 15 | cmb)
 
         def produce(i):
-            N.call("v100_pw_gemm_io", w1, x_in[i], None, None, None, None, 0, xs[i], None, None, None, 1, st, B, hid, cin, T, 1 | 4)
+            if args.cm:
+                N.call("v100_pw_gemm_io", w1, x_in[i], None, None, None, None, 0, xs[i], None, None, None, 1, st, 1, hid, cin, B * P, 1 | 4)
+            else:
+                N.call("v100_pw_gemm_io", w1, x_in[i], None, None, None, None, 0, xs[i], None, None, None, 1, st, B, hid, cin, T, 1 | 4)
 
         def timed(tag, body):
             for i in range(3):

@@ -126,6 +126,33 @@ def main():
                     cells.append(f"{'ERR ' + type(ex).__name__:>16s}")
             print(f"{name:58s} {cells[0]:>18s} {cells[1]:>16s} {cells[2]:>14s} {cells[3]:>14s}   {mode}")
         print(f"{'sum (batched column: 4 GEMMs; others: 6)':58s} {tot[0]*1e6:15.1f} us {tot[1]*1e6:13.1f} us {tot[2]*1e6:11.1f} us {tot[3]*1e6:11.1f} us")
+        # Layout A/B inside OUR kernels (review round 3, item 3: "measure it in the GEMM"): the four NN GEMMs in their in-step modes on
+        # CHANNEL-MAJOR operands [C][B P] = one GEMM over all columns (B = 1, T = B P; the kernels only see a longer row pitch) against
+        # the batch-major launches above.  Same buffers (bytes), T % 128 == 0 so both forms run the same tiles.
+        Np = B * P
+        stc_h, stc_c = torch.empty(N.helper("v100_pw_num_parts", 1, Np), hid, 2, device=dev), torch.empty(N.helper("v100_pw_num_parts", 1, Np), C, 2, device=dev)
+        cm_rows = [
+            ("expand fwd", L(lambda s: G(W1, s["xc"], None, None, None, None, 0, s["yh"], None, None, None, 1, st_h, B, hid, C, T, 5)),
+             L(lambda s: G(W1, s["xc"], None, None, None, None, 0, s["yh"], None, None, None, 1, stc_h, 1, hid, C, Np, 5))),
+            ("project fwd", L(lambda s: G(W2, s["xh"], None, ch[0], ch[1], None, 1, s["yc"], None, None, None, 1, st_c, B, C, hid, T, 5)),
+             L(lambda s: G(W2, s["xh"], None, ch[0], ch[1], None, 1, s["yc"], None, None, None, 1, stc_c, 1, C, hid, Np, 5))),
+            ("project bwd-data", L(lambda s: G(W2t, s["xc"], None, None, None, None, 0, s["yh"], ch[0], ch[1], s["xh2"], 4, st_h, B, hid, C, T, 13)),
+             L(lambda s: G(W2t, s["xc"], None, None, None, None, 0, s["yh"], ch[0], ch[1], s["xh2"], 4, stc_h, 1, hid, C, Np, 13))),
+            ("expand bwd-data", L(lambda s: G(W1t, s["xh"], s["xh2"], ch[0], ch[1], ch[2], 2, s["yc32"], None, None, s["x32"], 5, None, B, C, hid, T, 3)),
+             L(lambda s: G(W1t, s["xh"], s["xh2"], ch[0], ch[1], ch[2], 2, s["yc32"], None, None, s["x32"], 5, None, 1, C, hid, Np, 3))),
+        ]
+        print(f"layout A/B of this library's NN GEMMs (in-step modes): batch-major [B][C][T] launch vs channel-major [C][B T] as one GEMM")
+        ta = tb = 0.0
+        for name, fa, fb in cm_rows:
+            try:
+                da, db = timeit(fa, args.iters), timeit(fb, args.iters)
+                da2, db2 = timeit(fa, args.iters), timeit(fb, args.iters)          # interleaved second round
+                da, db = min(da, da2), min(db, db2)
+                ta += da; tb += db
+                print(f"  {name:18s} batch-major {da*1e6:7.1f} us   channel-major {db*1e6:7.1f} us   ({(db/da-1)*100:+5.1f} %)")
+            except Exception as ex:                                          # noqa: BLE001
+                print(f"  {name:18s} ERR {type(ex).__name__}: {ex}")
+        print(f"  {'sum':18s} batch-major {ta*1e6:7.1f} us   channel-major {tb*1e6:7.1f} us   ({(tb/max(ta,1e-12)-1)*100:+5.1f} %)")
         del sets
         torch.cuda.empty_cache()
 

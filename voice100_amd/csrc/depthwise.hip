@@ -429,10 +429,13 @@ int dw_fwd_train_io_fin(const void* a1, const float* w, const float* in_a, const
                         int T, int K, int io16, const DwFin& fin, const DwPre& pre, void* stream) {
     if (!a1 || !w || !in_a || !in_b || !a2 || !stats) return V100_ERR_NULL;
     if ((fin.mode != 0 || pre.f.mode != 0) && G != 1) return V100_ERR_SHAPE;
+    const int cm = (io16 >> 4) & 1;              // DW_IO_CM: channel-major tensors [C][B][P] (streaming kernels: rows of up to 768 outputs)
+    io16 &= 15;
     if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || (K & 1) == 0 || G <= 0 || G > B || io16 != (DW_IO_X | DW_IO_Y)) return V100_ERR_SHAPE;
     if ((size_t)B * C * dw_pitch16(T) * 4 >= 0x7fffff00ull) return V100_ERR_SHAPE;
     DwParams p{(const float*)a1, nullptr, w, in_a, in_b, nullptr, (float*)a2, nullptr, nullptr, nullptr, stats,
                B, C, T, T, K, 1, (K - 1) / 2, 0, 1, G, DW_IN_AFFINE_RELU6, DW_OUT_RAW_STATS, nullptr, io16, fin, pre};
+    p.cm = cm;
     hipStream_t st = (hipStream_t)stream;
     V100TimedLaunch timed(V100_T_DW_FWD, 2.0 * B * C * 2.0 * T + 4.0 * C * K + 8.0 * C);
     if (!dw_launch_fwd_train16(p, st, timed)) return V100_ERR_SHAPE;
@@ -479,10 +482,14 @@ int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga
     if ((fin.mode != 0 || pre.f.mode != 0) && G != 1) return V100_ERR_SHAPE;
     if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || (K & 1) == 0 || G <= 0 || G > B) return V100_ERR_SHAPE;
     if ((size_t)B * C * dw_pitch16(T) * 4 >= 0x7fffff00ull) return V100_ERR_SHAPE;
+    const int cm = (io16 >> 4) & 1;              // DW_IO_CM (see dw_fwd_train_io_fin)
+    io16 &= 15;
     hipStream_t st = (hipStream_t)stream;
     const int pad = (K - 1) / 2;
     DwParams p{(const float*)g, (const float*)g2, w, ga, gb, gc, (float*)dxin, (const float*)xpre, xa, xb, stats,
                B, C, T, T, K, 1, K - 1 - pad, 1, 1, G, DW_IN_AFFINE2, DW_OUT_MASK_STATS, wpartial, io16, fin, pre};
+    p.cm = cm;
+    if (cm && io16 != (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y)) return V100_ERR_SHAPE;
     const bool all16 = io16 == (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y);
     if (!all16 && io16 != (DW_IO_X2 | DW_IO_AUX)) return V100_ERR_SHAPE;
     V100TimedLaunch timed(V100_T_DW_BWD_DATA, (all16 ? 2.0 : 3.0) * B * C * 4.0 * T + 8.0 * C * K + 8.0 * C);

@@ -35,5 +35,6 @@ bool dw_launch_bwd_fused16g(const DwParams& p, hipStream_t st, const V100TimedLa
 #undef X
 #undef GO
     }
+    if (p.cm) return false;               // the general kernel addresses [B][C][P] only
     return dw_launch_specialised<DW_IN_AFFINE2, DW_OUT_MASK_STATS, true, DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y>(p, st, tl);
 }

@@ -36,5 +36,6 @@ bool dw_launch_fwd_train16(const DwParams& p, hipStream_t st, const V100TimedLau
 #undef X
 #undef GO
     }
+    if (p.cm) return false;               // the general kernel addresses [B][C][P] only
     return dw_launch_specialised<DW_IN_AFFINE_RELU6, DW_OUT_RAW_STATS, false, DW_IO_X | DW_IO_Y>(p, st, tl);
 }

@@ -52,8 +52,10 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
     // ORDER (the one summation order, see the header; ~10 cycles a sample: the increments come from LDS, unrolled so the reads run ahead of
     // the dependent adds), (3) all threads wrap, detect the 2 pi crossings and compact them in order.  The running phase never goes to
     // HBM; only the per-sample voicing flag (1 byte) and the pulse list do.
-    constexpr int CH = 2048;
+    constexpr int CH = 2048, NFR = 64;                   // samples per chunk; contour frames staged per chunk
     __shared__ double s_tot[CH + 1];                     // [0] = the last total of the previous chunk
+    __shared__ double s_wrap[CH + 1];
+    __shared__ double s_cf0[NFR], s_cv[NFR];
     __shared__ int s_cnt[4];
     __shared__ int s_base;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -84,7 +86,17 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
     double carry = 0.0;                                   // thread 0: the running phase
     for (int c0 = 0; c0 < ylen; c0 += CH) {
         const int n = min(CH, ylen - c0);
-        __syncthreads();                                  // the previous chunk's detection has read s_tot
+        // the contour frames this chunk's samples interpolate between, staged once (a chunk spans CH / (fs fp) + 2 frames; when the frame
+        // period is so short that they do not fit, the lookups below fall back to global memory)
+        int kf = (int)(((double)c0 / fs) / fp) - 1;
+        if (kf < 0) kf = 0;
+        __syncthreads();                                  // the previous chunk's detection has read s_tot / the contour window
+        if (tid < NFR) {
+            const int j = kf + tid;
+            s_cf0[tid] = j <= T ? cf0(j) : 0.0;
+            s_cv[tid] = j <= T ? cvuv(j) : 0.0;
+        }
+        __syncthreads();
         for (int j = tid; j < n; j += 256) {
             const int i = c0 + j;
             const double t = (double)i / fs;
@@ -95,7 +107,9 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
             while (k < T && t >= (double)k * fp) ++k;
             const double x0 = (double)(k - 1) * fp, x1 = (double)k * fp;
             const double s = (t - x0) / (x1 - x0);
-            const double fa = cf0(k - 1), fb = cf0(k), va = cvuv(k - 1), vb = cvuv(k);
+            const bool in_win = k - 1 >= kf && k < kf + NFR;
+            const double fa = in_win ? s_cf0[k - 1 - kf] : cf0(k - 1), fb = in_win ? s_cf0[k - kf] : cf0(k);
+            const double va = in_win ? s_cv[k - 1 - kf] : cvuv(k - 1), vb = in_win ? s_cv[k - kf] : cvuv(k);
             double fi = fa + s * (fb - fa);
             const double vi = va + s * (vb - va);
             const bool voiced = vi > 0.5;
@@ -108,16 +122,27 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
             s_tot[0] = carry;                             // total of sample c0 - 1 (0 before the first sample: never read there)
             double acc = carry;
             int j = 0;
-            for (; j + 16 <= n; j += 16) {
-                double v[16];
+            if (n >= 16) {
+                double v[16], u[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = s_tot[1 + j + e];
+                for (int e = 0; e < 16; ++e) v[e] = s_tot[1 + e];
+                for (; j + 32 <= n; j += 16) {             // the next 16 increments are read while these 16 are added
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) u[e] = s_tot[1 + j + 16 + e];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { acc += v[e]; s_tot[1 + j + e] = acc; }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = u[e];
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { acc += v[e]; s_tot[1 + j + e] = acc; }
+                j += 16;
             }
             for (; j < n; ++j) { acc += s_tot[1 + j]; s_tot[1 + j] = acc; }
             carry = acc;
         }
+        __syncthreads();
+        for (int j = tid; j <= n; j += 256) s_wrap[j] = fmod(s_tot[j], 2.0 * kPi);       // one fmod per sample
         __syncthreads();
         // crossings between samples i and i + 1, i = c0 - 1 + j for j = 0 .. n - 1 (i >= 0): |wrap[i + 1] - wrap[i]| > pi
         for (int j0 = 0; j0 < n; j0 += 256) {
@@ -126,8 +151,8 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
             bool hit = false;
             double w0 = 0.0, w1 = 0.0;
             if (j < n && i >= 0) {
-                w0 = fmod(s_tot[j], 2.0 * kPi);
-                w1 = fmod(s_tot[j + 1], 2.0 * kPi);
+                w0 = s_wrap[j];
+                w1 = s_wrap[j + 1];
                 hit = fabs(w1 - w0) > kPi;
             }
             const unsigned long long m = __ballot(hit);
@@ -260,14 +285,22 @@ __device__ __forceinline__ void irfft512(const cplx (&x)[4], cplx x256, float* s
 // minimum-phase spectrum exp(FFT(fold(IFFT(mirror(L))))) of the log-amplitude L[k] (k = lane + 64 q in l[q], L[256] in l256)
 __device__ __forceinline__ void min_phase(const float (&l)[4], float l256, float* r, float2* z, int lane, const cplx (&tw)[3][3],
                                           const cplx (&w512)[4], cplx (&h)[4], cplx& h256) {
+    // The mean of the mirrored log spectrum is taken out first and put back in the exponent at the end (exact: it only moves c[0]).  A
+    // log-amplitude around -9 (aperiodicity 0.001 under a 1e-2 envelope) otherwise makes every butterfly carry sums of ~ -4700, whose
+    // fp32 rounding (3e-4 absolute) spreads over all cepstral coefficients and comes back through the exponential as a 1e-4
+    // relative error of the response; without the mean the sums are the spectrum's variation only.
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part += (lane + 64 * q == 0) ? l[q] : 2.f * l[q];      // bins 1 .. 255 appear twice in the mirrored sequence
+    const float mu = (wave_sum(part) + l256) * (1.f / 512.f);
     // mirrored real sequence of 512: r[j] = L[j] (j <= 256), L[512 - j] beyond
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int k = lane + 64 * q;
-        r[k] = l[q];
-        if (k > 0) r[512 - k] = l[q];
+        r[k] = l[q] - mu;
+        if (k > 0) r[512 - k] = l[q] - mu;
     }
-    if (lane == 0) r[256] = l256;
+    if (lane == 0) r[256] = l256 - mu;
     WAVE_LDS_FENCE();
     cplx c[4], c256;
     rfft512(r, z, lane, tw, w512, c, c256);             // real cepstrum x 512 (imaginary parts are round-off: the input is even)
@@ -283,12 +316,12 @@ __device__ __forceinline__ void min_phase(const float (&l)[4], float l256, float
     rfft512(r, z, lane, tw, w512, m, m256);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float e = expf(m[q].re);
+        const float e = expf(m[q].re + mu);
         float sn, cs;
         sincosf(m[q].im, &sn, &cs);
         h[q] = {e * cs, e * sn};
     }
-    h256 = {expf(m256.re), 0.f};                       // the folded cepstrum is real: bin 256 of its spectrum is real
+    h256 = {expf(m256.re + mu), 0.f};                       // the folded cepstrum is real: bin 256 of its spectrum is real
 }
 
 __global__ __launch_bounds__(256) void world_pulse_kernel(WorldParams p) {
