@@ -191,7 +191,9 @@ int v100_exp_clip(const float* x, float* y, float offset, long long n, void* str
  *   v100_world_randn_host    HOST function, HOST pointer: the first n values of WORLD's randn() after randn_reseed() (every
  *                            Synthesis call reseeds: one fixed sequence for all utterances; callers upload it once)
  *   v100_world_decode_aperiodicity   coded [rows][nb] dB -> ap [rows][fft_size/2+1]
- *   v100_world_synthesize    f0 [B][T], sp / ap [B][T][257], frames [B] int32 (NULL: every utterance has T frames),
+ *   v100_world_synthesize    f0 [B][T], sp / ap [B][T][257] -- or, instead of ap (then NULL), coded_ap [B][T][nb] in dB, decoded per
+ *                            pulse without ever rounding an aperiodicity near 1 to fp32 (the reference decodes in double) --,
+ *                            frames [B] int32 (NULL: every utterance has T frames),
  *                            randn_table [table_len >= samples per utterance], tw256 [256][2] / tw512 [257][2] = cos, -sin
  *                            of 2 pi k / 256 and / 512, dc_remover [512] (oracle.world_synth.dc_remover), all built in double
  *                            by the caller -> y [B][Ymax] fp32, Ymax = (int)(T * frame_period_ms * fs / 1000), zero beyond
@@ -208,7 +210,7 @@ int v100_cm_to_btc(const float* in, float* out, int B, int C, int T, void* strea
 int v100_world_randn_host(float* host_out, long long n);
 int v100_world_decode_aperiodicity(const float* coded, float* ap, long long rows, int nb, int fs, int fft_size, void* stream);
 long long v100_world_synth_workspace_bytes(int B, int T, int fs, double frame_period_ms, int fft_size, int max_pulses);
-int v100_world_synthesize(const float* f0, const float* sp, const float* ap, const int* frames, const float* randn_table,
+int v100_world_synthesize(const float* f0, const float* sp, const float* ap, const float* coded_ap, int nb, const int* frames, const float* randn_table,
                           long long table_len, const float* tw256, const float* tw512, const float* dc_remover, float* y,
                           int* n_pulses, void* workspace, int B, int T, int fs, double frame_period_ms, int fft_size,
                           int max_pulses, void* stream);

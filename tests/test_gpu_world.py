@@ -180,3 +180,24 @@ def test_decode_is_a_drop_in_and_the_pipeline_ends_in_a_waveform(cuda):
     assert torch.equal(out["wave_len"].cpu(), (out["frames"].cpu() * 160).to(torch.int64))
     for b in range(3):
         assert float(out["wave"][b, int(out["wave_len"][b]):].abs().sum()) == 0.0
+
+
+def test_synthesize_from_coded_aperiodicity_vs_double_oracle(cuda):
+    """codeap= : the band aperiodicity decoded inside the kernel (as 1 - a, nothing near 1 rounded to fp32) against the oracle fed the
+    DOUBLE-precision decode -- the reference's own order of operations (vocoder.py:100-101 runs both steps in double)."""
+    from voice100_amd.vocoder import WORLDVocoder
+    rng = np.random.RandomState(21)
+    v = WORLDVocoder()
+    B, T = 3, 300
+    f0 = np.where(np.sin(np.arange(T)[None] / 25.0 + rng.rand(B, 1) * 6) > 0.3, 0.0, 100 + 120 * rng.rand(B, 1) + 15 * np.sin(np.arange(T)[None] / 5.0)).astype(np.float32)
+    sp = np.stack([_formant_sp(T, rng=rng) for _ in range(B)]).astype(np.float32)
+    cod = np.where(f0[..., None] > 0, -3 - 30 * rng.rand(B, T, 1), -0.3 * rng.rand(B, T, 1)).astype(np.float32)
+    y, n = v.synthesize(_dev(f0, cuda), _dev(sp, cuda), codeap=_dev(cod, cuda))
+    for b in range(B):
+        ap64 = W.decode_aperiodicity(cod[b].astype(np.float64), FS, N)
+        ref = W.synthesize_parts(f0[b].astype(np.float64), sp[b].astype(np.float64), ap64, FS, 10.0)
+        assert int(n[b]) == len(ref["idx"])
+        err = np.abs(y[b].double().cpu().numpy() - ref["y"]).max() / np.abs(ref["y"]).max()
+        assert err <= TOL, (b, err)
+    with pytest.raises(ValueError):
+        v.synthesize(_dev(f0, cuda), _dev(sp, cuda))

@@ -37,6 +37,7 @@ struct WorldParams {
     double frame_period;      // seconds
     double frame_period_ms;
     const float* tw256; const float* tw512; const float* dcr;
+    const float* coded; int nb;   // optional: coded band aperiodicity [B][T][nb] (dB) decoded on the fly instead of `ap`
 };
 
 // everything up to the matching "contract(fast)" must round like the C / numpy reference: no fused multiply-adds
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
     double carry = 0.0;                                   // thread 0: the running phase
     for (int c0 = 0; c0 < ylen; c0 += CH) {
         const int n = min(CH, ylen - c0);
-        // the contour frames this chunk's samples interpolate between, staged once (a chunk spans CH / (fs fp) + 2 frames; when the frame
-        // period is so short that they do not fit, the lookups below fall back to global memory)
+        // the contour frames this chunk's samples interpolate between, staged once (a chunk spans CH / (fs fp) + 2 frames <= NFR: checked
+        // by the launcher)
         int kf = (int)(((double)c0 / fs) / fp) - 1;
         if (kf < 0) kf = 0;
         __syncthreads();                                  // the previous chunk's detection has read s_tot / the contour window
@@ -107,9 +108,8 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
             while (k < T && t >= (double)k * fp) ++k;
             const double x0 = (double)(k - 1) * fp, x1 = (double)k * fp;
             const double s = (t - x0) / (x1 - x0);
-            const bool in_win = k - 1 >= kf && k < kf + NFR;
-            const double fa = in_win ? s_cf0[k - 1 - kf] : cf0(k - 1), fb = in_win ? s_cf0[k - kf] : cf0(k);
-            const double va = in_win ? s_cv[k - 1 - kf] : cvuv(k - 1), vb = in_win ? s_cv[k - kf] : cvuv(k);
+            const int kw = min(max(k - 1 - kf, 0), NFR - 2);         // inside the staged window (the launcher checked that a chunk's frames fit)
+            const double fa = s_cf0[kw], fb = s_cf0[kw + 1], va = s_cv[kw], vb = s_cv[kw + 1];
             double fi = fa + s * (fb - fa);
             const double vi = va + s * (vb - va);
             const bool voiced = vi > 0.5;
@@ -366,23 +366,49 @@ __global__ __launch_bounds__(256) void world_pulse_kernel(WorldParams p) {
         int fl, ce;
         float mix;
         world_frame_mix(id, p.fs, p.frame_period, T, fl, ce, mix);
-        float env[4], rat[4], env256, rat256;
+        // u = 1 - aperiodicity, carried instead of the aperiodicity itself: near 1 (every voiced frame above a few kHz) the fp32 value of a
+        // has an absolute error of 6e-8, i.e. 1 - a^2 -- whose logarithm shapes the periodic response's minimum phase EVERYWHERE -- a
+        // relative error of 1e-4 .. 1e-3; 1 - a of a stored fp32 a is exact, the interpolation of u is accurate to fp32's relative
+        // precision, and 1 - a^2 = u (2 - u).  With `coded` the band values are decoded here (u = -expm1(dB ln10 / 20)), so nothing near 1 is
+        // ever rounded to fp32.  WORLD's clip of a to [0.001, 1 - 1e-12] is u in [1e-12, 0.999].
+        float env[4], rat[4], omr[4], env256, rat256, omr256;                    // omr = 1 - ratio
         {
             const float* s0 = spb + (size_t)fl * NB;
             const float* s1 = spb + (size_t)ce * NB;
             const float* a0 = apb + (size_t)fl * NB;
             const float* a1 = apb + (size_t)ce * NB;
-            auto safe = [](float v) { return fminf(fmaxf(v, 0.001f), 1.0f); };          // (0.999999999999 is 1 in fp32)
+            const float* c0 = p.coded ? p.coded + ((size_t)b * p.T + fl) * p.nb : nullptr;
+            const float* c1 = p.coded ? p.coded + ((size_t)b * p.T + ce) * p.nb : nullptr;
+            auto u_of = [&](const float* arow, const float* crow, int k) -> float {
+                float u;
+                if (crow) {
+                    float mean = 0.f;
+                    for (int i = 0; i < p.nb; ++i) mean += crow[i];
+                    if (mean / (float)p.nb > -0.5f) return 1e-12f;              // unvoiced frame: a = 1 - 1e-12
+                    const float f = (float)p.fs / (float)NF * (float)k;
+                    int seg = (int)(f / 3000.f);
+                    if (seg > p.nb) seg = p.nb;
+                    const float x0 = 3000.f * seg, x1 = seg == p.nb ? 0.5f * p.fs : 3000.f * (seg + 1);
+                    const float y0 = seg == 0 ? -60.f : crow[seg - 1], y1 = seg == p.nb ? -1e-12f : crow[seg];
+                    const float db = y0 + (f - x0) / (x1 - x0) * (y1 - y0);
+                    u = -expm1f(db * 0.11512925464970229f);                      // 1 - 10^(dB / 20)
+                } else {
+                    u = 1.f - arow[k];
+                }
+                return fminf(fmaxf(u, 1e-12f), 0.999f);
+            };
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k = lane + 64 * q;
                 env[q] = (1.f - mix) * fabsf(s0[k]) + mix * fabsf(s1[k]);
-                const float a = (1.f - mix) * safe(a0[k]) + mix * safe(a1[k]);
-                rat[q] = a * a;
+                const float u = (1.f - mix) * u_of(a0, c0, k) + mix * u_of(a1, c1, k);
+                rat[q] = (1.f - u) * (1.f - u);
+                omr[q] = u * (2.f - u);
             }
             env256 = (1.f - mix) * fabsf(s0[256]) + mix * fabsf(s1[256]);
-            const float a = (1.f - mix) * safe(a0[256]) + mix * safe(a1[256]);
-            rat256 = a * a;
+            const float u = (1.f - mix) * u_of(a0, c0, 256) + mix * u_of(a1, c1, 256);
+            rat256 = (1.f - u) * (1.f - u);
+            omr256 = u * (2.f - u);
         }
         const float rat0 = __shfl(rat[0], 0, 64);
         const bool periodic = cur_v && !(rat0 > 0.999f);
@@ -391,8 +417,8 @@ __global__ __launch_bounds__(256) void world_pulse_kernel(WorldParams p) {
         if (periodic) {
             float l[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) l[q] = 0.5f * logf(env[q] * (1.f - rat[q]) + 1e-12f);
-            const float l256 = 0.5f * logf(env256 * (1.f - rat256) + 1e-12f);
+            for (int q = 0; q < 4; ++q) l[q] = 0.5f * logf(env[q] * omr[q] + 1e-12f);
+            const float l256 = 0.5f * logf(env256 * omr256 + 1e-12f);
             cplx h[4], h256;
             min_phase(l, l256, r, z, lane, tw, w512, h, h256);
             // fractional delay of xs samples: multiply by cos - i |sin| of 2 pi x k / 512
@@ -562,18 +588,20 @@ extern "C" long long v100_world_synth_workspace_bytes(int B, int T, int fs, doub
     return (long long)B * (Y + Pc * 4 + Pc * 4 + Pc * NF * 4) + 256;
 }
 
-extern "C" int v100_world_synthesize(const float* f0, const float* sp, const float* ap, const int* frames, const float* randn_table,
+extern "C" int v100_world_synthesize(const float* f0, const float* sp, const float* ap, const float* coded_ap, int nb, const int* frames, const float* randn_table,
                                      long long table_len, const float* tw256, const float* tw512, const float* dc_remover, float* y,
                                      int* n_pulses, void* workspace, int B, int T, int fs, double frame_period_ms, int fft_size,
                                      int max_pulses, void* stream) {
-    if (!f0 || !sp || !ap || !randn_table || !tw256 || !tw512 || !dc_remover || !y || !n_pulses || !workspace) return V100_ERR_NULL;
+    if (!f0 || !sp || (!ap && !coded_ap) || !randn_table || !tw256 || !tw512 || !dc_remover || !y || !n_pulses || !workspace) return V100_ERR_NULL;
+    if (coded_ap && (nb < 1 || nb > 5)) return V100_ERR_SHAPE;
     if (B <= 0 || T < 2 || fs <= 0 || fft_size != NF || max_pulses <= 0 || frame_period_ms <= 0) return V100_ERR_SHAPE;
     const int Ymax = world_ymax(T, fs, frame_period_ms);
     if (Ymax < 2 || table_len < Ymax || B > 65535) return V100_ERR_SHAPE;
+    if (2048.0 / ((double)fs * frame_period_ms / 1000.0) + 4.0 > 64.0) return V100_ERR_SHAPE;     // time-base kernel: a chunk's contour window (NFR)
     const long long Y = (Ymax + 63) & ~63LL, Pc = (max_pulses + 63) & ~63LL;
     char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     WorldParams p{};
-    p.f0 = f0; p.sp = sp; p.ap = ap; p.frames = frames; p.randn = randn_table; p.table_len = table_len; p.y = y; p.n_pulses = n_pulses;
+    p.f0 = f0; p.sp = sp; p.ap = ap ? ap : sp; p.coded = coded_ap; p.nb = nb; p.frames = frames; p.randn = randn_table; p.table_len = table_len; p.y = y; p.n_pulses = n_pulses;
     p.idx = (int*)w;                    w += (size_t)B * Pc * 4;
     p.xshift = (float*)w;               w += (size_t)B * Pc * 4;
     p.resp = (float*)w;                 w += (size_t)B * Pc * NF * 4;

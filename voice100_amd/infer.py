@@ -148,8 +148,7 @@ class TTSPipeline:
         out = {"align": align, "aligntext": aligntext, "aligntext_len": at_len, "f0": f0, "logspc": logspc, "spc": spc,
                "codeap": codeap, "frames": frames}
         if v is not None and self.synthesize and v.n_fft == 512 and f0.shape[1] >= 2:
-            ap = v.decode_aperiodicity(codeap)
-            wave, npulses = v.synthesize(f0, spc, ap, frames=frames, f0_ceil=self.f0_ceil)
+            wave, npulses = v.synthesize(f0, spc, frames=frames, f0_ceil=self.f0_ceil, codeap=codeap)
             out["wave"], out["n_pulses"] = wave, npulses
             out["wave_len"] = (frames.to(torch.float64) * v.frame_period * v.sample_rate / 1000).to(torch.int64)
         return out

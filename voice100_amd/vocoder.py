@@ -153,22 +153,32 @@ class WORLDVocoder(nn.Module):
         return ap
 
     @torch.no_grad()
-    def synthesize(self, f0: torch.Tensor, spc: torch.Tensor, ap: torch.Tensor, frames: torch.Tensor = None, f0_ceil: float = 1000.0):
+    def synthesize(self, f0: torch.Tensor, spc: torch.Tensor, ap: torch.Tensor = None, frames: torch.Tensor = None, f0_ceil: float = 1000.0,
+                   codeap: torch.Tensor = None):
         """pyworld.synthesize(f0, spc, ap, fs, frame_period) for a batch, on the device (vocoder.py:101).
 
         f0 [B, T], spc / ap [B, T, n_fft/2+1] fp32 CUDA; frames [B] int32 = valid frames per utterance (None: all T).
+        Instead of ap, `codeap` [B, T, nb] (dB) may be given: the band aperiodicity is then decoded per pulse inside the kernel, as
+        1 - aperiodicity, so values near 1 (everything above a few kHz in voiced frames) never pass through an fp32 tensor -- the
+        reference decodes and synthesises in double.
         Returns (waveform [B, int(T * frame_period * fs / 1000)] fp32, zero beyond an utterance's own length; n_pulses [B] int32).
         Room is made for f0_ceil / fs pulses per sample (unvoiced frames pulse at 500 Hz); an utterance that needs more comes
         back as NaN with n_pulses = -1 -- raise f0_ceil."""
-        for t, nm in ((f0, "f0"), (spc, "spc"), (ap, "ap")):
+        if (ap is None) == (codeap is None):
+            raise ValueError("synthesize: give exactly one of ap / codeap")
+        for t, nm in ((f0, "f0"), (spc, "spc"), (ap if ap is not None else codeap, "ap")):
             F_._check(t, "WORLDVocoder.synthesize " + nm)
         if self.n_fft != 512:
             raise RuntimeError("WORLDVocoder.synthesize: the device kernels are built for n_fft = 512 (16 kHz)")
-        f0, spc, ap = f0.contiguous(), spc.contiguous(), ap.contiguous()
+        f0, spc = f0.contiguous(), spc.contiguous()
         B, T = f0.shape
         nb = self.n_fft // 2 + 1
-        if spc.shape != (B, T, nb) or ap.shape != (B, T, nb):
+        if spc.shape != (B, T, nb) or (ap is not None and ap.shape != (B, T, nb)):
             raise ValueError("synthesize: spc / ap must be [B, T, n_fft/2+1]")
+        if codeap is not None and codeap.shape != (B, T, self.codeap_dim):
+            raise ValueError("synthesize: codeap must be [B, T, codeap_dim]")
+        ap = ap.contiguous() if ap is not None else None
+        codeap = codeap.contiguous() if codeap is not None else None
         if T < 2:
             raise ValueError("synthesize needs at least two frames (WORLD extrapolates the contour from its last two)")
         ymax = int(T * self.frame_period * self.sample_rate / 1000)
@@ -184,7 +194,7 @@ class WORLDVocoder(nn.Module):
         if nbytes < 0:
             raise RuntimeError("v100_world_synth_workspace_bytes: unsupported shape")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        N.call("v100_world_synthesize", f0, spc, ap, frames, table, table.numel(), tw_h, tw_f, dcr, y, npulses, ws,
+        N.call("v100_world_synthesize", f0, spc, ap, codeap, int(self.codeap_dim), frames, table, table.numel(), tw_h, tw_f, dcr, y, npulses, ws,
                B, T, int(self.sample_rate), float(self.frame_period), int(self.n_fft), cap)
         return y, npulses
 
@@ -229,10 +239,9 @@ class WORLDVocoder(nn.Module):
         else:
             logspc = feat
         spc = self.logspc_to_spc(logspc)[None]
-        ap = self.decode_aperiodicity(codeap.to(dev, torch.float32))[None]
         # pulses per sample are bounded by the largest interpolated F0 (the extrapolated end point can reach twice the maximum)
         ceil = max(500.0, 2.0 * float(f0.max())) + 1.0
-        y, n = self.synthesize(f0, spc, ap, f0_ceil=ceil)
+        y, n = self.synthesize(f0, spc, f0_ceil=ceil, codeap=codeap.to(dev, torch.float32)[None])
         if int(n[0]) < 0:
             raise RuntimeError("WORLDVocoder.decode: pulse list overflow")
         return y[0].double().cpu().numpy()
