@@ -222,13 +222,23 @@ def other_configs(device, N, F_):
         text = torch.randint(1, VOCAB, (16, 128), device=device)
         tlen = torch.randint(64, 129, (16,), device=device)
         dt_al = timeit(lambda: al(text))
-        chain = TTSPipeline(al, AlignTextToAudioModel(vocab_size=VOCAB, hidden_size=512, use_mcep=True).to(device).eval(),
-                            WORLDVocoder(use_mcep=True).to(device))
+        au = AlignTextToAudioModel(vocab_size=VOCAB, hidden_size=512, use_mcep=True).to(device).eval()
+        voc = WORLDVocoder(use_mcep=True).to(device)
+        chain = TTSPipeline(al, au, voc, synthesize=False)
         dt_ch = timeit(lambda: chain(text, tlen))
         wf = int(chain(text, tlen)["frames"].sum())
         out["config3_align_model_B16_L128"] = {"ms": round(dt_al * 1e3, 3), "tokens_per_s": round(16 * 128 / dt_al, 1)}
         out["config3_chain_text_to_spc_B16_L128"] = {"ms": round(dt_ch * 1e3, 3), "world_frames": wf,
                                                     "world_frames_per_s": round(wf / dt_ch, 1)}
+        # ... and on to the WAVEFORM (configs[2]: "... -> WORLD features + vocoder"): decode_aperiodicity + synthesize on the device
+        # (csrc/world.hip, parity unpinned), 160 samples per WORLD frame at 16 kHz
+        chain_w = TTSPipeline(al, au, voc, synthesize=True)
+        dt_w = timeit(lambda: chain_w(text, tlen))
+        ow = chain_w(text, tlen)
+        secs = float(ow["wave_len"].sum()) / 16000.0
+        out["config3_chain_text_to_wave_B16_L128"] = {"ms": round(dt_w * 1e3, 3), "world_frames": wf, "audio_seconds": round(secs, 1),
+                                                     "pulses": int(ow["n_pulses"].sum()), "x_realtime": round(secs / dt_w, 1),
+                                                     "vocoder_ms": round((dt_w - dt_ch) * 1e3, 3)}
         F_.set_matmul_precision("fp16")                 # config 5 names fp16
         mel = MelSpectrogramAudioTransform().to(device)
         B = 256

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
     };
     const int lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { s_base = 0; s_tot[0] = 0.0; }
-    double carry = 0.0;                                   // thread 0: the running phase
+    double carry_all = 0.0;                               // every thread: the running phase (total of the last sample so far)
     for (int c0 = 0; c0 < ylen; c0 += CH) {
         const int n = min(CH, ylen - c0);
         // the contour frames this chunk's samples interpolate between, staged once (a chunk spans CH / (fs fp) + 2 frames <= NFR: checked
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
         int kf = (int)(((double)c0 / fs) / fp) - 1;
         if (kf < 0) kf = 0;
         __syncthreads();                                  // the previous chunk's detection has read s_tot / the contour window
+        if (tid == 0) s_tot[0] = carry_all;               // total of sample c0 - 1 (the crossing test of this chunk's first sample reads it)
         if (tid < NFR) {
             const int j = kf + tid;
             s_cf0[tid] = j <= T ? cf0(j) : 0.0;
@@ -118,31 +119,96 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
             s_tot[1 + j] = 2.0 * kPi * fi / fs;          // the increment; accumulated in place below
         }
         __syncthreads();
-        if (tid == 0) {
-            s_tot[0] = carry;                             // total of sample c0 - 1 (0 before the first sample: never read there)
-            double acc = carry;
+        // The running phase of this chunk.  The reference accumulates sample by sample, total[i] = fl(total[i-1] + inc[i]), and which side
+        // of 2 pi a sample lands on can hinge on that exact rounding (header).  But INSIDE one binade of the running sum the rounding is
+        // a rounding of the INCREMENT alone: with u = ulp(total), total = A u (A an integer) and inc = q u, the exact sum (A + q) u
+        // rounds to (A + rn(q)) u whenever q is not exactly half-way between two integers and the result stays below 2^(e+1).  So the
+        // sequential sum of a chunk equals A0 u + (prefix sum of the integers rn(q_i)) u -- an exact INTEGER scan, done in parallel.
+        // Chunks in which the sum crosses a power of two, or in which some q_i is an exact tie (then the parity of the running sum
+        // decides), take the sequential loop: the first chunk, ~6 crossings of an utterance, a few percent of the rest.
+        __shared__ double s_scan[256];
+        __shared__ int s_flag;
+        const double A0 = carry_all;                      // total of sample c0 - 1, known to every thread (s_tot[0] of the previous round)
+        bool serial = !(A0 >= 1.0);
+        double u = 0.0, lim = 0.0;
+        if (!serial) {
+            int e;
+            (void)frexp(A0, &e);                          // A0 = m 2^e, 0.5 <= m < 1: the binade is [2^(e-1), 2^e), ulp 2^(e-53)
+            u = ldexp(1.0, e - 53);
+            lim = ldexp(1.0, e);
+        }
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
+        double loc[8];
+        double sum = 0.0;
+        bool bad = false;
+        if (!serial) {
+            const double inv_u = 1.0 / u;                 // a power of two: exact
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int j = 8 * tid + e8;
+                double r = 0.0;
+                if (j < n) {
+                    const double q = s_tot[1 + j] * inv_u;
+                    r = rint(q);
+                    bad |= fabs(q - r) == 0.5;            // exact tie: the running sum's parity decides -> sequential
+                }
+                sum += r;                                 // integers below 2^53: exact
+                loc[e8] = sum;
+            }
+            s_scan[tid] = sum;
+            if (bad) s_flag = 1;
+        }
+        __syncthreads();
+        if (!serial) {
+            // exclusive prefix of the 256 per-thread totals (one wave does it: 4 values per lane, then a wave scan)
+            if (tid < 64) {
+                double v0 = s_scan[4 * tid], v1 = s_scan[4 * tid + 1], v2 = s_scan[4 * tid + 2], v3 = s_scan[4 * tid + 3];
+                const double t = v0 + v1 + v2 + v3;
+                double inc = t;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const double up = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += up;
+                }
+                const double ex = inc - t;                // exclusive prefix of this lane's group
+                s_scan[4 * tid] = ex; s_scan[4 * tid + 1] = ex + v0; s_scan[4 * tid + 2] = ex + v0 + v1; s_scan[4 * tid + 3] = ex + v0 + v1 + v2;
+                if (tid == 63 && !(A0 + inc * u < lim)) s_flag = 1;       // the chunk's last total leaves the binade -> sequential
+            }
+        }
+        __syncthreads();
+        serial = serial || s_flag != 0;
+        if (!serial) {
+            const double base = s_scan[tid];
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int j = 8 * tid + e8;
+                if (j < n) s_tot[1 + j] = A0 + (base + loc[e8]) * u;      // (integer) u and the sum: both exact
+            }
+        } else if (tid == 0) {
+            double acc = A0;
             int j = 0;
             if (n >= 16) {
-                double v[16], u[16];
+                double v[16], w[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = s_tot[1 + e];
                 for (; j + 32 <= n; j += 16) {             // the next 16 increments are read while these 16 are added
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) u[e] = s_tot[1 + j + 16 + e];
+                    for (int e = 0; e < 16; ++e) w[e] = s_tot[1 + j + 16 + e];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) { acc += v[e]; s_tot[1 + j + e] = acc; }
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = u[e];
+                    for (int e = 0; e < 16; ++e) v[e] = w[e];
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { acc += v[e]; s_tot[1 + j + e] = acc; }
                 j += 16;
             }
             for (; j < n; ++j) { acc += s_tot[1 + j]; s_tot[1 + j] = acc; }
-            carry = acc;
         }
         __syncthreads();
-        for (int j = tid; j <= n; j += 256) s_wrap[j] = fmod(s_tot[j], 2.0 * kPi);       // one fmod per sample
+        carry_all = s_tot[n];                             // every thread: the running phase after this chunk
+        for (int j = tid; j <= n; j += 256) s_wrap[j] = fmod(s_tot[j], 2.0 * kPi);       // one fmod per sample (s_tot[0]: the previous chunk's last)
         __syncthreads();
         // crossings between samples i and i + 1, i = c0 - 1 + j for j = 0 .. n - 1 (i >= 0): |wrap[i + 1] - wrap[i]| > pi
         for (int j0 = 0; j0 < n; j0 += 256) {
