@@ -497,10 +497,14 @@ __global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __res
 // Channel-major inference layout (block.hip, v100_ir_fwd_eval with shape[10] == 2): [B][C][T] -> [C][B][P], P = (T + 7) & ~7, the padding
 // columns zeroed; and back out of it at the model's edge: [C][B][P] -> [B][T][C]  (asr.py:114: transpose(1, 2) of the logits)
 __global__ __launch_bounds__(256) void bct_to_cm_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int T, int P) {
-    const int c = blockIdx.y, b = blockIdx.z;
-    const float* src = in + ((size_t)b * C + c) * T;
-    float* dst = out + ((size_t)c * B + b) * P;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < P; t += gridDim.x * 256) dst[t] = t < T ? src[t] : 0.f;
+    // flat over the output (rows of 51 samples would leave a workgroup per row 80 % idle: 30 us for 256 x 256 rows)
+    const long long total = (long long)C * B * P;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long row = i / P;
+        const int t = (int)(i - row * P);
+        const int c = (int)(row / B), b = (int)(row - (long long)c * B);
+        out[i] = t < T ? in[((size_t)b * C + c) * T + t] : 0.f;
+    }
 }
 __global__ __launch_bounds__(256) void cm_to_btc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int T, int P) {
     __shared__ float tile[32][33];
@@ -728,10 +732,12 @@ extern "C" int v100_transpose_last2(const float* in, float* out, int B, int R, i
 
 extern "C" int v100_bct_to_cm(const float* in, float* out, int B, int C, int T, void* stream) {
     if (!in || !out) return V100_ERR_NULL;
-    if (B <= 0 || C <= 0 || T <= 0 || B > 65535 || C > 65535) return V100_ERR_SHAPE;
+    if (B <= 0 || C <= 0 || T <= 0) return V100_ERR_SHAPE;
     const int P = (T + 7) & ~7;
-    V100_GGL(bct_to_cm_kernel, dim3(ceil_div(P, 256) < 4 ? ceil_div(P, 256) : 4, (unsigned)C, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
-             in, out, B, C, T, P);
+    const long long total = (long long)C * B * P;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    V100_GGL(bct_to_cm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, B, C, T, P);
     return v100_launch_status();
 }
 
