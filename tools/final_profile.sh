@@ -3,10 +3,10 @@
 #   rocprofv3 --kernel-trace --stats of the bench command (per-kernel table + per-step breakdown), PMC passes of the depthwise
 #   micro-benchmark (HBM traffic ratio for bench.py's `roofline.traffic`, tagged with the kernel sources' hash), kernel tables of
 #   config 3 (tts predict + chain) and config 5 (log-mel -> encoder -> greedy decode), and the unprofiled bench line.
-tag=${1:-r03}
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/final; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python3 bench.py --steps 30 --warmup 5 --windows 0 --host-contention 0 --no-cpu-baseline --no-other-configs > $out/${tag}_bench_line_under_rocprof.json 2> $out/prof_err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python3 bench.py --steps 30 --warmup 5 --windows 0 --host-contention 0 --sustained-seconds 0 --no-extras --no-cpu-baseline --no-other-configs > $out/${tag}_bench_line_under_rocprof.json 2> $out/prof_err.txt
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1)
 cp "$f" $out/${tag}_bench_bf16_kernel_stats.csv
 python3 tools/prof_summary.py "$f" 36 60 > $out/${tag}_bench_bf16_summary.txt
@@ -16,7 +16,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1)
 python3 tools/prof_summary.py "$f" 1 40 > $out/${tag}_infer_configs_kernel_summary.txt
 rm -rf $out/prof
-tools/pmc_passes.sh $out/pmc --what dw16,dw > /dev/null 2>&1
-python3 tools/pmc_table.py $out/pmc --json $out/dw_fwd_pmc.json > $out/${tag}_pmc_counters.txt 2>&1
+# HBM traffic of the depthwise forward launches AS bench.py DISPATCHES THEM (one row per launch; round-3 review, item 2a) -> the file bench.py
+# reads for `roofline.traffic` (tagged with the depthwise sources' hash), refreshed before the unprofiled bench line below
+tools/pmc_bench_dw.sh $out/pmc_dw > /dev/null 2>&1
+python3 tools/pmc_dw_json.py $out/pmc_dw --json $out/dw_fwd_pmc.json > $out/${tag}_dw_fwd_pmc_per_launch.txt 2>&1
+cp $out/dw_fwd_pmc.json profiles/dw_fwd_pmc.json
+rm -rf $out/pmc_dw/*.csv
 python3 bench.py > $out/${tag}_bench_line.json 2> $out/bench_err.txt
 tail -c 600 $out/${tag}_bench_line.json

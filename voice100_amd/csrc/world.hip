@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
     __shared__ int s_cnt[4];
     __shared__ int s_base;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int T = p.frames ? p.frames[b] : p.T;
+    const int T = p.frames ? min(max(p.frames[b], 0), p.T) : p.T;      // an utterance's own frame count, never past the row
     const int ylen = T > 0 ? world_ylen(T, p.frame_period_ms, p.fs) : 0;
     const float* f0 = p.f0 + (size_t)b * p.T;
     unsigned char* vuv = p.vuv + (size_t)b * p.Ymax;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void world_pulse_kernel(WorldParams p) {
     cplx w512[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int k = lane + 64 * q; w512[q] = {p.tw512[2 * k], p.tw512[2 * k + 1]}; }
-    const int T = p.frames ? p.frames[b] : p.T;
+    const int T = p.frames ? min(max(p.frames[b], 0), p.T) : p.T;      // an utterance's own frame count, never past the row
     const int* idx = p.idx + (size_t)b * p.Pcap;
     const float* xs = p.xshift + (size_t)b * p.Pcap;
     const unsigned char* vuv = p.vuv + (size_t)b * p.Ymax;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void world_pulse_kernel(WorldParams p) {
 __global__ __launch_bounds__(256) void world_overlap_add_kernel(WorldParams p) {
     const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + threadIdx.x;
-    const int T = p.frames ? p.frames[b] : p.T;
+    const int T = p.frames ? min(max(p.frames[b], 0), p.T) : p.T;      // an utterance's own frame count, never past the row
     const int ylen = T > 0 ? world_ylen(T, p.frame_period_ms, p.fs) : 0;
     if (n >= p.Ymax) return;
     float* y = p.y + (size_t)b * p.Ymax;
