@@ -75,8 +75,11 @@ def test_unvoiced_frames_are_noise_at_the_envelope_level_and_linear():
     ap = W.decode_aperiodicity(np.zeros((T, 1)), FS, N)
     sp = np.full((T, N // 2 + 1), 0.04)
     r = W.synthesize_parts(f0, sp, ap, FS, 10.0)
-    # unvoiced frames are excited at the default 500 Hz: a pulse every 32 samples, periodic part off
-    assert np.all(np.diff(r["idx"]) == 32)
+    # unvoiced frames are excited at the default 500 Hz: a pulse every 32 samples, periodic part off.  500 Hz at 16 kHz puts every 2 pi
+    # crossing exactly ON a sample, so the rounding of the running phase decides which side each one falls: 31 / 32 / 33 occur (this is
+    # why the device kernel reproduces the sequential summation order exactly)
+    d = np.diff(r["idx"])
+    assert np.all((d >= 31) & (d <= 33)) and abs(d.mean() - 32.0) < 0.01
     y = r["y"][2000:-2000]
     assert abs(y.var() / 0.04 - 1.0) < 0.1                                    # white noise whose variance is the (flat) power spectrum
     assert abs(y.mean()) < 0.02
@@ -105,7 +108,8 @@ def test_mixed_voicing_and_pulse_bookkeeping():
     # F0 below fs / fft_size + 1 is treated as unvoiced; voiced stretches pulse at their own period
     v = r["vuv"][r["idx"]]
     d = np.diff(r["idx"])
-    assert np.all(d[(v[:-1] == 0) & (v[1:] == 0)] == 32)
+    du = d[(v[:-1] == 0) & (v[1:] == 0)]
+    assert np.all((du >= 31) & (du <= 33))
     assert d[(v[:-1] == 1) & (v[1:] == 1)].min() >= int(FS / 185) - 1
     # the response of every pulse is fft_size samples, overlap-added at idx - fft_size/2 + 1: energy sits right after the pulse
     i = int(np.argmax(v == 1)) + 3
