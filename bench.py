@@ -91,7 +91,18 @@ def gpu_clock_power(local_rank=0):
     cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
     if not cards:
         return out
-    dev = os.path.dirname(cards[min(local_rank, len(cards) - 1)])
+    dev = None
+    try:        # the card whose PCI address is this process's HIP device (a box may expose several cards of which one is ours)
+        pr = torch.cuda.get_device_properties(local_rank)
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+        for c in cards:
+            if os.path.basename(os.path.realpath(os.path.dirname(c))).startswith(want):
+                dev = os.path.dirname(c)
+    except Exception:                                            # noqa: BLE001
+        pass
+    if dev is None:
+        dev = os.path.dirname(cards[min(local_rank, len(cards) - 1)])
+        out["card_matched_by"] = "index (PCI address not matched)"
     out["source"] = dev
     try:
         for line in open(os.path.join(dev, "pp_dpm_sclk")):

@@ -20,7 +20,7 @@ T = int(sys.argv[sys.argv.index("--T") + 1]) if "--T" in sys.argv else 1024
 SPECS = [(256, 11, 2), (1024, 19, 1), (1024, 27, 1), (1024, 35, 1), (1024, 51, 1), (2048, 59, 1), (2048, 67, 1), (2048, 75, 1), (2048, 83, 1)]
 # forward kernels of the TRAINING step: the streaming kernel (rows <= 768 outputs, EV = false), the general Toeplitz-MFMA kernel in its
 # bf16-storage forward form (IM 1, OM 0, IO 9), the fp32-storage MFMA forward, and the register-window kernel of the stride-2 opener
-FWD = re.compile(r"dwconv_fwd16_stream_kernel<(\d+), \d+, \d+, \d+, \d+, false>|dwconv_mfma_kernel<(\d+), 1, 0, \d+, false, (?:9|0)>|"
+FWD = re.compile(r"dwconv_fwd16_stream_kernel<(\d+), \d+, \d+, \d+, \d+, false(?:, false)?>|dwconv_mfma_kernel<(\d+), 1, 0, \d+, false, (?:9|0)>|"
                  r"dwconv_kernel<(\d+), 2, 8, 1, 0, true, false>")
 
 
