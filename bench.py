@@ -621,7 +621,8 @@ def main():
                                    "augmentation+dropout on, Adam; 1x1 GEMM operands bf16 (fp32 accumulate); activation storage level "
                                    + str(F_.get_activation_storage()) + " (0 fp32 everywhere; >= 1 the tensors internal to a block -- and their "
                                    "gradients from 2 -- stored as bf16; 4 adds a bf16 copy of each block output as the next block's GEMM "
-                                   "operand); block inputs/outputs, BatchNorm statistics and all accumulation fp32"
+                                   "operand; 5: the forward residual stream inside a stack lives in that bf16 copy only, as under the "
+                                   "reference's autocast); gradients between blocks, BatchNorm statistics and all accumulation fp32"
                                    if args.precision == "bf16" else
                                    "configs[1] at fp32 throughout",
                        "global_batch": B_PER_GPU * world, "frames_per_utterance": T_FRAMES, "parallelism": f"dp{world}"},

@@ -20,7 +20,7 @@ def _run(net, x, gy, how, segment=None):
     return y.detach(), x.grad, {k: p.grad for k, p in net.named_parameters()}, bufs
 
 
-@pytest.mark.parametrize("precision,level", [("fp32", 0), ("bf16", 0), ("bf16", 2), ("bf16", 3), ("bf16", 4)])
+@pytest.mark.parametrize("precision,level", [("fp32", 0), ("bf16", 0), ("bf16", 2), ("bf16", 3), ("bf16", 4), ("bf16", 5)])
 def test_stack_equals_blocks(cuda, precision, level):
     from voice100_amd import functional as F_
     from voice100_amd.layers import InvertedResidual
@@ -136,3 +136,38 @@ def test_stack_sees_replaced_buffers(cuda):
     y = F_.ir_stack_train(list(net), x)
     y_ref = ref[1](ref[0](x))
     assert torch.equal(y, y_ref)
+
+
+def test_level5_residual_stream_vs_level4(cuda):
+    """Activation storage level 5: the forward residual stream kept in its bf16 form only (interior blocks of a stack write no fp32 output,
+    residuals are read from the bf16 copy).  Against level 4 on the same weights: outputs and gradients within the bf16 rounding of the
+    stream (one rounding per residual block), BatchNorm buffers likewise; the LAST block still returns an fp32 tensor."""
+    from voice100_amd import functional as F_
+    from voice100_amd.layers import InvertedResidual
+    F_.set_matmul_precision("bf16")
+    keep = F_.get_activation_storage()
+    try:
+        torch.manual_seed(31)
+        net = torch.nn.Sequential(InvertedResidual(16, 64, kernel_size=11, stride=2, use_residual=False),
+                                  InvertedResidual(64, 64, kernel_size=19), InvertedResidual(64, 64, kernel_size=27),
+                                  InvertedResidual(64, 256, kernel_size=35, use_residual=False), InvertedResidual(256, 256, kernel_size=5)).to(cuda)
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(4, 16, 400, generator=g).to(cuda)
+        gy = torch.randn(4, 256, 200, generator=g).to(cuda)
+        outs = {}
+        for level in (4, 5):
+            F_.set_activation_storage(level)
+            outs[level] = _run(net, x, gy, "stack")
+        y4, y5 = outs[4][0], outs[5][0]
+        assert y5.dtype == torch.float32 and torch.isfinite(y5).all()
+        assert not torch.equal(y4, y5)                                            # the stream really is rounded
+        assert float((y4 - y5).abs().max() / y4.abs().max()) < 2e-2
+        # gradients of this toy net (64 channels, B T = 800) move by ReLU6 mask flips as soon as any activation is rounded differently: the
+        # direction must hold (the bars that matter are taken at the metric shape against the fp32 oracle, test_gpu_models)
+        dot = sum(float((outs[4][2][k].double() * outs[5][2][k].double()).sum()) for k in outs[4][2])
+        n4 = sum(float(outs[4][2][k].double().pow(2).sum()) for k in outs[4][2]) ** 0.5
+        n5 = sum(float(outs[5][2][k].double().pow(2).sum()) for k in outs[4][2]) ** 0.5
+        assert dot / (n4 * n5) > 0.97 and abs(n5 / n4 - 1.0) < 0.05
+    finally:
+        F_.set_activation_storage(keep)
+        F_.set_matmul_precision("fp32")

@@ -55,17 +55,19 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.task == "learnable":
-        curves = {"fp32": run("fp32", 0, args.steps, dev, "learnable"), "bf16/act4": run("bf16", 4, args.steps, dev, "learnable")}
+        curves = {"fp32": run("fp32", 0, args.steps, dev, "learnable"), "bf16/act4": run("bf16", 4, args.steps, dev, "learnable"),
+                  "bf16/act5": run("bf16", 5, args.steps, dev, "learnable")}
         print(f"# learnable synthetic task (tools/loss_curve.py --task learnable), {args.steps} steps, asr_en_base, B = 32 x 1024 frames, "
               "augmentation + dropout on, Adam 1e-3; mean CTC loss per window of 20 steps")
         print("steps      " + " ".join(f"{k:>10s}" for k in curves))
         w = 20
         for i in range(0, args.steps, w):
             print(f"{i:4d}-{min(i + w, args.steps) - 1:4d}  " + " ".join(f"{np.mean(v[i:i + w]):10.4f}" for v in curves.values()))
-        a, b = np.array(curves["fp32"]), np.array(curves["bf16/act4"])
         tail = slice(max(0, args.steps - 100), args.steps)
-        print(f"first-20 mean: fp32 {a[:20].mean():.3f}  bf16/act4 {b[:20].mean():.3f};  last-100 mean: fp32 {a[tail].mean():.4f}  bf16/act4 {b[tail].mean():.4f};  "
-              f"steps to reach loss < 1.0: fp32 {int(np.argmax(a < 1.0)) if (a < 1.0).any() else None}  bf16/act4 {int(np.argmax(b < 1.0)) if (b < 1.0).any() else None}")
+        for name, v in curves.items():
+            a = np.array(v)
+            print(f"{name:10s}: first-20 mean {a[:20].mean():.3f}, last-100 mean {a[tail].mean():.4f}, first step with loss < 1.0: "
+                  f"{int(np.argmax(a < 1.0)) if (a < 1.0).any() else None}")
         return
     curves = {"fp32": run("fp32", 0, args.steps, dev), "bf16/act0": run("bf16", 0, args.steps, dev),
               "bf16/act2": run("bf16", 2, args.steps, dev), "bf16/act3": run("bf16", 3, args.steps, dev),

@@ -151,7 +151,11 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
         if (IR_FUSE_BN3) {     // BatchNorm 3 finalised by the block-output pass itself (one workgroup per channel)
             const DwPre pre{{1, (double)B * T2, (const float*)P[14], (const float*)P[15], nullptr, s3, t3, nullptr, m3, r3,
                              (float*)P[16], (float*)P[17], (long long*)P[18], kMom, kEps}, st, parts3};
-            CK(chan_affine2_fin(a3, res ? x : nullptr, y, y16, B, cout, T2, a316 ? 1 : 0, pre, stream));
+            // level 5: the residual comes from the bf16 shadow of x (what the expand GEMM above read), and an interior block of a stack
+            // (PREPPED bit 2: nothing reads its fp32 output) writes only the shadow of its own output
+            const bool r16 = sh[IR_ACT16] >= 5 && x16 && a316;            // (the previous block may not have written its fp32 output at all)
+            const bool noy = sh[IR_ACT16] >= 5 && y16 && a316 && (sh[IR_PREPPED] & 4);
+            CK(chan_affine2_fin(a3, res ? (r16 ? x16 : (const void*)x) : nullptr, noy ? nullptr : y, y16, B, cout, T2, a316 ? 1 : 0, pre, stream, r16 ? 1 : 0));
             return V100_OK;
         }
         CK(v100_bn_finalize_train(st, parts3, (long long)B * T2, (const float*)P[14], (const float*)P[15], (float*)P[16], (float*)P[17], (long long*)P[18],
@@ -502,6 +506,8 @@ int stack_layout(const int* desc, StackBlock* blk, size_t& blob_bytes, size_t& b
         b.y = (long long)off; off = al256(off + (size_t)B * cout * T2 * 4);
         b.y16 = -1;
         if (shadows && (i + 1 < n || desc[ST_SHADOW])) { b.y16 = (long long)off; off = al256(off + (size_t)B * cout * P2 * 2); }
+        // level 5: block i - 1 need not write its fp32 output when this block (its only reader inside the stack) takes x from the shadow
+        if (i > 0 && lv >= 5 && shadows && blk[i - 1].y16 >= 0 && blk[i - 1].sh[IR_ACT16] >= 5) blk[i - 1].sh[IR_PREPPED] |= 4;
         b.coef = (long long)off; off = al256(off + (size_t)12 * (hid > cout ? hid : cout) * 4);
         b.prep = (long long)off; off = al256(off + (size_t)v100_ir_prep_bytes(sh));
         const size_t fw = (size_t)v100_ir_fwd_workspace_bytes(sh), bw = (size_t)v100_ir_bwd_workspace_bytes(sh);

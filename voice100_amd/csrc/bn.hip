@@ -339,8 +339,11 @@ __global__ __launch_bounds__(256) void chan_affine2_shadow_kernel(const void* __
 // The forward block output with BatchNorm 3 finalised by the kernel itself: one 1024-thread workgroup per channel, whose first wave
 // turns the project GEMM's slab of partial sums into scale / shift (+ saved mean / rstd, running statistics: dw_finalize_parts), then
 // out = scale*u + shift (+ v) for the channel's B x T samples, optionally with the bf16 shadow (SH).
-template <bool UB, bool SH>
-__global__ __launch_bounds__(1024) void chan_affine2_fin_kernel(const void* __restrict__ u, const float* __restrict__ v, float* __restrict__ out,
+// Activation storage level 5 (VB / NOF): the residual v is read from its bf16 shadow (the previous block's output as the next expand GEMM
+// already reads it) and the fp32 copy of this block's output is not written at all (`out` == nullptr): interior blocks of a stack keep the
+// residual stream in ONE 16-bit form, as the reference's autocast run does (half the bytes of this pass).
+template <bool UB, bool SH, bool VB = false>
+__global__ __launch_bounds__(1024) void chan_affine2_fin_kernel(const void* __restrict__ u, const void* __restrict__ v, float* __restrict__ out,
                                                                 u16* __restrict__ shadow, int B, int C, int T, DwPre pre) {
     __shared__ float coef[3];
     const int c = blockIdx.x;
@@ -354,14 +357,16 @@ __global__ __launch_bounds__(1024) void chan_affine2_fin_kernel(const void* __re
         const size_t row = (size_t)b * C + c;
         float x[4], y[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
         chan_load4<UB>(u, row, T, P, t, x);
-        if (v) chan_load4<false>(v, row, T, P, t, y);
+        if (v) chan_load4<VB>(v, row, T, P, t, y);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = v ? fmaf(x[e], a, fmaf(y[e], 1.f, cc)) : fmaf(x[e], a, cc);
-        float* q = out + row * T + t;
-        if (t + 3 < T) { const f32x4 w = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4u*>(q) = w; }
-        else {
+        if (out) {
+            float* q = out + row * T + t;
+            if (t + 3 < T) { const f32x4 w = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4u*>(q) = w; }
+            else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (t + e < T) q[e] = o[e];
+                for (int e = 0; e < 4; ++e) if (t + e < T) q[e] = o[e];
+            }
         }
         if constexpr (SH) {
             const bn_u32x2 w16 = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
@@ -605,13 +610,16 @@ extern "C" int v100_chan_reduce2_io(const void* u, const void* v, float* partial
 }
 
 // block executor: BatchNorm-3 forward finalisation + block output (+ shadow) in one launch; u = a3 (bf16 when u_bf16)
-int chan_affine2_fin(const void* u, const float* v, float* out, void* shadow, int B, int C, int T, int u_bf16, const DwPre& pre, void* stream) {
-    if (!u || !out || !pre.stats) return V100_ERR_NULL;
+int chan_affine2_fin(const void* u, const void* v, float* out, void* shadow, int B, int C, int T, int u_bf16, const DwPre& pre, void* stream,
+                     int v_bf16) {
+    if (!u || (!out && !shadow) || !pre.stats) return V100_ERR_NULL;
     if (B <= 0 || C <= 0 || T <= 0 || pre.f.mode != 1 || pre.parts <= 0) return V100_ERR_SHAPE;
+    if (v_bf16 && !u_bf16) return V100_ERR_SHAPE;                       // level 5 runs on the all-bf16 form only
     hipStream_t st = (hipStream_t)stream;
-#define CAF(UB_, SH_) V100_GGL((chan_affine2_fin_kernel<UB_, SH_>), dim3(C), dim3(1024), 0, st, u, v, out, (u16*)shadow, B, C, T, pre)
-    if (u_bf16) { if (shadow) CAF(true, true); else CAF(true, false); }
-    else { if (shadow) CAF(false, true); else CAF(false, false); }
+#define CAF(UB_, SH_, VB_) V100_GGL((chan_affine2_fin_kernel<UB_, SH_, VB_>), dim3(C), dim3(1024), 0, st, u, v, out, (u16*)shadow, B, C, T, pre)
+    if (v_bf16) { if (shadow) CAF(true, true, true); else CAF(true, false, true); }
+    else if (u_bf16) { if (shadow) CAF(true, true, false); else CAF(true, false, false); }
+    else { if (shadow) CAF(false, true, false); else CAF(false, false, false); }
 #undef CAF
     return v100_launch_status();
 }

@@ -131,7 +131,8 @@ __device__ __forceinline__ void dw_finalize_parts(const DwPre& pre, int C, int c
     if (lane == 0) dw_finalize_d(pre.f, c, s0, s1, coef);
 }
 
-int chan_affine2_fin(const void* u, const float* v, float* out, void* shadow, int B, int C, int T, int u_bf16, const DwPre& pre, void* stream);   // bn.hip
+int chan_affine2_fin(const void* u, const void* v, float* out, void* shadow, int B, int C, int T, int u_bf16, const DwPre& pre, void* stream,
+                     int v_bf16 = 0);   // bn.hip
 int chan_bn3_bwd(const float* u, const void* v, float* partial, void* out, int B, int C, int T, const DwFin& fin, void* stream);   // bn.hip; 0 = not covered
 int chan_reduce2_io_fin(const void* u, const void* v, float* partial, int B, int C, int T, const DwFin& fin, void* stream);   // bn.hip
 // the act16 entry points with in-kernel BatchNorm finalisation (block executor; fin.mode != 0 requires G == 1)

@@ -41,16 +41,20 @@ _PRECISION = "fp32"
 # 0 = fp32 everywhere, 1 = a1 / a2 (the tensors saved for backward) as bf16, 2 = also the hidden gradients dz2 / dz1.
 # The reference under bf16 autocast keeps exactly these tensors in bf16; statistics and accumulators stay fp32 here.
 # 3 = also the project output a3 (saved for backward) and its gradient da3: every tensor that is internal to a block.
-_ACT16 = int(os.environ.get("VOICE100_ACT16", "4"))
+# 4 = plus a bf16 shadow of each block output for the next block's GEMMs; 5 (default) = the forward residual stream of a stack in that 16-bit form
+# only (set_activation_storage)
+_ACT16 = int(os.environ.get("VOICE100_ACT16", "5"))
 
 
 def set_activation_storage(level: int) -> None:
     """0: fp32 activations; 1: saved hidden activations bf16; 2: hidden gradients bf16 as well; 3: also the project output and
     its gradient; 4: plus a bf16 shadow of every block output beside the fp32 tensor, which the next block's expand GEMM and
-    expand weight gradient load as their X operand (bf16 precision only; block inputs / outputs themselves always stay fp32)."""
+    expand weight gradient load as their X operand (bf16 precision only; block inputs / outputs themselves stay fp32 up to here);
+    5: the forward residual stream of a stack in ONE 16-bit form -- a block's residual is read from that bf16 copy and interior blocks
+    of a stack do not write the fp32 copy of their output at all (what the reference's bf16 autocast run keeps; gradients stay fp32)."""
     global _ACT16
-    if level not in (0, 1, 2, 3, 4):
-        raise ValueError("activation storage level must be 0 ... 4")
+    if level not in (0, 1, 2, 3, 4, 5):
+        raise ValueError("activation storage level must be 0 ... 5")
     _ACT16 = level
 
 
