@@ -493,8 +493,8 @@ def main():
                 dp_line = {"ms_per_step": round(tot_d / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(host_d / args.steps * 1e3, 3),
                            "library_launches_per_step": round((N.launch_count() - l0) / args.steps, 1),
                            "buckets": len(dp_step.buckets.buckets), "flat_mb": round(dp_step.buckets.flat.numel() * 4 / 1e6, 1),
-                           "what": "one-rank RCCL group, force_exchange=True (flat buffer, bucketed async all-reduce from post-accumulate "
-                                   "hooks, mean), encoder as three-block autograd segments; same seeded step sequence running on"}
+                           "what": "one-rank RCCL group, force_exchange=True (flat buffer with the stack gradients written in place, bucketed async "
+                                   "all-reduce from post-accumulate hooks), encoder as three-block autograd segments; same seeded step sequence running on"}
                 dp_step.buckets.remove_hooks()
             finally:
                 F_.set_stack_segment(None)

@@ -4,8 +4,10 @@ The reference has no collective call site of its own; under Lightning's DDP it g
 bucketed gradient all-reduce (mean) once per step, per-rank BatchNorm statistics and
 rank-local metrics.  This module reproduces exactly that exchange:
 
-* gradients are exchanged through ONE flat fp32 buffer cut into buckets in reverse parameter
-  order (the order backward produces them); a bucket is packed with one multi-tensor copy;
+* gradients are exchanged through ONE flat fp32 buffer (parameters in forward order, 16-byte slots) cut into
+  buckets walking the parameters in reverse (the order backward produces them); the stack executor writes a run of
+  blocks' gradients straight into its slice of that buffer (`grad_arena`), the few remaining tensors are packed with
+  one multi-tensor copy; the mean is taken inside the collective (ncclAvg) on RCCL;
 * a post-accumulate hook per parameter launches the bucket's all-reduce as soon as its
   last gradient is written, so the exchange overlaps the rest of backward;
 * xGMI is point-to-point (7 links/GPU), the whole message is 46.5 MB, so a few large
@@ -24,8 +26,8 @@ class FlatGradBuckets:
 
     Parameters are cut into buckets in reverse order (the order backward produces gradients).  A
     post-accumulate hook per parameter counts a bucket down; when its last gradient has been written the
-    bucket's gradients are packed into the flat buffer with one multi-tensor copy and its all-reduce is
-    launched asynchronously, so the exchange overlaps the rest of backward.  After finish_step() every
+    gradients that are not already in the flat buffer (see grad_arena) are packed into it with one multi-tensor
+    copy and the bucket's all-reduce is launched asynchronously, so the exchange overlaps the rest of backward.  After finish_step() every
     p.grad is a view into the (averaged) flat buffer.  With a single process nothing is registered and
     gradients stay where autograd put them (no extra kernels on the step).
     """
@@ -42,24 +44,39 @@ class FlatGradBuckets:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force_exchange: run the bucket / all-reduce machinery even in a group of one (tests of the RCCL path on one GPU)
         self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev) if self.exchange else None
-        order = list(reversed(self.params))
+        # Layout of the flat buffer: parameters in FORWARD order, every slot starting on a 16-byte boundary.  Forward order, because
+        # the stack executor writes a run of blocks' parameter gradients as ONE contiguous array in exactly that order (w1 g1 b1 wd g2
+        # b2 w3 g3 b3 per block, functional.IRStackTrainFn): handed the matching slice of this buffer (grad_arena) it writes the
+        # gradients where the all-reduce reads them and the per-bucket packing copy disappears (on one rank at the full size: 0.12 ms of
+        # multi-tensor copies per step).  Aligned slots, because one odd-sized tensor (the 29-float vocabulary bias) otherwise shifts
+        # every later gradient off the 16-byte accesses of the fused Adam kernel (84 instead of 58 us).
+        self._view = {}
+        off = 0
+        for p in self.params:
+            self._view[p] = (off, off + p.numel())
+            off = (off + p.numel() + 3) & ~3
+        self.flat = torch.zeros(off, dtype=dt, device=dev) if self.exchange else None
+        # Buckets are cut walking the parameters in REVERSE (the order backward produces gradients) and launched strictly in that
+        # index order; each is one contiguous range of the flat buffer.
         self._bucket_of = {}
         self.buckets = []          # (start, end, [params])
-        off, start, members = 0, 0, []
         itemsize = 4 if self.flat is None else self.flat.element_size()
-        self._view = {}
-        for p in order:
-            n = p.numel()
-            self._view[p] = (off, off + n)
+        members, hi = [], None
+        for p in reversed(self.params):
+            s0, e0 = self._view[p]
+            if hi is None:
+                hi = (e0 + 3) & ~3
             self._bucket_of[p] = len(self.buckets)
-            off += n
             members.append(p)
-            if (off - start) * itemsize >= bucket_bytes:
-                self.buckets.append((start, off, members))
-                start, members = off, []
+            if (hi - s0) * itemsize >= bucket_bytes:
+                self.buckets.append((s0, hi, members))
+                members, hi = [], None
         if members:
-            self.buckets.append((start, off, members))
+            self.buckets.append((self._view[members[-1]][0], hi, members))
+        # mean = sum / world: RCCL averages inside the collective (ncclAvg); gloo (the CPU tests) has no AVG: divide afterwards
+        # (a group of ONE -- force_exchange, bench.py's dp_path_single_rank -- sums: RCCL implements a one-rank AVG as a separate
+        # pre-multiply pass over the buffer, 39 us per 16 MB bucket, which no rank of a real job runs)
+        self._avg_in_collective = self.exchange and self.world > 1 and dist.get_backend(process_group) == "nccl"
         self._pending = [0] * len(self.buckets)
         self._next = 0             # buckets are launched strictly in index order, so every rank issues the same collectives
         self._handles = []
@@ -67,7 +84,25 @@ class FlatGradBuckets:
         if self.exchange:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            from . import functional as F_
+            F_.register_grad_arena(self)
         self.begin_step()
+
+    def grad_arena(self, tensors):
+        """The slice of the flat buffer in which `tensors` (parameters, in order) have their gradient slots back to back, or None when
+        they are not consecutive / padded apart / not ours: a producer that writes its gradients as one array writes them HERE."""
+        if not self.exchange or not tensors:
+            return None
+        first = self._view.get(tensors[0])
+        if first is None:
+            return None
+        pos = first[0]
+        for t in tensors:
+            v = self._view.get(t)
+            if v is None or v[0] != pos:
+                return None
+            pos = v[1]
+        return self.flat[first[0]:pos]
 
     def begin_step(self):
         """Drop last step's gradients (autograd then assigns instead of accumulating) and re-arm the buckets."""
@@ -80,12 +115,19 @@ class FlatGradBuckets:
 
     def _launch(self, b):
         s, e, members = self.buckets[b]
-        views = [self.flat[self._view[p][0]:self._view[p][1]].view_as(p) for p in members]
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in members]
-        torch._foreach_copy_(views, grads)
-        for p, v in zip(members, views):
+        views, grads = [], []
+        for p in members:
+            v = self.flat[self._view[p][0]:self._view[p][1]].view_as(p)
+            g = p.grad
+            if g is not None and g.data_ptr() == v.data_ptr():
+                continue                                   # written in place by its producer (grad_arena): nothing to pack
+            views.append(v)
+            grads.append(g if g is not None else torch.zeros_like(p))
             p.grad = v
-        self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if views:
+            torch._foreach_copy_(views, grads)
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+        self._handles.append(dist.all_reduce(self.flat[s:e], op=op, group=self.group, async_op=True))
         self._pending[b] = -1
 
     def _on_grad(self, p):
@@ -111,12 +153,15 @@ class FlatGradBuckets:
             self._next += 1
         for h in self._handles:
             h.wait()
-        self.flat.div_(self.world)
+        if not self._avg_in_collective and self.world > 1:
+            self.flat.div_(self.world)
 
     def remove_hooks(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        from . import functional as F_
+        F_.unregister_grad_arena(self)
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, process_group=None) -> None:

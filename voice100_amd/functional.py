@@ -254,6 +254,26 @@ def _block_tensors(blk):
 
 
 _STACK_PLANS = {}
+_GRAD_ARENAS = []              # data-parallel gradient buffers that want stack gradients written in place (dist.FlatGradBuckets)
+
+
+def register_grad_arena(a) -> None:
+    if a not in _GRAD_ARENAS:
+        _GRAD_ARENAS.append(a)
+
+
+def unregister_grad_arena(a) -> None:
+    if a in _GRAD_ARENAS:
+        _GRAD_ARENAS.remove(a)
+
+
+def _grad_arena_for(weights, numel):
+    """A registered buffer slice in which `weights` (the stack's trainable tensors, in its gradient order) lie back to back."""
+    for a in _GRAD_ARENAS:
+        buf = a.grad_arena(weights)
+        if buf is not None and buf.numel() == numel:
+            return buf
+    return None
 _STACK_SEGMENT = None          # blocks per autograd node of a stack; None = automatic (ir_stack_train)
 
 
@@ -332,7 +352,11 @@ class IRStackTrainFn(torch.autograd.Function):
         if dy is None:
             dy = torch.zeros(ctx.y_shape, dtype=torch.float32, device=x.device)
         dy = dy.contiguous()
-        grads = _f32(totals[2], like=x)
+        # under data parallelism the gradients are written straight into the exchange buffer (no packing copy): same values, another home
+        weights = [params[18 * b + j] for b in range(n) for j in (0, 1, 2, 6, 7, 8, 12, 13, 14)]
+        grads = _grad_arena_for(weights, totals[2]) if _GRAD_ARENAS else None
+        if grads is None:
+            grads = _f32(totals[2], like=x)
         ws = torch.empty(totals[1], dtype=torch.uint8, device=x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ptab = (ctypes.c_void_p * (18 * n))(*[t.data_ptr() for t in params])
