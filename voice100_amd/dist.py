@@ -77,6 +77,15 @@ class FlatGradBuckets:
         # (a group of ONE -- force_exchange, bench.py's dp_path_single_rank -- sums: RCCL implements a one-rank AVG as a separate
         # pre-multiply pass over the buffer, 39 us per 16 MB bucket, which no rank of a real job runs)
         self._avg_in_collective = self.exchange and self.world > 1 and dist.get_backend(process_group) == "nccl"
+        if self._avg_in_collective:
+            # probe once (every rank takes part): a backend build without ncclAvg falls back to sum + divide instead of failing mid-step
+            try:
+                probe = torch.ones(4, dtype=dt, device=dev)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
+                if not bool((probe == 1).all()):
+                    self._avg_in_collective = False
+            except Exception:                                    # noqa: BLE001
+                self._avg_in_collective = False
         self._pending = [0] * len(self.buckets)
         self._next = 0             # buckets are launched strictly in index order, so every rank issues the same collectives
         self._handles = []
