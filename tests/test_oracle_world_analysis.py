@@ -1,0 +1,135 @@
+"""Property tests of the WORLD ANALYSIS restatement (oracle/world_analysis.py: DIO, CheapTrick, D4C, code_aperiodicity).
+
+There is no pyworld in this image (parity UNPINNED: see the oracle's header), so the restatement is held to what the published
+algorithms guarantee on signals whose parameters are known by construction.
+"""
+import numpy as np
+import pytest
+
+from oracle import world_analysis as wa
+from oracle import world_synth as ws
+
+FS = 16000
+
+
+def harmonic_signal(seconds=1.5, f_lo=150.0, swing=30.0, noise=1e-3, seed=1, tilt=1.0):
+    t = np.arange(int(FS * seconds)) / FS
+    f0 = f_lo + swing * np.sin(2 * np.pi * 0.7 * t)
+    ph = 2 * np.pi * np.cumsum(f0) / FS
+    x = sum(np.cos(k * ph) / k ** tilt for k in range(1, 20)) * 0.1
+    x[:2400] = 0
+    x[-2400:] = 0
+    x = x + np.random.default_rng(seed).standard_normal(len(x)) * noise
+    return x, f0
+
+
+@pytest.fixture(scope="module")
+def analysed():
+    x, f0_true = harmonic_signal()
+    f0, tp = wa.dio(x, FS, f0_floor=80.0, f0_ceil=400.0, frame_period=10.0)
+    sp = wa.cheaptrick(x, f0, tp, FS, fft_size=512)
+    ap = wa.d4c(x, f0, tp, FS, fft_size=512)
+    return x, f0_true, f0, tp, sp, ap
+
+
+def test_dio_frame_count_and_positions():
+    x = np.zeros(16000)
+    f0, tp = wa.dio(x, FS, f0_floor=80.0, f0_ceil=400.0, frame_period=10.0)
+    assert len(f0) == 101 == wa.samples_for_dio(FS, 16000, 10.0)
+    assert np.allclose(tp, np.arange(101) * 0.01)
+    assert not f0.any()                                   # silence: no event in any band
+
+
+def test_dio_tracks_a_known_contour(analysed):
+    x, f0_true, f0, tp, _, _ = analysed
+    voiced = f0 > 0
+    idx = np.minimum((tp * FS).astype(int), len(x) - 1)
+    inner = voiced & (tp > 0.25) & (tp < tp[-1] - 0.25)
+    assert inner.sum() > 80
+    err = np.abs(f0[inner] - f0_true[idx][inner])
+    assert np.median(err) < 0.1 and err.max() < 2.0
+    assert not f0[tp < 0.1].any() and not f0[tp > tp[-1] - 0.1].any()      # the silent margins are unvoiced
+    assert ((f0 == 0) | ((f0 >= 80.0) & (f0 <= 400.0))).all()
+
+
+def test_dio_octave_bands():
+    nb = 1 + int(np.log(400.0 / 80.0) / wa.K_LOG2 * 2.0)
+    assert nb == 5
+    for f in (90.0, 220.0, 380.0):                       # one tone per region of the search range
+        t = np.arange(FS) / FS
+        x = np.sin(2 * np.pi * f * t) * 0.3 + np.random.default_rng(0).standard_normal(FS) * 1e-4
+        f0, _ = wa.dio(x, FS, f0_floor=80.0, f0_ceil=400.0, frame_period=10.0)
+        mid = f0[20:80]
+        assert (mid > 0).all() and np.abs(mid - f).max() < 0.5, f
+
+
+def test_cheaptrick_envelope(analysed):
+    x, _, f0, tp, sp, _ = analysed
+    assert sp.shape == (len(f0), 257) and (sp > 0).all() and np.isfinite(sp).all()
+    # harmonics of amplitude 0.1 / k: the envelope at k f0 falls 6 dB per octave
+    i = int(np.argmin(np.abs(tp - 0.7)))
+    f = f0[i]
+    assert f > 0
+    bins = lambda hz: int(round(hz * 512 / FS))
+    lvl = [10 * np.log10(sp[i, bins(k * f)]) for k in (2, 4, 8)]
+    assert 4.0 < lvl[0] - lvl[1] < 8.0 and 4.0 < lvl[1] - lvl[2] < 8.0
+    # unvoiced frames are analysed at the default F0: the noise floor is flat and far below the voiced level
+    j = 2
+    assert f0[j] == 0 and sp[j].max() / sp[j].min() < 100 and sp[j].max() < sp[i].max() * 1e-3
+
+
+def test_cheaptrick_f0_floor():
+    assert abs(wa.cheaptrick_f0_floor(FS, 512) - 3.0 * FS / 509.0) < 1e-12
+    x, _ = harmonic_signal(0.5)
+    tp = np.arange(51) * 0.01
+    lo = wa.cheaptrick(x, np.full(51, 90.0), tp, FS, fft_size=512)     # below the floor (94.3 Hz): analysed at 500 Hz
+    df = wa.cheaptrick(x, np.full(51, 0.0), tp, FS, fft_size=512)
+    assert np.array_equal(lo, df)
+
+
+def test_d4c_periodic_vs_noise(analysed):
+    _, _, f0, tp, _, ap = analysed
+    v = (f0 > 0) & (tp > 0.3) & (tp < tp[-1] - 0.3)
+    assert ((ap > 0) & (ap <= 1.0)).all()
+    assert np.allclose(ap[f0 == 0], 1.0 - 1e-12)
+    assert np.allclose(ap[v, 0], 10 ** (-60 / 20.0))                   # the 0 Hz anchor: -60 dB
+    assert (np.diff(ap[v], axis=1) >= -1e-15).all()                    # one band at 16 kHz: monotone ramps between the anchors
+    assert ap[v, 96].mean() < 0.8                                      # 3 kHz, harmonics present
+    noise = np.random.default_rng(0).standard_normal(FS) * 0.1
+    apn = wa.d4c(noise, np.full(101, 150.0), np.arange(101) * 0.01, FS, fft_size=512)
+    assert (apn > 0.999).all()                                         # the love-train check rejects every frame
+
+
+def test_code_aperiodicity_roundtrip(analysed):
+    _, _, f0, _, _, ap = analysed
+    coded = wa.code_aperiodicity(ap, FS)
+    assert coded.shape == (len(f0), 1)
+    back = ws.decode_aperiodicity(coded, FS, 512)
+    v = f0 > 0
+    # decode rebuilds the -60 dB / coded / 0 dB ramp the D4C output was made of
+    assert np.abs(20 * np.log10(back[v]) - 20 * np.log10(ap[v])).max() < 1e-6
+    assert np.allclose(back[~v], 1.0 - 1e-12)
+
+
+def test_analysis_synthesis_roundtrip(analysed):
+    x, _, f0, tp, sp, ap = analysed
+    y = ws.synthesize(f0, sp, ap, FS, 10.0)
+    f0b, tpb = wa.dio(y, FS, f0_floor=80.0, f0_ceil=400.0, frame_period=10.0)
+    n = min(len(f0), len(f0b))
+    both = (f0[:n] > 0) & (f0b[:n] > 0)
+    assert both.sum() > 0.9 * (f0 > 0).sum()
+    assert np.median(np.abs(f0[:n][both] - f0b[:n][both])) < 0.5
+    spb = wa.cheaptrick(y, f0b, tpb, FS, fft_size=512)
+    inner = both & (tp[:n] > 0.3) & (tp[:n] < tp[n - 1] - 0.3)
+    d = 10 * np.log10(spb[:n][inner][:, :200]) - 10 * np.log10(sp[:n][inner][:, :200])
+    assert np.abs(d.mean()) < 1.0 and np.sqrt((d ** 2).mean()) < 3.0   # dB
+
+
+def test_randn_stream_is_consumed_in_order():
+    x, _ = harmonic_signal(0.4)
+    tp = np.arange(41) * 0.01
+    f0 = np.where((tp > 0.1) & (tp < 0.3), 160.0, 0.0)
+    a = wa.cheaptrick(x * 0, f0, tp, FS, fft_size=512)                  # digital silence: only the safeguard noise is left
+    assert np.isfinite(a).all() and (a > 0).all() and a.max() < 1e-10
+    b = wa.cheaptrick(x * 0, f0, tp, FS, fft_size=512)
+    assert np.array_equal(a, b)
