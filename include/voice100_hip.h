@@ -375,6 +375,44 @@ int v100_ctc_best_path(const float* logp, const long long* labels, const int* in
 int v100_align_expand(const long long* text, const double* align, const int* text_len, long long* out, int* out_len, int B, int Lmax,
                       int Tmax, int head, int tail, void* stream);
 
+
+/* ---- WORLD analysis (csrc/world_analysis.hip; SURVEY.md 8f rank 4, second half) -- PARITY UNPINNED -------------------------------
+ * pyworld.dio / cheaptrick / d4c / code_aperiodicity as WORLDVocoder.encode calls them (voice100/vocoder.py:61-74), in fp64 (the
+ * reference converts the waveform to double).  pyworld 0.3.2 (C++ WORLD) is not in the reference tree: the kernels follow the
+ * published algorithms as restated in oracle/world_analysis.py.  Waveforms x [B][pitch] fp32 with lengths [B] (samples); frame t of
+ * an utterance sits at t * frame_period_ms / 1000 s and an utterance of n samples has v100_world_frames(fs, n, frame_period_ms) =
+ * (int)(1000 n / fs / frame_period_ms) + 1 frames; Tmax = that of max_len is the row pitch of every per-frame array.
+ *   v100_world_randn_host_f64   HOST function, HOST pointer: WORLD's randn() sequence in double (the safeguard noise of the
+ *                               analysis: every call of cheaptrick / d4c restarts it); v100_world_randn_bound(kind, T, fs, fft_size)
+ *                               = draws T frames can consume (kind 0 cheaptrick, 1 d4c): the least table_len to pass.
+ *   v100_world_dio_bands        number of DIO bands; half_lengths [bands] (HOST) = matlab_round(fs / boundary_f0 / 2) of each.
+ *   v100_world_dio              speed = 1 (no decimation).  lowcut [2 hc + 1], hc = matlab_round(fs / 50): the centred taps of
+ *                               DesignLowCutFilter; nuttall [bands][4 hmax]: row i = NuttallWindow(4 half_lengths[i]), hmax = the
+ *                               largest half length, both built in double by the caller -> f0 [B][Tmax] (0 = unvoiced, 0 beyond an
+ *                               utterance's frames).
+ *   v100_world_cheaptrick       f0 [B][Tmax] double; twiddle [fft_size/2][2] = cos, -sin of 2 pi k / fft_size; offsets [B][Tmax]
+ *                               int64 scratch -> sp [B][Tmax][fft_size/2+1] double and/or logsp = (float) log(sp + log_offset)
+ *                               (vocoder.py:70); rows of frames the table or LDS cannot serve come back NaN.
+ *   v100_world_d4c              twiddle [1024][2] for the internal 2048-point FFTs, nuttall [window_length] = NuttallWindow(
+ *                               (int)(3000 * 2048 / fs) * 2 + 1) -> ap [B][Tmax][fft_size/2+1] double and/or coded (double) /
+ *                               coded32 (float) [B][Tmax][bands of 3 kHz] = pyworld.code_aperiodicity of it (vocoder.py:72-73). */
+int v100_world_randn_host_f64(double* host_out, long long n);
+long long v100_world_randn_bound(int kind, int T, int fs, int fft_size);
+int v100_world_frames(int fs, int length, double frame_period_ms);
+int v100_world_dio_bands(int fs, double f0_floor, double f0_ceil, double channels_in_octave, int* half_lengths, int max_bands);
+long long v100_world_dio_workspace_bytes(int B, int max_len, int fs, double f0_floor, double f0_ceil, double channels_in_octave,
+                                         double frame_period_ms);
+int v100_world_dio(const float* x, const int* lengths, int B, int max_len, int pitch, int fs, double f0_floor, double f0_ceil,
+                   double channels_in_octave, double frame_period_ms, double allowed_range, const double* lowcut,
+                   const double* nuttall, double* f0, void* workspace, void* stream);
+int v100_world_cheaptrick(const float* x, const int* lengths, const double* f0, int B, int max_len, int pitch, int fs,
+                          double frame_period_ms, double q1, int fft_size, const double* randn_table, long long table_len,
+                          const double* twiddle, double* sp, float* logsp, double log_offset, long long* offsets, void* stream);
+long long v100_world_d4c_workspace_bytes(int B, int max_len, int fs, double frame_period_ms);
+int v100_world_d4c(const float* x, const int* lengths, const double* f0, int B, int max_len, int pitch, int fs, double frame_period_ms,
+                   double threshold, int fft_size, const double* randn_table, long long table_len, const double* twiddle,
+                   const double* nuttall, int window_length, double* ap, double* coded, float* coded32, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

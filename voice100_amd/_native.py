@@ -68,7 +68,7 @@ def load():
         for name, params in protos.items():
             fn = getattr(lib, name)        # AttributeError if the header declares a symbol the .so lacks
             fn.argtypes = [t for t, _ in params]
-            fn.restype = ctypes.c_longlong if (name.endswith("_bytes") or name in ("v100_launch_count", "v100_ir_stack_plan")) else ctypes.c_int
+            fn.restype = ctypes.c_longlong if (name.endswith("_bytes") or name in ("v100_launch_count", "v100_ir_stack_plan", "v100_world_randn_bound")) else ctypes.c_int
         _lib, _protos = lib, protos
         return lib
 

@@ -3,8 +3,8 @@ spectrum matrices (host, float64, built once), their application and the log/exp
 per-frame products on the GPU.  Round 4: decode() -- pyworld.decode_aperiodicity + pyworld.synthesize, vocoder.py:100-101 --
 runs on the device too (csrc/world.hip: pulse instants from the F0 contour, one minimum-phase response per pulse, deterministic
 overlap-add).  PARITY UNPINNED: pyworld's C++ is not in the reference tree; the kernels follow the published algorithm as restated
-in oracle/world_synth.py and are tested against that restatement and its properties.  DIO / CheapTrick / D4C (encode) stay in
-pyworld: encode() calls it when installed and raises otherwise.
+in oracle/world_synth.py and are tested against that restatement and its properties.  encode() -- pyworld.dio / cheaptrick / d4c /
+code_aperiodicity, vocoder.py:66-73 -- runs on the device as well (csrc/world_analysis.hip, float64), against oracle/world_analysis.py.
 """
 from typing import Tuple
 
@@ -198,30 +198,166 @@ class WORLDVocoder(nn.Module):
                B, T, int(self.sample_rate), float(self.frame_period), int(self.n_fft), cap)
         return y, npulses
 
-    # ---- pyworld-owned analysis ----------------------------------------------------------------------
+    # ---- WORLD analysis on the device (second half; parity unpinned) ------------------------------------------
+    _randn64_cache = {}        # device -> float64 tensor: the same sequence in double (the analysis' safeguard noise)
+
+    @classmethod
+    def _randn_table_f64(cls, n: int, device) -> torch.Tensor:
+        t = cls._randn64_cache.get(device)
+        if t is None or t.numel() < n:
+            import ctypes
+            m = max(n, 1 << 18, 0 if t is None else 2 * t.numel())
+            host = torch.empty(m, dtype=torch.float64)
+            rc = N.load().v100_world_randn_host_f64(ctypes.c_void_p(host.data_ptr()), m)
+            if rc != 0:
+                raise RuntimeError(f"v100_world_randn_host_f64 failed (status {rc})")
+            t = cls._randn64_cache[device] = host.to(device)
+        return t
+
     @staticmethod
-    def _pyworld():
-        try:
-            import pyworld
-        except ImportError as e:
-            raise RuntimeError("WORLD analysis/synthesis (DIO, CheapTrick, D4C, synthesize) needs pyworld, which is "
-                               "not installed; only the reference-owned glue runs without it") from e
-        return pyworld
+    def _nuttall(n: int) -> np.ndarray:
+        i = np.arange(n) / (n - 1.0)
+        return 0.355768 - 0.487396 * np.cos(2 * np.pi * i) + 0.144232 * np.cos(4 * np.pi * i) - 0.012604 * np.cos(6 * np.pi * i)
+
+    @staticmethod
+    def _twiddle(n: int) -> np.ndarray:
+        k = np.arange(n // 2, dtype=np.float64)
+        return np.stack([np.cos(2 * np.pi * k / n), -np.sin(2 * np.pi * k / n)], axis=1)
+
+    def _analysis_tables(self, device, key, build):
+        cache = self.__dict__.setdefault("_analysis_tabs", {})
+        ent = cache.get((device, key))
+        if ent is None:
+            ent = cache[(device, key)] = tuple(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device) for a in build())
+        return ent
+
+    def _wave_batch(self, x: torch.Tensor, lengths):
+        if not torch.cuda.is_available():
+            raise RuntimeError("WORLD analysis runs on the GPU only (no CPU fallback; oracle/world_analysis.py is the checker)")
+        dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        x = x.to(dev, torch.float32)
+        if x.dim() == 1:
+            x = x[None]
+        if x.dim() != 2 or x.shape[1] < 1:
+            raise ValueError("waveform must be [samples] or [B, samples]")
+        x = x.contiguous()
+        if lengths is None:
+            lengths = torch.full((x.shape[0],), x.shape[1], dtype=torch.int32, device=dev)
+        else:
+            lengths = torch.as_tensor(lengths).to(dev, torch.int32).contiguous()
+            if lengths.shape != (x.shape[0],) or int(lengths.min()) < 1 or int(lengths.max()) > x.shape[1]:
+                raise ValueError("lengths must be [B] with 1 <= length <= samples")
+        return x, lengths
+
+    def frames(self, samples: int) -> int:
+        """Frames pyworld.dio returns for `samples` samples: int(1000 samples / fs / frame_period) + 1."""
+        return int(N.helper("v100_world_frames", int(self.sample_rate), int(samples), float(self.frame_period)))
+
+    @torch.no_grad()
+    def dio(self, x: torch.Tensor, lengths=None, f0_floor: float = 71.0, f0_ceil: float = 800.0, channels_in_octave: float = 2.0,
+            allowed_range: float = 0.1) -> torch.Tensor:
+        """pyworld.dio(x, fs, f0_floor, f0_ceil, channels_in_octave, frame_period, speed=1, allowed_range) for a batch on the device
+        (vocoder.py:66-68): x [B, samples] (or [samples]) -> f0 [B, frames(samples)] float64, 0 = unvoiced / beyond the utterance.
+        The temporal positions are t * frame_period / 1000."""
+        import ctypes
+        x, lengths = self._wave_batch(x, lengths)
+        B, L = x.shape
+        fs = int(self.sample_rate)
+        halves = (ctypes.c_int * 16)()
+        nb = N.helper("v100_world_dio_bands", fs, float(f0_floor), float(f0_ceil), float(channels_in_octave), halves, 16)
+        if nb < 1:
+            raise ValueError("dio: unsupported f0_floor / f0_ceil / channels_in_octave")
+        hl = [int(halves[i]) for i in range(nb)]
+
+        def build():
+            hc = int(fs / 50.0 + 0.5)
+            n = 2 * hc + 1
+            w = 0.5 - 0.5 * np.cos(np.arange(1, n + 1) * 2.0 * np.pi / (n + 1))
+            g = -w / w.sum()
+            g[hc] += 1.0                                                    # DesignLowCutFilter, centred: delta - unit-sum Hanning
+            nut = np.zeros((nb, 4 * max(hl)))
+            for i, h in enumerate(hl):
+                nut[i, :4 * h] = self._nuttall(4 * h)
+            return g, nut
+        lowcut, nut = self._analysis_tables(x.device, ("dio", float(f0_floor), float(f0_ceil), float(channels_in_octave)), build)
+        nbytes = N.helper("v100_world_dio_workspace_bytes", B, L, fs, float(f0_floor), float(f0_ceil), float(channels_in_octave),
+                          float(self.frame_period))
+        if nbytes < 0:
+            raise RuntimeError("v100_world_dio_workspace_bytes: unsupported shape")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        f0 = torch.empty((B, self.frames(L)), dtype=torch.float64, device=x.device)
+        N.call("v100_world_dio", x, lengths, B, L, L, fs, float(f0_floor), float(f0_ceil), float(channels_in_octave), float(self.frame_period),
+               float(allowed_range), lowcut, nut, f0, ws)
+        return f0
+
+    @torch.no_grad()
+    def cheaptrick(self, x: torch.Tensor, f0: torch.Tensor, lengths=None, q1: float = -0.15, log: bool = False) -> torch.Tensor:
+        """pyworld.cheaptrick(x, f0, t, fs, q1, fft_size=n_fft) for a batch on the device (vocoder.py:69): f0 [B, frames] float64 ->
+        spectrogram [B, frames, n_fft/2+1] float64, or with log=True float32 log(spectrogram + log_offset) (vocoder.py:70)."""
+        x, lengths = self._wave_batch(x, lengths)
+        B, L = x.shape
+        T = self.frames(L)
+        f0 = f0.to(x.device, torch.float64).reshape(B, -1).contiguous()
+        if f0.shape[1] != T:
+            raise ValueError(f"cheaptrick: f0 must have {T} frames")
+        n = int(self.n_fft)
+        (tw,) = self._analysis_tables(x.device, ("tw", n), lambda: (self._twiddle(n),))
+        table = self._randn_table_f64(int(N.helper("v100_world_randn_bound", 0, T, int(self.sample_rate), n)), x.device)
+        out = torch.empty((B, T, n // 2 + 1), dtype=torch.float32 if log else torch.float64, device=x.device)
+        off = torch.empty((B, T), dtype=torch.int64, device=x.device)
+        N.call("v100_world_cheaptrick", x, lengths, f0, B, L, L, int(self.sample_rate), float(self.frame_period), float(q1), n, table,
+               table.numel(), tw, None if log else out, out if log else None, float(self.log_offset), off)
+        return out
+
+    @torch.no_grad()
+    def d4c(self, x: torch.Tensor, f0: torch.Tensor, lengths=None, threshold: float = 0.85, coded_only: bool = False):
+        """pyworld.d4c(x, f0, t, fs, threshold, fft_size=n_fft) + pyworld.code_aperiodicity for a batch on the device (vocoder.py:71-73):
+        -> (aperiodicity [B, frames, n_fft/2+1] float64, coded [B, frames, codeap_dim] float64); coded_only: (None, coded float32)."""
+        x, lengths = self._wave_batch(x, lengths)
+        B, L = x.shape
+        T = self.frames(L)
+        fs = int(self.sample_rate)
+        f0 = f0.to(x.device, torch.float64).reshape(B, -1).contiguous()
+        if f0.shape[1] != T:
+            raise ValueError(f"d4c: f0 must have {T} frames")
+        wl = int(3000.0 * 2048 / fs) * 2 + 1
+        tw, win = self._analysis_tables(x.device, ("d4c", fs), lambda: (self._twiddle(2048), self._nuttall(wl)))
+        table = self._randn_table_f64(int(N.helper("v100_world_randn_bound", 1, T, fs, int(self.n_fft))), x.device)
+        ap = None if coded_only else torch.empty((B, T, self.n_fft // 2 + 1), dtype=torch.float64, device=x.device)
+        coded = torch.empty((B, T, self.codeap_dim), dtype=torch.float32 if coded_only else torch.float64, device=x.device)
+        nbytes = N.helper("v100_world_d4c_workspace_bytes", B, L, fs, float(self.frame_period))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        N.call("v100_world_d4c", x, lengths, f0, B, L, L, fs, float(self.frame_period), float(threshold), int(self.n_fft), table, table.numel(),
+               tw, win, wl, ap, None if coded_only else coded, coded if coded_only else None, ws)
+        return ap, coded
+
+    @torch.no_grad()
+    def encode_batch(self, x: torch.Tensor, lengths=None, f0_floor: float = 80.0, f0_ceil: float = 400.0):
+        """encode() for a batch, everything left on the device: (f0 [B, T] fp32, features [B, T, D] fp32, codeap [B, T, nb] fp32);
+        rows beyond an utterance's own frames (frames(length)) hold unvoiced / default-F0 analysis of the padding."""
+        x, lengths = self._wave_batch(x, lengths)
+        f0 = self.dio(x, lengths, f0_floor=f0_floor, f0_ceil=f0_ceil)
+        logspc = self.cheaptrick(x, f0, lengths, log=True)
+        _, codeap = self.d4c(x, f0, lengths, coded_only=True)
+        if self.use_mcep:
+            if self._sp2mc_t.device != x.device:
+                self.to(x.device)
+            B, T, nbins = logspc.shape
+            feat = self.logspc_to_mcep(logspc.reshape(B * T, nbins)).reshape(B, T, -1)
+        else:
+            feat = logspc
+        return f0.float(), feat, codeap
 
     def forward(self, waveform: torch.Tensor):
         return self.encode(waveform)
 
     def encode(self, waveform: torch.Tensor, f0_floor: float = 80.0, f0_ceil: float = 400.0):
-        pyworld = self._pyworld()
-        w = waveform.cpu().numpy().astype(np.double)
-        f0, time_axis = pyworld.dio(w, self.sample_rate, f0_floor=f0_floor, f0_ceil=f0_ceil, frame_period=self.frame_period)
-        spc = pyworld.cheaptrick(w, f0, time_axis, self.sample_rate, fft_size=self.n_fft)
-        logspc = np.log(spc + self.log_offset)
-        ap = pyworld.d4c(w, f0, time_axis, self.sample_rate, fft_size=self.n_fft)
-        codeap = pyworld.code_aperiodicity(ap, self.sample_rate)
-        feat = logspc @ self.sp2mc_matrix if self.use_mcep else logspc
-        return (torch.from_numpy(f0.astype(np.float32)), torch.from_numpy(feat.astype(np.float32)),
-                torch.from_numpy(codeap.astype(np.float32)))
+        """vocoder.py:61-87 for one waveform [samples]: (f0 [T], logspc or mcep [T, D], codeap [T, nb]) as float32 CPU tensors, like
+        the reference returns them.  DIO, CheapTrick, D4C and the aperiodicity coding run on the GPU in float64 (no pyworld)."""
+        if waveform.dim() != 1:
+            raise ValueError("encode takes one waveform [samples]; encode_batch takes [B, samples]")
+        f0, feat, codeap = self.encode_batch(waveform[None], None, f0_floor, f0_ceil)
+        return f0[0].cpu(), feat[0].cpu(), codeap[0].cpu()
 
     def decode(self, f0: torch.Tensor, logspc_or_mcep: torch.Tensor, codeap: torch.Tensor) -> np.ndarray:
         """vocoder.py:89-102 for one utterance (f0 [T], features [T, D], codeap [T, nb]) -> waveform, float64 numpy as the reference
