@@ -11,8 +11,7 @@
 //               domain (the reference multiplies spectra of a 2^18-point FFT: the same linear convolution, its buffer is sized so
 //               that nothing wraps); zero-crossing events are compacted in order by one workgroup per (utterance, band, kind);
 //               candidates and scores per frame; the contour fix-up is sequential by nature and runs on one lane per utterance.
-//   CheapTrick  one workgroup per frame: window, 3 FFTs of fft_size in LDS, smoothing by differences of a SEQUENTIAL cumulative sum
-//               (the subtraction cancels, so the summation order is kept), liftering.
+//   CheapTrick  one workgroup per frame: window, 3 FFTs of fft_size in LDS, smoothing by differences of a cumulative sum, liftering.
 //   D4C         one workgroup per voiced frame: "love train" voicing check (1 FFT of 2048), then 5 + bands FFTs of 2048, four
 //               smoothings, a bitonic sort of the band's power spectrum.
 // WORLD's safeguard noise (randn() * 1e-12 on window samples, |randn()| * eps on CheapTrick's power bins) is drawn from the fixed
@@ -45,35 +44,48 @@ __device__ inline double wave_sum_f64(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
-// sum over the workgroup, returned to every thread; red: >= 4 doubles of LDS
+// sum over the workgroup, returned to every thread; red: >= 16 doubles of LDS
 __device__ inline double block_sum(double v, double* red) {
+    const int nw = blockDim.x >> 6;
     v = wave_sum_f64(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     double s = 0.0;
-    for (int i = 0; i < NT / 64; ++i) s += red[i];
+    for (int i = 0; i < nw; ++i) s += red[i];
     return s;
 }
-// exclusive scan of one int per thread over the workgroup; *total = sum.  red: >= 4 ints of LDS
-__device__ inline int block_excl_scan(int v, int* red, int* total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int inc = v;
+// exclusive scan of one value per thread over the workgroup; *total = sum.  red: >= 16 values of LDS
+template <typename V>
+__device__ inline V block_excl_scan(V v, V* red, V* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    V inc = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(inc, off, 64);
+        const V o = __shfl_up(inc, off, 64);
         if (lane >= off) inc += o;
     }
     __syncthreads();
     if (lane == 63) red[w] = inc;
     __syncthreads();
-    int base = 0, tot = 0;
-    for (int i = 0; i < NT / 64; ++i) {
+    V base = 0, tot = 0;
+    for (int i = 0; i < nw; ++i) {
         if (i < w) base += red[i];
         tot += red[i];
     }
     *total = tot;
     return base + inc - v;
+}
+// in-place cumulative sum of a[0 .. n) in LDS: every thread sums a contiguous chunk, a workgroup scan joins the chunks
+__device__ inline void cumsum_lds(double* a, int n, double* red) {
+    const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x, i0 = (int)threadIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = i0; i < i1; ++i) s += a[i];
+    double tot;
+    double acc = block_excl_scan<double>(s, red, &tot);
+    for (int i = i0; i < i1; ++i) { acc += a[i]; a[i] = acc; }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(NT) void dio_band_kernel(DioParams p) {
 
 // the four kinds of events of one band: negative-going zero crossings of f, -f, d/dt(-f) ... (ZeroCrossingEngine), compacted in order
 __global__ __launch_bounds__(NT) void dio_events_kernel(DioParams p) {
-    __shared__ int red[4];
+    __shared__ int red[16];
     const int kind = blockIdx.x, band = blockIdx.y, b = blockIdx.z, ylen = p.lengths[b] + 1;
     const double* f = p.filt + ((long long)b * p.nbands + band) * p.fpitch;
     double* out = p.fine + (((long long)b * p.nbands + band) * 4 + kind) * p.epitch;
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(NT) void dio_events_kernel(DioParams p) {
             }
         }
         int tot;
-        const int off = block_excl_scan(n, red, &tot);
+        const int off = block_excl_scan<int>(n, red, &tot);
         for (int j = 0; j < n; ++j) out[written + off + j] = ev[j];
         written += tot;
     }
@@ -306,7 +318,7 @@ __device__ void fft_lds(cd* a, int logN, const cd* __restrict__ tw, int logNT, b
     const int n2 = 1 << (logN - 1);
     for (int s = 1; s <= logN; ++s) {
         const int h = 1 << (s - 1);
-        for (int idx = threadIdx.x; idx < n2; idx += NT) {
+        for (int idx = threadIdx.x; idx < n2; idx += blockDim.x) {
             const int k = idx & (h - 1), i = ((idx >> (s - 1)) << s) + k;
             cd w = tw[k << (logNT - s)];
             if (inverse) w.y = -w.y;
@@ -324,7 +336,7 @@ __device__ inline unsigned brev(unsigned i, int logN) { return __brev(i) >> (32 
 __device__ void fft_real_lds(cd* a, const double* r, int n, double scale_index, int logN, const cd* tw, int logNT) {
     const int N = 1 << logN;
     __syncthreads();
-    for (int i = threadIdx.x; i < N; i += NT) {
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
         double v = i < n ? r[i] : 0.0;
         if (scale_index != 0.0) v *= (double)i + 1.0;
         a[brev(i, logN)] = {v, 0.0};
@@ -345,7 +357,7 @@ __device__ inline double interp1q(double x0, double dx, const double* y, int n, 
 __device__ void dc_correction(double* p, double f0, int fs, int F, double* scratch) {
     const int upper = 2 + (int)(f0 * F / fs), rn = upper - 1;
     __syncthreads();
-    for (int i = threadIdx.x; i < rn; i += NT) {
+    for (int i = threadIdx.x; i < rn; i += blockDim.x) {
         const double axis = (double)i * fs / F;
         const double xi = (axis - f0) / (-(double)fs / F);
         int base = (int)xi;
@@ -354,28 +366,25 @@ __device__ void dc_correction(double* p, double f0, int fs, int F, double* scrat
         scratch[i] = p[base] + (p[base + 1] - p[base]) * frac;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < rn; i += NT) p[i] += scratch[i];
+    for (int i = threadIdx.x; i < rn; i += blockDim.x) p[i] += scratch[i];
     __syncthreads();
 }
 
 // LinearSmoothing (common.cpp): moving average of `width` Hz as differences of the cumulative sum of the mirrored spectrum.
 // src[0 .. F/2], dst may be src; seg: >= F/2 + 2 boundary + 1 doubles
-__device__ void linear_smoothing(const double* src, double* dst, double* seg, double width, int fs, int F) {
+__device__ void linear_smoothing(const double* src, double* dst, double* seg, double width, int fs, int F, double* red) {
     const int half = F / 2, boundary = (int)(width * F / fs) + 1, n = half + 2 * boundary + 1;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += NT) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
         double v;
         if (i < boundary) v = src[boundary - i];
         else if (i < half + boundary) v = src[i - boundary];
         else v = src[half - (i - (half + boundary))];
         seg[i] = v * fs / F;
     }
-    __syncthreads();
-    if (threadIdx.x == 0)
-        for (int i = 1; i < n; ++i) seg[i] += seg[i - 1];        // sequential on purpose: the differences below cancel
-    __syncthreads();
+    cumsum_lds(seg, n, red);
     const double origin = -((double)boundary - 0.5) * fs / F, dx = (double)fs / F;
-    for (int k = threadIdx.x; k <= half; k += NT) {
+    for (int k = threadIdx.x; k <= half; k += blockDim.x) {
         const double freq = (double)k / F * fs;
         const double lo = interp1q(origin, dx, seg, n, freq - width / 2.0);
         const double hi = interp1q(origin, dx, seg, n, freq + width / 2.0);
@@ -392,7 +401,7 @@ __device__ int windowed_waveform(const float* x, int len, int fs, double f0, dou
     const int nwin = 2 * half + 1, origin = mround(position * fs + 0.001);
     __syncthreads();
     double sq = 0.0;
-    for (int i = threadIdx.x; i < nwin; i += NT) {
+    for (int i = threadIdx.x; i < nwin; i += blockDim.x) {
         const int base = i - half;
         double w;
         if (type == 0) {
@@ -407,10 +416,10 @@ __device__ int windowed_waveform(const float* x, int len, int fs, double f0, dou
     }
     if (type == 0) {
         const double nrm = sqrt(block_sum(sq, red));
-        for (int i = threadIdx.x; i < nwin; i += NT) wbuf[i] = wbuf[i] / nrm;
+        for (int i = threadIdx.x; i < nwin; i += blockDim.x) wbuf[i] = wbuf[i] / nrm;
     }
     double s1 = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < nwin; i += NT) {
+    for (int i = threadIdx.x; i < nwin; i += blockDim.x) {
         int si = origin + i - half;
         si = si < 0 ? 0 : (si > len - 1 ? len - 1 : si);
         const double w = wbuf[i], v = (double)x[si] * w + rnd[i] * kSafeMin;
@@ -421,36 +430,44 @@ __device__ int windowed_waveform(const float* x, int len, int fs, double f0, dou
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
     const double coef = s1 / s2;
-    for (int i = threadIdx.x; i < nwin; i += NT) wav[i] -= wbuf[i] * coef;
+    for (int i = threadIdx.x; i < nwin; i += blockDim.x) wav[i] -= wbuf[i] * coef;
     __syncthreads();
     return nwin;
 }
 
-// offsets into WORLD's randn() sequence at which the frames of one call start consuming it (one lane per utterance: T is ~1e3)
-// mode 0: CheapTrick (window + power bins); 1: D4C love train; 2: D4C general body (after the love train's draws)
-__global__ void world_offsets_kernel(const double* f0, const int* lengths, const double* ap0, long long* off, int B, int Tmax, int fs,
-                                     double frame_period, int mode, double arg, int fft_size) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const int T = dio_frames(fs, lengths[b], frame_period);
+// offsets into WORLD's randn() sequence at which the frames of one call start consuming it: an exclusive scan over the frames of an
+// utterance (one workgroup each).  mode 0: CheapTrick (window + power bins); 1: D4C love train; 2: D4C general body (after ALL the
+// love train's draws)
+__global__ __launch_bounds__(NT) void world_offsets_kernel(const double* f0, const int* lengths, const double* ap0, long long* off, int Tmax,
+                                                           int fs, double frame_period, int mode, double arg, int fft_size) {
+    __shared__ long long red[16];
+    const int b = blockIdx.x, T = dio_frames(fs, lengths[b], frame_period);
     const double* f = f0 + (long long)b * Tmax;
     long long* o = off + (long long)b * Tmax;
-    long long acc = 0;
-    if (mode == 2)
-        for (int t = 0; t < T; ++t)
-            if (f[t] != 0.0) acc += 2 * mround(3.0 * fs / (f[t] > kLoveTrainF0 ? f[t] : kLoveTrainF0) / 2.0) + 1;
-    for (int t = 0; t < T; ++t) {
-        o[t] = acc;
-        const double v = f[t];
-        if (mode == 0) {
-            const double c = v <= arg ? kDefaultF0 : v;         // arg = CheapTrick's F0 floor
-            acc += 2 * mround(1.5 * fs / c) + 1 + fft_size / 2 + 1;
-        } else if (mode == 1) {
-            if (v != 0.0) acc += 2 * mround(3.0 * fs / (v > kLoveTrainF0 ? v : kLoveTrainF0) / 2.0) + 1;
-        } else {
-            if (v != 0.0 && ap0[(long long)b * Tmax + t] > arg) // arg = the voicing threshold
-                acc += 3 * (2 * mround(4.0 * fs / (v > kFloorF0D4C ? v : kFloorF0D4C) / 2.0) + 1);
+    auto love = [&](double v) -> long long { return v != 0.0 ? 2 * mround(3.0 * fs / (v > kLoveTrainF0 ? v : kLoveTrainF0) / 2.0) + 1 : 0; };
+    long long start = 0, tot;
+    if (mode == 2) {
+        long long s = 0;
+        for (int t = threadIdx.x; t < T; t += NT) s += love(f[t]);
+        block_excl_scan<long long>(s, red, &start);
+    }
+    for (int t0 = 0; t0 < T; t0 += NT) {
+        const int t = t0 + (int)threadIdx.x;
+        long long n = 0;
+        if (t < T) {
+            const double v = f[t];
+            if (mode == 0) {
+                const double c = v <= arg ? kDefaultF0 : v;     // arg = CheapTrick's F0 floor
+                n = 2 * mround(1.5 * fs / c) + 1 + fft_size / 2 + 1;
+            } else if (mode == 1) {
+                n = love(v);
+            } else if (v != 0.0 && ap0[(long long)b * Tmax + t] > arg) {   // arg = the voicing threshold
+                n = 3 * (2 * mround(4.0 * fs / (v > kFloorF0D4C ? v : kFloorF0D4C) / 2.0) + 1);
+            }
         }
+        const long long e = block_excl_scan<long long>(n, red, &tot);
+        if (t < T) o[t] = start + e;
+        start += tot;
     }
 }
 
@@ -473,7 +490,7 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(CtParams p) {
     double* wbuf = pw + half + 8;            // F
     double* wav = wbuf + F;                  // F
     double* seg = wav + F;                   // half + 2 * boundary + 1
-    __shared__ double red[8];
+    __shared__ double red[16];
     const float* x = p.x + (long long)b * p.pitch;
     const double f = p.f0[(long long)b * p.Tmax + t], cf0 = f <= p.f0_floor ? kDefaultF0 : f;
     const long long off = p.off[(long long)b * p.Tmax + t];
@@ -482,7 +499,7 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(CtParams p) {
     const int nwin_need = 2 * mround(1.5 * fs / cf0) + 1;
     const int bnd = (int)(cf0 * 2.0 / 3.0 * F / fs) + 1;                 // the smoothing's mirror margin must fit the spectrum and `seg`
     if (off + nwin_need + half + 1 > p.rnd_len || nwin_need > F || 2 * bnd > F || !(cf0 > 0.0)) {       // fail loudly: NaN rows
-        for (int k = threadIdx.x; k <= half; k += NT) {
+        for (int k = threadIdx.x; k <= half; k += blockDim.x) {
             if (spo) spo[k] = __builtin_nan("");
             if (lso) lso[k] = __builtin_nanf("");
         }
@@ -491,27 +508,27 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(CtParams p) {
     const double position = (double)t * p.frame_period / 1000.0;
     const int nwin = windowed_waveform(x, len, fs, cf0, position, 0, 1.5, p.rnd + off, wav, wbuf, red);
     fft_real_lds(buf, wav, nwin, 0.0, p.logF, p.tw, p.logF);
-    for (int k = threadIdx.x; k <= half; k += NT) pw[k] = buf[k].x * buf[k].x + buf[k].y * buf[k].y;
+    for (int k = threadIdx.x; k <= half; k += blockDim.x) pw[k] = buf[k].x * buf[k].x + buf[k].y * buf[k].y;
     dc_correction(pw, cf0, fs, F, seg);
-    linear_smoothing(pw, pw, seg, cf0 * 2.0 / 3.0, fs, F);
+    linear_smoothing(pw, pw, seg, cf0 * 2.0 / 3.0, fs, F, red);
     const double* noise = p.rnd + off + nwin;
-    for (int k = threadIdx.x; k <= half; k += NT) pw[k] = log(pw[k] + fabs(noise[k]) * kEps);
+    for (int k = threadIdx.x; k <= half; k += blockDim.x) pw[k] = log(pw[k] + fabs(noise[k]) * kEps);
     __syncthreads();
     // cepstrum of the (even) log spectrum, liftered, back: SmoothingWithRecovery
-    for (int i = threadIdx.x; i < F; i += NT) buf[brev(i, p.logF)] = {pw[i <= half ? i : F - i], 0.0};
+    for (int i = threadIdx.x; i < F; i += blockDim.x) buf[brev(i, p.logF)] = {pw[i <= half ? i : F - i], 0.0};
     __syncthreads();
     fft_lds(buf, p.logF, p.tw, p.logF, false);
-    for (int k = threadIdx.x; k <= half; k += NT) {
+    for (int k = threadIdx.x; k <= half; k += blockDim.x) {
         const double quef = (double)k / (double)fs;
         const double sm = k == 0 ? 1.0 : sin(kPi * cf0 * quef) / (kPi * cf0 * quef);
         const double comp = (1.0 - 2.0 * p.q1) + 2.0 * p.q1 * cos(2.0 * kPi * quef * cf0);
         wbuf[k] = buf[k].x * sm * comp;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < F; i += NT) buf[brev(i, p.logF)] = {wbuf[i <= half ? i : F - i], 0.0};
+    for (int i = threadIdx.x; i < F; i += blockDim.x) buf[brev(i, p.logF)] = {wbuf[i <= half ? i : F - i], 0.0};
     __syncthreads();
     fft_lds(buf, p.logF, p.tw, p.logF, true);
-    for (int k = threadIdx.x; k <= half; k += NT) {
+    for (int k = threadIdx.x; k <= half; k += blockDim.x) {
         const double v = exp(buf[k].x / (double)F);
         if (spo) spo[k] = v;
         if (lso) lso[k] = (float)log(v + p.log_offset);
@@ -528,11 +545,12 @@ struct D4cParams {
 };
 
 constexpr int D4C_SEG = 2048 / 2 + 2 * 320 + 8;
+constexpr int DT = 1024;           // threads per workgroup of the D4C kernels (one workgroup per CU: their LDS footprint allows no more)
 
 // D4CLoveTrain: the share of the power below 4 kHz in the power below 7.9 kHz (both above 100 Hz) of a 3-period Blackman window
-__global__ __launch_bounds__(NT) void d4c_lovetrain_kernel(D4cParams p) {
+__global__ __launch_bounds__(DT) void d4c_lovetrain_kernel(D4cParams p) {
     extern __shared__ double sh[];
-    __shared__ double red[8];
+    __shared__ double red[16];
     const int b = blockIdx.y, t = blockIdx.x, fs = p.fs, F2 = p.F2;
     const int len = p.lengths[b], T = dio_frames(fs, len, p.frame_period);
     if (t >= T) return;
@@ -552,16 +570,16 @@ __global__ __launch_bounds__(NT) void d4c_lovetrain_kernel(D4cParams p) {
     const int nwin = windowed_waveform(x, len, fs, cf0, position, 2, 3.0, p.rnd + off, wav, wbuf, red);
     fft_real_lds(buf, wav, nwin, 0.0, p.logF2, p.tw, p.logF2);
     const int b0 = (int)ceil(100.0 * F2 / fs), b1 = (int)ceil(4000.0 * F2 / fs), b2 = (int)ceil(7900.0 * F2 / fs);
-    for (int k = threadIdx.x; k <= F2 / 2; k += NT) pw[k] = k <= b0 ? 0.0 : buf[k].x * buf[k].x + buf[k].y * buf[k].y;
+    for (int k = threadIdx.x; k <= F2 / 2; k += blockDim.x) pw[k] = k <= b0 ? 0.0 : buf[k].x * buf[k].x + buf[k].y * buf[k].y;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double acc = 0.0, at1 = 0.0;
-        for (int k = 0; k <= b2; ++k) {
-            acc += pw[k];
-            if (k == b1) at1 = acc;
-        }
-        *out = at1 / acc;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = threadIdx.x; k <= b2; k += blockDim.x) {
+        s2 += pw[k];
+        if (k <= b1) s1 += pw[k];
     }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) *out = s1 / s2;
 }
 
 // ascending bitonic sort of a[0 .. 2^logn) in LDS
@@ -570,7 +588,7 @@ __device__ void bitonic_sort(double* a, int logn) {
     __syncthreads();
     for (int k = 2; k <= n; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n; i += NT) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
                 const int l = i ^ j;
                 if (l > i) {
                     const double u = a[i], v = a[l];
@@ -582,9 +600,9 @@ __device__ void bitonic_sort(double* a, int logn) {
         }
 }
 
-__global__ __launch_bounds__(NT) void d4c_general_kernel(D4cParams p) {
+__global__ __launch_bounds__(DT) void d4c_general_kernel(D4cParams p) {
     extern __shared__ double sh[];
-    __shared__ double red[8];
+    __shared__ double red[16];
     __shared__ double coarse[8];
     const int b = blockIdx.y, t = blockIdx.x, fs = p.fs, F2 = p.F2, h2 = F2 / 2, half = p.F / 2, nb = p.nb;
     const int len = p.lengths[b], T = dio_frames(fs, len, p.frame_period);
@@ -597,7 +615,7 @@ __global__ __launch_bounds__(NT) void d4c_general_kernel(D4cParams p) {
     const double unv = 1.0 - kSafeMin;
     if (!voiced || bad) {
         const double v = bad ? __builtin_nan("") : unv;
-        for (int k = threadIdx.x; k <= half; k += NT) if (apo) apo[k] = v;
+        for (int k = threadIdx.x; k <= half; k += blockDim.x) if (apo) apo[k] = v;
         if (threadIdx.x < nb) {
             const double c = 20.0 * log10(v);
             if (p.coded) p.coded[row * nb + threadIdx.x] = c;
@@ -619,7 +637,7 @@ __global__ __launch_bounds__(NT) void d4c_general_kernel(D4cParams p) {
     const long long off = p.off_gb[row];
     const int bmax = (int)(cf0 * F2 / fs) + 1;
     if (off + 3LL * nw4 > p.rnd_len || nw4 > F2 || h2 + 2 * bmax + 1 > D4C_SEG) {
-        for (int k = threadIdx.x; k <= half; k += NT) if (apo) apo[k] = __builtin_nan("");
+        for (int k = threadIdx.x; k <= half; k += blockDim.x) if (apo) apo[k] = __builtin_nan("");
         if (threadIdx.x < nb) {
             if (p.coded) p.coded[row * nb + threadIdx.x] = __builtin_nan("");
             if (p.coded32) p.coded32[row * nb + threadIdx.x] = __builtin_nanf("");
@@ -629,56 +647,65 @@ __global__ __launch_bounds__(NT) void d4c_general_kernel(D4cParams p) {
     const float* x = p.x + (long long)b * p.pitch;
     const double position = (double)t * p.frame_period / 1000.0;
     // static centroid: two Blackman windows of four periods, a quarter period either side
-    for (int k = threadIdx.x; k <= h2; k += NT) cen[k] = 0.0;
+    for (int k = threadIdx.x; k <= h2; k += blockDim.x) cen[k] = 0.0;
     for (int side = 0; side < 2; ++side) {
         const double pos = side == 0 ? position - 0.25 / cf0 : position + 0.25 / cf0;
         const int nwin = windowed_waveform(x, len, fs, cf0, pos, 2, 4.0, p.rnd + off + (long long)side * nw4, wav, wbuf, red);
         double pwr = 0.0;
-        for (int i = threadIdx.x; i < nwin; i += NT) pwr += wav[i] * wav[i];
+        for (int i = threadIdx.x; i < nwin; i += blockDim.x) pwr += wav[i] * wav[i];
         pwr = sqrt(block_sum(pwr, red));
-        for (int i = threadIdx.x; i < nwin; i += NT) wav[i] = wav[i] / pwr;
+        for (int i = threadIdx.x; i < nwin; i += blockDim.x) wav[i] = wav[i] / pwr;
         fft_real_lds(buf, wav, nwin, 0.0, p.logF2, p.tw, p.logF2);
-        for (int k = threadIdx.x; k <= h2; k += NT) { tmpr[k] = buf[k].x; tmpi[k] = buf[k].y; }
+        for (int k = threadIdx.x; k <= h2; k += blockDim.x) { tmpr[k] = buf[k].x; tmpi[k] = buf[k].y; }
         fft_real_lds(buf, wav, nwin, 1.0, p.logF2, p.tw, p.logF2);
-        for (int k = threadIdx.x; k <= h2; k += NT) cen[k] += buf[k].x * tmpr[k] + tmpi[k] * buf[k].y;
+        for (int k = threadIdx.x; k <= h2; k += blockDim.x) cen[k] += buf[k].x * tmpr[k] + tmpi[k] * buf[k].y;
     }
     dc_correction(cen, cf0, fs, F2, seg);
     // smoothed power spectrum: a Hanning window of four periods
     {
         const int nwin = windowed_waveform(x, len, fs, cf0, position, 1, 4.0, p.rnd + off + 2LL * nw4, wav, wbuf, red);
         fft_real_lds(buf, wav, nwin, 0.0, p.logF2, p.tw, p.logF2);
-        for (int k = threadIdx.x; k <= h2; k += NT) pw[k] = buf[k].x * buf[k].x + buf[k].y * buf[k].y;
+        for (int k = threadIdx.x; k <= h2; k += blockDim.x) pw[k] = buf[k].x * buf[k].x + buf[k].y * buf[k].y;
         dc_correction(pw, cf0, fs, F2, seg);
-        linear_smoothing(pw, pw, seg, cf0, fs, F2);
+        linear_smoothing(pw, pw, seg, cf0, fs, F2, red);
     }
     // static group delay, its smooth part taken out
-    for (int k = threadIdx.x; k <= h2; k += NT) gd[k] = cen[k] / pw[k];
-    linear_smoothing(gd, gd, seg, cf0 / 2.0, fs, F2);
-    linear_smoothing(gd, tmpr, seg, cf0, fs, F2);
-    for (int k = threadIdx.x; k <= h2; k += NT) gd[k] -= tmpr[k];
+    for (int k = threadIdx.x; k <= h2; k += blockDim.x) gd[k] = cen[k] / pw[k];
+    linear_smoothing(gd, gd, seg, cf0 / 2.0, fs, F2, red);
+    linear_smoothing(gd, tmpr, seg, cf0, fs, F2, red);
+    for (int k = threadIdx.x; k <= h2; k += blockDim.x) gd[k] -= tmpr[k];
     __syncthreads();
     // band aperiodicity: the tail of the sorted power spectrum of the windowed group delay
     const int wlen = p.wlen, hw = wlen / 2, boundary = mround(F2 * 8.0 / wlen);
-    double* sortbuf = (double*)buf;
     for (int i = 0; i < nb; ++i) {
         const int center = (int)(kFreqInterval * (i + 1) * F2 / fs);
         __syncthreads();
-        for (int j = threadIdx.x; j < F2; j += NT) {
+        for (int j = threadIdx.x; j < F2; j += blockDim.x) {
             const double v = j < wlen ? gd[center - hw + j] * p.nuttall[j] : 0.0;
             buf[brev(j, p.logF2)] = {v, 0.0};
         }
         __syncthreads();
         fft_lds(buf, p.logF2, p.tw, p.logF2, false);
-        for (int k = threadIdx.x; k <= h2; k += NT) tmpr[k] = buf[k].x * buf[k].x + buf[k].y * buf[k].y;
-        __syncthreads();
-        for (int k = threadIdx.x; k < F2; k += NT) sortbuf[k] = k <= h2 ? tmpr[k] : __builtin_inf();
-        bitonic_sort(sortbuf, p.logF2);
+        // power spectrum: bins 0 .. h2-1 are sorted (a power of two), the Nyquist bin is ranked into them
+        const double extra = buf[h2].x * buf[h2].x + buf[h2].y * buf[h2].y;
+        for (int k = threadIdx.x; k < h2; k += blockDim.x) tmpr[k] = buf[k].x * buf[k].x + buf[k].y * buf[k].y;
+        bitonic_sort(tmpr, p.logF2 - 1);
+        // sorted cumulative sum at index h2 - boundary - 1 = the m = h2 - boundary smallest of the h2 + 1 values
+        const int m = h2 - boundary;
+        double below = 0.0;
+        for (int k = threadIdx.x; k < h2; k += blockDim.x) below += tmpr[k] < extra ? 1.0 : 0.0;
+        const int rank = (int)block_sum(below, red);
+        const int take = rank < m ? m - 1 : m;
+        double at = 0.0, acc = 0.0;
+        for (int k = threadIdx.x; k < h2; k += blockDim.x) {
+            acc += tmpr[k];
+            if (k < take) at += tmpr[k];
+        }
+        at = block_sum(at, red);
+        acc = block_sum(acc, red);
         if (threadIdx.x == 0) {
-            double acc = 0.0, at = 0.0;
-            for (int k = 0; k <= h2; ++k) {
-                acc += sortbuf[k];
-                if (k == h2 - boundary - 1) at = acc;
-            }
+            if (rank < m) at += extra;
+            acc += extra;
             double c = 10.0 * log10(at / acc);
             c = c + (cf0 - 100.0) / 50.0;
             coarse[i] = c < 0.0 ? c : 0.0;
@@ -688,7 +715,7 @@ __global__ __launch_bounds__(NT) void d4c_general_kernel(D4cParams p) {
     // GetAperiodicity: the coarse values between -60 dB at 0 Hz and -1e-12 dB at fs / 2, linear in dB over frequency
     auto axis = [&](int j) -> double { return j <= nb ? (double)j * kFreqInterval : fs / 2.0; };
     auto val = [&](int j) -> double { return j == 0 ? -60.0 : (j <= nb ? coarse[j - 1] : -kSafeMin); };
-    for (int k = threadIdx.x; k <= half; k += NT) {
+    for (int k = threadIdx.x; k <= half; k += blockDim.x) {
         const double xi = (double)k * fs / p.F;
         int j = 0;
         while (j < nb + 2 && axis(j) <= xi) ++j;                 // first grid point beyond xi
@@ -839,8 +866,8 @@ extern "C" int v100_world_cheaptrick(const float* x, const int* lengths, const d
     p.frame_period = frame_period_ms; p.q1 = q1; p.f0_floor = 3.0 * fs / (fft_size - 3.0); p.log_offset = log_offset;
     p.rnd = randn_table; p.rnd_len = table_len; p.off = offsets; p.tw = (const cd*)twiddle; p.sp = sp; p.logsp = logsp;
     hipStream_t st = (hipStream_t)stream;
-    V100_GGL(world_offsets_kernel, dim3((B + 63) / 64), dim3(64), 0, st, f0, lengths, (const double*)nullptr, offsets, B, Tmax, fs, frame_period_ms, 0,
-             p.f0_floor, fft_size);
+    V100_GGL(world_offsets_kernel, dim3(B), dim3(NT), 0, st, f0, lengths, (const double*)nullptr, offsets, Tmax, fs, frame_period_ms, 0, p.f0_floor,
+             fft_size);
     // LDS: F complex + (F/2 + 8) + F + F + (F/2 + 2 * boundary + 1), boundary <= F/2
     const size_t lds = sizeof(double) * (2 * fft_size + fft_size / 2 + 8 + 2 * fft_size + fft_size / 2 + fft_size + 8);
     static bool attr[3] = {false, false, false};
@@ -889,11 +916,11 @@ extern "C" int v100_world_d4c(const float* x, const int* lengths, const double* 
             return V100_ERR_LAUNCH;
         attr = true;
     }
-    V100_GGL(world_offsets_kernel, dim3((B + 63) / 64), dim3(64), 0, st, f0, lengths, (const double*)nullptr, (long long*)p.off_lt, B, Tmax, fs,
-             frame_period_ms, 1, 0.0, fft_size);
-    V100_GGL(d4c_lovetrain_kernel, dim3(Tmax, B), dim3(NT), sizeof(double) * (2 * F2 + F2 + F2 + F2 / 2 + 8), st, p);
-    V100_GGL(world_offsets_kernel, dim3((B + 63) / 64), dim3(64), 0, st, f0, lengths, (const double*)p.ap0, (long long*)p.off_gb, B, Tmax, fs,
-             frame_period_ms, 2, threshold, fft_size);
-    V100_GGL(d4c_general_kernel, dim3(Tmax, B), dim3(NT), sizeof(double) * (2 * F2 + F2 + 5 * (F2 / 2 + 8) + D4C_SEG), st, p);
+    V100_GGL(world_offsets_kernel, dim3(B), dim3(NT), 0, st, f0, lengths, (const double*)nullptr, (long long*)p.off_lt, Tmax, fs, frame_period_ms, 1,
+             0.0, fft_size);
+    V100_GGL(d4c_lovetrain_kernel, dim3(Tmax, B), dim3(DT), sizeof(double) * (2 * F2 + F2 + F2 + F2 / 2 + 8), st, p);
+    V100_GGL(world_offsets_kernel, dim3(B), dim3(NT), 0, st, f0, lengths, (const double*)p.ap0, (long long*)p.off_gb, Tmax, fs, frame_period_ms, 2,
+             threshold, fft_size);
+    V100_GGL(d4c_general_kernel, dim3(Tmax, B), dim3(DT), sizeof(double) * (2 * F2 + F2 + 5 * (F2 / 2 + 8) + D4C_SEG), st, p);
     return v100_launch_status();
 }
