@@ -156,3 +156,42 @@ def test_stack_plan_layout(lib):
             assert totals[2] == sum(hid * cin + 2 * hid + hid * k + 2 * hid + cout * hid + 2 * cout for cin, hid, cout, k, _, _ in cfgs)
     bad = (ctypes.c_int * 12)(1, 32, 0, 1, 4, 0, 64, 256, 256, 11, 2, 0)
     assert lib.v100_ir_stack_plan(bad, (ctypes.c_longlong * 14)()) < 0
+
+
+def test_world_analysis_host_side(lib):
+    """The host-only pieces of the WORLD analysis entry points (csrc/world_analysis.hip): frame count, DIO band plan, the randn
+    sequence in double against the oracle's, table bounds, workspace sizes, and argument validation (all of which return before
+    anything touches a device)."""
+    import ctypes
+    import numpy as np
+    from oracle import world_analysis as wa
+    from oracle import world_synth as ws
+    for n in (1, 159, 160, 16000, 163680):
+        assert lib.v100_world_frames(16000, n, 10.0) == wa.samples_for_dio(16000, n, 10.0)
+    assert lib.v100_world_frames(22050, 22050, 5.0) == wa.samples_for_dio(22050, 22050, 5.0)
+    assert lib.v100_world_frames(0, 10, 10.0) == -1
+    half = (ctypes.c_int * 16)()
+    nb = lib.v100_world_dio_bands(16000, 80.0, 400.0, 2.0, half, 16)
+    assert nb == 5 == 1 + int(np.log(400.0 / 80.0) / wa.K_LOG2 * 2.0)
+    assert [half[i] for i in range(nb)] == [wa.matlab_round(16000 / (80.0 * 2.0 ** ((i + 1) / 2.0)) / 2.0) for i in range(nb)]
+    assert lib.v100_world_dio_bands(16000, 71.0, 800.0, 2.0, half, 16) == 7
+    assert lib.v100_world_dio_bands(16000, 400.0, 80.0, 2.0, half, 16) == -1          # ceil below floor
+    assert lib.v100_world_dio_bands(16000, 71.0, 800.0, 2.0, half, 3) == -1           # more bands than the caller has room for
+    tab = np.empty(4096, np.float64)
+    assert lib.v100_world_randn_host_f64(tab.ctypes.data_as(ctypes.c_void_p), 4096) == 0
+    assert np.array_equal(tab, np.asarray(ws.randn_table(4096), np.float64))
+    assert abs(tab.mean()) < 0.1 and abs(tab.std() - 1.0) < 0.05
+    assert lib.v100_world_randn_host_f64(None, 4) == 3
+    # cheaptrick consumes at most (fft_size - 2) + fft_size/2 + 1 draws per frame, d4c a 3-period window at 40 Hz + three 4-period windows at 47 Hz
+    assert lib.v100_world_randn_bound(0, 100, 16000, 512) >= 100 * (510 + 257)
+    assert lib.v100_world_randn_bound(1, 100, 16000, 512) == 100 * ((2 * wa.matlab_round(1.5 * 16000 / 40.0) + 1) + 3 * (2 * wa.matlab_round(2.0 * 16000 / 47.0) + 1))
+    assert lib.v100_world_dio_workspace_bytes(16, 163680, 16000, 80.0, 400.0, 2.0, 10.0) > 16 * 163680 * 8 * 6
+    assert lib.v100_world_dio_workspace_bytes(0, 163680, 16000, 80.0, 400.0, 2.0, 10.0) == -1
+    assert lib.v100_world_d4c_workspace_bytes(16, 163680, 16000, 10.0) >= 3 * 16 * 1024 * 8
+    one = ctypes.c_void_p(16)
+    assert lib.v100_world_dio(None, one, 1, 100, 100, 16000, 80.0, 400.0, 2.0, 10.0, 0.1, one, one, one, one, None) == 3
+    assert lib.v100_world_dio(one, one, 1, 100, 50, 16000, 80.0, 400.0, 2.0, 10.0, 0.1, one, one, one, one, None) == 1       # pitch < max_len
+    assert lib.v100_world_cheaptrick(one, one, one, 1, 100, 100, 16000, 10.0, -0.15, 768, one, 1000, one, one, None, 1e-15, one, None) == 1
+    assert lib.v100_world_cheaptrick(one, one, one, 1, 100, 100, 16000, 10.0, -0.15, 512, one, 1000, one, None, None, 1e-15, one, None) == 3
+    assert lib.v100_world_d4c(one, one, one, 1, 100, 100, 16000, 10.0, 0.85, 512, one, 1000, one, one, 700, one, None, None, one, None) == 1   # window length
+    assert lib.v100_world_d4c(one, one, one, 1, 100, 100, 8000, 10.0, 0.85, 512, one, 1000, one, one, 769, one, None, None, one, None) == 1    # 8 kHz: no band
