@@ -187,7 +187,8 @@ int v100_exp_clip(const float* x, float* y, float offset, long long n, void* str
 /* ---- WORLD synthesis (csrc/world.hip; SURVEY.md 8f rank 4, first half) -- PARITY UNPINNED -----------------------
  * pyworld.decode_aperiodicity + pyworld.synthesize as WORLDVocoder.decode calls them (voice100/vocoder.py:100-101).
  * pyworld 0.3.2 (C++ WORLD) is not in the reference tree: the kernels follow the published algorithm as restated in
- * oracle/world_synth.py.  fft_size 512 (16 kHz) only.
+ * oracle/world_synth.py.  fft_size 512 (16 kHz): one WAVE per pulse, fp32 with the tables below; any other power of two up to 2048 (1024:
+ * the 22.05 kHz models): one workgroup per pulse in fp64, tw256 / tw512 / dc_remover may be NULL.
  *   v100_world_randn_host    HOST function, HOST pointer: the first n values of WORLD's randn() after randn_reseed() (every
  *                            Synthesis call reseeds: one fixed sequence for all utterances; callers upload it once)
  *   v100_world_decode_aperiodicity   coded [rows][nb] dB -> ap [rows][fft_size/2+1]

@@ -201,3 +201,39 @@ def test_synthesize_from_coded_aperiodicity_vs_double_oracle(cuda):
         assert err <= TOL, (b, err)
     with pytest.raises(ValueError):
         v.synthesize(_dev(f0, cuda), _dev(sp, cuda))
+
+
+def test_synthesize_22k_fft1024_vs_oracle(cuda):
+    """The other sample rate WORLDVocoder supports (vocoder.py:34-41: 22.05 kHz, n_fft 1024, two aperiodicity bands): the general-size
+    fp64 pulse kernel against the oracle, from a decoded aperiodicity tensor and from the coded bands."""
+    from voice100_amd.vocoder import WORLDVocoder
+    fs, n = 22050, 1024
+    rng = np.random.RandomState(11)
+    v = WORLDVocoder(sample_rate=fs)
+    assert v.n_fft == n and v.codeap_dim == 2
+    B, T = 2, 150
+    f0 = np.where(np.sin(np.arange(T)[None] / 20.0 + rng.rand(B, 1) * 6) > 0.3, 0.0, 110 + 100 * rng.rand(B, 1) + 12 * np.sin(np.arange(T)[None] / 5.0)).astype(np.float32)
+    k = np.arange(n // 2 + 1)
+    sp = (1e-2 * (1 + 4 * np.exp(-((k * fs / n - 1500) / 300.0) ** 2))[None, None] * np.exp(0.3 * rng.randn(B, T, 1)) * (1 + 0.2 * rng.rand(B, T, n // 2 + 1))).astype(np.float32)
+    cod = np.where(f0[..., None] > 0, -3 - 30 * rng.rand(B, T, 2), -0.3 * rng.rand(B, T, 2)).astype(np.float32)
+    frames = torch.tensor([T, T - 37], dtype=torch.int32)
+    y, npl = v.synthesize(_dev(f0, cuda), _dev(sp, cuda), codeap=_dev(cod, cuda), frames=frames)
+    assert y.shape == (B, int(T * 10.0 * fs / 1000))
+    for b in range(B):
+        t = int(frames[b])
+        ap64 = W.decode_aperiodicity(cod[b, :t].astype(np.float64), fs, n)
+        ref = W.synthesize_parts(f0[b, :t].astype(np.float64), sp[b, :t].astype(np.float64), ap64, fs, 10.0)
+        assert int(npl[b]) == len(ref["idx"])
+        got = y[b].double().cpu().numpy()
+        err = np.abs(got[:len(ref["y"])] - ref["y"]).max() / np.abs(ref["y"]).max()
+        assert err <= 1e-6, (b, err)                            # fp64 kernel, fp32 only in the stored responses
+        assert not got[len(ref["y"]):].any()
+    ap32 = v.decode_aperiodicity(_dev(cod, cuda))
+    assert ap32.shape == (B, T, n // 2 + 1)
+    y2, n2 = v.synthesize(_dev(f0, cuda), _dev(sp, cuda), ap32)
+    ref = W.synthesize_parts(f0[0].astype(np.float64), sp[0].astype(np.float64), ap32[0].double().cpu().numpy(), fs, 10.0)
+    assert int(n2[0]) == len(ref["idx"])
+    assert np.abs(y2[0].double().cpu().numpy() - ref["y"]).max() / np.abs(ref["y"]).max() <= 1e-6
+    # decode() as the reference's drop-in at this rate
+    w = v.decode(torch.from_numpy(f0[0]), torch.log(torch.from_numpy(sp[0]) + 1e-15), torch.from_numpy(cod[0]))
+    assert w.dtype == np.float64 and w.shape == (int(T * 10.0 * fs / 1000),) and np.isfinite(w).all()

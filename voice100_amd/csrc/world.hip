@@ -22,9 +22,10 @@
 // fp32 except the time base.  fft_size 512 (16 kHz) only: 22.05 kHz / 1024 returns V100_ERR_SHAPE (the oracle restates both).
 #include "common.h"
 #include "../../include/voice100_hip.h"
+#include "world_f64.h"
 
 namespace {
-constexpr int NF = 512, NH = 256, NB = 257;          // fft size, half, bins
+constexpr int NF = 512, NH = 256, NB = 257;          // fft size, half, bins of the fp32 wave-per-pulse kernel (16 kHz)
 constexpr double kPi = 3.1415926535897932384626433832795;
 constexpr double kDefaultF0 = 500.0;
 
@@ -38,6 +39,7 @@ struct WorldParams {
     double frame_period_ms;
     const float* tw256; const float* tw512; const float* dcr;
     const float* coded; int nb;   // optional: coded band aperiodicity [B][T][nb] (dB) decoded on the fly instead of `ap`
+    int nf;                       // fft size (512: the fp32 wave-per-pulse kernel; other powers of two: world_pulse_f64_kernel)
 };
 
 // everything up to the matching "contract(fast)" must round like the C / numpy reference: no fused multiply-adds
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
     int* idx = p.idx + (size_t)b * p.Pcap;
     float* xs = p.xshift + (size_t)b * p.Pcap;
     const double fp = p.frame_period, fs = (double)p.fs;
-    const double lowest = fs / (double)NF + 1.0;
+    const double lowest = fs / (double)p.nf + 1.0;
     if (T < 2 || ylen < 2) {              // the reference extrapolates the contour from its last two frames: fewer is undefined there
         if (tid == 0) p.n_pulses[b] = 0;
         return;
@@ -563,7 +565,173 @@ __global__ __launch_bounds__(256) void world_pulse_kernel(WorldParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// 3. overlap-add: y[n] = sum over pulses with idx in [n - 256, n + 255] of resp[pulse][n - idx + 255], pulse order
+// ---------------------------------------------------------------------------------------------------------------------------
+// 2b. one response per pulse at ANY power-of-two fft size (22.05 kHz models: 1024), in fp64: one workgroup per pulse, the transforms as
+// radix-2 FFTs on an LDS array (world_f64.h).  Same steps as world_pulse_kernel; in double none of its fp32 precautions (mean removal,
+// carrying 1 - a) are needed.  Twiddles and the DC remover are computed here, no tables.
+#pragma clang fp contract(off)
+__device__ void min_phase_f64(const double* lg, cd* buf, cd* out, int N, int logN, const cd* tw) {
+    const int H = N / 2;
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += blockDim.x) buf[brev(i, logN)] = {lg[i <= H ? i : N - i], 0.0};
+    __syncthreads();
+    fft_lds(buf, logN, tw, logN, false);
+    double mine[8];                                       // folded cepstrum of this thread's positions (N <= 8 * blockDim.x)
+    int c = 0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x, ++c) {
+        const double v = buf[i].x / (double)N;
+        mine[c] = i == 0 || i == H ? v : (i < H ? 2.0 * v : 0.0);
+    }
+    __syncthreads();
+    c = 0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x, ++c) buf[brev(i, logN)] = {mine[c], 0.0};
+    __syncthreads();
+    fft_lds(buf, logN, tw, logN, false);
+    for (int k = threadIdx.x; k <= H; k += blockDim.x) {
+        const double e = exp(buf[k].x);
+        out[k] = {e * cos(buf[k].y), e * sin(buf[k].y)};
+    }
+    __syncthreads();
+}
+// unnormalised inverse real transform of the half spectrum hs[0 .. N/2] (imaginary parts of bins 0 and N/2 ignored) -> buf[n].x
+__device__ void irfft_f64(const cd* hs, cd* buf, int N, int logN, const cd* tw) {
+    const int H = N / 2;
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        cd v;
+        if (i == 0 || i == H) v = {hs[i].x, 0.0};
+        else if (i < H) v = hs[i];
+        else v = {hs[N - i].x, -hs[N - i].y};
+        buf[brev(i, logN)] = v;
+    }
+    __syncthreads();
+    fft_lds(buf, logN, tw, logN, true);
+}
+
+__global__ __launch_bounds__(256) void world_pulse_f64_kernel(WorldParams p, int logN) {
+    extern __shared__ double shd[];
+    __shared__ double red[16];
+    const int N = 1 << logN, H = N / 2, NBN = H + 1;
+    cd* buf = (cd*)shd;                        // N
+    cd* tw = buf + N;                          // H
+    cd* hs = tw + H;                           // H + 2
+    cd* nz = hs + H + 2;                       // H + 2
+    double* env = (double*)(nz + H + 2);       // H + 2 each
+    double* rat = env + H + 2;
+    double* lg = rat + H + 2;
+    double* per = lg + H + 2;                  // N
+    const int b = blockIdx.y, P = p.n_pulses[b];
+    if (P <= 0) return;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        double sn, cs;
+        sincospi(2.0 * (double)k / (double)N, &sn, &cs);
+        tw[k] = {cs, -sn};
+    }
+    double hsum = 0.0;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) hsum += 0.5 - 0.5 * cos(2.0 * kPi * ((double)i + 1.0) / (1.0 + (double)N));
+    hsum = 2.0 * block_sum(hsum, red);
+    auto dcr = [&](int i) -> double {                     // GetDCRemover: a Hann window of unit sum, mirrored
+        const int j = i < H ? i : N - 1 - i;
+        return (0.5 - 0.5 * cos(2.0 * kPi * ((double)j + 1.0) / (1.0 + (double)N))) / hsum;
+    };
+    const int T = p.frames ? min(max(p.frames[b], 0), p.T) : p.T;
+    const int* idx = p.idx + (size_t)b * p.Pcap;
+    const float* xs = p.xshift + (size_t)b * p.Pcap;
+    const unsigned char* vuv = p.vuv + (size_t)b * p.Ymax;
+    const float* spb = p.sp + (size_t)b * p.T * NBN;
+    const float* apb = p.ap + (size_t)b * p.T * NBN;
+    float* respb = p.resp + (size_t)b * p.Pcap * N;
+    const int idx0 = idx[0];
+    for (int pi = blockIdx.x; pi < P; pi += gridDim.x) {
+        const int id = idx[pi];
+        const int ns = idx[pi + 1 < P ? pi + 1 : P - 1] - id;
+        const bool cur_v = vuv[id] != 0;
+        const double pos = ((double)id / (double)p.fs) / p.frame_period;
+        const int f0_ = (int)floor(pos), c0_ = (int)ceil(pos);
+        const int fl = f0_ < T - 1 ? f0_ : T - 1, ce = c0_ < T - 1 ? c0_ : T - 1;
+        const double mix = fl == ce ? 0.0 : pos - (double)fl;
+        const float* s0 = spb + (size_t)fl * NBN;
+        const float* s1 = spb + (size_t)ce * NBN;
+        const float* a0 = apb + (size_t)fl * NBN;
+        const float* a1 = apb + (size_t)ce * NBN;
+        const float* c0 = p.coded ? p.coded + ((size_t)b * p.T + fl) * p.nb : nullptr;
+        const float* c1 = p.coded ? p.coded + ((size_t)b * p.T + ce) * p.nb : nullptr;
+        auto a_of = [&](const float* arow, const float* crow, int k) -> double {
+            double a;
+            if (crow) {                                    // DecodeAperiodicity of this frame's bands, in double
+                double mean = 0.0;
+                for (int i = 0; i < p.nb; ++i) mean += (double)crow[i];
+                if (mean / (double)p.nb > -0.5) a = 1.0 - 1e-12;
+                else {
+                    const double f = (double)k * (double)p.fs / (double)N;
+                    int seg = (int)(f / 3000.0);
+                    if (seg > p.nb) seg = p.nb;
+                    const double x0 = 3000.0 * seg, x1 = seg == p.nb ? 0.5 * p.fs : 3000.0 * (seg + 1);
+                    const double y0 = seg == 0 ? -60.0 : (double)crow[seg - 1], y1 = seg == p.nb ? -1e-12 : (double)crow[seg];
+                    a = pow(10.0, (y0 + (f - x0) / (x1 - x0) * (y1 - y0)) / 20.0);
+                }
+            } else a = (double)arow[k];
+            return fmin(fmax(a, 0.001), 0.999999999999);
+        };
+        __syncthreads();
+        for (int k = threadIdx.x; k <= H; k += blockDim.x) {
+            env[k] = (1.0 - mix) * fabs((double)s0[k]) + mix * fabs((double)s1[k]);
+            const double a = (1.0 - mix) * a_of(a0, c0, k) + mix * a_of(a1, c1, k);
+            rat[k] = a * a;
+        }
+        const double a00 = (1.0 - mix) * a_of(a0, c0, 0) + mix * a_of(a1, c1, 0);
+        const bool periodic = cur_v && !(a00 * a00 > 0.999);
+        __syncthreads();
+        if (periodic) {
+            for (int k = threadIdx.x; k <= H; k += blockDim.x) lg[k] = log(env[k] * (1.0 - rat[k]) + 1e-12) / 2.0;
+            min_phase_f64(lg, buf, hs, N, logN, tw);
+            const double coef = 2.0 * kPi * (double)xs[pi] / (double)N;
+            for (int k = threadIdx.x; k <= H; k += blockDim.x) {
+                const double re2 = cos(coef * (double)k), im2 = sqrt(fmax(0.0, 1.0 - re2 * re2));
+                const cd h = hs[k];
+                hs[k] = {h.x * re2 + h.y * im2, h.y * re2 - h.x * im2};          // h * (re2 - i im2)
+            }
+            irfft_f64(hs, buf, N, logN, tw);
+            double part = 0.0;
+            for (int i = threadIdx.x; i < H; i += blockDim.x) part += buf[i].x;     // the causal half: the shifted response's second half
+            const double dc = block_sum(part, red);
+            for (int i = threadIdx.x; i < N; i += blockDim.x) per[i] = i < H ? -dc * dcr(i) : buf[i - H].x - dc * dcr(i);
+        } else {
+            for (int i = threadIdx.x; i < N; i += blockDim.x) per[i] = 0.0;
+        }
+        // aperiodic part: zero-mean burst of WORLD's randn of ns samples, coloured by the minimum-phase envelope
+        {
+            const long base = (long)id - idx0;
+            const int nuse = ns < N ? ns : N;
+            double sum = 0.0;
+            for (int i = threadIdx.x; i < ns; i += blockDim.x) sum += (base + i < p.table_len) ? (double)p.randn[base + i] : 0.0;
+            const double mean = ns > 0 ? block_sum(sum, red) / (double)ns : 0.0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < N; i += blockDim.x)
+                buf[brev(i, logN)] = {(i < nuse && base + i < p.table_len) ? (double)p.randn[base + i] - mean : 0.0, 0.0};
+            __syncthreads();
+            fft_lds(buf, logN, tw, logN, false);
+            for (int k = threadIdx.x; k <= H; k += blockDim.x) nz[k] = buf[k];
+        }
+        for (int k = threadIdx.x; k <= H; k += blockDim.x) lg[k] = log(cur_v ? env[k] * rat[k] : env[k]) / 2.0;
+        min_phase_f64(lg, buf, hs, N, logN, tw);
+        for (int k = threadIdx.x; k <= H; k += blockDim.x) {
+            const cd h = hs[k], z = nz[k];
+            hs[k] = {h.x * z.x - h.y * z.y, h.x * z.y + h.y * z.x};
+        }
+        irfft_f64(hs, buf, N, logN, tw);
+        const double sq = sqrt((double)ns);
+        float* out = respb + (size_t)pi * N;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+            const double ap_ = buf[i < H ? i + H : i - H].x;                        // fftshift
+            out[i] = (float)((per[i] * sq + ap_) / (double)N);
+        }
+        __syncthreads();
+    }
+}
+#pragma clang fp contract(fast)
+
+// 3. overlap-add: y[n] = sum over pulses with idx in [n - N/2, n + N/2 - 1] of resp[pulse][n - idx + N/2 - 1], pulse order
 __global__ __launch_bounds__(256) void world_overlap_add_kernel(WorldParams p) {
     const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -575,17 +743,18 @@ __global__ __launch_bounds__(256) void world_overlap_add_kernel(WorldParams p) {
     if (n >= ylen) { y[n] = 0.f; return; }
     if (P < 0) { y[n] = __builtin_nanf(""); return; }   // pulse list overflowed: fail loudly
     const int* idx = p.idx + (size_t)b * p.Pcap;
-    const float* resp = p.resp + (size_t)b * p.Pcap * NF;
+    const int nf = p.nf, nh = nf / 2;
+    const float* resp = p.resp + (size_t)b * p.Pcap * nf;
     int lo = 0, hi = P;                                  // first pulse with idx >= n - 256
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (idx[mid] < n - NH) lo = mid + 1; else hi = mid;
+        if (idx[mid] < n - nh) lo = mid + 1; else hi = mid;
     }
     float acc = 0.f;
     for (int q = lo; q < P; ++q) {
         const int id = idx[q];
-        if (id > n + NH - 1) break;
-        acc += resp[(size_t)q * NF + (n - id + NH - 1)];
+        if (id > n + nh - 1) break;
+        acc += resp[(size_t)q * nf + (n - id + nh - 1)];
     }
     y[n] = acc;
 }
@@ -648,19 +817,20 @@ static int world_ymax(int T, int fs, double frame_period_ms) { return (int)((dou
 
 // bytes of the `workspace` argument of v100_world_synthesize
 extern "C" long long v100_world_synth_workspace_bytes(int B, int T, int fs, double frame_period_ms, int fft_size, int max_pulses) {
-    if (B <= 0 || T <= 0 || fs <= 0 || fft_size != NF || max_pulses <= 0 || frame_period_ms <= 0) return -1;
+    if (B <= 0 || T <= 0 || fs <= 0 || fft_size < 64 || fft_size > 2048 || (fft_size & (fft_size - 1)) || max_pulses <= 0 || frame_period_ms <= 0) return -1;
     const long long Y = (world_ymax(T, fs, frame_period_ms) + 63) & ~63LL;
     const long long Pc = (max_pulses + 63) & ~63LL;
-    return (long long)B * (Y + Pc * 4 + Pc * 4 + Pc * NF * 4) + 256;
+    return (long long)B * (Y + Pc * 4 + Pc * 4 + Pc * fft_size * 4) + 256;
 }
 
 extern "C" int v100_world_synthesize(const float* f0, const float* sp, const float* ap, const float* coded_ap, int nb, const int* frames, const float* randn_table,
                                      long long table_len, const float* tw256, const float* tw512, const float* dc_remover, float* y,
                                      int* n_pulses, void* workspace, int B, int T, int fs, double frame_period_ms, int fft_size,
                                      int max_pulses, void* stream) {
-    if (!f0 || !sp || (!ap && !coded_ap) || !randn_table || !tw256 || !tw512 || !dc_remover || !y || !n_pulses || !workspace) return V100_ERR_NULL;
+    if (!f0 || !sp || (!ap && !coded_ap) || !randn_table || !y || !n_pulses || !workspace) return V100_ERR_NULL;
+    if (fft_size == NF && (!tw256 || !tw512 || !dc_remover)) return V100_ERR_NULL;       // the tables of the 512-point fp32 kernel
     if (coded_ap && (nb < 1 || nb > 5)) return V100_ERR_SHAPE;
-    if (B <= 0 || T < 2 || fs <= 0 || fft_size != NF || max_pulses <= 0 || frame_period_ms <= 0) return V100_ERR_SHAPE;
+    if (B <= 0 || T < 2 || fs <= 0 || fft_size < 64 || fft_size > 2048 || (fft_size & (fft_size - 1)) || max_pulses <= 0 || frame_period_ms <= 0) return V100_ERR_SHAPE;
     const int Ymax = world_ymax(T, fs, frame_period_ms);
     if (Ymax < 2 || table_len < Ymax || B > 65535) return V100_ERR_SHAPE;
     if (2048.0 / ((double)fs * frame_period_ms / 1000.0) + 4.0 > 64.0) return V100_ERR_SHAPE;     // time-base kernel: a chunk's contour window (NFR)
@@ -670,20 +840,35 @@ extern "C" int v100_world_synthesize(const float* f0, const float* sp, const flo
     p.f0 = f0; p.sp = sp; p.ap = ap ? ap : sp; p.coded = coded_ap; p.nb = nb; p.frames = frames; p.randn = randn_table; p.table_len = table_len; p.y = y; p.n_pulses = n_pulses;
     p.idx = (int*)w;                    w += (size_t)B * Pc * 4;
     p.xshift = (float*)w;               w += (size_t)B * Pc * 4;
-    p.resp = (float*)w;                 w += (size_t)B * Pc * NF * 4;
+    p.resp = (float*)w;                 w += (size_t)B * Pc * fft_size * 4;
     p.vuv = (unsigned char*)w;
     p.B = B; p.T = T; p.fs = fs; p.Ymax = Ymax; p.Pcap = (int)Pc;
     p.frame_period = frame_period_ms / 1000.0; p.frame_period_ms = frame_period_ms;
-    p.tw256 = tw256; p.tw512 = tw512; p.dcr = dc_remover;
+    p.tw256 = tw256; p.tw512 = tw512; p.dcr = dc_remover; p.nf = fft_size;
     // (Ymax as the row pitch of total / vuv would leave rows of `total` 8-byte aligned only when Ymax is even: use the padded Y)
     p.Ymax = Ymax;
     hipStream_t st = (hipStream_t)stream;
     WorldParams pt = p;
     pt.Ymax = (int)Y;                   // workspace rows are Y long; y rows are Ymax long (kernels 1 and 2 only touch the workspace)
     V100_GGL(world_timebase_kernel, dim3((unsigned)B), dim3(256), 0, st, pt);
-    int gx = (max_pulses + 3) / 4;
-    if (gx > 2048) gx = 2048;
-    V100_GGL(world_pulse_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, st, pt);
+    if (fft_size == NF) {
+        int gx = (max_pulses + 3) / 4;
+        if (gx > 2048) gx = 2048;
+        V100_GGL(world_pulse_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, st, pt);
+    } else {
+        int logN = 0;
+        while ((1 << logN) < fft_size) ++logN;
+        const int H = fft_size / 2;
+        const size_t lds = sizeof(double) * (2 * (size_t)fft_size + 2 * H + 2 * 2 * (H + 2) + 3 * (H + 2) + fft_size);
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)world_pulse_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+                return V100_ERR_LAUNCH;
+            attr = true;
+        }
+        int gx = max_pulses < 4096 ? max_pulses : 4096;
+        V100_GGL(world_pulse_f64_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), lds, st, pt, logN);
+    }
     // overlap-add reads idx / resp (pitch Pcap) and writes y (pitch Ymax)
     V100_GGL(world_overlap_add_kernel, dim3((unsigned)((Ymax + 255) / 256), (unsigned)B), dim3(256), 0, st, p);
     return v100_launch_status();

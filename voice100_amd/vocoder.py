@@ -168,8 +168,6 @@ class WORLDVocoder(nn.Module):
             raise ValueError("synthesize: give exactly one of ap / codeap")
         for t, nm in ((f0, "f0"), (spc, "spc"), (ap if ap is not None else codeap, "ap")):
             F_._check(t, "WORLDVocoder.synthesize " + nm)
-        if self.n_fft != 512:
-            raise RuntimeError("WORLDVocoder.synthesize: the device kernels are built for n_fft = 512 (16 kHz)")
         f0, spc = f0.contiguous(), spc.contiguous()
         B, T = f0.shape
         nb = self.n_fft // 2 + 1
@@ -184,7 +182,8 @@ class WORLDVocoder(nn.Module):
         ymax = int(T * self.frame_period * self.sample_rate / 1000)
         cap = int(ymax * max(float(f0_ceil), 500.0) / self.sample_rate) + 2
         dev = f0.device
-        tw_h, tw_f, dcr = self._synth_tables(dev)
+        # n_fft 512 (16 kHz): the fp32 wave-per-pulse kernel with its tables; other sizes (1024 at 22.05 kHz): the fp64 workgroup-per-pulse kernel
+        tw_h, tw_f, dcr = self._synth_tables(dev) if self.n_fft == 512 else (None, None, None)
         table = self._randn_table(ymax, dev)
         if frames is not None:
             frames = frames.to(device=dev, dtype=torch.int32).contiguous()
