@@ -218,3 +218,32 @@ def test_normalize_matches_reference_formula():
         std = torch.sqrt(((seg - mean) ** 2).mean(0, keepdim=True))
         assert torch.allclose(out[b, :n], (seg - mean) / (std + 1e-15), atol=1e-5)
         assert torch.count_nonzero(out[b, n:]) == 0
+
+
+def test_derived_tensor_cache_follows_versions_and_lifetimes():
+    """functional._derived (16-bit weight copies, re-laid-out matrices kept per parameter OBJECT): rebuilt when the parameter's version
+    counter moves -- which FusedAdam and the BatchNorm-updating forwards advance themselves (functional._touched), since their kernels
+    write through raw pointers --, never served to another tensor, dropped with the parameter."""
+    import gc
+    from voice100_amd import functional as F_
+    w = torch.nn.Parameter(torch.zeros(4, 4))
+    built = []
+
+    def build():
+        built.append(1)
+        return object()
+    a = F_._derived(w, "t", build)
+    assert F_._derived(w, "t", build) is a and len(built) == 1
+    assert F_._derived(w, "other tag", build) is not a and len(built) == 2
+    F_._touched([w])                                   # what optim.FusedAdam.step does after its kernel
+    b = F_._derived(w, "t", build)
+    assert b is not a and len(built) == 3
+    with torch.no_grad():
+        w.mul_(2.0)                                    # any in-place write through torch does the same
+    assert F_._derived(w, "t", build) is not b
+    w2 = torch.nn.Parameter(torch.zeros(4, 4))
+    assert F_._derived(w2, "t", build) is not b        # another object: its own entry
+    n = len(F_._DERIVED)
+    del w
+    gc.collect()
+    assert len(F_._DERIVED) == n - 2                   # both tags of the dead parameter are gone

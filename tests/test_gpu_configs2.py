@@ -170,3 +170,48 @@ def test_eval_models_run_outside_no_grad(cuda):
         warnings.simplefilter("ignore")
         out = a(text)
     assert out[2].shape == (2, 79, 257)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_eval_after_fused_training_sees_the_new_weights(cuda, precision):
+    """validate -> train -> validate, the ordinary loop: the eval-mode forwards keep folded BatchNorm coefficients and 16-bit weight copies
+    keyed on tensor VERSIONS, while FusedAdam and the training forwards write parameters / running statistics through raw pointers --
+    they must advance the counters themselves (functional._touched), or the second validation silently runs the first one's weights."""
+    import copy
+    from voice100_amd import functional as F_
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd.optim import FusedAdam
+    F_.set_matmul_precision(precision)
+    try:
+        torch.manual_seed(3)
+        model = AudioToTextCTC(audio_size=64, embed_size=64, vocab_size=29, hidden_size=64).to(cuda)
+        opt = FusedAdam(model.parameters(), lr=5e-2)
+        x = torch.randn(4, 200, 64, device=cuda)
+        xl = torch.tensor([200, 180, 150, 120], device=cuda)
+        y = torch.randint(1, 29, (4, 12), device=cuda)
+        yl = torch.tensor([12, 10, 9, 7], device=cuda)
+        model.eval()
+        with torch.no_grad():
+            before = model(x).clone()
+        versions = {n: t._version for n, t in list(model.named_parameters()) + list(model.named_buffers())}
+        model.train()
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = model._calc_batch_loss(((x, xl), (y, yl)))
+            loss.backward()
+            opt.step()
+        moved = [n for n, t in list(model.named_parameters()) + list(model.named_buffers()) if t._version == versions[n]]
+        assert not moved, f"version counters that did not advance: {moved[:5]}"
+        model.eval()
+        with torch.no_grad():
+            after = model(x).clone()
+        # the same weights in a FRESH model (no cache of any kind) give the reference for "after"
+        fresh = AudioToTextCTC(audio_size=64, embed_size=64, vocab_size=29, hidden_size=64).to(cuda)
+        fresh.load_state_dict(copy.deepcopy(model.state_dict()))
+        fresh.eval()
+        with torch.no_grad():
+            want = fresh(x)
+        assert rel_err(after, want) < 1e-6
+        assert rel_err(after, before) > 1e-3               # and training did move the output
+    finally:
+        F_.set_matmul_precision("fp32")

@@ -14,6 +14,7 @@ BatchNorm + ReLU6 are applied by the *consumer* while it loads its input:
       --pw GEMM (BN2+ReLU6 on load)--> a3 (+stats) --affine(+x)--> y
 """
 import ctypes
+import weakref
 import os
 from typing import Optional
 
@@ -130,6 +131,39 @@ class _Weights:
             N.call("v100_weight_prep", w2d, m, k, self.w_bf, self.wt, self.wt_bf)
 
 
+# Tensors DERIVED from a parameter -- 16-bit copies, re-laid-out matrices -- kept while the parameter object lives and its version
+# counter stands (an optimizer step, load_state_dict or any in-place write bumps it): an inference forward then launches no
+# weight-preparation kernel at all, a training step rebuilds exactly what it rebuilt before.  Keyed by the parameter OBJECT (weak
+# reference: a new tensor at a recycled address can never hit an old entry), one entry per (parameter, tag).
+_DERIVED = {}
+
+
+def _derived(w: torch.Tensor, tag, build):
+    key = (id(w), tag)
+    ent = _DERIVED.get(key)
+    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == w.data_ptr():
+        return ent[3]
+    val = build()
+    try:
+        ref = weakref.ref(w, lambda _r, k=key: _DERIVED.pop(k, None))
+    except TypeError:
+        return val
+    _DERIVED[key] = (ref, w._version, w.data_ptr(), val)
+    return val
+
+
+def _weights_of(w: torch.Tensor, rows: int, cols: int, fmt, transposed: bool) -> "_Weights":
+    """_Weights of the parameter w viewed as [rows, cols], through the derived-tensor cache."""
+    return _derived(w, ("w", rows, cols, int(fmt), bool(transposed)), lambda: _Weights(w.detach().reshape(rows, cols), fmt, transposed))
+
+
+def _touched(tensors) -> None:
+    """The library has written these module tensors (parameters, BatchNorm running statistics) through raw pointers: advance their autograd
+    version counters, which is what every cache keyed on `_version` (the folded eval coefficients, _derived) and autograd's own
+    saved-tensor checks rely on.  Host-side metadata only, no launch."""
+    torch.autograd.graph.increment_version(tensors)
+
+
 def _pw_gemm(a_f32, a_bf, x, y, m, k, t, b, bf16, x2=None, xa=None, xb=None, xc=None, x_mode=0, bias=None,
              ea=None, eb=None, r=None, epi=0, stats=None):
     N.call("v100_pw_gemm", a_f32, a_bf, x, x2, xa, xb, xc, x_mode, y, bias, ea, eb, r, epi, stats, b, m, k, t, int(bf16))
@@ -138,6 +172,7 @@ def _pw_gemm(a_f32, a_bf, x, y, m, k, t, b, bf16, x2=None, xa=None, xb=None, xc=
 def _bn_train(stats, parts, count, bn_w, bn_b, rm, rv, nbt, c, like):
     scale, shift, mean, rstd = (_f32(c, like=like) for _ in range(4))
     N.call("v100_bn_finalize_train", stats, parts, count, bn_w, bn_b, rm, rv, nbt, BN_MOMENTUM, BN_EPS, scale, shift, mean, rstd, c)
+    _touched((rm, rv, nbt))
     return scale, shift, mean, rstd
 
 
@@ -207,6 +242,7 @@ class InvertedResidualTrainFn(torch.autograd.Function):
             if not t.is_contiguous() or not t.is_cuda:
                 raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors")
         N.call("v100_ir_fwd_train", shape, _ptr_table(tensors))
+        _touched((rm1, rv1, nbt1, rm2, rv2, nbt2, rm3, rv3, nbt3))
         ctx.save_for_backward(x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, prep, x16 if x16 is not None else coef)
         ctx.has_x16 = x16 is not None
         ctx.shape = shape
@@ -327,6 +363,7 @@ class IRStackTrainFn(torch.autograd.Function):
         blob = torch.empty(totals[0], dtype=torch.uint8, device=x.device)
         ptab = (ctypes.c_void_p * (18 * n))(*[t.data_ptr() for t in params])
         N.call("v100_ir_stack_fwd_train", desc, ptab, x, x16, blob)
+        _touched([params[18 * i + j] for i in range(n) for j in (3, 4, 5, 9, 10, 11, 15, 16, 17)])     # the blocks' running statistics
         o = blocks[-1]
         cout, T2 = cfgs[-1][2], o[7]
         y = blob[o[3]:o[3] + 4 * B * cout * T2].view(torch.float32).view(B, cout, T2)
@@ -462,9 +499,8 @@ def prepare_block_weights(blocks, precision: Optional[str] = None) -> None:
     """bf16 / transposed copies of the two 1x1 weights of every InvertedResidual in `blocks`, in ONE launch
     (v100_ir_prep_batched), into slices of ONE freshly allocated buffer that the blocks' next forward hands to the
     executor and saves for its backward.  Called by the stacks (ConvVoiceEncoder, VoiceDecoder, ...) at the top of EVERY
-    training-mode forward: nothing is cached or overwritten across forwards (weights change under the optimiser, fused
-    optimiser kernels do not bump tensor versions, and a backward that runs after a later forward must still see the
-    copies of ITS forward).  A block that runs without this call prepares its own copies as before."""
+    training-mode forward: nothing is cached or overwritten across forwards (weights change under the optimiser, and a
+    backward that runs after a later forward must still see the copies of ITS forward).  A block that runs without this call prepares its own copies as before."""
     bf16 = _fmt(precision)
     _no_fp16_training(bf16, "InvertedResidual (training mode)")
     todo, total = [], 0
@@ -619,7 +655,7 @@ def pointwise_conv1d_cm(x: torch.Tensor, w: torch.Tensor, bias, precision: Optio
     cout, cin = w.shape[0], w.shape[1]
     n = x.shape[1]
     fmt = _fmt(precision)
-    W = _Weights(w.detach().reshape(cout, cin), fmt, False)
+    W = _weights_of(w, cout, cin, fmt, False)
     y = _f32(cout, n, like=x)
     _pw_gemm(W.w, W.w_bf, x, y, cout, cin, n, 1, fmt, bias=bias.detach() if bias is not None else None, epi=0)
     return y
@@ -662,7 +698,7 @@ class PointwiseConvFn(torch.autograd.Function):
         B, cin, T = x.shape
         cout = w.shape[0]
         bf16 = _fmt(precision)
-        W = _Weights(w.detach().reshape(cout, cin), bf16, False)
+        W = _weights_of(w, cout, cin, bf16, False)
         y = _f32(B, cout, T, like=x)
         _pw_gemm(W.w, W.w_bf, x, y, cout, cin, T, B, bf16, bias=bias.detach() if bias is not None else None, epi=0)
         ctx.save_for_backward(x, w)
@@ -678,7 +714,7 @@ class PointwiseConvFn(torch.autograd.Function):
         cout = w.shape[0]
         bf16 = ctx.bf16
         _no_fp16_training(bf16, "backward")
-        W = _Weights(w.detach().reshape(cout, cin), bf16, True)
+        W = _weights_of(w, cout, cin, bf16, True)
         S = N.helper("v100_pw_wgrad_splits", B, cout, cin)
         partial = _f32(S, cout, cin, like=x)
         dW = _f32(cout, cin, like=x)
@@ -885,8 +921,10 @@ class ConvTranspose1dK5S2Fn(torch.autograd.Function):
         B, cin, L = x.shape
         cout = w.shape[1]
         bf16 = _fmt(precision)
-        ae, ao = ConvTranspose1dK5S2Fn._mats(w)
-        We, Wo = _Weights(ae, bf16, False), _Weights(ao, bf16, False)
+        def _phase_weights():
+            ae, ao = ConvTranspose1dK5S2Fn._mats(w)
+            return _Weights(ae, bf16, False), _Weights(ao, bf16, False)
+        We, Wo = _derived(w, ("convt_fwd", int(bf16)), _phase_weights)
         ye, yo = _f32(B, cout, L, like=x), _f32(B, cout, L, like=x)
         tx = (L + 2 + 3) // 4 * 4
         # no tap-stacked copies: both phases read one zero-padded copy of x through the tap-addressed GEMM
@@ -1023,8 +1061,8 @@ class Conv1dDenseFn(torch.autograd.Function):
         if tout <= 0:
             raise RuntimeError("conv1d_dense: input shorter than the kernel")
         bf16 = _fmt(precision)
-        w2d = w.detach().permute(0, 2, 1).reshape(cout, k * cin).contiguous()       # [Cout][j*Cin + c]
-        W = _Weights(w2d, bf16, False)
+        W = _derived(w, ("dense_fwd", int(bf16)),
+                     lambda: _Weights(w.detach().permute(0, 2, 1).reshape(cout, k * cin).contiguous(), bf16, False))    # [Cout][j*Cin + c]
         y = _f32(B, cout, tout, like=x)
         bias_d = bias.detach() if bias is not None else None
         # "same" stride-1 convolutions skip the im2col copy: the GEMM reads a zero-padded copy of x once per tap

@@ -110,6 +110,9 @@ class FusedAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             N.call("v100_adam_step", t["chunks"], t["nchunks"], t["p"], t["g"], t["m"], t["v"], float(group["lr"]), float(b1), float(b2),
                    float(group["eps"]), float(group["weight_decay"]), t["step"])
+            # the kernel wrote the parameters through raw pointers: advance their version counters (host-side metadata), or everything
+            # keyed on them -- the eval-mode caches of folded coefficients / 16-bit weight copies -- would keep serving the old weights
+            torch.autograd.graph.increment_version(ps)
             t["step_tensor"] = torch.tensor(float(t["step"]))
             for p in ps:
                 self.state[p]["step"] = t["step_tensor"]
