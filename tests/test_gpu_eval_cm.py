@@ -132,3 +132,36 @@ def test_asr_eval_channel_major_model(cuda):
             assert m(long).shape == (1, 850, 29)
     finally:
         F_.set_matmul_precision("fp32")
+
+
+def test_graphed_forward_replays_the_eager_result(cuda):
+    """infer.GraphedForward: an eval-mode forward recorded as a HIP graph gives bit-identical results on new inputs of the recorded shape,
+    refuses other shapes, and works for a multi-output callable (predict)."""
+    from voice100_amd import functional as F_
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd.tts import AlignTextToAudioModel
+    from voice100_amd.infer import GraphedForward
+    F_.set_matmul_precision("bf16")
+    try:
+        torch.manual_seed(0)
+        m = AudioToTextCTC(64, 128, 29, 128).to(cuda).eval()
+        x = torch.rand(2, 256, 64, device=cuda)
+        g = GraphedForward(m, x)
+        for seed in (1, 2):
+            torch.manual_seed(seed)
+            xi = torch.rand(2, 256, 64, device=cuda)
+            with torch.no_grad():
+                want = m(xi)
+            assert torch.equal(g(xi), want)
+        with pytest.raises(RuntimeError):
+            g(torch.rand(2, 200, 64, device=cuda))
+        t = AlignTextToAudioModel(vocab_size=29, hidden_size=128, use_mcep=True).to(cuda).eval()
+        at = torch.randint(0, 29, (2, 40), device=cuda)
+        gp = GraphedForward(t.predict, at)
+        at2 = torch.randint(0, 29, (2, 40), device=cuda)
+        with torch.no_grad():
+            want = t.predict(at2)
+        got = gp(at2)
+        assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+    finally:
+        F_.set_matmul_precision("fp32")

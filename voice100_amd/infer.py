@@ -18,7 +18,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_indices", "scatter_run", "TTSPipeline", "ASRPipeline"]
+__all__ = ["shard_indices", "scatter_run", "TTSPipeline", "ASRPipeline", "GraphedForward"]
 
 
 def shard_indices(n_items: int, rank: int, world: int, mode: str = "contiguous") -> torch.Tensor:
@@ -167,3 +167,40 @@ class ASRPipeline:
         feats = self.mel(wav_or_mel) if self.mel is not None else wav_or_mel
         ids, n = ctc_greedy_decode(self.model(feats))
         return ids, n
+
+
+class GraphedForward:
+    """One eval-mode forward recorded as a HIP graph (torch.cuda.CUDAGraph) and replayed per call.
+
+    The small shapes are launch-bound, not GPU-bound: configs[0] (AudioToTextCTC on 2 x 256 frames) is ~30 launches of a few microseconds
+    each, so the host's per-launch cost IS the latency; a graph submits them as one unit.  Large batches gain nothing (the GPU is the
+    bottleneck there) and the training step is not capturable (its augmentation draws upload fresh host data every iteration).
+
+    fn: a callable of CUDA tensors whose shapes never change (a model in eval mode, `model.predict`, a pipeline without host read-backs);
+    example inputs fix the shapes.  Calls copy their arguments into the graph's static inputs and return the graph's static outputs --
+    OVERWRITTEN by the next call (clone what must survive).  Weights are read in place: an optimizer step or load_state_dict between calls
+    is seen by the next replay only if no derived copy is involved -- re-record after changing weights."""
+
+    def __init__(self, fn, *example: torch.Tensor, warmup: int = 3):
+        if not example or not all(isinstance(e, torch.Tensor) and e.is_cuda for e in example):
+            raise RuntimeError("GraphedForward: example inputs must be CUDA tensors")
+        self.static_in = [e.clone() for e in example]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(1, warmup)):            # one-time work (derived weight copies, plans, table uploads) happens here, not in the graph
+                fn(*self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.static_out = fn(*self.static_in)
+
+    def __call__(self, *args: torch.Tensor):
+        if len(args) != len(self.static_in):
+            raise TypeError(f"GraphedForward: expected {len(self.static_in)} inputs")
+        for dst, a in zip(self.static_in, args):
+            if a.shape != dst.shape or a.dtype != dst.dtype:
+                raise RuntimeError(f"GraphedForward: recorded for {tuple(dst.shape)} {dst.dtype}, got {tuple(a.shape)} {a.dtype} (record another graph)")
+            dst.copy_(a, non_blocking=True)
+        self.graph.replay()
+        return self.static_out
