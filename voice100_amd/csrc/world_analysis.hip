@@ -756,7 +756,7 @@ extern "C" int v100_world_dio(const float* x, const int* lengths, int B, int max
                               const double* nuttall, double* f0, void* workspace, void* stream) {
     if (!x || !lengths || !lowcut || !nuttall || !f0 || !workspace) return V100_ERR_NULL;
     DioPlan pl;
-    if (pitch < max_len || !dio_plan(B, max_len, fs, f0_floor, f0_ceil, channels_in_octave, frame_period_ms, &pl)) return V100_ERR_SHAPE;
+    if (pitch < max_len || B > 65535 || !dio_plan(B, max_len, fs, f0_floor, f0_ceil, channels_in_octave, frame_period_ms, &pl)) return V100_ERR_SHAPE;
     char* ws = (char*)workspace;
     DioParams p{};
     p.x = x; p.lengths = lengths; p.B = B; p.pitch = pitch; p.fs = fs;
@@ -789,7 +789,7 @@ extern "C" int v100_world_cheaptrick(const float* x, const int* lengths, const d
                                      double frame_period_ms, double q1, int fft_size, const double* randn_table, long long table_len,
                                      const double* twiddle, double* sp, float* logsp, double log_offset, long long* offsets, void* stream) {
     if (!x || !lengths || !f0 || !randn_table || !twiddle || !offsets || (!sp && !logsp)) return V100_ERR_NULL;
-    if (B <= 0 || max_len <= 0 || pitch < max_len || fs <= 0 || !(frame_period_ms > 0) || (fft_size != 512 && fft_size != 1024 && fft_size != 2048))
+    if (B <= 0 || B > 65535 || max_len <= 0 || pitch < max_len || fs <= 0 || !(frame_period_ms > 0) || (fft_size != 512 && fft_size != 1024 && fft_size != 2048))
         return V100_ERR_SHAPE;
     const int Tmax = dio_frames(fs, max_len, frame_period_ms);
     CtParams p{};
@@ -822,7 +822,7 @@ extern "C" int v100_world_d4c(const float* x, const int* lengths, const double* 
                               double threshold, int fft_size, const double* randn_table, long long table_len, const double* twiddle,
                               const double* nuttall, int window_length, double* ap, double* coded, float* coded32, void* workspace, void* stream) {
     if (!x || !lengths || !f0 || !randn_table || !twiddle || !nuttall || !workspace || (!ap && !coded && !coded32)) return V100_ERR_NULL;
-    if (B <= 0 || max_len <= 0 || pitch < max_len || fs <= 0 || !(frame_period_ms > 0) || fft_size < 4 || (fft_size & (fft_size - 1))) return V100_ERR_SHAPE;
+    if (B <= 0 || B > 65535 || max_len <= 0 || pitch < max_len || fs <= 0 || !(frame_period_ms > 0) || fft_size < 4 || (fft_size & (fft_size - 1))) return V100_ERR_SHAPE;
     const int F2 = (int)pow(2.0, 1.0 + (int)(log(4.0 * fs / kFloorF0D4C + 1) / 0.69314718055994529));
     const int FL = (int)pow(2.0, 1.0 + (int)(log(3.0 * fs / kLoveTrainF0 + 1) / 0.69314718055994529));
     const double lim = (fs / 2.0 - kFreqInterval) < 15000.0 ? (fs / 2.0 - kFreqInterval) : 15000.0;

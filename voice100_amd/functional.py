@@ -305,6 +305,8 @@ def unregister_grad_arena(a) -> None:
 
 def _grad_arena_for(weights, numel):
     """A registered buffer slice in which `weights` (the stack's trainable tensors, in its gradient order) lie back to back."""
+    if any(w.grad is not None for w in weights):
+        return None             # gradients are being ACCUMULATED (no begin_step since the last backward): the arena holds the running sum
     for a in _GRAD_ARENAS:
         buf = a.grad_arena(weights)
         if buf is not None and buf.numel() == numel:
