@@ -225,4 +225,11 @@ def test_random_speechlike_signals_agree_frame_for_frame(voc):
         assert np.abs(np.log(gs[i, :T]) - np.log(sp)).max() < 1e-6, i
         apo = wa.d4c(xd, f0, tp, FS, fft_size=512)
         assert np.abs(ga[i, :T] - apo).max() < 1e-8 and np.abs(gc[i, :T] - wa.code_aperiodicity(apo, FS)).max() < 1e-7, i
+        assert not g0[i, T:].any() and not gs[i, T:].any() and not ga[i, T:].any() and not gc[i, T:].any()     # ragged rows end in zeros
     assert voiced > 200
+    f0b, featb, capb = voc.encode_batch(batch.cuda(), lengths)
+    for i, x in enumerate(xs):
+        T = voc.frames(len(x))
+        a, b_, c = voc.encode(torch.from_numpy(x))
+        assert torch.equal(f0b[i, :T].cpu(), a) and torch.equal(featb[i, :T].cpu(), b_) and torch.equal(capb[i, :T].cpu(), c)
+        assert not featb[i, T:].any() and not capb[i, T:].any()

@@ -415,7 +415,13 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(CtParams p) {
     extern __shared__ double sh[];
     const int b = blockIdx.y, t = blockIdx.x, F = p.F, half = F / 2, fs = p.fs;
     const int len = p.lengths[b], T = dio_frames(fs, len, p.frame_period);
-    if (t >= T) return;
+    if (t >= T) {                            // beyond this utterance's frames (ragged batch): zero rows
+        for (int k = threadIdx.x; k <= half; k += blockDim.x) {
+            if (p.sp) p.sp[((long long)b * p.Tmax + t) * (half + 1) + k] = 0.0;
+            if (p.logsp) p.logsp[((long long)b * p.Tmax + t) * (half + 1) + k] = 0.f;
+        }
+        return;
+    }
     cd* buf = (cd*)sh;                       // F complex
     double* pw = sh + 2 * F;                 // half + 1 (+ pad)
     double* wbuf = pw + half + 8;            // F
@@ -537,10 +543,17 @@ __global__ __launch_bounds__(DT) void d4c_general_kernel(D4cParams p) {
     __shared__ double coarse[8];
     const int b = blockIdx.y, t = blockIdx.x, fs = p.fs, F2 = p.F2, h2 = F2 / 2, half = p.F / 2, nb = p.nb;
     const int len = p.lengths[b], T = dio_frames(fs, len, p.frame_period);
-    if (t >= T) return;
     const long long row = (long long)b * p.Tmax + t;
-    const double f = p.f0[row];
     double* apo = p.ap ? p.ap + row * (half + 1) : nullptr;
+    if (t >= T) {                             // beyond this utterance's frames (ragged batch): zero rows
+        for (int k = threadIdx.x; k <= half; k += blockDim.x) if (apo) apo[k] = 0.0;
+        if (threadIdx.x < nb) {
+            if (p.coded) p.coded[row * nb + threadIdx.x] = 0.0;
+            if (p.coded32) p.coded32[row * nb + threadIdx.x] = 0.f;
+        }
+        return;
+    }
+    const double f = p.f0[row];
     const bool voiced = f != 0.0 && p.ap0[row] > p.threshold;       // a NaN love-train value (table too short) stays unvoiced-coded as NaN below
     const bool bad = f != 0.0 && !(p.ap0[row] == p.ap0[row]);
     const double unv = 1.0 - kSafeMin;

@@ -333,7 +333,7 @@ class WORLDVocoder(nn.Module):
     @torch.no_grad()
     def encode_batch(self, x: torch.Tensor, lengths=None, f0_floor: float = 80.0, f0_ceil: float = 400.0):
         """encode() for a batch, everything left on the device: (f0 [B, T] fp32, features [B, T, D] fp32, codeap [B, T, nb] fp32);
-        rows beyond an utterance's own frames (frames(length)) hold unvoiced / default-F0 analysis of the padding."""
+        rows beyond an utterance's own frames (frames(length)) are zero (the mel-cepstrum of a zero row is zero too)."""
         x, lengths = self._wave_batch(x, lengths)
         f0 = self.dio(x, lengths, f0_floor=f0_floor, f0_ceil=f0_ceil)
         logspc = self.cheaptrick(x, f0, lengths, log=True)
