@@ -3,7 +3,7 @@ inference requests over the GPUs of a node (SURVEY.md 8e "Inference": replicas o
 
 Reference call sites this serves:
   * voice100/update_samples.py:30-90 -- text -> align model -> align() -> audio model predict -> vocoder glue, one batch
-    of sample sentences (here: `TTSPipeline`, every step up to the pyworld call on the GPU);
+    of sample sentences (here: `TTSPipeline`, every step INCLUDING the pyworld synthesis on the GPU: it ends in a waveform);
   * voice100/models/asr.py:110-116 -- AudioToTextCTC.forward over independent utterances / 1-second chunks
     (here: `ASRPipeline`, log-mel -> encoder -> logits -> greedy CTC ids);
   * BASELINE.json configs[4]: "streaming 1-second chunks at 16 kHz, 8 x MI355X" -- chunks are independent, so rank r of
@@ -105,7 +105,7 @@ def scatter_run(fn: Callable[..., Sequence[torch.Tensor]], inputs: Sequence[torc
 
 
 class TTSPipeline:
-    """BASELINE configs[2] end to end on the device (update_samples.py:46-84 up to the pyworld call):
+    """BASELINE configs[2] end to end on the device (update_samples.py:46-84, the pyworld synthesis included):
 
         text [B, L] int64, text_len [B]
           -> TextToAlignTextModel.forward                 [B, L, 2]  log(gap + 1), log(len + 1)        (tts.py:79-87)
