@@ -276,6 +276,20 @@ __device__ void fft_real_lds(cd* a, const double* r, int n, double scale_index, 
     fft_lds(a, logN, tw, logNT, false);
 }
 
+// real input r[0 .. n) (zero beyond) -> spectrum in a, one butterfly per thread, twiddles in registers (the D4C kernels: 2048 points, 1024 threads)
+template <int LOGN>
+__device__ void fft_real_lds_reg(cd* a, const double* r, int n, double scale_index, const cd (&twr)[LOGN]) {
+    const int N = 1 << LOGN;
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        double v = i < n ? r[i] : 0.0;
+        if (scale_index != 0.0) v *= (double)i + 1.0;
+        a[brev(i, LOGN)] = {v, 0.0};
+    }
+    __syncthreads();
+    fft_lds_reg<LOGN>(a, twr, false);
+}
+
 __device__ inline double interp1q(double x0, double dx, const double* y, int n, double xi) {
     const double pos = (xi - x0) / dx;
     int base = (int)pos;
@@ -498,6 +512,8 @@ __global__ __launch_bounds__(DT) void d4c_lovetrain_kernel(D4cParams p) {
     double* wav = sh + 2 * F2;
     double* wbuf = wav + F2;
     double* pw = wbuf + F2;
+    cd twr[11];
+    fft_twiddles_reg<11>(twr, p.tw);
     const double cf0 = f > kLoveTrainF0 ? f : kLoveTrainF0;
     const long long off = p.off_lt[(long long)b * p.Tmax + t];
     const int need = 2 * mround(3.0 * fs / cf0 / 2.0) + 1;
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(DT) void d4c_lovetrain_kernel(D4cParams p) {
     const float* x = p.x + (long long)b * p.pitch;
     const double position = (double)t * p.frame_period / 1000.0;
     const int nwin = windowed_waveform(x, len, fs, cf0, position, 2, 3.0, p.rnd + off, wav, wbuf, red);
-    fft_real_lds(buf, wav, nwin, 0.0, p.logF2, p.tw, p.logF2);
+    fft_real_lds_reg<11>(buf, wav, nwin, 0.0, twr);
     const int b0 = (int)ceil(100.0 * F2 / fs), b1 = (int)ceil(4000.0 * F2 / fs), b2 = (int)ceil(7900.0 * F2 / fs);
     for (int k = threadIdx.x; k <= F2 / 2; k += blockDim.x) pw[k] = k <= b0 ? 0.0 : buf[k].x * buf[k].x + buf[k].y * buf[k].y;
     __syncthreads();
@@ -519,22 +535,31 @@ __global__ __launch_bounds__(DT) void d4c_lovetrain_kernel(D4cParams p) {
     if (threadIdx.x == 0) *out = s1 / s2;
 }
 
-// ascending bitonic sort of a[0 .. 2^logn) in LDS
+// ascending bitonic sort of a[0 .. n) in LDS, n = blockDim.x: a thread keeps element tid in a register; partner distances below 64 are
+// lane exchanges inside a wave (45 of the 55 stages at n = 1024), the others go through LDS
 __device__ void bitonic_sort(double* a, int logn) {
-    const int n = 1 << logn;
+    const int n = 1 << logn, i = threadIdx.x;
     __syncthreads();
+    double v = i < n ? a[i] : 0.0;
     for (int k = 2; k <= n; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const double u = a[i], v = a[l];
-                    const bool up = (i & k) == 0;
-                    if ((u > v) == up) { a[i] = v; a[l] = u; }
-                }
+            double o;
+            if (j >= 64) {
+                __syncthreads();
+                if (i < n) a[i] = v;
+                __syncthreads();
+                o = i < n ? a[i ^ j] : 0.0;
+            } else {
+                o = __shfl_xor(v, j, 64);
             }
-            __syncthreads();
+            const bool lower = (i & j) == 0, up = (i & k) == 0;
+            // the lower index of a pair keeps the smaller value in an ascending merge (and the larger in a descending one)
+            const double lo = v < o ? v : o, hi = v < o ? o : v;
+            v = (lower == up) ? lo : hi;
         }
+    __syncthreads();
+    if (i < n) a[i] = v;
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(DT) void d4c_general_kernel(D4cParams p) {
@@ -576,6 +601,8 @@ __global__ __launch_bounds__(DT) void d4c_general_kernel(D4cParams p) {
     double* gd = pw + h2 + 8;                 // h2 + 8
     double* seg = gd + h2 + 8;                // D4C_SEG
     double* wbuf = tmpr;
+    cd twr[11];
+    fft_twiddles_reg<11>(twr, p.tw);
     const double cf0 = f > kFloorF0D4C ? f : kFloorF0D4C;
     const int nw4 = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
     const long long off = p.off_gb[row];
@@ -599,16 +626,16 @@ __global__ __launch_bounds__(DT) void d4c_general_kernel(D4cParams p) {
         for (int i = threadIdx.x; i < nwin; i += blockDim.x) pwr += wav[i] * wav[i];
         pwr = sqrt(block_sum(pwr, red));
         for (int i = threadIdx.x; i < nwin; i += blockDim.x) wav[i] = wav[i] / pwr;
-        fft_real_lds(buf, wav, nwin, 0.0, p.logF2, p.tw, p.logF2);
+        fft_real_lds_reg<11>(buf, wav, nwin, 0.0, twr);
         for (int k = threadIdx.x; k <= h2; k += blockDim.x) { tmpr[k] = buf[k].x; tmpi[k] = buf[k].y; }
-        fft_real_lds(buf, wav, nwin, 1.0, p.logF2, p.tw, p.logF2);
+        fft_real_lds_reg<11>(buf, wav, nwin, 1.0, twr);
         for (int k = threadIdx.x; k <= h2; k += blockDim.x) cen[k] += buf[k].x * tmpr[k] + tmpi[k] * buf[k].y;
     }
     dc_correction(cen, cf0, fs, F2, seg);
     // smoothed power spectrum: a Hanning window of four periods
     {
         const int nwin = windowed_waveform(x, len, fs, cf0, position, 1, 4.0, p.rnd + off + 2LL * nw4, wav, wbuf, red);
-        fft_real_lds(buf, wav, nwin, 0.0, p.logF2, p.tw, p.logF2);
+        fft_real_lds_reg<11>(buf, wav, nwin, 0.0, twr);
         for (int k = threadIdx.x; k <= h2; k += blockDim.x) pw[k] = buf[k].x * buf[k].x + buf[k].y * buf[k].y;
         dc_correction(pw, cf0, fs, F2, seg);
         linear_smoothing(pw, pw, seg, cf0, fs, F2, red);
@@ -629,7 +656,7 @@ __global__ __launch_bounds__(DT) void d4c_general_kernel(D4cParams p) {
             buf[brev(j, p.logF2)] = {v, 0.0};
         }
         __syncthreads();
-        fft_lds(buf, p.logF2, p.tw, p.logF2, false);
+        fft_lds_reg<11>(buf, twr, false);
         // power spectrum: bins 0 .. h2-1 are sorted (a power of two), the Nyquist bin is ranked into them
         const double extra = buf[h2].x * buf[h2].x + buf[h2].y * buf[h2].y;
         for (int k = threadIdx.x; k < h2; k += blockDim.x) tmpr[k] = buf[k].x * buf[k].x + buf[k].y * buf[k].y;
