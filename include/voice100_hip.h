@@ -102,6 +102,13 @@ int v100_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 /* backward: slab of (sum dz, sum dz*a) -> da = p*dz + q*a + r coefficients, dgamma, dbeta */
 int v100_bn_bwd_finalize(const float* partial, int parts, long long count, const float* gamma, const float* mean,
                          const float* rstd, float* p, float* q, float* r, float* dgamma, float* dbeta, int C, void* stream);
+/* FROZEN statistics under autograd (a block in eval() inside a training model: nn.BatchNorm1d normalises with the running statistics
+ * and back-propagates through that fixed affine, asr.py:36,52 in eval mode): frozen_coeffs = eval_coeffs plus (mean, rstd) = (running_mean,
+ * 1 / sqrt(running_var + eps)) for the backward; bwd_finalize_frozen: p = gamma * rstd, q = r = 0, dgamma / dbeta as in training. */
+int v100_bn_frozen_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                          float eps, float* scale, float* shift, float* mean, float* rstd, int C, void* stream);
+int v100_bn_bwd_finalize_frozen(const float* partial, int parts, long long count, const float* gamma, const float* mean,
+                                const float* rstd, float* p, float* q, float* r, float* dgamma, float* dbeta, int C, void* stream);
 
 /* ---- per-channel elementwise / layout glue --------------------------------------------------*/
 /* partial[g][c] = (sum u, sum u*v) over (b in group g, t); v NULL -> sum u*u */

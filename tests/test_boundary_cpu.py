@@ -197,12 +197,14 @@ def test_reference_keyed_checkpoint_loads_strict(tmp_path):
         assert torch.equal(v.reshape(-1), state[k].reshape(-1)), k
 
 
-def test_eval_block_refuses_autograd_input():
-    """Eval-mode blocks are inference-only: an input that wants a gradient raises instead of silently returning a constant."""
+def test_eval_block_with_autograd_has_no_cpu_path_either():
+    """An eval-mode block that takes part in autograd runs the differentiable frozen-statistics path -- on the GPU only, like everything
+    else: a CPU tensor is refused, not silently computed elsewhere or returned detached."""
     from voice100_amd.layers import InvertedResidual
     blk = InvertedResidual(8, 8, kernel_size=5).eval()
-    with pytest.raises(RuntimeError, match="inference-only"):
-        blk(torch.rand(1, 8, 16, requires_grad=True))
+    with pytest.warns(UserWarning, match="frozen-statistics"):
+        with pytest.raises(RuntimeError, match="GPU only"):
+            blk(torch.rand(1, 8, 16, requires_grad=True))
 
 
 def test_normalize_matches_reference_formula():

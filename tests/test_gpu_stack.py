@@ -7,6 +7,8 @@ import copy
 import pytest
 import torch
 
+from conftest import rel_err
+
 pytestmark = pytest.mark.gpu
 
 
@@ -101,10 +103,16 @@ def test_frozen_block_and_hooks_take_per_module_dispatch(cuda):
     y_rest = F_.ir_stack_train(list(enc2.layers)[1:], h)
     assert torch.allclose(y_rest, y, rtol=0, atol=0)
     assert all(p.grad is not None for p in enc.layers[1].parameters())
-    # a frozen block that would need a gradient is refused instead of silently detached
+    # a frozen block in the MIDDLE needs a gradient for what is upstream of it: it runs with frozen statistics and back-propagates
     enc.layers[3].eval()
-    with pytest.raises(RuntimeError, match="frozen-BatchNorm"):
-        enc(x)
+    mid = {k: v.clone() for k, v in enc.layers[3].named_buffers()}
+    enc.zero_grad()
+    with pytest.warns(UserWarning, match="frozen-statistics"):
+        enc(x).sum().backward()
+    for k, v in enc.layers[3].named_buffers():
+        assert torch.equal(v, mid[k]), k
+    assert all(p.grad is not None and p.grad.abs().sum() > 0 for p in enc.layers[1].parameters())      # upstream of it still learns
+    assert all(p.grad is not None for p in enc.layers[3].parameters())                                 # and so do its own parameters
     enc.layers[3].train()
     # forward hooks on an inner block fire (the stack path bypasses Module.__call__)
     seen = []
@@ -170,4 +178,58 @@ def test_level5_residual_stream_vs_level4(cuda):
         assert dot / (n4 * n5) > 0.97 and abs(n5 / n4 - 1.0) < 0.05
     finally:
         F_.set_activation_storage(keep)
+        F_.set_matmul_precision("fp32")
+
+
+@pytest.mark.parametrize("precision,tol,gtol", [("fp32", 2e-4, 2e-4), ("bf16", 3e-2, 1e-1)])
+@pytest.mark.parametrize("cfg", [(8, 8, 7, 1, True), (8, 16, 11, 2, False), (16, 16, 33, 1, True)])
+def test_frozen_statistics_block_matches_torch_autograd(cuda, precision, tol, gtol, cfg):
+    """block.eval() inside autograd (partial-freeze fine-tuning, asr.py:40-59 with nn.BatchNorm1d in eval mode): output, input gradient and
+    every parameter gradient against plain torch ops on the same parameters (voice100_amd/_stock.py is the aten restatement the tracer
+    uses: conv1d / batch_norm(training=False) / relu6), running statistics untouched."""
+    import warnings
+    from voice100_amd import _stock
+    from voice100_amd import functional as F_
+    from voice100_amd.layers import InvertedResidual
+    cin, cout, k, stride, res = cfg
+    F_.set_matmul_precision(precision)
+    try:
+        torch.manual_seed(11)
+        blk = InvertedResidual(cin, cout, kernel_size=k, stride=stride, use_residual=res).to(cuda)
+        with torch.no_grad():
+            for bn in (blk.conv[0][1], blk.conv[1][1], blk.conv[3]):
+                bn.running_mean.normal_(0, 0.3)
+                bn.running_var.uniform_(0.5, 2.0)
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_(0, 0.2)
+        blk.eval()
+        buffers = {n: b.clone() for n, b in blk.named_buffers()}
+        x = torch.randn(3, cin, 50, device=cuda, requires_grad=True)
+        xr = x.detach().clone().requires_grad_(True)
+        gy = None
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y = blk(x)
+        yr = _stock.inverted_residual(blk, xr)
+        assert y.shape == yr.shape and rel_err(y.detach(), yr.detach()) < tol
+        gy = torch.randn_like(yr)
+        y.backward(gy)
+        got = {n: p.grad.clone() for n, p in blk.named_parameters()}
+        blk.zero_grad()
+        yr.backward(gy)
+        # fp32: max-norm; bf16 (8-bit operands: a pre-activation within rounding of 0 or 6 flips its ReLU6 mask, one element of a
+        # gradient then differs by its whole value): L2-relative
+        def gerr(a, b):
+            if precision == "fp32":
+                return rel_err(a, b)
+            return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-12))
+        assert gerr(x.grad, xr.grad) < gtol
+        for n, p in blk.named_parameters():
+            assert gerr(got[n], p.grad) < gtol, n
+        for n, b in blk.named_buffers():
+            assert torch.equal(b, buffers[n]), n
+        # and the no_grad forward (inference kernels) gives the same values
+        with torch.no_grad():
+            assert rel_err(blk(x.detach()), yr.detach()) < tol
+    finally:
         F_.set_matmul_precision("fp32")

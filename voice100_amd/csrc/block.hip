@@ -125,6 +125,17 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
         CK(v100_weight_prep(w3, cout, hid, pw.w3bf, pw.w3t, pw.w3tbf, stream));
     }
     const int parts1 = v100_pw_num_parts(B, T), parts3 = v100_pw_num_parts(B, T2), G = v100_dw_num_groups(B, hid);
+    // PREPPED bit 3: FROZEN BatchNorm statistics (the block is in eval() but takes part in autograd): the same kernels with the running
+    // statistics in place of the batch's (nothing updated), on the fp32-storage path only (no fused finalisers to teach the mode to)
+    const bool frozen = (sh[IR_PREPPED] & 8) != 0;
+    if (frozen && sh[IR_ACT16]) return V100_ERR_SHAPE;
+    auto finalize = [&](const float* stats, int parts, long long count, int j, float* s_, float* t_, float* m_, float* r_, int C) -> int {
+        // j: first slot of this BatchNorm in the pointer table (gamma, beta, running_mean, running_var, num_batches_tracked)
+        if (frozen)
+            return v100_bn_frozen_coeffs((const float*)P[j], (const float*)P[j + 1], (const float*)P[j + 2], (const float*)P[j + 3], kEps, s_, t_, m_, r_, C, stream);
+        return v100_bn_finalize_train(stats, parts, count, (const float*)P[j], (const float*)P[j + 1], (float*)P[j + 2], (float*)P[j + 3],
+                                      (long long*)P[j + 4], kMom, kEps, s_, t_, m_, r_, C, stream);
+    };
     if (sh[IR_ACT16]) {
         if (!v100_ir_act16_supported(sh)) return V100_ERR_SHAPE;
         const void* x16 = (sh[IR_ACT16] >= 4 && (sh[IR_PREPPED] & 2)) ? P[26] : nullptr;
@@ -166,14 +177,11 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
         return V100_OK;
     }
     CK(v100_pw_gemm(w1, w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, a1, nullptr, nullptr, nullptr, nullptr, 1, st, B, hid, cin, T, bf, stream));
-    CK(v100_bn_finalize_train(st, parts1, (long long)B * T, (const float*)P[2], (const float*)P[3], (float*)P[4], (float*)P[5], (long long*)P[6],
-                              kMom, kEps, s1, t1, m1, r1, hid, stream));
+    CK(finalize(st, parts1, (long long)B * T, 2, s1, t1, m1, r1, hid));
     CK(v100_dwconv(a1, nullptr, wd, s1, t1, nullptr, 1, a2, nullptr, nullptr, nullptr, 0, st, G, B, hid, T, T2, K, S, pad, 0, 1, 0, stream));
-    CK(v100_bn_finalize_train(st, G, (long long)B * T2, (const float*)P[8], (const float*)P[9], (float*)P[10], (float*)P[11], (long long*)P[12],
-                              kMom, kEps, s2, t2, m2, r2, hid, stream));
+    CK(finalize(st, G, (long long)B * T2, 8, s2, t2, m2, r2, hid));
     CK(v100_pw_gemm(w3, w3bf, a2, nullptr, s2, t2, nullptr, 1, a3, nullptr, nullptr, nullptr, nullptr, 1, st, B, cout, hid, T2, bf, stream));
-    CK(v100_bn_finalize_train(st, parts3, (long long)B * T2, (const float*)P[14], (const float*)P[15], (float*)P[16], (float*)P[17], (long long*)P[18],
-                              kMom, kEps, s3, t3, m3, r3, cout, stream));
+    CK(finalize(st, parts3, (long long)B * T2, 14, s3, t3, m3, r3, cout));
     // a block that itself keeps fp32 storage (the stride-2 first layer) still emits the shadow its successor reads: the caller
     // passes P[27] only in bf16 precision at act16 level 4 (26 / 27 are not read otherwise)
     if (bf == 1 && (sh[IR_PREPPED] & 2) && P[27]) CK(v100_chan_affine2_shadow(a3, res ? x : nullptr, s3, t3, y, const_cast<void*>(P[27]), B, cout, T2, 0, stream));
@@ -239,6 +247,9 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     IrPrep pw;
     ir_prep_carve(sh, const_cast<void*>(P[23]), pw);
     (void)w1; (void)w3;
+    const bool frozen = (sh[IR_PREPPED] & 8) != 0;     // frozen BatchNorm statistics (see v100_ir_fwd_train): q = r = 0 in every coefficient set
+    if (frozen && sh[IR_ACT16]) return V100_ERR_SHAPE;
+    auto bwd_finalize = frozen ? v100_bn_bwd_finalize_frozen : v100_bn_bwd_finalize;
     // BN3 backward
     const int Gr = v100_dw_num_groups(B, cout);
     const bool a316 = sh[IR_ACT16] >= 3;              // a3 (saved) and da3 (workspace) stored as bf16
@@ -253,7 +264,7 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     } else {
         if (a316) CK(v100_chan_reduce2_io(dy, a3, w.part, Gr, B, cout, T2, 2, stream));
         else CK(v100_chan_reduce2(dy, a3, w.part, Gr, B, cout, T2, stream));
-        CK(v100_bn_bwd_finalize(w.part, Gr, (long long)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], cout, stream));
+        CK(bwd_finalize(w.part, Gr, (long long)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], cout, stream));
     }
     if (da3_done) {}
     else if (a316) CK(v100_chan_affine2_io(dy, a3, pp, qq, rr, w.da3, B, cout, T2, 6, stream));
@@ -298,11 +309,11 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
                      B, cout, hid, T2, bf, stream));
     const int parts = v100_pw_num_parts(B, T2);
     CK(v100_pw_gemm(pw.w3t, pw.w3tbf, w.da3, nullptr, nullptr, nullptr, nullptr, 0, w.dz2, nullptr, s2, t2, a2, 4, w.part, B, hid, cout, T2, bf, stream));
-    CK(v100_bn_bwd_finalize(w.part, parts, (long long)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], hid, stream));
+    CK(bwd_finalize(w.part, parts, (long long)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], hid, stream));
     // depthwise: weight grad, then data grad through ReLU6 with BN1-backward sums
     const int G = v100_dw_num_groups(B, hid);
     CK(v100_dwconv_bwd(w.dz2, a2, wd, pp, qq, rr, a1, s1, t1, w.dz1, w.part, w.slab, (float*)P[16], G, B, hid, T, T2, K, S, pad, 0, stream));
-    CK(v100_bn_bwd_finalize(w.part, G, (long long)B * T, g1, m1, r1, pp, qq, rr, (float*)P[14], (float*)P[15], hid, stream));
+    CK(bwd_finalize(w.part, G, (long long)B * T, g1, m1, r1, pp, qq, rr, (float*)P[14], (float*)P[15], hid, stream));
     // pw: weight grad, data grad (+ residual)
     CK(v100_pw_wgrad(w.dz1, a1, pp, qq, rr, 2, x, nullptr, nullptr, 0, w.slab, (float*)P[13], v100_pw_wgrad_splits(B, hid, cin),
                      B, hid, cin, T, bf, stream));

@@ -56,6 +56,23 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
     shift[c] = beta[c] - running_mean[c] * sc;
 }
 
+// FROZEN statistics under autograd (a block in eval() inside a model that trains: the reference's nn.BatchNorm1d then normalises with the
+// running statistics and back-propagates through that fixed affine): the forward coefficients plus the (mean, rstd) pair the backward
+// finaliser reads, all from the running statistics; nothing is updated.
+__global__ void bn_frozen_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                        float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                        float* __restrict__ mean, float* __restrict__ rstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rs = 1.0f / sqrtf(running_var[c] + eps);
+    const float sc = gamma[c] / sqrtf(running_var[c] + eps);          // exactly bn_eval_coeffs_kernel's value: eval and frozen-train forwards agree
+    scale[c] = sc;
+    shift[c] = beta[c] - running_mean[c] * sc;
+    mean[c] = running_mean[c];
+    rstd[c] = rs;
+}
+
 // Backward of y = gamma * (a - mean) * rstd + beta given the slab of (sum dz, sum dz*a):
 //   dgamma = rstd * (sum dz*a - mean * sum dz),  dbeta = sum dz
 //   da = p*dz + q*a + r   with  p = gamma*rstd,  q = -gamma*rstd^2 * dgamma/n,
@@ -63,7 +80,7 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int parts, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, float* __restrict__ p, float* __restrict__ q,
-                                       float* __restrict__ r, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+                                       float* __restrict__ r, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int frozen) {
     const int c = blockIdx.x;
     const int lane = threadIdx.x;
     double s0 = 0.0, s1 = 0.0;
@@ -77,8 +94,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int pa
     const double mu = mean[c], rs = rstd[c], ga = gamma[c];
     const double dg = rs * (s1 - mu * s0);
     const double pp = ga * rs;
-    const double qq = -ga * rs * rs * dg / count;
-    const double rr = -pp * s0 / count - qq * mu;
+    // frozen statistics: mean and rstd are constants, only the direct term is left (da = gamma * rstd * dz); dgamma / dbeta as above
+    const double qq = frozen ? 0.0 : -ga * rs * rs * dg / count;
+    const double rr = frozen ? 0.0 : -pp * s0 / count - qq * mu;
     p[c] = (float)pp;
     q[c] = (float)qq;
     r[c] = (float)rr;
@@ -590,7 +608,25 @@ extern "C" int v100_bn_bwd_finalize(const float* partial, int parts, long long c
     if (!partial || !gamma || !mean || !rstd || !p || !q || !r) return V100_ERR_NULL;
     if (C <= 0 || parts <= 0 || count <= 0) return V100_ERR_SHAPE;
     V100_GGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, parts, (double)count,
-                       gamma, mean, rstd, p, q, r, dgamma, dbeta, C);
+                       gamma, mean, rstd, p, q, r, dgamma, dbeta, C, 0);
+    return v100_launch_status();
+}
+
+extern "C" int v100_bn_bwd_finalize_frozen(const float* partial, int parts, long long count, const float* gamma, const float* mean,
+                                           const float* rstd, float* p, float* q, float* r, float* dgamma, float* dbeta, int C, void* stream) {
+    if (!partial || !gamma || !mean || !rstd || !p || !q || !r) return V100_ERR_NULL;
+    if (C <= 0 || parts <= 0 || count <= 0) return V100_ERR_SHAPE;
+    V100_GGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, parts, (double)count,
+                       gamma, mean, rstd, p, q, r, dgamma, dbeta, C, 1);
+    return v100_launch_status();
+}
+
+extern "C" int v100_bn_frozen_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                     float eps, float* scale, float* shift, float* mean, float* rstd, int C, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || !mean || !rstd) return V100_ERR_NULL;
+    if (C <= 0) return V100_ERR_SHAPE;
+    V100_GGL(bn_frozen_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, eps, scale, shift, mean, rstd, C);
     return v100_launch_status();
 }
 

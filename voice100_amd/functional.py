@@ -202,7 +202,10 @@ class InvertedResidualTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, wd, g2, b2, w3, g3, b3, rm1, rv1, nbt1, rm2, rv2, nbt2, rm3, rv3, nbt3,
-                kernel_size, stride, use_residual, precision, prep=None, x16=None, want_shadow=False):
+                kernel_size, stride, use_residual, precision, prep=None, x16=None, want_shadow=False, frozen=False):
+        # frozen: the block is in eval() but inside autograd (partial-freeze fine-tuning; an eval-mode model called without no_grad):
+        # BatchNorm normalises with its RUNNING statistics, updates nothing, and back-propagates through that fixed affine -- what
+        # nn.BatchNorm1d does in eval mode (asr.py:36,52).  Runs on the executor's fp32-storage path (shape[9] bit 3).
         _check(x, "InvertedResidual")
         x = x.contiguous()
         B, cin, T = x.shape
@@ -212,10 +215,10 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         bf16 = _fmt(precision)
         _no_fp16_training(bf16, "InvertedResidual (training mode)")
         # shape[9]: bit 0 = weights prepared by the stack, bit 1 = the pointer table carries the bf16-shadow slots (level 4)
-        shadows = bf16 == 1 and _ACT16 >= 4
+        shadows = bf16 == 1 and _ACT16 >= 4 and not frozen
         shape = (ctypes.c_int * 11)(B, cin, hid, cout, T, k, int(stride), int(bool(use_residual)), int(bf16),
-                                    int(prep is not None) | (2 if shadows else 0), 0)
-        if bf16 == 1 and _ACT16 and N.helper("v100_ir_act16_supported", shape):
+                                    int(prep is not None) | (2 if shadows else 0) | (8 if frozen else 0), 0)
+        if bf16 == 1 and _ACT16 and not frozen and N.helper("v100_ir_act16_supported", shape):
             shape[10] = _ACT16
             pitch = (T + 7) & ~7                       # bf16 rows are padded to a multiple of 8 samples (aligned 8 / 16-byte accesses)
             a1 = torch.empty((B, hid, pitch), dtype=torch.bfloat16, device=x.device)
@@ -242,7 +245,8 @@ class InvertedResidualTrainFn(torch.autograd.Function):
             if not t.is_contiguous() or not t.is_cuda:
                 raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors")
         N.call("v100_ir_fwd_train", shape, _ptr_table(tensors))
-        _touched((rm1, rv1, nbt1, rm2, rv2, nbt2, rm3, rv3, nbt3))
+        if not frozen:
+            _touched((rm1, rv1, nbt1, rm2, rv2, nbt2, rm3, rv3, nbt3))
         ctx.save_for_backward(x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, prep, x16 if x16 is not None else coef)
         ctx.has_x16 = x16 is not None
         ctx.shape = shape
@@ -277,7 +281,7 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         extra = (x16,) if (shape[9] & 2) else ()
         N.call("v100_ir_bwd", shape, _ptr_table((x, a1, a2, a3, w1, wd, w3, g1, g2, g3, coef, dy, dx) + tuple(parts) + (ws, prep) + extra))
         dW1, dg1, db1, dWd, dg2, db2, dW3, dg3, db3 = parts
-        return (dx, dW1.view_as(w1), dg1, db1, dWd.view_as(wd), dg2, db2, dW3.view_as(w3), dg3, db3) + (None,) * 16
+        return (dx, dW1.view_as(w1), dg1, db1, dWd.view_as(wd), dg2, db2, dW3.view_as(w3), dg3, db3) + (None,) * 17
 
 
 def _block_tensors(blk):
@@ -453,18 +457,11 @@ def ir_stack_train(blocks, x, precision: Optional[str] = None, segment: Optional
     """Training-mode forward of consecutive InvertedResidual modules through the stack executor.  `segment` = blocks per autograd
     node: None -> the whole run as one node in a single-process job, three blocks per node under data parallelism (the gradient
     buckets of the later blocks are then all-reduced while the earlier blocks' backward still runs, voice100_amd/dist.py).
-    Falls back to calling the modules one by one (what the reference's nn.Sequential does) when any block is in eval mode or
-    carries forward hooks."""
+    Falls back to calling the modules one by one (what the reference's nn.Sequential does) when any block is in eval mode
+    (partial-freeze fine-tuning: that block then runs with frozen BatchNorm statistics and still back-propagates) or carries forward hooks."""
     blocks = list(blocks)
     if not _stack_eligible(blocks):
-        for b in blocks:
-            if not b.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in b.parameters())):
-                # a frozen (eval-mode) block inside a training run: the reference back-propagates through its frozen BatchNorm; the
-                # eval-mode kernels here are inference-only, and handing back a detached result would silently cut every gradient
-                # upstream of the block (or the block's own, if its parameters still require grad)
-                raise RuntimeError("InvertedResidual in eval mode inside a training-mode stack needs a gradient (its input or its "
-                                   "parameters require grad): frozen-BatchNorm fine-tuning is not built.  Freeze it completely "
-                                   "(requires_grad_(False) on the block and on everything upstream), or keep it in train() mode")
+        for b in blocks:          # (an eval-mode block that takes part in autograd runs with FROZEN statistics: layers.InvertedResidual.forward)
             x = b(x)
         return x
     if segment is None:

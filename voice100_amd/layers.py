@@ -61,9 +61,9 @@ class InvertedResidual(nn.Module):
             raise ValueError("use_residual needs in_channels == out_channels and stride == 1")
 
     def train(self, mode: bool = True):
-        # Any train()/eval() switch drops the eval-mode cache (folded BatchNorm coefficients, bf16 weights): training
-        # updates parameters and running statistics through raw pointers / fused optimiser kernels, which do not bump
-        # the tensor versions the cache is keyed on.
+        # Any train()/eval() switch drops the eval-mode cache (folded BatchNorm coefficients, bf16 weights).  (The cache is keyed on
+        # tensor versions, which the fused optimiser and the training forwards advance themselves -- functional._touched; this is the
+        # belt to those braces.)
         self._eval_key = None
         return super().train(mode)
 
@@ -88,19 +88,27 @@ class InvertedResidual(nn.Module):
             if y16 is not None:
                 y._v100_shadow = (y16, y._version)
             return y
-        # eval mode: frozen statistics, inference only (autograd through eval-mode BN is not on the reference's training path
-        # and is not built).  The reference's inference scripts call model.eval(); model(x) without torch.no_grad(), and the
-        # embedding-fed models hand this block an x that requires grad (the table is a Parameter): that must keep working, so
-        # the result is returned detached.  Only an x the USER marked requires_grad (a leaf: somebody wants d/dx) is refused,
-        # instead of silently handing back a gradient-less constant.
-        if torch.is_grad_enabled() and x.requires_grad:
-            if x.is_leaf:
-                raise RuntimeError("InvertedResidual in eval mode is inference-only (frozen-BatchNorm fine-tuning is not "
-                                   "built): call it under torch.no_grad(), or switch the block to train()")
-            # (python's default warning filter shows this once per call site; every call warns so that a filter of "always" sees all)
-            warnings.warn("voice100_amd: eval-mode InvertedResidual called with autograd on; its output is DETACHED "
-                          "(inference only: nothing upstream of this block receives a gradient). Wrap inference in "
-                          "torch.no_grad() to silence this.", stacklevel=2)
+        # eval mode.  Without autograd (torch.no_grad(), or nothing that requires grad): the inference kernels -- BatchNorm folded into
+        # the three launches, 16-bit hidden tensors, cached coefficients.  WITH autograd the reference's block is an ordinary
+        # differentiable function of x and of its parameters whose BatchNorms use their running statistics (partial-freeze fine-tuning:
+        # block.eval() inside a training model; also every `model.eval(); model(x)` without no_grad, where the graph is built and
+        # thrown away): that runs the training executor with FROZEN statistics -- same values as the inference kernels up to rounding,
+        # gradients to x and to every parameter that requires one, nothing updated.  It is several times slower than the inference
+        # kernels, hence the warning: wrap inference in torch.no_grad().
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if prec == "fp16":
+                raise RuntimeError("InvertedResidual: precision 'fp16' is inference-only (no gradient kernels); call it under "
+                                   "torch.no_grad(), or use 'bf16' / 'fp32'")
+            warnings.warn("voice100_amd: eval-mode InvertedResidual called with autograd on: running the differentiable "
+                          "frozen-statistics path (training kernels, several times slower than the inference kernels). "
+                          "Wrap inference in torch.no_grad().", stacklevel=2)
+            y, _ = F_.InvertedResidualTrainFn.apply(
+                x, pw[0].weight, bn1.weight, bn1.bias, dw[0].weight, bn2.weight, bn2.bias, pl.weight, bn3.weight, bn3.bias,
+                bn1.running_mean, bn1.running_var, bn1.num_batches_tracked,
+                bn2.running_mean, bn2.running_var, bn2.num_batches_tracked,
+                bn3.running_mean, bn3.running_var, bn3.num_batches_tracked,
+                self.kernel_size, self.stride, self.use_residual, prec, None, None, False, True)
+            return y
         with torch.no_grad():
             return F_.inverted_residual_eval_cached(self, x.detach(), prec)
 
