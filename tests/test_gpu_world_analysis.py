@@ -233,3 +233,33 @@ def test_random_speechlike_signals_agree_frame_for_frame(voc):
         a, b_, c = voc.encode(torch.from_numpy(x))
         assert torch.equal(f0b[i, :T].cpu(), a) and torch.equal(featb[i, :T].cpu(), b_) and torch.equal(capb[i, :T].cpu(), c)
         assert not featb[i, T:].any() and not capb[i, T:].any()
+
+
+def test_edge_cases_short_inputs_and_extreme_f0(voc):
+    """One-frame inputs, inputs shorter than any analysis window, F0 contours at and beyond the estimators' floors and far above the
+    search range (the per-frame estimators accept any contour): against the oracle."""
+    rng = np.random.default_rng(9)
+    for n in (1, 37, 159, 160, 700):
+        x = (rng.standard_normal(n) * 0.1).astype(np.float32)
+        want, tp = wa.dio(x.astype(np.float64), FS, f0_floor=80.0, f0_ceil=400.0, frame_period=10.0)
+        got = voc.dio(torch.from_numpy(x).cuda(), f0_floor=80.0, f0_ceil=400.0)[0].cpu().numpy()
+        assert got.shape == want.shape == (n * 100 // FS + 1,) and np.array_equal(got, want), n
+        f0 = np.full(len(want), 123.0)
+        sp = wa.cheaptrick(x.astype(np.float64), f0, tp, FS, fft_size=512)
+        gs = voc.cheaptrick(torch.from_numpy(x).cuda(), torch.from_numpy(f0)[None].cuda())[0].cpu().numpy()
+        assert np.abs(np.log(gs) - np.log(sp)).max() < 1e-6, n
+        ap = wa.d4c(x.astype(np.float64), f0, tp, FS, fft_size=512)
+        ga, gc = voc.d4c(torch.from_numpy(x).cuda(), torch.from_numpy(f0)[None].cuda())
+        assert np.abs(ga[0].cpu().numpy() - ap).max() < 1e-8, n
+    x = harmonic_signal(0.6)
+    tp = np.arange(61) * 0.01
+    for f in (30.0, 40.0, 47.0, 60.0, 94.0, 95.0, 700.0, 1500.0):
+        f0 = np.full(61, f)
+        sp = wa.cheaptrick(x.astype(np.float64), f0, tp, FS, fft_size=512)
+        gs = voc.cheaptrick(torch.from_numpy(x).cuda(), torch.from_numpy(f0)[None].cuda())[0].cpu().numpy()
+        assert np.isfinite(gs).all() and np.abs(np.log(gs) - np.log(sp)).max() < 1e-6, f
+        ap = wa.d4c(x.astype(np.float64), f0, tp, FS, fft_size=512)
+        ga, gc = voc.d4c(torch.from_numpy(x).cuda(), torch.from_numpy(f0)[None].cuda())
+        ga = ga[0].cpu().numpy()
+        assert np.isfinite(ga).all() and np.abs(ga - ap).max() < 1e-8, f
+        assert np.abs(gc[0].cpu().numpy() - wa.code_aperiodicity(ap, FS)).max() < 1e-7, f
