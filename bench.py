@@ -250,14 +250,19 @@ def other_configs(device, N, F_):
         out["config3_chain_text_to_wave_B16_L128"] = {"ms": round(dt_w * 1e3, 3), "world_frames": wf, "audio_seconds": round(secs, 1),
                                                      "pulses": int(ow["n_pulses"].sum()), "x_realtime": round(secs / dt_w, 1),
                                                      "vocoder_ms": round((dt_w - dt_ch) * 1e3, 3)}
-        # ... and the way back (the dataset side of the same models, vocoder.py:61-87): WORLD ANALYSIS of those 16 waveforms on the
-        # device -- DIO + CheapTrick + D4C + aperiodicity coding + mcep GEMM, fp64 kernels (csrc/world_analysis.hip, parity unpinned)
-        wl = ow["wave_len"].clamp(min=1)
-        dt_an = timeit(lambda: voc.encode_batch(ow["wave"], wl))
-        an_f0 = voc.encode_batch(ow["wave"], wl)[0]
-        out["config3_world_analysis_B16"] = {"ms": round(dt_an * 1e3, 3), "audio_seconds": round(secs, 1), "x_realtime": round(secs / dt_an, 1),
+        # ... and the way back (the dataset side of the same models, vocoder.py:61-87): WORLD ANALYSIS on the device -- DIO + CheapTrick +
+        # D4C + aperiodicity coding + mcep GEMM, fp64 kernels (csrc/world_analysis.hip, parity unpinned) -- of 16 speech-like signals of
+        # 10.23 s (harmonics on a wandering F0 gated voiced / unvoiced over a noise floor; the untrained chain's own output is almost
+        # entirely unvoiced, which D4C skips)
+        from tools.bench_world_analysis import speechlike
+        sig = torch.from_numpy(np.stack([speechlike(10.23, 16000, s) for s in range(16)])).to(device)
+        dt_an = timeit(lambda: voc.encode_batch(sig))
+        an_f0 = voc.encode_batch(sig)[0]
+        secs_an = 16 * 10.23
+        out["config3_world_analysis_B16"] = {"ms": round(dt_an * 1e3, 3), "audio_seconds": round(secs_an, 1), "x_realtime": round(secs_an / dt_an, 1),
                                              "world_frames_per_s": round(an_f0.numel() / dt_an, 1), "dtype": "f64",
-                                             "voiced_frames": int((an_f0 > 0).sum()), "frames": int(an_f0.numel())}
+                                             "voiced_frames": int((an_f0 > 0).sum()), "frames": int(an_f0.numel()),
+                                             "input": "16 x 10.23 s synthetic speech-like signals (tools/bench_world_analysis.py)"}
         F_.set_matmul_precision("fp16")                 # config 5 names fp16
         mel = MelSpectrogramAudioTransform().to(device)
         B = 256

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(CtParams p) {
     float* lso = p.logsp ? p.logsp + ((long long)b * p.Tmax + t) * (half + 1) : nullptr;
     const int nwin_need = 2 * mround(1.5 * fs / cf0) + 1;
     const int bnd = (int)(cf0 * 2.0 / 3.0 * F / fs) + 1;                 // the smoothing's mirror margin must fit the spectrum and `seg`
-    if (off + nwin_need + half + 1 > p.rnd_len || nwin_need > F || 2 * bnd > F || !(cf0 > 0.0)) {       // fail loudly: NaN rows
+    if (off + nwin_need + half + 1 > p.rnd_len || nwin_need > F || 2 * bnd > F || 2 + (int)(cf0 * F / fs) > half || !(cf0 > 0.0)) {       // fail loudly: NaN rows
         for (int k = threadIdx.x; k <= half; k += blockDim.x) {
             if (spo) spo[k] = __builtin_nan("");
             if (lso) lso[k] = __builtin_nanf("");
