@@ -152,6 +152,14 @@ def _derived(w: torch.Tensor, tag, build):
     return val
 
 
+def clear_derived_cache() -> None:
+    """Drop every cached derived tensor (16-bit weight copies, re-laid-out matrices).  Needed only after writing parameters in a way that
+    bypasses autograd's version counter -- `w.data.copy_(...)`, a foreign kernel on `w.data_ptr()` -- ; everything that goes through torch
+    (optimizers, load_state_dict, nn.init under no_grad) or through this package's own kernels is seen without it.  (The eval-mode block
+    caches are dropped by module.train() / module.eval().)"""
+    _DERIVED.clear()
+
+
 def _weights_of(w: torch.Tensor, rows: int, cols: int, fmt, transposed: bool) -> "_Weights":
     """_Weights of the parameter w viewed as [rows, cols], through the derived-tensor cache."""
     return _derived(w, ("w", rows, cols, int(fmt), bool(transposed)), lambda: _Weights(w.detach().reshape(rows, cols), fmt, transposed))
