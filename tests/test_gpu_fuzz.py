@@ -2,6 +2,7 @@
 three operand precisions) against the CPU oracle: specialised and generic kernel sizes, both strides, tiny and ragged
 lengths, channel counts that are not tile multiples."""
 import random
+import warnings
 
 import pytest
 import torch
@@ -83,10 +84,15 @@ def test_block_eval_random_shapes_all_precisions(cuda):
         for prec, tol in (("fp32", 2e-4), ("bf16", 4e-2), ("fp16", 6e-3)):
             F_.set_matmul_precision(prec)
             try:
-                yd = md(x.to(cuda))
+                with torch.no_grad():
+                    yd = md(x.to(cuda))                   # the inference kernels
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    yg = md(x.to(cuda))                   # autograd on: the differentiable frozen-statistics path (fp16: detached inference)
             finally:
                 F_.set_matmul_precision("fp32")
             assert rel_err(yd, yr) < tol, (prec, cin, cout, k, stride, res, B, T)
+            assert rel_err(yg, yr) < tol and yg.requires_grad == (prec != "fp16"), (prec, cin, cout, k, stride, res, B, T)
 
 
 @pytest.mark.parametrize("precision,stride", [("fp32", 1), ("bf16", 1), ("fp32", 2)])

@@ -97,8 +97,15 @@ class InvertedResidual(nn.Module):
         # kernels, hence the warning: wrap inference in torch.no_grad().
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             if prec == "fp16":
-                raise RuntimeError("InvertedResidual: precision 'fp16' is inference-only (no gradient kernels); call it under "
-                                   "torch.no_grad(), or use 'bf16' / 'fp32'")
+                # the inference-only precision has no gradient kernels: an input whose gradient somebody asked for is refused, anything
+                # else (model.eval(); model(x) without no_grad) gets the inference result, DETACHED, with a warning
+                if x.requires_grad and x.is_leaf:
+                    raise RuntimeError("InvertedResidual: precision 'fp16' is inference-only (no gradient kernels); call it under "
+                                       "torch.no_grad(), or use 'bf16' / 'fp32'")
+                warnings.warn("voice100_amd: eval-mode InvertedResidual at precision 'fp16' called with autograd on; 'fp16' is "
+                              "inference-only, the output is DETACHED. Wrap inference in torch.no_grad().", stacklevel=2)
+                with torch.no_grad():
+                    return F_.inverted_residual_eval_cached(self, x.detach(), prec)
             warnings.warn("voice100_amd: eval-mode InvertedResidual called with autograd on: running the differentiable "
                           "frozen-statistics path (training kernels, several times slower than the inference kernels). "
                           "Wrap inference in torch.no_grad().", stacklevel=2)
