@@ -237,3 +237,24 @@ def test_synthesize_22k_fft1024_vs_oracle(cuda):
     # decode() as the reference's drop-in at this rate
     w = v.decode(torch.from_numpy(f0[0]), torch.log(torch.from_numpy(sp[0]) + 1e-15), torch.from_numpy(cod[0]))
     assert w.dtype == np.float64 and w.shape == (int(T * 10.0 * fs / 1000),) and np.isfinite(w).all()
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_synthesize_long_utterance_many_chunks(cuda, seed):
+    """25 s (40 chunks of the chained time base: the running phase handed from workgroup to workgroup, binade crossings up to 2^16, ties):
+    the pulse count and the waveform must still match the sequential float64 oracle."""
+    from voice100_amd.vocoder import WORLDVocoder
+    rng = np.random.RandomState(seed)
+    v = WORLDVocoder()
+    T = 2500
+    f0 = np.where(np.sin(np.arange(T) / 37.0 + rng.rand() * 6) > 0.3, 0.0, 80 + 250 * rng.rand() + 25 * np.sin(np.arange(T) / 6.0)).astype(np.float32)
+    if seed == 4:
+        f0[:] = np.where(f0 > 0, 200.0, 0.0)                 # constant voiced F0 / the unvoiced default: constant increments (tie stretches)
+    sp = _formant_sp(T, rng=rng).astype(np.float32)
+    cod = np.where(f0[:, None] > 0, -5 - 30 * rng.rand(T, 1), -0.3 * rng.rand(T, 1)).astype(np.float32)
+    y, n = v.synthesize(_dev(f0[None], cuda), _dev(sp[None], cuda), codeap=_dev(cod[None], cuda))
+    ap64 = W.decode_aperiodicity(cod.astype(np.float64), FS, N)
+    ref = W.synthesize_parts(f0.astype(np.float64), sp.astype(np.float64), ap64, FS, 10.0)
+    assert int(n[0]) == len(ref["idx"])
+    err = np.abs(y[0].double().cpu().numpy() - ref["y"]).max() / np.abs(ref["y"]).max()
+    assert err <= TOL, err

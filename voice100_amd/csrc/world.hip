@@ -23,6 +23,7 @@
 #include "common.h"
 #include "../../include/voice100_hip.h"
 #include "world_f64.h"
+#include <stdlib.h>
 
 namespace {
 constexpr int NF = 512, NH = 256, NB = 257;          // fft size, half, bins of the fp32 wave-per-pulse kernel (16 kHz)
@@ -243,6 +244,319 @@ __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
     }
     if (tid == 0) p.n_pulses[b] = s_base <= p.Pcap ? s_base : -1;       // -1: more pulses than the caller made room for
 }
+
+// 1b. the same time base with the chunks of an utterance on DIFFERENT workgroups (round 4, late): the only thing a chunk needs from
+// its predecessor is the exact running phase at its first sample -- one double -- and, for its slice of the pulse list, the number of
+// pulses before it -- one int.  Both travel down a chain of per-chunk mailboxes in global memory (value, then a flag with release /
+// acquire at agent scope: workgroups of one utterance may sit on different XCDs).  Chunk numbers are handed out by a per-utterance
+// ticket, so a chunk's predecessor is always held by a workgroup that is already running (no dependence on dispatch order).  What is on
+// the chain per chunk is the exact integer scan alone (~2 us); interpolation before it and wrap / detect / compact after it overlap
+// with the neighbours'.  A chunk in which the running sum crosses a power of two is scanned in two segments (ulp u before the crossing
+// sample, the reference's own fl(total + inc) AT it, ulp 2u after); exact ties and the first chunk (total < 1) take the one-lane loop.
+constexpr int TBC_CH = 8192, TBC_NFR = 128, TBC_NT = 1024;          // samples per chunk of the chained time base; contour frames staged per chunk
+struct TbChain { int* ticket; int* cflag; double* cval; int* nflag; int* nval; int nchunks; };
+
+#ifdef TBC_DEBUG
+__device__ long long g_tbc_dbg[8 * 64];
+#endif
+__global__ __launch_bounds__(TBC_NT) void world_timebase_chain_kernel(WorldParams p, TbChain ch) {
+    constexpr int CH = TBC_CH, NFR = TBC_NFR, NTH = TBC_NT, PER = CH / NTH, NW = NTH / 64, PL = NTH / 64;     // PL: per-thread sums a lane of the scanning wave takes
+    // s_tot[TI(j)]: one pad slot per PER entries, so that the scans' per-thread runs of PER consecutive samples (thread stride PER + 1 doubles)
+    // do not all start in the same banks; consecutive j stay consecutive.  j = 0 holds the previous chunk's last total.
+    __shared__ double s_tot[CH + 1 + (CH + 1) / PER + 1];
+#define TI(j) ((j) + ((j) / PER))
+    __shared__ double s_cf0[NFR], s_cv[NFR];
+    __shared__ double s_scan[NTH];
+    __shared__ int s_cnt[NW];
+    __shared__ int s_flag, s_chunk, s_first, s_base;
+    __shared__ double s_carry, s_tk;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = p.frames ? min(max(p.frames[b], 0), p.T) : p.T;
+    const int ylen = T > 0 ? world_ylen(T, p.frame_period_ms, p.fs) : 0;
+    if (tid == 0) s_chunk = atomicAdd(ch.ticket + b, 1);
+    __syncthreads();
+    const int c = s_chunk, c0 = c * CH;
+#ifdef TBC_DEBUG          /* -DTBC_DEBUG: wall-clock stamps of utterance 0's chunks (tools/tbc_timeline.py): how the 64-way bank conflict of the first version was found */
+#define TBC_STAMP(slot) if (tid == 0 && b == 0) g_tbc_dbg[c * 8 + (slot)] = wall_clock64()
+#else
+#define TBC_STAMP(slot)
+#endif
+    TBC_STAMP(0);
+    if (T < 2 || ylen < 2) {
+        if (c == 0 && tid == 0) p.n_pulses[b] = 0;
+        return;
+    }
+    if (c0 >= ylen) return;
+    const int n = min(CH, ylen - c0);
+    const bool last = c0 + n >= ylen;
+    const float* f0 = p.f0 + (size_t)b * p.T;
+    unsigned char* vuv = p.vuv + (size_t)b * p.Ymax;
+    int* idx = p.idx + (size_t)b * p.Pcap;
+    float* xs = p.xshift + (size_t)b * p.Pcap;
+    int* cflag = ch.cflag + (size_t)b * ch.nchunks;
+    double* cval = ch.cval + (size_t)b * ch.nchunks;
+    int* nflag = ch.nflag + (size_t)b * ch.nchunks;
+    int* nval = ch.nval + (size_t)b * ch.nchunks;
+    const double fp = p.frame_period, fs = (double)p.fs;
+    const double lowest = fs / (double)p.nf + 1.0;
+    auto cf0 = [&](int j) -> double {
+        if (j < T) { const double v = (double)f0[j]; return v < lowest ? 0.0 : v; }
+        const double a = (double)f0[T - 1], cc = (double)f0[T - 2];
+        return (a < lowest ? 0.0 : a) * 2 - (cc < lowest ? 0.0 : cc);
+    };
+    auto cvuv = [&](int j) -> double {
+        if (j < T) return ((double)f0[j] < lowest) ? 0.0 : 1.0;
+        return (((double)f0[T - 1] < lowest) ? 0.0 : 1.0) * 2 - (((double)f0[T - 2] < lowest) ? 0.0 : 1.0);
+    };
+    // ---- increments of this chunk (independent of every other chunk) ----
+    int kf = (int)(((double)c0 / fs) / fp) - 1;
+    if (kf < 0) kf = 0;
+    if (tid < NFR) {
+        const int j = kf + tid;
+        s_cf0[tid] = j <= T ? cf0(j) : 0.0;
+        s_cv[tid] = j <= T ? cvuv(j) : 0.0;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += NTH) {
+        const int i = c0 + j;
+        const double t = (double)i / fs;
+        int k = (int)(t / fp) + 1;
+        if (k < 1) k = 1;
+        if (k > T) k = T;
+        while (k > 1 && t < (double)(k - 1) * fp) --k;
+        while (k < T && t >= (double)k * fp) ++k;
+        const double x0 = (double)(k - 1) * fp, x1 = (double)k * fp;
+        const double sft = (t - x0) / (x1 - x0);
+        const int kw = min(max(k - 1 - kf, 0), NFR - 2);
+        const double fa = s_cf0[kw], fb = s_cf0[kw + 1], va = s_cv[kw], vb = s_cv[kw + 1];
+        double fi = fa + sft * (fb - fa);
+        const double vi = va + sft * (vb - va);
+        const bool voiced = vi > 0.5;
+        if (!voiced) fi = kDefaultF0;
+        vuv[i] = voiced ? 1 : 0;
+        s_tot[TI(1 + j)] = 2.0 * kPi * fi / fs;
+    }
+    TBC_STAMP(1);
+    // ---- the running phase at this chunk's first sample: from the predecessor's mailbox ----
+    if (tid == 0) {
+        double a0 = 0.0;
+        if (c > 0) {
+            // poll with RELAXED loads (an acquire per poll would invalidate this XCD's L2 each time, under everybody else's feet), one acquire
+            // fence once the flag is up
+            while (__hip_atomic_load(cflag + c - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            a0 = __hip_atomic_load(cval + c - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_carry = a0;
+        s_tot[TI(0)] = a0;
+        s_flag = 0;
+        s_first = n;                                      // first sample at which the sum has left the binade (n: none)
+    }
+    __syncthreads();
+    TBC_STAMP(2);
+    const double A0 = s_carry;
+    bool serial = !(A0 > 0.0) && c > 0;                  // (a non-positive running phase: degenerate input)
+    double u = 0.0, lim = 0.0;
+    // exact integer scan of rint(inc / unit) over samples [from, n) on top of `start`: s_tot[TI(1 + j)] = start + prefix * unit.  Returns
+    // (through s_flag) whether a tie was met; (through s_first) the first sample whose total is >= limit.
+    double incr[PER];                                     // this thread's run of increments, read once (the rounds below re-scan them)
+#pragma unroll
+    for (int e8 = 0; e8 < PER; ++e8) {
+        const int j = PER * tid + e8;
+        incr[e8] = j < n ? s_tot[TI(1 + j)] : 0.0;
+    }
+    auto scan = [&](int from, double start, double unit, double limit) {
+        const double inv = 1.0 / unit;
+        double loc[PER];
+        double sum = 0.0;
+        unsigned ties = 0;                                 // samples whose increment is EXACTLY half-way between two multiples of the unit
+#pragma unroll
+        for (int e8 = 0; e8 < PER; ++e8) {
+            const int j = PER * tid + e8;
+            double r = 0.0;
+            if (j >= from && j < n) {
+                const double q = incr[e8] * inv;
+                r = rint(q);
+                if (fabs(q - r) == 0.5) ties |= 1u << e8;
+            }
+            sum += r;
+            loc[e8] = sum;
+        }
+        s_scan[tid] = sum;
+        __syncthreads();
+        if (tid < 64) {
+            double v[PL];
+            double t4 = 0.0;
+#pragma unroll
+            for (int q = 0; q < PL; ++q) { v[q] = s_scan[PL * tid + q]; t4 += v[q]; }
+            double inc = t4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double up = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += up;
+            }
+            double ex = inc - t4;
+#pragma unroll
+            for (int q = 0; q < PL; ++q) { s_scan[PL * tid + q] = ex; ex += v[q]; }
+        }
+        __syncthreads();
+        const double base = s_scan[tid];
+        int firstbad = n;
+#pragma unroll
+        for (int e8 = 0; e8 < PER; ++e8) {
+            const int j = PER * tid + e8;
+            if (j >= from && j < n) {
+                const double v = start + (base + loc[e8]) * unit;
+                // a break point: the sum leaves the binade here, or this sample is a tie (round-half-even looks at the running sum's parity):
+                // everything BEFORE it is exact, the sample itself is added as the reference adds it, the scan restarts behind it
+                if ((!(v < limit) || ((ties >> e8) & 1u)) && j < firstbad) firstbad = j;
+                loc[e8] = v;
+            }
+        }
+        if (firstbad < n) atomicMin(&s_first, firstbad);
+        __syncthreads();
+        const int stop = s_first;
+#pragma unroll
+        for (int e8 = 0; e8 < PER; ++e8) {
+            const int j = PER * tid + e8;
+            if (j >= from && j < n && j < stop) s_tot[TI(1 + j)] = loc[e8];
+        }
+        __syncthreads();
+    };
+    // segments between the samples at which the running sum leaves its binade: each an exact integer scan; the crossing sample itself is
+    // added as the reference adds it (one fp64 addition).  The utterance's first sample starts from 0 (0 + inc is exact).
+    if (!serial || A0 == 0.0) {
+        serial = false;
+        int pos = 0;
+        double cur = A0;
+        if (cur == 0.0) {
+            // the utterance's first samples: the sum runs through a binade every few samples and most increments are ties at this
+            // scale -- one lane adds them in order until the sum has reached 64 (at most 512 samples), the segments take over from there
+            if (tid == 0) {
+                double acc = 0.0;
+                int j = 0;
+                const int m = n < 512 ? n : 512;
+                for (; j < m && acc < 64.0; ++j) { acc += s_tot[TI(1 + j)]; s_tot[TI(1 + j)] = acc; }
+                s_tk = acc;
+                s_first = j;
+            }
+            __syncthreads();
+            cur = s_tk;
+            pos = s_first;
+            __syncthreads();
+        }
+        int rounds = 0;
+        while (pos < n && !serial) {
+            if (++rounds > 96) { serial = true; break; }  // pathological contours (a tie on every sample of a long stretch): the one-lane loop
+            int e;
+            (void)frexp(cur, &e);
+            u = ldexp(1.0, e - 53);
+            lim = ldexp(1.0, e);
+            if (tid == 0) s_first = n;
+            __syncthreads();
+            scan(pos, cur, u, lim);
+            const int k = s_first;
+            if (k >= n) break;
+            if (tid == 0) {
+                s_tk = s_tot[TI(k)] + s_tot[TI(1 + k)];            // s_tot[TI(k)] = total of sample k - 1 (exact), s_tot[TI(1 + k)] still the increment
+                s_tot[TI(1 + k)] = s_tk;
+            }
+            __syncthreads();
+            cur = s_tk;
+            pos = k + 1;
+        }
+    }
+    if (serial) {
+        // one lane, in order.  The increments of samples the scans above already replaced by totals must be rebuilt: recompute nothing,
+        // re-derive from the contour (cheap: serial chunks are the first one and the rare ties)
+        __syncthreads();
+        for (int j = tid; j < n; j += NTH) {
+            const int i = c0 + j;
+            const double t = (double)i / fs;
+            int k = (int)(t / fp) + 1;
+            if (k < 1) k = 1;
+            if (k > T) k = T;
+            while (k > 1 && t < (double)(k - 1) * fp) --k;
+            while (k < T && t >= (double)k * fp) ++k;
+            const double x0 = (double)(k - 1) * fp, x1 = (double)k * fp;
+            const double sft = (t - x0) / (x1 - x0);
+            const int kw = min(max(k - 1 - kf, 0), NFR - 2);
+            double fi = s_cf0[kw] + sft * (s_cf0[kw + 1] - s_cf0[kw]);
+            const double vi = s_cv[kw] + sft * (s_cv[kw + 1] - s_cv[kw]);
+            if (!(vi > 0.5)) fi = kDefaultF0;
+            s_tot[TI(1 + j)] = 2.0 * kPi * fi / fs;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double acc = A0;
+            for (int j = 0; j < n; ++j) { acc += s_tot[TI(1 + j)]; s_tot[TI(1 + j)] = acc; }
+        }
+        __syncthreads();
+    }
+    TBC_STAMP(3);
+    // ---- hand the running phase on, then the work that nobody waits for ----
+    if (tid == 0 && !last) {
+        __hip_atomic_store(cval + c, s_tot[TI(n)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cflag + c, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int j = tid; j <= n; j += NTH) s_tot[TI(j)] = fmod(s_tot[TI(j)], 2.0 * kPi);      // in place: nobody needs the unwrapped phase any more
+    __syncthreads();
+    TBC_STAMP(4);
+    // crossings between samples i and i + 1, i = c0 - 1 + j (i >= 0): thread t owns the PER consecutive j of its run, so the pulse order
+    // is thread order: count, one workgroup scan, place behind the predecessors' pulses
+    unsigned hits = 0;
+#pragma unroll
+    for (int e8 = 0; e8 < PER; ++e8) {
+        const int j = PER * tid + e8, i = c0 - 1 + j;
+        if (j < n && i >= 0 && fabs(s_tot[TI(j + 1)] - s_tot[TI(j)]) > kPi) hits |= 1u << e8;
+    }
+    const int mine = __popc(hits);
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) s_cnt[wave] = inc;
+    __syncthreads();
+    int total = 0, mybase = inc - mine;
+    for (int w = 0; w < NW; ++w) {
+        if (w < wave) mybase += s_cnt[w];
+        total += s_cnt[w];
+    }
+    if (tid == 0) {
+        int before = 0;
+        if (c > 0) {
+            while (__hip_atomic_load(nflag + c - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            before = __hip_atomic_load(nval + c - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!last) {
+            __hip_atomic_store(nval + c, before + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(nflag + c, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            p.n_pulses[b] = before + total <= p.Pcap ? before + total : -1;
+        }
+        s_base = before;
+    }
+    __syncthreads();
+    int slot = s_base + mybase;
+#pragma unroll
+    for (int e8 = 0; e8 < PER; ++e8) {
+        if ((hits >> e8) & 1u) {
+            const int j = PER * tid + e8;
+            if (slot < p.Pcap) {
+                const double w0 = s_tot[TI(j)], w1 = s_tot[TI(j + 1)];
+                idx[slot] = c0 - 1 + j;
+                const double y1 = w0 - 2.0 * kPi;
+                xs[slot] = (float)(-y1 / (w1 - y1));
+            }
+            ++slot;
+        }
+    }
+    TBC_STAMP(5);
+}
+#undef TI
 
 // frame pair and interpolation weight of the pulse at sample `id` (GetSpectralEnvelope / GetAperiodicRatio: floor / ceil of the frame
 // position in double)
@@ -816,11 +1130,15 @@ extern "C" int v100_world_decode_aperiodicity(const float* coded, float* ap, lon
 static int world_ymax(int T, int fs, double frame_period_ms) { return (int)((double)T * frame_period_ms * (double)fs / 1000.0); }
 
 // bytes of the `workspace` argument of v100_world_synthesize
+#ifdef TBC_DEBUG
+extern "C" int v100_tbc_debug_read(long long* host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tbc_dbg), sizeof(long long) * 8 * 64) == hipSuccess ? 0 : 2; }
+#endif
 extern "C" long long v100_world_synth_workspace_bytes(int B, int T, int fs, double frame_period_ms, int fft_size, int max_pulses) {
     if (B <= 0 || T <= 0 || fs <= 0 || fft_size < 64 || fft_size > 2048 || (fft_size & (fft_size - 1)) || max_pulses <= 0 || frame_period_ms <= 0) return -1;
     const long long Y = (world_ymax(T, fs, frame_period_ms) + 63) & ~63LL;
     const long long Pc = (max_pulses + 63) & ~63LL;
-    return (long long)B * (Y + Pc * 4 + Pc * 4 + Pc * fft_size * 4) + 256;
+    const long long nch = (world_ymax(T, fs, frame_period_ms) + 2047) / 2048 + 1;          // time-base chain mailboxes (20 B per chunk; room for 2048-sample chunks) + tickets
+    return (long long)B * (Y + Pc * 4 + Pc * 4 + Pc * fft_size * 4) + 256 + (((long long)B * (4 + nch * 20) + 255) & ~255LL) + 256;
 }
 
 extern "C" int v100_world_synthesize(const float* f0, const float* sp, const float* ap, const float* coded_ap, int nb, const int* frames, const float* randn_table,
@@ -841,7 +1159,18 @@ extern "C" int v100_world_synthesize(const float* f0, const float* sp, const flo
     p.idx = (int*)w;                    w += (size_t)B * Pc * 4;
     p.xshift = (float*)w;               w += (size_t)B * Pc * 4;
     p.resp = (float*)w;                 w += (size_t)B * Pc * fft_size * 4;
-    p.vuv = (unsigned char*)w;
+    p.vuv = (unsigned char*)w;          w += (size_t)B * Y;
+    w = (char*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
+    const int nch = (Ymax + TBC_CH - 1) / TBC_CH + 1;
+    char* chain0 = w;
+    TbChain ch{};
+    ch.nchunks = nch;
+    ch.cval = (double*)w;               w += (size_t)B * nch * 8;
+    ch.cflag = (int*)w;                 w += (size_t)B * nch * 4;
+    ch.nflag = (int*)w;                 w += (size_t)B * nch * 4;
+    ch.nval = (int*)w;                  w += (size_t)B * nch * 4;
+    ch.ticket = (int*)w;                w += (size_t)B * 4;
+    const size_t chain_bytes = (size_t)(w - chain0);
     p.B = B; p.T = T; p.fs = fs; p.Ymax = Ymax; p.Pcap = (int)Pc;
     p.frame_period = frame_period_ms / 1000.0; p.frame_period_ms = frame_period_ms;
     p.tw256 = tw256; p.tw512 = tw512; p.dcr = dc_remover; p.nf = fft_size;
@@ -850,7 +1179,13 @@ extern "C" int v100_world_synthesize(const float* f0, const float* sp, const flo
     hipStream_t st = (hipStream_t)stream;
     WorldParams pt = p;
     pt.Ymax = (int)Y;                   // workspace rows are Y long; y rows are Ymax long (kernels 1 and 2 only touch the workspace)
-    V100_GGL(world_timebase_kernel, dim3((unsigned)B), dim3(256), 0, st, pt);
+    static const bool tb_serial_env = []() { const char* e = getenv("V100_WORLD_TB_SERIAL"); return e && e[0] == '1'; }();     // A/B: one workgroup per utterance
+    const bool tb_serial = tb_serial_env || (double)TBC_CH / ((double)fs * frame_period_ms / 1000.0) + 4.0 > (double)TBC_NFR;     // a chunk's contour window must fit
+    if (tb_serial) V100_GGL(world_timebase_kernel, dim3((unsigned)B), dim3(256), 0, st, pt);
+    else {
+        if (hipMemsetAsync(chain0, 0, chain_bytes, st) != hipSuccess) return V100_ERR_LAUNCH;
+        V100_GGL(world_timebase_chain_kernel, dim3((unsigned)((Ymax + TBC_CH - 1) / TBC_CH), (unsigned)B), dim3(TBC_NT), 0, st, pt, ch);
+    }
     if (fft_size == NF) {
         int gx = (max_pulses + 3) / 4;
         if (gx > 2048) gx = 2048;
