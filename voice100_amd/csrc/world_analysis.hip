@@ -227,36 +227,52 @@ __global__ __launch_bounds__(NT) void dio_fix_kernel(DioParams p, double* s1) {
     }
     __syncthreads();
     const int center = (vrm - 1) / 2;
+    // steps 2-4 on an LDS copy of the contour when it fits (<= 4096 frames = 41 s at 10 ms): the section growing below is one lane walking
+    // the contour, and dependent global loads cost it ~0.3 us a frame
+    extern __shared__ double fix_lds[];
+    const bool in_lds = p.Tmax <= 4096;             // (the launcher sizes the LDS by Tmax)
+    double* w = in_lds ? fix_lds : f0;
+    int* neg = in_lds ? (int*)(fix_lds + T) : p.negi + (long long)b * p.Tmax;
+    int* pos = in_lds ? neg + T / 2 + 2 : p.posi + (long long)b * p.Tmax;
+    // ... and the candidates of every band beside it when they fit too (each frame a section grows by reads one candidate per band)
+    const bool cand_lds = in_lds && (long long)p.nbands * p.Tmax * 8 <= 96 * 1024;
+    if (cand_lds) {
+        double* sc = (double*)(((uintptr_t)(pos + T / 2 + 2) + 7) & ~(uintptr_t)7);
+        for (int i = threadIdx.x; i < p.nbands * p.Tmax; i += NT) sc[i] = cand[i];
+        cand = sc;
+    }
     for (int i = threadIdx.x; i < T; i += NT) {
         double v = a[i];
         if (i >= center && i < T - center)
             for (int j = -center; j <= center; ++j)
                 if (a[i + j] == 0.0) { v = 0.0; break; }
-        f0[i] = v;                                             // step 2 (the best contour is not needed any more)
+        w[i] = v;                                              // step 2 (the best contour is not needed any more)
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int* neg = p.negi + (long long)b * p.Tmax;
-        int* pos = p.posi + (long long)b * p.Tmax;
         int nneg = 0, npos = 0;
         for (int i = 1; i < T; ++i) {
-            if (f0[i] == 0.0 && f0[i - 1] != 0.0) neg[nneg++] = i - 1;
-            else if (f0[i - 1] == 0.0 && f0[i] != 0.0) pos[npos++] = i;
+            if (w[i] == 0.0 && w[i - 1] != 0.0) neg[nneg++] = i - 1;
+            else if (w[i - 1] == 0.0 && w[i] != 0.0) pos[npos++] = i;
         }
         for (int i = 0; i < nneg; ++i) {
             const int limit = i == nneg - 1 ? T - 1 : neg[i + 1];
             for (int j = neg[i]; j < limit; ++j) {
-                f0[j + 1] = dio_select_best(f0[j], f0[j - 1], cand, p.nbands, p.Tmax, j + 1, p.allowed_range);
-                if (f0[j + 1] == 0.0) break;
+                w[j + 1] = dio_select_best(w[j], w[j - 1], cand, p.nbands, p.Tmax, j + 1, p.allowed_range);
+                if (w[j + 1] == 0.0) break;
             }
         }
         for (int i = npos - 1; i >= 0; --i) {
             const int limit = i == 0 ? 1 : pos[i - 1];
             for (int j = pos[i]; j > limit; --j) {
-                f0[j - 1] = dio_select_best(f0[j], f0[j + 1], cand, p.nbands, p.Tmax, j - 1, p.allowed_range);
-                if (f0[j - 1] == 0.0) break;
+                w[j - 1] = dio_select_best(w[j], w[j + 1], cand, p.nbands, p.Tmax, j - 1, p.allowed_range);
+                if (w[j - 1] == 0.0) break;
             }
         }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += NT) f0[i] = w[i];
     }
 }
 
@@ -815,7 +831,16 @@ extern "C" int v100_world_dio(const float* x, const int* lengths, int B, int max
     V100_GGL(dio_band_kernel, dim3((pl.ylen + NT - 1) / NT, pl.nbands, B), dim3(NT), sizeof(double) * (NT + pl.npitch), st, p);
     V100_GGL(dio_events_kernel, dim3(4, pl.nbands, B), dim3(NT), 0, st, p);
     V100_GGL(dio_candidates_kernel, dim3((pl.Tmax + NT - 1) / NT, B), dim3(NT), 0, st, p);
-    V100_GGL(dio_fix_kernel, dim3(B), dim3(NT), 0, st, p, (double*)(ws + pl.o_s1));
+    // LDS: the contour + the two section lists when an utterance has <= 4096 frames (else the kernel works in global memory)
+    const int tl = pl.Tmax <= 4096 ? pl.Tmax : 0;
+    size_t fix_lds = tl ? sizeof(double) * tl + sizeof(int) * (2 * (tl / 2 + 2)) + 32 : 0;
+    if (tl && (long long)pl.nbands * pl.Tmax * 8 <= 96 * 1024) fix_lds += sizeof(double) * (size_t)pl.nbands * pl.Tmax;
+    static bool fix_attr = false;
+    if (!fix_attr) {
+        if (hipFuncSetAttribute((const void*)dio_fix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return V100_ERR_LAUNCH;
+        fix_attr = true;
+    }
+    V100_GGL(dio_fix_kernel, dim3(B), dim3(NT), fix_lds, st, p, (double*)(ws + pl.o_s1));
     return v100_launch_status();
 }
 
