@@ -263,3 +263,25 @@ def test_edge_cases_short_inputs_and_extreme_f0(voc):
         ga = ga[0].cpu().numpy()
         assert np.isfinite(ga).all() and np.abs(ga - ap).max() < 1e-8, f
         assert np.abs(gc[0].cpu().numpy() - wa.code_aperiodicity(ap, FS)).max() < 1e-7, f
+
+
+def test_device_on_the_references_own_world_synthesised_sample(voc):
+    """The reference's docs/sample-en-1.wav (tests/golden/README.md: real pyworld-synthesised speech, int16): device == oracle frame for frame on
+    it, and the device's own analysis -> synthesis keeps length and level."""
+    import os
+    import wave
+    w = wave.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_docs_sample_en_1.wav"))
+    x = (np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0)
+    xd = x.astype(np.float64)
+    f0, tp = wa.dio(xd, FS, f0_floor=80.0, f0_ceil=400.0, frame_period=10.0)
+    g0 = voc.dio(torch.from_numpy(x).cuda(), f0_floor=80.0, f0_ceil=400.0)
+    assert np.array_equal(g0[0].cpu().numpy() > 0, f0 > 0) and np.abs(g0[0].cpu().numpy() - f0).max() < 1e-7
+    sp = wa.cheaptrick(xd, f0, tp, FS, fft_size=512)
+    gs = voc.cheaptrick(torch.from_numpy(x).cuda(), g0)[0].cpu().numpy()
+    assert np.abs(np.log(gs) - np.log(sp)).max() < 1e-6
+    ap = wa.d4c(xd, f0, tp, FS, fft_size=512)
+    ga, gc = voc.d4c(torch.from_numpy(x).cuda(), g0)
+    assert np.abs(ga[0].cpu().numpy() - ap).max() < 1e-8
+    a, b, c = voc.encode(torch.from_numpy(x))
+    y = voc.decode(a[:718], b[:718], c[:718])
+    assert len(y) == len(x) and 0.8 < np.abs(y).max() / np.abs(x).max() < 1.25

@@ -133,3 +133,48 @@ def test_randn_stream_is_consumed_in_order():
     assert np.isfinite(a).all() and (a > 0).all() and a.max() < 1e-10
     b = wa.cheaptrick(x * 0, f0, tp, FS, fft_size=512)
     assert np.array_equal(a, b)
+
+
+def _reference_sample():
+    import os
+    import wave
+    w = wave.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_docs_sample_en_1.wav"))
+    assert w.getframerate() == FS and w.getnchannels() == 1 and w.getsampwidth() == 2
+    return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float64) / 32768.0
+
+
+def test_on_the_references_own_world_synthesised_sample():
+    """tests/golden/ref_docs_sample_en_1.wav is a waveform pyworld.synthesize produced in the reference's TTS chain (docs/sample-en-1.wav): the one
+    artefact of pyworld's arithmetic in the image.  It pins three conventions of the SYNTHESIS restatement outright -- the output length
+    int(T * frame_period * fs / 1000) (a whole number of 160-sample frames); the PHASE of the time base and the placement of a response: an
+    utterance that starts unvoiced pulses at the 500 Hz default, its first pulse sits at sample 30 and its (causal, minimum-phase) response
+    begins at sample 31 -- exactly 31 zero samples lead the reference's file, and exactly 31 lead the oracle's output; and, through the round
+    trip, the LEVEL convention between CheapTrick's power spectrum and the synthesiser (a factor of 2 or of fft_size anywhere would move the
+    re-synthesised peak) -- and everything else must at least make sense of real WORLD speech: a plausible, continuous F0, low aperiodicity at
+    1 kHz rising towards Nyquist, and a stable analysis -> synthesis -> analysis loop."""
+    x = _reference_sample()
+    assert len(x) % 160 == 0 and len(x) // 160 == 718
+    assert not x[:31].any() and x[31] != 0
+    r = ws.synthesize_parts(np.zeros(20), np.full((20, 257), 1e-4), np.full((20, 257), 1 - 1e-12), FS, 10.0)
+    peak = np.abs(r["y"]).max()
+    assert r["idx"][0] == 30 and np.abs(r["y"][:31]).max() < 1e-12 * peak and abs(r["y"][31]) > 1e-2 * peak      # (round-off before it)
+    f0, tp = wa.dio(x, FS, f0_floor=80.0, f0_ceil=400.0, frame_period=10.0)
+    assert len(f0) == 719                                     # dio: one more frame than the synthesiser consumed
+    v = f0 > 0
+    assert 0.4 < v.mean() < 0.75 and 150.0 < np.median(f0[v]) < 300.0
+    d = np.abs(np.diff(f0))[v[1:] & v[:-1]]
+    assert np.median(d) < 6.0 and d.max() < 45.0              # allowed_range = 10 % per frame
+    sp = wa.cheaptrick(x, f0, tp, FS, fft_size=512)
+    ap = wa.d4c(x, f0, tp, FS, fft_size=512)
+    apv = ap[v]
+    assert apv[:, 32].mean() < 0.1 < apv[:, 96].mean() < apv[:, 192].mean() < 0.9      # 1 kHz, 3 kHz, 6 kHz
+    assert np.isclose(apv[:, 0], 1 - 1e-12).mean() < 0.1      # the love-train check keeps almost every DIO-voiced frame
+    y = ws.synthesize(f0[:718], sp[:718], ap[:718], FS, 10.0)
+    assert len(y) == len(x)
+    assert 0.8 < np.abs(y).max() / np.abs(x).max() < 1.25     # level convention
+    f0b, tpb = wa.dio(y, FS, f0_floor=80.0, f0_ceil=400.0, frame_period=10.0)
+    both = v & (f0b > 0)
+    assert both.sum() > 0.9 * v.sum() and np.median(np.abs(f0[both] - f0b[both])) < 3.0
+    spb = wa.cheaptrick(y, f0b, tpb, FS, fft_size=512)
+    dd = 10 * np.log10(spb[both][:, :200]) - 10 * np.log10(sp[both][:, :200])
+    assert abs(dd.mean()) < 1.5 and np.sqrt((dd ** 2).mean()) < 4.0
