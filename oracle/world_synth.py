@@ -1,11 +1,17 @@
-"""WORLD synthesis restatement (float64 numpy).  TEST INFRASTRUCTURE -- PARITY UNPINNED.
+"""WORLD synthesis restatement (float64 numpy).  TEST INFRASTRUCTURE -- PARITY PARTIALLY PINNED (no input/output vector; see below).
 
 Reference call site: voice100/vocoder.py:89-102 --
     ap = pyworld.decode_aperiodicity(codeap, sample_rate, n_fft)
     waveform = pyworld.synthesize(f0, spc, ap, sample_rate, frame_period=frame_period)
 The arithmetic lives in pyworld 0.3.2 (poetry.lock: pyworld 0.3.2, a Cython wrapper over M. Morise's C++ WORLD library), which is
-NOT in the reference tree and not in this image, and no pyworld output exists here: nothing in this file has ever met a WORLD
-output.  It restates the published algorithm --
+NOT in the reference tree and not in this image, and no input/output pair of pyworld exists here.  What does exist are the reference's own
+docs samples -- waveforms its TTS chain synthesised with pyworld -- and they pin part of this file (tests/golden/README.md,
+tests/test_oracle_world_analysis.py): the output length; the time base's phase and the response placement (an unvoiced start pulses at the
+500 Hz default from sample 30, the first response begins at sample 31: the reference's files lead with exactly 31 zeros, as does this
+restatement); and the whole NOISE path -- WORLD's xorshift randn, burst per pulse, mean removal, minimum-phase colouring, fftshift and
+overlap-add -- because a re-synthesis from an analysis of those files reproduces their unvoiced lead-in sample by sample (correlation
+0.93 - 0.98 per 20-ms window; any other generator / alignment gives ~0).  The PERIODIC path (fractional-delay pulse, DC removal) and the
+exact F0-to-pulse arithmetic beyond the default rate have no such witness.  The file restates the published algorithm --
   * M. Morise, F. Yokomori, K. Ozawa, "WORLD: a vocoder-based high-quality speech synthesis system for real-time applications",
     IEICE Trans. Inf. & Syst. E99-D(7), 2016 (synthesis: excitation pulses at the F0-derived instants, a minimum-phase response
     per pulse from the spectral envelope, periodic + aperiodic parts, overlap-add);

@@ -285,3 +285,21 @@ def test_device_on_the_references_own_world_synthesised_sample(voc):
     a, b, c = voc.encode(torch.from_numpy(x))
     y = voc.decode(a[:718], b[:718], c[:718])
     assert len(y) == len(x) and 0.8 < np.abs(y).max() / np.abs(x).max() < 1.25
+
+
+@pytest.mark.parametrize("name,windows", [("ref_docs_sample_ja_1_head.wav", 3), ("ref_docs_sample_en_2_head.wav", 1)])
+def test_device_reproduces_the_reference_samples_unvoiced_lead_in(voc, name, windows):
+    """tests/test_oracle_world_analysis.py::test_unvoiced_lead_in_... on the DEVICE: encode() -> decode() of the reference's own file gives back
+    its unvoiced lead-in sample by sample (WORLD's randn bursts through the minimum-phase envelope), at the reference's level."""
+    import os
+    import wave
+    w = wave.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+    x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+    f0, feat, codeap = voc.encode(torch.from_numpy(x))
+    T = len(x) // 160
+    y = voc.decode(f0[:T], feat[:T], codeap[:T])
+    assert len(y) == T * 160
+    for i in range(windows):
+        c = np.corrcoef(x[320 * i: 320 * (i + 1)], y[320 * i: 320 * (i + 1)])[0, 1]
+        assert c > 0.85, (i, c)
+    assert 0.4 < np.sqrt((y[:320] ** 2).mean()) / np.sqrt((x[:320].astype(np.float64) ** 2).mean()) < 2.5
