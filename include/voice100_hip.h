@@ -191,7 +191,7 @@ int v100_world_loss_bwd(const float* unit, const float* gout, float* dpred, int 
 /* y = max(exp(x) - offset, 0)   (WORLDVocoder.decode, voice100/vocoder.py:99) */
 int v100_exp_clip(const float* x, float* y, float offset, long long n, void* stream);
 
-/* ---- WORLD synthesis (csrc/world.hip; SURVEY.md 8f rank 4, first half) -- PARITY UNPINNED -----------------------
+/* ---- WORLD synthesis (csrc/world.hip; SURVEY.md 8f rank 4, first half) -- PARITY PARTIALLY PINNED ----
  * pyworld.decode_aperiodicity + pyworld.synthesize as WORLDVocoder.decode calls them (voice100/vocoder.py:100-101).
  * pyworld 0.3.2 (C++ WORLD) is not in the reference tree: the kernels follow the published algorithm as restated in
  * oracle/world_synth.py.  fft_size 512 (16 kHz): one WAVE per pulse, fp32 with the tables below; any other power of two up to 2048 (1024:

@@ -1,7 +1,8 @@
 // WORLD synthesis on the device: pyworld.decode_aperiodicity + pyworld.synthesize as the reference calls them
 // (voice100/vocoder.py:100-101), the last step of BASELINE configs[2] ("... -> WORLD features + vocoder").
 //
-// PARITY UNPINNED: the arithmetic lives in pyworld 0.3.2 (C++ WORLD), which is neither in the reference tree nor in the build
+// PARITY PARTIALLY PINNED (the reference's docs samples witness the noise path, time-base phase, placement, length, level; no
+// input/output vector exists): the arithmetic lives in pyworld 0.3.2 (C++ WORLD), which is neither in the reference tree nor in the build
 // image.  These kernels follow the published algorithm as restated in oracle/world_synth.py (Morise et al. 2016; D4C 2016) and
 // are held to that restatement (<= 1e-4 of the waveform's peak, pulse instants bit-exact).
 //

@@ -112,7 +112,7 @@ class WORLDVocoder(nn.Module):
         N.call("v100_exp_clip", x, y, float(self.log_offset), x.numel())
         return y
 
-    # ---- WORLD synthesis on the device (first half; parity unpinned) -------------------------------
+    # ---- WORLD synthesis on the device (first half; parity partially pinned: DESIGN.md 2) ------------
     _randn_cache = {}          # device -> float32 tensor: WORLD's randn() sequence (one fixed sequence, see csrc/world.hip)
 
     @classmethod
