@@ -511,11 +511,11 @@ struct D4cParams {
     double* ap0; double* ap; double* coded; float* coded32;
 };
 
-constexpr int D4C_SEG = 2048 / 2 + 2 * 320 + 8;
-constexpr int DT = 1024;           // threads per workgroup of the D4C kernels (one workgroup per CU: their LDS footprint allows no more)
+constexpr int D4C_SEG = 1880;        // doubles: the longest 4-period window (1877 samples at 47 Hz, 22.05 kHz) and a smoothing's mirrored cumulative sum share it
+constexpr int DG = 512;              // threads of the D4C kernels: with <= 80 KB of LDS two of their workgroups share a CU
 
 // D4CLoveTrain: the share of the power below 4 kHz in the power below 7.9 kHz (both above 100 Hz) of a 3-period Blackman window
-__global__ __launch_bounds__(DT) void d4c_lovetrain_kernel(D4cParams p) {
+__global__ __launch_bounds__(DG) void d4c_lovetrain_kernel(D4cParams p) {
     extern __shared__ double sh[];
     __shared__ double red[16];
     const int b = blockIdx.y, t = blockIdx.x, fs = p.fs, F2 = p.F2;
@@ -528,8 +528,6 @@ __global__ __launch_bounds__(DT) void d4c_lovetrain_kernel(D4cParams p) {
     double* wav = sh + 2 * F2;
     double* wbuf = wav + F2;
     double* pw = wbuf + F2;
-    cd twr[11];
-    fft_twiddles_reg<11>(twr, p.tw);
     const double cf0 = f > kLoveTrainF0 ? f : kLoveTrainF0;
     const long long off = p.off_lt[(long long)b * p.Tmax + t];
     const int need = 2 * mround(3.0 * fs / cf0 / 2.0) + 1;
@@ -537,7 +535,7 @@ __global__ __launch_bounds__(DT) void d4c_lovetrain_kernel(D4cParams p) {
     const float* x = p.x + (long long)b * p.pitch;
     const double position = (double)t * p.frame_period / 1000.0;
     const int nwin = windowed_waveform(x, len, fs, cf0, position, 2, 3.0, p.rnd + off, wav, wbuf, red);
-    fft_real_lds_reg<11>(buf, wav, nwin, 0.0, twr);
+    fft_real_lds(buf, wav, nwin, 0.0, p.logF2, p.tw, p.logF2);
     const int b0 = (int)ceil(100.0 * F2 / fs), b1 = (int)ceil(4000.0 * F2 / fs), b2 = (int)ceil(7900.0 * F2 / fs);
     for (int k = threadIdx.x; k <= F2 / 2; k += blockDim.x) pw[k] = k <= b0 ? 0.0 : buf[k].x * buf[k].x + buf[k].y * buf[k].y;
     __syncthreads();
@@ -551,34 +549,49 @@ __global__ __launch_bounds__(DT) void d4c_lovetrain_kernel(D4cParams p) {
     if (threadIdx.x == 0) *out = s1 / s2;
 }
 
-// ascending bitonic sort of a[0 .. n) in LDS, n = blockDim.x: a thread keeps element tid in a register; partner distances below 64 are
-// lane exchanges inside a wave (45 of the 55 stages at n = 1024), the others go through LDS
+// ascending bitonic sort of a[0 .. n) in LDS, n = E * blockDim.x: a thread keeps elements tid + e * blockDim.x in registers; partner distances
+// below 64 are lane exchanges inside a wave (45 of the 55 stages at n = 1024), distances of blockDim.x and more stay inside the thread, the
+// others go through LDS
+template <int E>
 __device__ void bitonic_sort(double* a, int logn) {
-    const int n = 1 << logn, i = threadIdx.x;
+    const int n = 1 << logn, nt = blockDim.x, tid = threadIdx.x;
     __syncthreads();
-    double v = i < n ? a[i] : 0.0;
+    double v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = a[tid + e * nt];
     for (int k = 2; k <= n; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            double o;
-            if (j >= 64) {
+            double o[E];
+            if (j >= nt) {                                     // partner in this thread's own registers
+                const int de = j / nt;
+#pragma unroll
+                for (int e = 0; e < E; ++e) o[e] = v[e ^ de];
+            } else if (j >= 64) {
                 __syncthreads();
-                if (i < n) a[i] = v;
+#pragma unroll
+                for (int e = 0; e < E; ++e) a[tid + e * nt] = v[e];
                 __syncthreads();
-                o = i < n ? a[i ^ j] : 0.0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) o[e] = a[(tid ^ j) + e * nt];
             } else {
-                o = __shfl_xor(v, j, 64);
+#pragma unroll
+                for (int e = 0; e < E; ++e) o[e] = __shfl_xor(v[e], j, 64);
             }
-            const bool lower = (i & j) == 0, up = (i & k) == 0;
-            // the lower index of a pair keeps the smaller value in an ascending merge (and the larger in a descending one)
-            const double lo = v < o ? v : o, hi = v < o ? o : v;
-            v = (lower == up) ? lo : hi;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = tid + e * nt;
+                const bool lower = (i & j) == 0, up = (i & k) == 0;
+                const double lo = v[e] < o[e] ? v[e] : o[e], hi = v[e] < o[e] ? o[e] : v[e];
+                v[e] = (lower == up) ? lo : hi;
+            }
         }
     __syncthreads();
-    if (i < n) a[i] = v;
+#pragma unroll
+    for (int e = 0; e < E; ++e) a[tid + e * nt] = v[e];
     __syncthreads();
 }
 
-__global__ __launch_bounds__(DT) void d4c_general_kernel(D4cParams p) {
+__global__ __launch_bounds__(DG) void d4c_general_kernel(D4cParams p) {
     extern __shared__ double sh[];
     __shared__ double red[16];
     __shared__ double coarse[8];
@@ -608,22 +621,23 @@ __global__ __launch_bounds__(DT) void d4c_general_kernel(D4cParams p) {
         }
         return;
     }
-    cd* buf = (cd*)sh;                        // F2 complex (also the sort buffer: 2 F2 doubles)
-    double* wav = sh + 2 * F2;                // F2
-    double* tmpr = wav + F2;                  // h2 + 8   } the two together hold the window (<= F2 values) while a waveform is built
-    double* tmpi = tmpr + h2 + 8;             // h2 + 8   }
-    double* cen = tmpi + h2 + 8;              // h2 + 8
-    double* pw = cen + h2 + 8;                // h2 + 8
-    double* gd = pw + h2 + 8;                 // h2 + 8
-    double* seg = gd + h2 + 8;                // D4C_SEG
+    // 80.6 KB, so that TWO workgroups share a CU (every phase here is a short latency-bound step): buffers whose lives do not overlap share
+    // storage -- the windowed waveform and the smoothings' cumulative sums (a waveform is dead once its last FFT has read it), the window
+    // values and the first spectrum of a centroid pair, the imaginary half of that spectrum and the group delay
+    cd* buf = (cd*)sh;                        // F2 complex
+    double* seg = sh + 2 * F2;                // D4C_SEG
+    double* wav = seg;
+    double* tmpr = seg + D4C_SEG;             // h2 + 1   } the two together hold the window (<= D4C_SEG values) while a waveform is built
+    double* tmpi = tmpr + h2 + 1;             // h2 + 1   }
+    double* cen = tmpi + h2 + 1;              // h2 + 1
+    double* pw = cen + h2 + 1;                // h2 + 1
+    double* gd = tmpi;
     double* wbuf = tmpr;
-    cd twr[11];
-    fft_twiddles_reg<11>(twr, p.tw);
     const double cf0 = f > kFloorF0D4C ? f : kFloorF0D4C;
     const int nw4 = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
     const long long off = p.off_gb[row];
     const int bmax = (int)(cf0 * F2 / fs) + 1;
-    if (off + 3LL * nw4 > p.rnd_len || nw4 > F2 || h2 + 2 * bmax + 1 > D4C_SEG) {
+    if (off + 3LL * nw4 > p.rnd_len || nw4 > D4C_SEG || nw4 > 2 * (h2 + 1) || h2 + 2 * bmax + 1 > D4C_SEG) {
         for (int k = threadIdx.x; k <= half; k += blockDim.x) if (apo) apo[k] = __builtin_nan("");
         if (threadIdx.x < nb) {
             if (p.coded) p.coded[row * nb + threadIdx.x] = __builtin_nan("");
@@ -642,16 +656,16 @@ __global__ __launch_bounds__(DT) void d4c_general_kernel(D4cParams p) {
         for (int i = threadIdx.x; i < nwin; i += blockDim.x) pwr += wav[i] * wav[i];
         pwr = sqrt(block_sum(pwr, red));
         for (int i = threadIdx.x; i < nwin; i += blockDim.x) wav[i] = wav[i] / pwr;
-        fft_real_lds_reg<11>(buf, wav, nwin, 0.0, twr);
+        fft_real_lds(buf, wav, nwin, 0.0, p.logF2, p.tw, p.logF2);
         for (int k = threadIdx.x; k <= h2; k += blockDim.x) { tmpr[k] = buf[k].x; tmpi[k] = buf[k].y; }
-        fft_real_lds_reg<11>(buf, wav, nwin, 1.0, twr);
+        fft_real_lds(buf, wav, nwin, 1.0, p.logF2, p.tw, p.logF2);
         for (int k = threadIdx.x; k <= h2; k += blockDim.x) cen[k] += buf[k].x * tmpr[k] + tmpi[k] * buf[k].y;
     }
     dc_correction(cen, cf0, fs, F2, seg);
     // smoothed power spectrum: a Hanning window of four periods
     {
         const int nwin = windowed_waveform(x, len, fs, cf0, position, 1, 4.0, p.rnd + off + 2LL * nw4, wav, wbuf, red);
-        fft_real_lds_reg<11>(buf, wav, nwin, 0.0, twr);
+        fft_real_lds(buf, wav, nwin, 0.0, p.logF2, p.tw, p.logF2);
         for (int k = threadIdx.x; k <= h2; k += blockDim.x) pw[k] = buf[k].x * buf[k].x + buf[k].y * buf[k].y;
         dc_correction(pw, cf0, fs, F2, seg);
         linear_smoothing(pw, pw, seg, cf0, fs, F2, red);
@@ -672,11 +686,11 @@ __global__ __launch_bounds__(DT) void d4c_general_kernel(D4cParams p) {
             buf[brev(j, p.logF2)] = {v, 0.0};
         }
         __syncthreads();
-        fft_lds_reg<11>(buf, twr, false);
+        fft_lds(buf, p.logF2, p.tw, p.logF2, false);
         // power spectrum: bins 0 .. h2-1 are sorted (a power of two), the Nyquist bin is ranked into them
         const double extra = buf[h2].x * buf[h2].x + buf[h2].y * buf[h2].y;
         for (int k = threadIdx.x; k < h2; k += blockDim.x) tmpr[k] = buf[k].x * buf[k].x + buf[k].y * buf[k].y;
-        bitonic_sort(tmpr, p.logF2 - 1);
+        bitonic_sort<2>(tmpr, p.logF2 - 1);
         // sorted cumulative sum at index h2 - boundary - 1 = the m = h2 - boundary smallest of the h2 + 1 values
         const int m = h2 - boundary;
         double below = 0.0;
@@ -914,9 +928,9 @@ extern "C" int v100_world_d4c(const float* x, const int* lengths, const double* 
     }
     V100_GGL(world_offsets_kernel, dim3(B), dim3(NT), 0, st, f0, lengths, (const double*)nullptr, (long long*)p.off_lt, Tmax, fs, frame_period_ms, 1,
              0.0, fft_size);
-    V100_GGL(d4c_lovetrain_kernel, dim3(Tmax, B), dim3(DT), sizeof(double) * (2 * F2 + F2 + F2 + F2 / 2 + 8), st, p);
+    V100_GGL(d4c_lovetrain_kernel, dim3(Tmax, B), dim3(DG), sizeof(double) * (2 * F2 + F2 + F2 + F2 / 2 + 8), st, p);
     V100_GGL(world_offsets_kernel, dim3(B), dim3(NT), 0, st, f0, lengths, (const double*)p.ap0, (long long*)p.off_gb, Tmax, fs, frame_period_ms, 2,
              threshold, fft_size);
-    V100_GGL(d4c_general_kernel, dim3(Tmax, B), dim3(DT), sizeof(double) * (2 * F2 + F2 + 5 * (F2 / 2 + 8) + D4C_SEG), st, p);
+    V100_GGL(d4c_general_kernel, dim3(Tmax, B), dim3(DG), sizeof(double) * (2 * F2 + D4C_SEG + 4 * (F2 / 2 + 1)), st, p);
     return v100_launch_status();
 }
