@@ -292,20 +292,6 @@ __device__ void fft_real_lds(cd* a, const double* r, int n, double scale_index, 
     fft_lds(a, logN, tw, logNT, false);
 }
 
-// real input r[0 .. n) (zero beyond) -> spectrum in a, one butterfly per thread, twiddles in registers (the D4C kernels: 2048 points, 1024 threads)
-template <int LOGN>
-__device__ void fft_real_lds_reg(cd* a, const double* r, int n, double scale_index, const cd (&twr)[LOGN]) {
-    const int N = 1 << LOGN;
-    __syncthreads();
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-        double v = i < n ? r[i] : 0.0;
-        if (scale_index != 0.0) v *= (double)i + 1.0;
-        a[brev(i, LOGN)] = {v, 0.0};
-    }
-    __syncthreads();
-    fft_lds_reg<LOGN>(a, twr, false);
-}
-
 __device__ inline double interp1q(double x0, double dx, const double* y, int n, double xi) {
     const double pos = (xi - x0) / dx;
     int base = (int)pos;

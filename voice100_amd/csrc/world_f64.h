@@ -81,33 +81,5 @@ __device__ void fft_lds(cd* a, int logN, const cd* __restrict__ tw, int logNT, b
 __device__ inline unsigned brev(unsigned i, int logN) { return __brev(i) >> (32 - logN); }
 
 
-// The same transform for the case of ONE butterfly per thread (blockDim.x == 2^(logN-1)): a thread's twiddle of stage s depends on its
-// index only, so the logN twiddles are loaded ONCE per kernel into registers (fft_twiddles_reg) instead of once per stage and call --
-// that (latency-exposed) load was what a stage waited for.
-template <int LOGN>
-__device__ inline void fft_twiddles_reg(cd (&twr)[LOGN], const cd* __restrict__ tw) {
-#pragma unroll
-    for (int s = 1; s <= LOGN; ++s) {
-        const int h = 1 << (s - 1), k = (int)threadIdx.x & (h - 1);
-        twr[s - 1] = tw[k << (LOGN - s)];
-    }
-}
-template <int LOGN>
-__device__ inline void fft_lds_reg(cd* a, const cd (&twr)[LOGN], bool inverse) {
-    const int idx = threadIdx.x;
-#pragma unroll
-    for (int s = 1; s <= LOGN; ++s) {
-        const int h = 1 << (s - 1);
-        const int k = idx & (h - 1), i = ((idx >> (s - 1)) << s) + k;
-        cd w = twr[s - 1];
-        if (inverse) w.y = -w.y;
-        const cd u = a[i], v = a[i + h];
-        const double tr = v.x * w.x - v.y * w.y, ti = v.x * w.y + v.y * w.x;
-        a[i] = {u.x + tr, u.y + ti};
-        a[i + h] = {u.x - tr, u.y - ti};
-        if (s < 7 && s < LOGN) WAVE_LDS_ORDER();
-        else __syncthreads();
-    }
-}
 #pragma clang fp contract(fast)
 }   // namespace
