@@ -266,12 +266,10 @@ def test_edge_cases_short_inputs_and_extreme_f0(voc):
 
 
 def test_device_on_the_references_own_world_synthesised_sample(voc):
-    """The reference's docs/sample-en-1.wav (tests/golden/README.md: real pyworld-synthesised speech, int16): device == oracle frame for frame on
+    """The reference's docs/sample-en-1.wav (tests/golden/world_ref_samples.npz, README.md there: real pyworld-synthesised speech, int16): device == oracle frame for frame on
     it, and the device's own analysis -> synthesis keeps length and level."""
     import os
-    import wave
-    w = wave.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_docs_sample_en_1.wav"))
-    x = (np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0)
+    x = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "world_ref_samples.npz"))["en1"].astype(np.float32) / 32768.0
     xd = x.astype(np.float64)
     f0, tp = wa.dio(xd, FS, f0_floor=80.0, f0_ceil=400.0, frame_period=10.0)
     g0 = voc.dio(torch.from_numpy(x).cuda(), f0_floor=80.0, f0_ceil=400.0)
@@ -287,14 +285,12 @@ def test_device_on_the_references_own_world_synthesised_sample(voc):
     assert len(y) == len(x) and 0.8 < np.abs(y).max() / np.abs(x).max() < 1.25
 
 
-@pytest.mark.parametrize("name,windows", [("ref_docs_sample_ja_1_head.wav", 3), ("ref_docs_sample_en_2_head.wav", 1)])
+@pytest.mark.parametrize("name,windows", [("ja1_head", 3), ("en2_head", 1)])
 def test_device_reproduces_the_reference_samples_unvoiced_lead_in(voc, name, windows):
     """tests/test_oracle_world_analysis.py::test_unvoiced_lead_in_... on the DEVICE: encode() -> decode() of the reference's own file gives back
     its unvoiced lead-in sample by sample (WORLD's randn bursts through the minimum-phase envelope), at the reference's level."""
     import os
-    import wave
-    w = wave.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
-    x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+    x = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "world_ref_samples.npz"))[name].astype(np.float32) / 32768.0
     f0, feat, codeap = voc.encode(torch.from_numpy(x))
     T = len(x) // 160
     y = voc.decode(f0[:T], feat[:T], codeap[:T])

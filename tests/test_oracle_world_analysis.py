@@ -135,16 +135,19 @@ def test_randn_stream_is_consumed_in_order():
     assert np.array_equal(a, b)
 
 
-def _reference_sample():
+def _ref_samples():
     import os
-    import wave
-    w = wave.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_docs_sample_en_1.wav"))
-    assert w.getframerate() == FS and w.getnchannels() == 1 and w.getsampwidth() == 2
-    return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float64) / 32768.0
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "world_ref_samples.npz"))
+
+
+def _reference_sample():
+    d = _ref_samples()
+    assert int(d["sample_rate"]) == FS
+    return d["en1"].astype(np.float64) / 32768.0
 
 
 def test_on_the_references_own_world_synthesised_sample():
-    """tests/golden/ref_docs_sample_en_1.wav is a waveform pyworld.synthesize produced in the reference's TTS chain (docs/sample-en-1.wav): the one
+    """tests/golden/world_ref_samples.npz[en1] is a waveform pyworld.synthesize produced in the reference's TTS chain (docs/sample-en-1.wav): the one
     artefact of pyworld's arithmetic in the image.  It pins three conventions of the SYNTHESIS restatement outright -- the output length
     int(T * frame_period * fs / 1000) (a whole number of 160-sample frames); the PHASE of the time base and the placement of a response: an
     utterance that starts unvoiced pulses at the 500 Hz default, its first pulse sits at sample 30 and its (causal, minimum-phase) response
@@ -181,13 +184,10 @@ def test_on_the_references_own_world_synthesised_sample():
 
 
 def _head(name):
-    import os
-    import wave
-    w = wave.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
-    return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float64) / 32768.0
+    return _ref_samples()[name].astype(np.float64) / 32768.0
 
 
-@pytest.mark.parametrize("name,windows", [("ref_docs_sample_ja_1_head.wav", 3), ("ref_docs_sample_en_2_head.wav", 1)])
+@pytest.mark.parametrize("name,windows", [("ja1_head", 3), ("en2_head", 1)])
 def test_unvoiced_lead_in_of_reference_samples_is_reproduced_sample_by_sample(name, windows):
     """The strongest pin available without pyworld (tests/golden/README.md): the reference's docs samples begin unvoiced, where the waveform is
     WORLD's fixed randn sequence, burst by burst at the 500 Hz default, through the minimum-phase envelope.  Analysis of the file ->
