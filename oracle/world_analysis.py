@@ -56,6 +56,27 @@ def samples_for_dio(fs, x_length, frame_period):
     return int(1000.0 * x_length / fs / frame_period) + 1
 
 
+# DIGITAL SILENCE.  In a stretch of exact zeros WORLD's band signals are the rounding noise of its FFT convolution (relative 1e-16): noise-like,
+# full of spurious zero crossings, so the F0 candidates there are garbage and get rejected -- an accident of the arithmetic that the
+# algorithm nevertheless relies on: WITHOUT that noise a silent stretch has no events at all, interp1 EXTRAPOLATES the first real
+# intervals across it, and a smooth, plausible, entirely fictitious F0 contour comes out (seen on the device, whose time-domain filters
+# leave exact silence exactly silent: voiced frames deep inside zeroed lead-ins).  FFTW's rounding noise cannot be reproduced, so the
+# noise floor is made explicit and deterministic: a dither of 1e-13 of the utterance's peak, from an integer hash of the sample index, is
+# added to the input of the filters -- three orders above any implementation's rounding noise (silence behaves the same in the oracle and
+# on the device, decision for decision), ten below anything an estimate could feel (F0 moves by ~1e-13 relative elsewhere).
+DIO_DITHER = 1e-13
+
+
+def dio_dither(n):
+    """uniform in [-1, 1) from a 32-bit integer hash of the sample index (lowbias32), exactly reproducible anywhere"""
+    h = np.arange(n, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    m = np.uint64(0xFFFFFFFF)
+    h = ((h ^ (h >> np.uint64(16))) * np.uint64(0x7FEB352D)) & m
+    h = ((h ^ (h >> np.uint64(15))) * np.uint64(0x846CA68B)) & m
+    h = h ^ (h >> np.uint64(16))
+    return h.astype(np.float64) / 2147483648.0 - 1.0
+
+
 def _low_cut_filter(n, fft_size):
     f = np.zeros(fft_size)
     i = np.arange(1, n + 1)
@@ -94,6 +115,7 @@ def dio(x, fs, f0_floor=71.0, f0_ceil=800.0, channels_in_octave=2.0, frame_perio
     y = np.zeros(fft_size)
     y[:x_length] = x
     y[:y_length] -= y[:y_length].sum() / y_length
+    y[:y_length] += dio_dither(y_length) * (DIO_DITHER * np.abs(x).max() if x_length else 0.0)
     y_spec = np.fft.rfft(y)
     cutoff = matlab_round(fs / K_CUTOFF)
     y_spec = y_spec * np.fft.rfft(_low_cut_filter(cutoff * 2 + 1, fft_size))

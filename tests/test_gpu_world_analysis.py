@@ -191,9 +191,9 @@ def test_22k_shapes(voc):
 
 def test_random_speechlike_signals_agree_frame_for_frame(voc):
     """A small fuzz (tools/fuzz_world_analysis.py is the long one, profiles/r04_world_analysis_fuzz.txt): random harmonic + noise signals of
-    random lengths in one ragged batch, some clipped.  None contains DIGITAL silence next to speech: there the band signals are the rounding
-    noise of the filter implementation (FFT convolution in WORLD / the oracle, a FIR here) and the frames at the edge of the silence may
-    differ -- the one place where the device is not comparable to any other implementation, the reference's included."""
+    random lengths in one ragged batch, one clipped, one with a third of DIGITAL silence in front -- where WORLD lives off the rounding noise of
+    its FFT convolution and the restatement (oracle and device alike) off an explicit dither of 1e-13 of the peak: silence must come out
+    unvoiced, not as the extrapolated contour a noise-free filter produces."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -204,6 +204,8 @@ def test_random_speechlike_signals_agree_frame_for_frame(voc):
         x = speechlike(float(rng.uniform(0.4, 2.0)), FS, 300 + i)
         if i == 3:
             x = (x * 30).clip(-1, 1).astype(np.float32)
+        if i == 4:
+            x[: len(x) // 3] = 0                      # digital silence: defined by the explicit noise floor (oracle: DIGITAL SILENCE), see below
         xs.append(x)
     L = max(len(x) for x in xs)
     batch = torch.zeros((len(xs), L))
@@ -226,6 +228,8 @@ def test_random_speechlike_signals_agree_frame_for_frame(voc):
         apo = wa.d4c(xd, f0, tp, FS, fft_size=512)
         assert np.abs(ga[i, :T] - apo).max() < 1e-8 and np.abs(gc[i, :T] - wa.code_aperiodicity(apo, FS)).max() < 1e-7, i
         assert not g0[i, T:].any() and not gs[i, T:].any() and not ga[i, T:].any() and not gc[i, T:].any()     # ragged rows end in zeros
+        if i == 4:
+            assert not g0[i, : len(x) // 3 // 160 - 2].any()            # nothing voiced inside the silence
     assert voiced > 200
     f0b, featb, capb = voc.encode_batch(batch.cuda(), lengths)
     for i, x in enumerate(xs):

@@ -27,6 +27,7 @@ namespace {
 constexpr double kPi = 3.1415926535897932384;
 constexpr double kSafeMin = 1e-12;
 constexpr double kEps = 2.220446049250313e-16;
+constexpr double kDioDither = 1e-13;
 constexpr double kMaxValue = 100000.0;
 constexpr double kDefaultF0 = 500.0;
 constexpr double kFloorF0D4C = 47.0;
@@ -51,19 +52,36 @@ struct DioParams {
 };
 
 __global__ __launch_bounds__(1024) void dio_mean_kernel(DioParams p) {
-    __shared__ double red[16];
+    __shared__ double red[16], redm[16];
     const int b = blockIdx.x, len = p.lengths[b];
     const float* x = p.x + (long long)b * p.pitch;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < len; i += 1024) s += (double)x[i];
+    double s = 0.0, mx = 0.0;
+    for (int i = threadIdx.x; i < len; i += 1024) {
+        const double v = (double)x[i];
+        s += v;
+        mx = fmax(mx, fabs(v));
+    }
     s = wave_sum_f64(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; redm[threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < 16; ++i) t += red[i];
+        double t = 0.0, m = 0.0;
+        for (int i = 0; i < 16; ++i) { t += red[i]; m = fmax(m, redm[i]); }
         p.mean[b] = t / (double)(len + 1);                      // y has x_length + 1 samples, the last one zero
+        p.mean[p.B + b] = m * kDioDither;                       // amplitude of the explicit noise floor (see dio_dither)
     }
+}
+
+// The noise floor WORLD gets by accident from its FFT convolution, made explicit and deterministic (oracle/world_analysis.py, DIGITAL
+// SILENCE): uniform in [-1, 1) from an integer hash of the sample index (lowbias32)
+__device__ inline double dio_dither(unsigned m) {
+    unsigned h = m;
+    h = (h ^ (h >> 16)) * 0x7FEB352Du;
+    h = (h ^ (h >> 15)) * 0x846CA68Bu;
+    h = h ^ (h >> 16);
+    return (double)h / 2147483648.0 - 1.0;
 }
 
 // z = y' (*) low cut, y' = y - mean on [0, y_length), for n in [-zp, y_length + zp)
@@ -73,11 +91,14 @@ __global__ __launch_bounds__(NT) void dio_lowcut_kernel(DioParams p) {
     const int n0 = (int)blockIdx.x * NT - p.zp;
     if (n0 >= ylen + p.zp) return;
     const float* x = p.x + (long long)b * p.pitch;
-    const double mean = p.mean[b];
+    const double mean = p.mean[b], amp = p.mean[p.B + b];
     for (int i = threadIdx.x; i < NT + 2 * hc; i += NT) {
         const int m = n0 - hc + i;
         double v = 0.0;
-        if (m >= 0 && m < ylen) v = (m < len ? (double)x[m] : 0.0) - mean;
+        if (m >= 0 && m < ylen) {
+            v = (m < len ? (double)x[m] : 0.0) - mean;
+            v = v + dio_dither((unsigned)m) * amp;
+        }
         sh[i] = v;
     }
     __syncthreads();
@@ -753,7 +774,7 @@ bool dio_plan(int B, int max_len, int fs, double f0_floor, double f0_ceil, doubl
     pl->ylen = max_len + 1;
     pl->Tmax = dio_frames(fs, max_len, frame_period);
     long long o = 0;
-    pl->o_mean = o; o += al(8LL * B);
+    pl->o_mean = o; o += al(8LL * 2 * B);              // means, then dither amplitudes
     pl->zpitch = (pl->ylen + 2LL * pl->zp + 7) & ~7LL;
     pl->o_z = o; o += al(8LL * B * pl->zpitch);
     pl->fpitch = (pl->ylen + 7LL) & ~7LL;
