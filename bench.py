@@ -282,6 +282,46 @@ def other_configs(device, N, F_):
     return out
 
 
+def lean_line(out):
+    """The printed line: same keys and figures, without the long prose / per-launch tables (those are in the details record)."""
+    import copy
+    o = copy.deepcopy(out)
+
+    def cut(d, key, n):
+        if isinstance(d, dict) and isinstance(d.get(key), str) and len(d[key]) > n:
+            d[key] = d[key][:n - 3] + "..."
+    cfg = o.get("config") or {}
+    if isinstance(cfg.get("workload"), str):
+        cfg["workload"] = cfg["workload"].split(" (0 fp32 everywhere")[0]
+        cut(cfg, "workload", 330)
+    r = o.get("roofline")
+    if isinstance(r, dict):
+        r.pop("traffic_per_launch", None)
+        cut(r, "kernel", 90)
+        cut(r, "traffic_source", 110)
+    if isinstance(o.get("launches_per_step"), dict):
+        o["launches_per_step"] = o["launches_per_step"].get("value")
+    cut(o.get("dp_path_single_rank"), "what", 60)
+    cb = o.get("cpu_baseline")
+    if isinstance(cb, dict):
+        cut(cb, "sample", 150)
+        for k in [k for k in cb if k.startswith("config")]:
+            cb.pop(k)
+    oc = o.get("other_configs")
+    if isinstance(oc, dict):
+        keep = ("ms", "frames_per_s", "world_frames_per_s", "tokens_per_s", "chunks_per_s", "x_realtime", "error")
+        for k, v in list(oc.items()):
+            if isinstance(v, dict):
+                oc[k] = {kk: vv for kk, vv in v.items() if kk in keep}
+    su = o.get("sustained")
+    if isinstance(su, dict):
+        for k in ("before",):
+            su.pop(k, None)
+        if isinstance(su.get("under_load"), dict):
+            su["under_load"] = {k: v for k, v in su["under_load"].items() if k in ("sclk_mhz", "power_w")}
+    return o
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -666,7 +706,18 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:                                   # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
-        json_out.write(json.dumps(out) + "\n")
+        # ONE line on stdout, kept SHORT (a harness that keeps only a few KB of a run's tail must still see "metric" and "value" at its
+        # start): every contract key, the roofline and cpu_baseline objects with their figures, the extras as figures only.  The full
+        # record (per-launch PMC rows, prose provenance of every number, every key of the other configs) goes to stderr and, where the
+        # directory is writable, to gpurun_out/bench_details.json.
+        sys.stderr.write("bench details: " + json.dumps(out) + "\n")
+        try:
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open(os.path.join("gpurun_out", "bench_details.json"), "w") as f:
+                json.dump(out, f)
+        except OSError:
+            pass
+        json_out.write(json.dumps(lean_line(out)) + "\n")
         json_out.flush()
     if world > 1:
         dist.barrier()

@@ -23,4 +23,5 @@ python3 tools/pmc_dw_json.py $out/pmc_dw --json $out/dw_fwd_pmc.json > $out/${ta
 cp $out/dw_fwd_pmc.json profiles/dw_fwd_pmc.json
 rm -rf $out/pmc_dw/*.csv
 python3 bench.py > $out/${tag}_bench_line.json 2> $out/bench_err.txt
+cp gpurun_out/bench_details.json $out/${tag}_bench_details.json 2>/dev/null
 tail -c 600 $out/${tag}_bench_line.json
