@@ -113,6 +113,44 @@ def _double_backward_worker(port, out):
     dist.destroy_process_group()
 
 
+def _arena_claim_worker(port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from voice100_amd import functional as F_
+    from voice100_amd.dist import FlatGradBuckets
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4))
+    ps = list(lin.parameters())
+    old = FlatGradBuckets(ps, bucket_bytes=1 << 20, force_exchange=True)
+    new = FlatGradBuckets(ps, bucket_bytes=1 << 20, force_exchange=True)          # a TrainStep recreated for the same model
+    res = []
+    a = F_._grad_arena_for(ps[:2], 20)
+    res.append(a is not None and a.data_ptr() == new.flat.data_ptr())             # the NEWEST arena serves the request ...
+    res.append(F_._grad_arena_for(ps[:2], 20) is None)                            # ... once per step
+    new.begin_step()
+    res.append(F_._grad_arena_for(ps[:2], 20) is not None)                        # re-armed by begin_step
+    new.remove_hooks()
+    b = F_._grad_arena_for(ps[:2], 20)
+    res.append(b is not None and b.data_ptr() == old.flat.data_ptr())             # unregistered: the older one is next
+    del old, b
+    import gc
+    gc.collect()
+    res.append(F_._grad_arena_for(ps[:2], 20) is None)                            # weak references: a dropped arena is gone
+    out.put(res)
+    dist.destroy_process_group()
+
+
+def test_grad_arena_is_claimed_once_per_step_and_weakly_held():
+    """functional._grad_arena_for / FlatGradBuckets.grad_arena (round-4 advice): a slice of the flat exchange buffer is handed to at
+    most one producer per step; the registry prefers the most recently created buffer and does not keep dropped ones alive."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_arena_claim_worker, args=(_free_port(), out))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0
+    assert out.get(timeout=10) == [True, True, True, True, True]
+
+
 def test_shard_batch_covers_everything():
     from voice100_amd.dist import shard_batch
     for n in (1, 7, 32, 256):

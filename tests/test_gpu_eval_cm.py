@@ -134,6 +134,36 @@ def test_asr_eval_channel_major_model(cuda):
         F_.set_matmul_precision("fp32")
 
 
+def test_asr_eval_bf16_with_autograd_on_keeps_gradients(cuda):
+    """BatchNorm-frozen fine-tuning (round-4 advice): an eval-mode AudioToTextCTC with trainable parameters called with autograd ON
+    must NOT take the detached channel-major path at bf16 -- the logits carry a graph and every parameter the reference's
+    eval-mode forward (asr.py:110-116 under model.eval()) would reach receives a gradient; under no_grad the same call is detached
+    and equals it value for value at the precision's bar."""
+    from voice100_amd import functional as F_
+    from voice100_amd.asr import AudioToTextCTC
+    torch.manual_seed(21)
+    m = AudioToTextCTC(64, 64, 29, 64).to(cuda).eval()
+    x = torch.randn(3, 120, 64, device=cuda)
+    keep = F_.get_matmul_precision()
+    try:
+        F_.set_matmul_precision("bf16")
+        y = m(x)
+        assert y.requires_grad and y.grad_fn is not None
+        y.square().mean().backward()
+        missing = [k for k, p in m.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+        assert not missing, missing
+        assert any(float(p.grad.abs().max()) > 0 for p in m.encoder.parameters())
+        with torch.no_grad():
+            y0 = m(x)
+        assert not y0.requires_grad
+        assert rel_err(y0, y.detach()) < 3e-2
+        for p in m.parameters():
+            p.requires_grad_(False)
+        assert not m(x).requires_grad                      # nothing can ask for a gradient: the channel-major path again
+    finally:
+        F_.set_matmul_precision(keep)
+
+
 def test_graphed_forward_replays_the_eager_result(cuda):
     """infer.GraphedForward: an eval-mode forward recorded as a HIP graph gives bit-identical results on new inputs of the recorded shape,
     refuses other shapes, and works for a multi-output callable (predict)."""

@@ -246,6 +246,48 @@ def test_rccl_gradient_exchange_single_rank(cuda):
             dist.destroy_process_group()
 
 
+def test_two_forwards_one_backward_under_exchange(cuda):
+    """Round-4 advice: with the data-parallel flat buffer registered as the stack executor's gradient arena, two forwards of the same
+    model followed by ONE backward ((loss(m(x1)) + loss(m(x2))).backward()) put two stack backward nodes in one graph, both of which
+    run before AccumulateGrad has set w.grad.  Each arena slice must be handed out once per step (the second node takes its own
+    buffer), so that the exchanged gradient is G1 + G2 -- equal to the plain single-process gradients -- and not 2 * G2."""
+    import os
+    import torch.distributed as dist
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd.dist import FlatGradBuckets
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        torch.manual_seed(4)
+        m1 = AudioToTextCTC(64, 32, 29, 32).to(cuda)
+        m2 = AudioToTextCTC(64, 32, 29, 32).to(cuda)
+        m2.load_state_dict(m1.state_dict())
+        g = torch.Generator().manual_seed(6)
+        x1 = torch.randn(4, 96, 64, generator=g).to(cuda)
+        x2 = torch.randn(4, 96, 64, generator=g).to(cuda)
+        grads = []
+        for m, force in ((m1, False), (m2, True)):
+            m.train()
+            m.decoder.layers[0].p = 0.0
+            buckets = FlatGradBuckets(m.parameters(), bucket_bytes=1 << 16, force_exchange=force)
+            buckets.begin_step()
+            (m(x1).square().mean() + m(x2).square().mean()).backward()
+            buckets.finish_step()
+            grads.append({k: p.grad.detach().clone() for k, p in m.named_parameters()})
+            buckets.remove_hooks()
+        k0 = "encoder.layers.1.conv.0.0.weight"
+        scale = float(grads[0][k0].abs().max())
+        for k in grads[0]:
+            assert torch.allclose(grads[0][k], grads[1][k], rtol=1e-5, atol=1e-6 * max(scale, 1e-6)), k
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_config4_phone_vocab(cuda):
     """BASELINE configs[3]: asr_en_phone_base = the same network with the 71-symbol CMU vocabulary (text.py:19-31),
     32 utterances per rank.  Reduced width against the CPU oracle (forward, CTC loss, gradients), then the full-size

@@ -79,7 +79,12 @@ class AudioToTextCTC(Voice100ModelBase):
         if tracing():                            # torch.jit.trace / torch.onnx.export: plain aten ops (_stock.py)
             return torch.transpose(self.decoder(self.encoder(torch.transpose(audio, 1, 2))), 1, 2)
         x = F_.transpose_last2(audio)            # [B,T,C] -> [B,C,T]
-        if not self.training and not (torch.is_grad_enabled() and audio.requires_grad):
+        # The channel-major path runs under no_grad (its result is detached): take it only when nothing could ask for a gradient
+        # through this forward -- autograd off, or neither the input nor any parameter requires one (an eval-mode model with
+        # trainable parameters called with autograd ON is BatchNorm-frozen fine-tuning: the per-module path below is
+        # differentiable like the reference's eval-mode BatchNorm) -- or at precision "fp16", which is inference-only by design.
+        if not self.training and (not torch.is_grad_enabled() or F_.get_matmul_precision() == "fp16"
+                                  or not (audio.requires_grad or any(p.requires_grad for p in self.parameters()))):
             y = self._forward_eval_cm(x)
             if y is not None:
                 return y
@@ -102,7 +107,7 @@ class AudioToTextCTC(Voice100ModelBase):
         T1 = int(enc.output_length(torch.tensor(T)))
         if layers[0].stride != 2 or T1 != F_.conv_out_len(T, int(layers[0].kernel_size), 2):
             return None
-        if not F_.eval_cm_supported(layers[1:], T1):
+        if not F_.eval_cm_supported(layers[1:], T1, batch=B):
             return None
         with torch.no_grad():
             y = layers[0](x)                     # the stride-2 opener: batch-major (its depthwise kernel is the register-window one)

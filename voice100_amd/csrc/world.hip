@@ -20,7 +20,9 @@
 //                              the aperiodic minimum-phase spectrum -> a 512-sample response per pulse.
 //   3. world_overlap_add_kernel  one thread per output sample gathers the responses that cover it, in pulse order (deterministic; no
 //                              float atomics).
-// fp32 except the time base.  fft_size 512 (16 kHz) only: 22.05 kHz / 1024 returns V100_ERR_SHAPE (the oracle restates both).
+// fp32 except the time base.  fft_size 512 (16 kHz) runs the fp32 wave-per-pulse kernel, every other power of two in 64 ... 2048 (22.05 kHz /
+// 1024) the fp64 workgroup-per-pulse kernel.  V100_ERR_SHAPE only when a time-base chunk's contour window fits neither the chained
+// kernel (TBC_CH / TBC_NFR) nor the serial one (TBS_CH / TBS_NFR): fewer than ~34 samples per frame (frame periods below ~2.1 ms at 16 kHz).
 #include "common.h"
 #include "../../include/voice100_hip.h"
 #include "world_f64.h"
@@ -52,12 +54,13 @@ __device__ __forceinline__ int world_ylen(int frames, double frame_period_ms, in
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // 1. time base
+constexpr int TBS_CH = 2048, TBS_NFR = 64;             // the SERIAL kernel (one workgroup per utterance): samples per chunk; contour frames staged per chunk
 __global__ __launch_bounds__(256) void world_timebase_kernel(WorldParams p) {
     // Chunks of CH samples through LDS: (1) all threads interpolate the contour -> phase increments, (2) thread 0 accumulates them IN
     // ORDER (the one summation order, see the header; ~10 cycles a sample: the increments come from LDS, unrolled so the reads run ahead of
     // the dependent adds), (3) all threads wrap, detect the 2 pi crossings and compact them in order.  The running phase never goes to
     // HBM; only the per-sample voicing flag (1 byte) and the pulse list do.
-    constexpr int CH = 2048, NFR = 64;                   // samples per chunk; contour frames staged per chunk
+    constexpr int CH = TBS_CH, NFR = TBS_NFR;            // samples per chunk; contour frames staged per chunk
     __shared__ double s_tot[CH + 1];                     // [0] = the last total of the previous chunk
     __shared__ double s_wrap[CH + 1];
     __shared__ double s_cf0[NFR], s_cv[NFR];
@@ -1138,7 +1141,7 @@ extern "C" long long v100_world_synth_workspace_bytes(int B, int T, int fs, doub
     if (B <= 0 || T <= 0 || fs <= 0 || fft_size < 64 || fft_size > 2048 || (fft_size & (fft_size - 1)) || max_pulses <= 0 || frame_period_ms <= 0) return -1;
     const long long Y = (world_ymax(T, fs, frame_period_ms) + 63) & ~63LL;
     const long long Pc = (max_pulses + 63) & ~63LL;
-    const long long nch = (world_ymax(T, fs, frame_period_ms) + 2047) / 2048 + 1;          // time-base chain mailboxes (20 B per chunk; room for 2048-sample chunks) + tickets
+    const long long nch = (world_ymax(T, fs, frame_period_ms) + TBC_CH - 1) / TBC_CH + 1;   // time-base chain mailboxes (20 B per chunk of the CHAINED kernel, as v100_world_synthesize lays them out) + tickets
     return (long long)B * (Y + Pc * 4 + Pc * 4 + Pc * fft_size * 4) + 256 + (((long long)B * (4 + nch * 20) + 255) & ~255LL) + 256;
 }
 
@@ -1152,7 +1155,11 @@ extern "C" int v100_world_synthesize(const float* f0, const float* sp, const flo
     if (B <= 0 || T < 2 || fs <= 0 || fft_size < 64 || fft_size > 2048 || (fft_size & (fft_size - 1)) || max_pulses <= 0 || frame_period_ms <= 0) return V100_ERR_SHAPE;
     const int Ymax = world_ymax(T, fs, frame_period_ms);
     if (Ymax < 2 || table_len < Ymax || B > 65535) return V100_ERR_SHAPE;
-    if (2048.0 / ((double)fs * frame_period_ms / 1000.0) + 4.0 > 64.0) return V100_ERR_SHAPE;     // time-base kernel: a chunk's contour window (NFR)
+    // a chunk's contour window must fit the kernel that runs: the chained kernel's (TBC_CH samples in TBC_NFR frames) or, failing
+    // that, the serial kernel's (TBS_CH in TBS_NFR); only when neither does is the shape refused
+    const double spf = (double)fs * frame_period_ms / 1000.0;
+    const bool chain_fits = (double)TBC_CH / spf + 4.0 <= (double)TBC_NFR, serial_fits = (double)TBS_CH / spf + 4.0 <= (double)TBS_NFR;
+    if (!chain_fits && !serial_fits) return V100_ERR_SHAPE;
     const long long Y = (Ymax + 63) & ~63LL, Pc = (max_pulses + 63) & ~63LL;
     char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     WorldParams p{};
@@ -1181,7 +1188,7 @@ extern "C" int v100_world_synthesize(const float* f0, const float* sp, const flo
     WorldParams pt = p;
     pt.Ymax = (int)Y;                   // workspace rows are Y long; y rows are Ymax long (kernels 1 and 2 only touch the workspace)
     static const bool tb_serial_env = []() { const char* e = getenv("V100_WORLD_TB_SERIAL"); return e && e[0] == '1'; }();     // A/B: one workgroup per utterance
-    const bool tb_serial = tb_serial_env || (double)TBC_CH / ((double)fs * frame_period_ms / 1000.0) + 4.0 > (double)TBC_NFR;     // a chunk's contour window must fit
+    const bool tb_serial = (tb_serial_env && serial_fits) || !chain_fits;
     if (tb_serial) V100_GGL(world_timebase_kernel, dim3((unsigned)B), dim3(256), 0, st, pt);
     else {
         if (hipMemsetAsync(chain0, 0, chain_bytes, st) != hipSuccess) return V100_ERR_LAUNCH;

@@ -84,7 +84,12 @@ class FlatGradBuckets:
                 dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
                 if not bool((probe == 1).all()):
                     self._avg_in_collective = False
-            except Exception:                                    # noqa: BLE001
+            except RuntimeError as e:
+                # only "this backend build has no AVG" is a reason to fall back; any other failure of a collective (a dead peer,
+                # a communicator in an error state) must surface here, not as a hang or a wrong sum in the first step
+                msg = str(e).lower()
+                if not ("avg" in msg or "not supported" in msg or "unsupported" in msg or "invalid argument" in msg):
+                    raise
                 self._avg_in_collective = False
         self._pending = [0] * len(self.buckets)
         self._next = 0             # buckets are launched strictly in index order, so every rank issues the same collectives
@@ -111,12 +116,22 @@ class FlatGradBuckets:
             if v is None or v[0] != pos:
                 return None
             pos = v[1]
+            if self._pending[self._bucket_of[t]] < 0:
+                return None                                # its bucket is already on the wire this step
+        # A slice is handed out at most ONCE per step.  Two backward nodes of the same stack in one graph (two forwards, one backward;
+        # shared weights) both run before AccumulateGrad has set w.grad, so both would be handed this slice, the second would
+        # overwrite the first and autograd would sum two aliases of it (G2 + G2 instead of G1 + G2): the second node gets None
+        # and takes the ordinary path (its own buffer; autograd accumulates, _launch packs the sum).
+        if first[0] in self._claimed:
+            return None
+        self._claimed.add(first[0])
         return self.flat[first[0]:pos]
 
     def begin_step(self):
         """Drop last step's gradients (autograd then assigns instead of accumulating) and re-arm the buckets."""
         for p in self.params:
             p.grad = None
+        self._claimed = set()
         for i, (_, _, members) in enumerate(self.buckets):
             self._pending[i] = len(members)
         self._next = 0

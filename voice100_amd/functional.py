@@ -302,27 +302,39 @@ def _block_tensors(blk):
 
 
 _STACK_PLANS = {}
-_GRAD_ARENAS = []              # data-parallel gradient buffers that want stack gradients written in place (dist.FlatGradBuckets)
+# data-parallel gradient buffers that want stack gradients written in place (dist.FlatGradBuckets).  WEAK references, newest first:
+# a FlatGradBuckets that is simply dropped (a TrainStep recreated for the same model) neither stays alive through this list with its
+# flat buffer nor keeps receiving the stack gradients in place of its successor.
+_GRAD_ARENAS = []
 
 
 def register_grad_arena(a) -> None:
-    if a not in _GRAD_ARENAS:
-        _GRAD_ARENAS.append(a)
+    import weakref
+    unregister_grad_arena(a)
+    _GRAD_ARENAS.insert(0, weakref.ref(a))
 
 
 def unregister_grad_arena(a) -> None:
-    if a in _GRAD_ARENAS:
-        _GRAD_ARENAS.remove(a)
+    _GRAD_ARENAS[:] = [r for r in _GRAD_ARENAS if r() is not None and r() is not a]
 
 
 def _grad_arena_for(weights, numel):
     """A registered buffer slice in which `weights` (the stack's trainable tensors, in its gradient order) lie back to back."""
     if any(w.grad is not None for w in weights):
         return None             # gradients are being ACCUMULATED (no begin_step since the last backward): the arena holds the running sum
-    for a in _GRAD_ARENAS:
+    for r in _GRAD_ARENAS:
+        a = r()
+        if a is None or not a._hooks:
+            continue            # collected, or its hooks were removed: it no longer takes part in the step
+        if weights[0] not in a._view:
+            continue            # another model's buffer
+        # the newest live buffer that holds these parameters decides alone: when it declines (slice claimed already this step,
+        # bucket on the wire, layout mismatch) the gradients take the ordinary path, never an older buffer
         buf = a.grad_arena(weights)
-        if buf is not None and buf.numel() == numel:
-            return buf
+        if buf is not None and buf.numel() != numel:
+            a._claimed.discard(a._view[weights[0]][0])
+            buf = None
+        return buf
     return None
 _STACK_SEGMENT = None          # blocks per autograd node of a stack; None = automatic (ir_stack_train)
 
@@ -590,11 +602,15 @@ def inverted_residual_eval_cached(blk, x, precision: Optional[str] = None):
 EVAL_CM = os.environ.get("VOICE100_EVAL_CM", "1") not in ("", "0")
 
 
-def eval_cm_supported(blocks, T: int, precision: Optional[str] = None) -> bool:
+def eval_cm_supported(blocks, T: int, precision: Optional[str] = None, batch: int = 1) -> bool:
     """True when a run of eval-mode InvertedResidual blocks can run channel-major: 16-bit precision, stride 1, kernel sizes with a
-    matrix-pipe depthwise kernel, rows that fit one wave item, nothing that Module.__call__ would have to do (hooks)."""
+    matrix-pipe depthwise kernel, rows that fit one wave item, nothing that Module.__call__ would have to do (hooks), and a batch
+    inside the kernels' index ranges (v100_cm_to_btc puts the batch in grid.z: B <= 65535; v100_ir_fwd_eval addresses the
+    [C][B * P] matrix with 32-bit byte offsets: B * P <= 0x7fffff00 -- past either the per-module path runs instead of an error)."""
     import torch.nn.modules.module as _m
     if not EVAL_CM or _fmt(precision) == 0 or T > 768 or T < 1:
+        return False
+    if batch > 65535 or batch * ((T + 7) & ~7) > 0x7fffff00:
         return False
     if _m._global_forward_hooks or _m._global_forward_pre_hooks:
         return False
