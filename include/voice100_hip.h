@@ -79,7 +79,8 @@ int v100_pw_gemm(const float* A, const void* A_bf16, const float* X, const float
                  int use_bf16, void* stream);
 
 /* dW[m][k] = sum_{b,t} g'[b][m][t] * x'[b][k][t]   (weight gradient of the same 1x1 conv).
- * partial: [S][M][K] workspace, S = v100_pw_wgrad_splits(B, M, K). */
+ * partial: [S][M][K] workspace, S = v100_pw_wgrad_splits(B, M, K): S <= B splits the batch, S = B * TS (small weight matrices)
+ * also cuts every utterance's t range into TS chunks. */
 int v100_pw_wgrad_splits(int B, int M, int K);
 int v100_pw_wgrad(const float* G, const float* G2, const float* ga, const float* gb, const float* gc, int g_mode,
                   const float* X, const float* xa, const float* xb, int x_mode, float* partial, float* dW,

@@ -100,9 +100,15 @@ def _zero_crossing_engine(sig, fs):
     return locations, intervals
 
 
-def dio(x, fs, f0_floor=71.0, f0_ceil=800.0, channels_in_octave=2.0, frame_period=5.0, speed=1, allowed_range=0.1):
+def dio(x, fs, f0_floor=71.0, f0_ceil=800.0, channels_in_octave=2.0, frame_period=5.0, speed=1, allowed_range=0.1, dither=None):
     """pyworld.dio(x, fs, f0_floor, f0_ceil, channels_in_octave, frame_period, speed, allowed_range) -> (f0 [T], temporal_positions [T]).
-    speed = 1 only (no decimation: the reference does not pass it)."""
+    speed = 1 only (no decimation: the reference does not pass it).
+    dither: amplitude of the explicit noise floor relative to the utterance's peak (see DIGITAL SILENCE above).  None = DIO_DITHER,
+    the value the DEVICE kernels use (csrc/world_analysis.hip), so oracle and device agree decision for decision in silence;
+    dither = 0 is WORLD AS PUBLISHED -- no term that pyworld does not have -- and is what any comparison with pyworld vectors
+    (tests/golden/thirdparty_world.npz, when it exists) must use."""
+    if dither is None:
+        dither = DIO_DITHER
     if speed != 1:
         raise NotImplementedError("decimation (speed > 1) is not restated")
     x = np.asarray(x, np.float64)
@@ -115,7 +121,8 @@ def dio(x, fs, f0_floor=71.0, f0_ceil=800.0, channels_in_octave=2.0, frame_perio
     y = np.zeros(fft_size)
     y[:x_length] = x
     y[:y_length] -= y[:y_length].sum() / y_length
-    y[:y_length] += dio_dither(y_length) * (DIO_DITHER * np.abs(x).max() if x_length else 0.0)
+    if dither:
+        y[:y_length] += dio_dither(y_length) * (dither * np.abs(x).max() if x_length else 0.0)
     y_spec = np.fft.rfft(y)
     cutoff = matlab_round(fs / K_CUTOFF)
     y_spec = y_spec * np.fft.rfft(_low_cut_filter(cutoff * 2 + 1, fft_size))

@@ -422,7 +422,31 @@ __global__ __launch_bounds__(256) void weight_prep_batched_kernel(PrepBatch t) {
     const int rows = t.rows[e], cols = t.cols[e];
     const int tr = (rows + 63) >> 6, tc = (cols + 63) >> 6;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;            // 64 columns x 4 row groups
-    for (int tl = blockIdx.x; tl < tr * tc; tl += gridDim.x) {
+    // Whole 64 x 64 tiles of a bf16-only preparation (every 1x1 weight of the step's networks): 16-byte loads, 8-byte packed stores on
+    // both copies (the element-wise form below moved the transposed copy 2 bytes per lane: 30.7 us for the step's 86.7 MB, 2.8 TB/s).
+    const bool fast = !(rows & 63) && !(cols & 63) && t.wt[e] == nullptr && t.wbf[e] != nullptr && t.wtbf[e] != nullptr;
+    for (int tl = blockIdx.x; fast && tl < tr * tc; tl += gridDim.x) {
+        const int r0 = (tl / tc) << 6, c0 = (tl % tc) << 6;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = threadIdx.x + 256 * q;                      // 64 rows x 16 float4
+            const int i = id >> 4, c4 = (id & 15) << 2;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)(r0 + i) * cols + c0 + c4);
+            uint2 o; o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]);
+            *reinterpret_cast<uint2*>(t.wbf[e] + (size_t)(r0 + i) * cols + c0 + c4) = o;
+            tile[i][c4] = v[0]; tile[i][c4 + 1] = v[1]; tile[i][c4 + 2] = v[2]; tile[i][c4 + 3] = v[3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = threadIdx.x + 256 * q;                      // 64 columns x 16 groups of 4 rows
+            const int c = id >> 4, r4 = (id & 15) << 2;
+            uint2 o; o.x = pack_bf16(tile[r4][c], tile[r4 + 1][c]); o.y = pack_bf16(tile[r4 + 2][c], tile[r4 + 3][c]);
+            *reinterpret_cast<uint2*>(t.wtbf[e] + (size_t)(c0 + c) * rows + r0 + r4) = o;
+        }
+    }
+    for (int tl = blockIdx.x; !fast && tl < tr * tc; tl += gridDim.x) {
         const int r0 = (tl / tc) << 6, c0 = (tl % tc) << 6;
         __syncthreads();                                               // the previous tile's reads are done
 #pragma unroll 4

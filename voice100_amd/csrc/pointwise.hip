@@ -81,7 +81,13 @@ extern "C" int v100_pw_wgrad_splits(int B, int M, int K) {
     const int tiles = ceil_div(M, PW_BM) * ceil_div(K, PW_BN);
     static const int target = [] { const char* e = getenv("V100_WG_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
     int S = ceil_div(target, tiles);
-    if (S > B) S = B;
+    if (S > B) {
+        // fewer (tile, utterance) pairs than the chip has CUs (the 64 -> 256 opener's two tiles, the vocabulary head): split each
+        // utterance's t range too -- S = B * TS, TS a power of two <= 8 with one workgroup per CU as the aim (WgSpan, pointwise_common.h)
+        int TS = 1;
+        while (TS < 8 && tiles * B * TS * 2 <= 256) TS *= 2;
+        S = B * TS;
+    }
     if (S < 1) S = 1;
     return S;
 }
@@ -200,7 +206,7 @@ extern "C" int v100_pw_wgrad(const float* G, const float* G2, const float* ga, c
                              const float* X, const float* xa, const float* xb, int x_mode, float* partial, float* dW,
                              int S, int B, int M, int K, int T, int use_bf16, void* stream) {
     if (!G || !X || !partial || !dW) return V100_ERR_NULL;
-    if (B <= 0 || M <= 0 || K <= 0 || T <= 0 || S <= 0 || S > B) return V100_ERR_SHAPE;
+    if (B <= 0 || M <= 0 || K <= 0 || T <= 0 || S <= 0 || (S > B && (S % B != 0 || S / B > 64))) return V100_ERR_SHAPE;
     if (g_mode < 0 || g_mode > 2 || x_mode < 0 || x_mode > 1) return V100_ERR_SHAPE;
     if (g_mode != PW_X_NONE && (!ga || !gb)) return V100_ERR_NULL;
     if (g_mode == PW_X_AFFINE2 && (!G2 || !gc)) return V100_ERR_NULL;
@@ -243,7 +249,7 @@ extern "C" int v100_pw_wgrad_io(const void* G, const void* G2, const float* ga, 
                                 const void* X, const float* xa, const float* xb, int x_mode, float* partial, float* dW, int S, int B,
                                 int M, int K, int T, int io16, void* stream) {
     if (!G || !X || !partial || !dW) return V100_ERR_NULL;
-    if (B <= 0 || M <= 0 || K <= 0 || T <= 0 || S <= 0 || S > B || io16 <= 0 || io16 > 7) return V100_ERR_SHAPE;
+    if (B <= 0 || M <= 0 || K <= 0 || T <= 0 || S <= 0 || (S > B && (S % B != 0 || S / B > 64)) || io16 <= 0 || io16 > 7) return V100_ERR_SHAPE;
     if (g_mode != PW_X_NONE && (!ga || !gb)) return V100_ERR_NULL;
     if (g_mode == PW_X_AFFINE2 && (!G2 || !gc)) return V100_ERR_NULL;
     if (x_mode != PW_X_NONE && (!xa || !xb)) return V100_ERR_NULL;
@@ -336,7 +342,7 @@ extern "C" int v100_pw_gemm_taps(const float* A, const void* A_bf16, const float
 extern "C" int v100_pw_wgrad_taps(const float* G, int Tg, int g_off, const float* Xp, float* partial, float* dW, int S, int B, int M,
                                   int cx, int T, int Tx, int ntap, const int* shifts, int use_bf16, void* stream) {
     if (!G || !Xp || !partial || !dW) return V100_ERR_NULL;
-    if (S <= 0 || S > B || g_off < 0 || Tg < g_off + T || use_bf16 < 0 || use_bf16 > 1) return V100_ERR_SHAPE;
+    if (S <= 0 || (S > B && (S % B != 0 || S / B > 64)) || g_off < 0 || Tg < g_off + T || use_bf16 < 0 || use_bf16 > 1) return V100_ERR_SHAPE;
     if (!v100_pw_taps_supported(B, M, cx, ntap, T, Tx, use_bf16)) return V100_ERR_SHAPE;
     bool ok;
     const unsigned packed = pw_pack_shifts(shifts, ntap, T, Tx, ok);

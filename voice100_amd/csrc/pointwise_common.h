@@ -54,6 +54,20 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #ifndef PW_OV_MASK
 #define PW_OV_MASK 1         /* ... and project backward-data (mask epilogue) */
 #endif
+#ifndef PW_OV_XTR
+#define PW_OV_XTR 1          /* round 5: the overlapped-epilogue kernel keeps its X image [k][t] as loaded (16-byte copies) and reads the B
+                                fragments with ds_read_b64_tr_b16 (0: [t][k] image built with byte permutes + 8-byte column stores) */
+#endif
+#ifndef PW_OV_TOUCH
+#define PW_OV_TOUCH 0        /* overlapped-epilogue kernel: L2 touch of a tile's R lines (bit 0) / Y lines (bit 1) at the start of its k-loop */
+#endif
+#ifndef PW_OV_CP_Y
+#define PW_OV_CP_Y 0         /* cache policy (buffer aux bits) of the overlapped-epilogue kernel's Y stores: 1 sc0, 2 nt, 3 both */
+#endif
+#ifndef PW_OV_ABL
+#define PW_OV_ABL 0          /* timing-only builds of pw_gemm_bf16_ov_kernel (WRONG results): 1 no epilogue, 2 no X staging, 4 no A staging,
+                                8 no barrier, 16 no fragment reads, 32 no Y stores, 64 no statistics (partial sums through LDS), 128 no R loads */
+#endif
 #ifndef PW_OV_GAP
 #define PW_OV_GAP 8
 #endif
@@ -587,6 +601,33 @@ struct WgParams {
     int io16;        // WG_IO_* mask: G / G2 / X are bf16 [B][rows][pw_pitch16(T)] (see PwParams::io16)
 };
 
+
+// The contraction range of split s.  S <= B: a run of whole utterances (all their t-steps).  S > B (round 5: small weight
+// matrices -- the 64 -> 256 opener, heads -- have so few (m, k) tiles that even one utterance per workgroup leaves most of the
+// chip idle): S = B * TS, split s = (utterance s / TS, chunk s % TS of that utterance's nt t-steps).  Step i of the split is
+// utterance b_lo + i / ntl at t-step t_first + i % ntl; nsteps = nb * ntl.  ntl >= 1 always (an empty split has nb = 0).
+struct WgSpan { int b_lo, nb, t_first, ntl; };
+__device__ __forceinline__ WgSpan wg_span(const WgParams& p, int s, int nt) {
+    WgSpan sp;
+    if (p.S <= p.B) {
+        const int bper = (p.B + p.S - 1) / p.S;
+        sp.b_lo = s * bper;
+        const int b_hi = min(p.B, sp.b_lo + bper);
+        sp.nb = b_hi > sp.b_lo ? b_hi - sp.b_lo : 0;
+        sp.t_first = 0;
+        sp.ntl = nt > 0 ? nt : 1;
+        if (nt <= 0) sp.nb = 0;
+    } else {
+        const int TS = p.S / p.B;                     // the launcher guarantees S % B == 0
+        const int c = s % TS;
+        sp.b_lo = s / TS;
+        const int lo = (int)((long)c * nt / TS), hi = (int)((long)(c + 1) * nt / TS);
+        sp.t_first = lo;
+        sp.ntl = hi > lo ? hi - lo : 1;
+        sp.nb = (hi > lo && sp.b_lo < p.B) ? 1 : 0;
+    }
+    return sp;
+}
 
 // work item -> (split, m-tile, k-tile), k-tile fastest: one split's tiles sit on one XCD
 __device__ __forceinline__ void wg_work(const WgParams& p, int& s, int& mt, int& kt) {

@@ -115,8 +115,6 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32_kernel(WgParams p) {
     const int m0 = mt * PW_BM, n0 = ktile * PW_BN;
     const int M = p.M, K = p.K, T = p.T;
     const int g_mode = PW_MODE(GM_, p.g_mode), x_mode = PW_MODE(XM_, p.x_mode);
-    const int bper = (p.B + p.S - 1) / p.S;
-    const int b_lo = s * bper, b_hi = min(p.B, b_lo + bper);
 
     const int l_t = (tid & 3) * 4;          // 4 consecutive t inside the 16-wide step
     const int l_r = tid >> 2;               // row (m or k), + 64*i
@@ -179,17 +177,18 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32_kernel(WgParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nt = (T + F32_BK - 1) / F32_BK;
-    const int nsteps = (b_hi > b_lo) ? (b_hi - b_lo) * nt : 0;
+    const WgSpan sp = wg_span(p, s, nt);
+    const int nsteps = sp.nb * sp.ntl, b_lo = sp.b_lo;
     const int lr = lane & 31, lk = lane >> 5;
     if (nsteps > 0) {
-        load_tiles(b_lo, 0);
-        store_tiles(0, 0);
+        load_tiles(b_lo, sp.t_first * F32_BK);
+        store_tiles(0, sp.t_first * F32_BK);
     }
     __syncthreads();
     for (int st = 0; st < nsteps; ++st) {
         const int cur = st & 1;
         const int nxt = st + 1;
-        const int nb = b_lo + nxt / nt, ntt = (nxt % nt) * F32_BK;
+        const int nb = b_lo + nxt / sp.ntl, ntt = (sp.t_first + nxt % sp.ntl) * F32_BK;
         if (nxt < nsteps) load_tiles(nb, ntt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
