@@ -1763,7 +1763,7 @@ __global__ __launch_bounds__(512) void pw_gemm_bf16_ov_kernel(PwParams p) {
         OV_PIPE(); OV_SB();
 #undef OV_MID
 #undef OV_PIPE
-        if constexpr (!(PW_OV_ABL & 8)) __syncthreads();
+        if constexpr (!(PW_OV_ABL & 8)) { if constexpr (PW_OV_RAWBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads(); }
     };
     unsigned touch = 0, touch2 = 0;
     auto kloop = [&](auto epc) {
@@ -1783,7 +1783,7 @@ __global__ __launch_bounds__(512) void pw_gemm_bf16_ov_kernel(PwParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) load_x(2, S0{}, e);
         OV_SB();
-        __syncthreads();
+        if constexpr (PW_OV_RAWBAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads();
         ktile(std::integral_constant<int, 0>{}, epc); ktile(std::integral_constant<int, 1>{}, epc);
         ktile(std::integral_constant<int, 2>{}, epc); ktile(std::integral_constant<int, 3>{}, epc);
         if constexpr (NK == 8) {
@@ -1853,6 +1853,349 @@ __global__ __launch_bounds__(512) void pw_gemm_bf16_ov_kernel(PwParams p) {
     __syncthreads();
     epi_final();
 #undef OV_SB
+}
+
+// ---------------------------------------------------------------------------------------------
+// Short-K GEMM with SPLIT ROLES (round 5; plain bf16 X, bf16 Y, whole 256-row tiles, K = 64 NK).
+// What the overlapped-epilogue kernel above could not hide (profiles/r05_ov_ablation.txt): its k-loop alone runs the wide expand
+// forward GEMM in 34 us, the epilogue's VALU / LDS work adds 6, but the epilogue's MEMORY instructions add 16 (Y stores) and, in the
+// mask form, another 18 (R loads) -- although they ride on the next tile's k-loop.  The reason is the in-order vmcnt counter: a wave
+// that issues an HBM-latency store or load cannot consume any YOUNGER staging load until it has completed, so every wave that both
+// stages operands (latency-critical, one k-tile ahead) and runs epilogue memory traffic stalls on the latter.  Here no wave does
+// both.  Twelve waves (three per SIMD, 168 registers each).  Waves 0-7 (two per SIMD: the MATRIX waves) stage A pieces and X chunks (as
+// loaded, 16 bytes at a time), read fragments (A by ds_read_b128, B by ds_read_b64_tr_b16 from the [k][t] image) and run the MFMAs of
+// a 64 x 64 block each (one matrix wave per SIMD with a 64 x 128 block needs 128 accumulator registers and spills); at the end of a
+// tile they put the accumulators, rounded to bf16 (what Y stores), into a 64 KB LDS tile and go straight on to the next tile.  The MFMAs
+// run with their operands SWAPPED (acc = X^T-fragment x A-fragment: the 32 x 32 x 16 operand layouts are symmetric, so this is only
+// the argument order): a lane then holds four CONSECUTIVE t of one output row per accumulator quad, i.e. 8 packed bytes of Y, and the
+// hand-over is 16 ds_write_b64 per lane instead of scalar stores through a transposing image.  Waves 8-11 (one per SIMD:
+// the EPILOGUE waves) turn the PREVIOUS tile's LDS tile into the output -- two 256-byte rows per pass: ReLU6 mask from R (the whole R
+// sub-tile requested one TILE ahead into 64 registers), BatchNorm partial sums (a wave owns whole rows: no cross-wave step),
+// 256-byte row stores -- and never touch the operands.  The workgroup's barriers (one per k-tile + one at the hand-over) are the only
+// coupling: an epilogue wave processes 32 / NK passes between two of them.  LDS: 96 KB of operand stages + the 64 KB tile = all 160 KB.
+// The partial sums are taken from the bf16 values Y stores (the fp32 tile would be 128 KB): BatchNorm statistics of the rounded
+// tensor, which is what the reference's autocast run computes them from (its conv output IS the bf16 tensor).
+// The workgroup barrier WITHOUT the vmcnt(0) that __syncthreads() puts in front of it (a workgroup-scope fence drains the wave's
+// vector-memory queue): here that would make a matrix wave wait for its two-k-tiles-ahead prefetch and an epilogue wave for its Y
+// stores' HBM acknowledgements at every one of a tile's nine barriers (measured: the epilogue waves then take 11 us a tile).  What a
+// barrier has to order in this kernel is LDS traffic only: the wave's own ds_write / ds_read are complete (lgkmcnt(0)) when it arrives.
+#if PW_SL_RAWBAR
+#define SL_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define SL_BARRIER() __syncthreads()
+#endif
+template <int EPI, int NK>
+__global__ __launch_bounds__(768) void pw_gemm_bf16_sl_kernel(PwParams p) {
+    static_assert(EPI == PW_EPI_STATS || EPI == PW_EPI_MASK_STATS, "expand forward on the bf16 shadow / project backward-data");
+    static_assert(NK >= 2 && NK <= 32 && (32 % NK) == 0, "32 row passes are spread over the NK k-tile intervals");
+    constexpr bool MASK = EPI == PW_EPI_MASK_STATS;
+    constexpr int BM = 256;
+    constexpr int A_BYTES = BM * 128, X_BYTES = 64 * 256, OUT_BYTES = BM * PW_BN * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 2 * X_BYTES + OUT_BYTES];     // 96 KB + 64 KB = all of the CU's LDS
+    // (a DS instruction's immediate offset is 16 bits and the image is 160 KB: the region bases B_OFF / O_OFF are folded into the
+    //  per-lane address registers, so that what is left of every address is a constant below 64 KB -- with the bases left in the
+    //  constants hipcc materialises ~60 address registers and spills)
+    unsigned char* As = smem;
+    constexpr int B_OFF = 2 * A_BYTES, O_OFF = 2 * A_BYTES + 2 * X_BYTES;     // X stages; the hand-over tile [256 rows][32 slots of 8 bytes], slot = (t / 4) ^ (row & 31)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.M, K = p.K;
+    const int P16 = pw_pitch16(p.T);
+    const int total = p.n_mtiles * p.n_ttiles * p.B;
+    const int ntl = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;       // tiles of this workgroup (>= 1: grid <= total)
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    if (wave < 8 && !(PW_SL_DBG & 1)) {
+        // ================================================= matrix waves ==================================================
+        const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.Abf, (unsigned)M * K * 2u);
+        const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.X, (unsigned)p.B * K * P16 * 2u);
+        int v = blockIdx.x;
+        int b, tt, mt;
+        pw_work_v(p, v, total, b, tt, mt);
+        // A: 256 rows x 8 chunks of 16 bytes per k-tile = 4 pieces per lane (rows arow + 64 i, chunk tid & 7; the image's XOR term
+        // (row >> 1) & 7 is the same for all four), X: 64 k-rows x 16 chunks = 2 per lane (rows x_row + 32 e, chunk tid & 15)
+        const int arow = tid >> 3;
+        const int ldsA0 = bf_off(arow, tid & 7);
+        const int stepA = 128 * K, stepX = P16 * 2;
+        const int x_row = tid >> 4, x_ch = tid & 15;
+        const int ldsX = B_OFF + 256 * x_row + 16 * (x_ch ^ (((x_row & 3) << 2) | ((x_row >> 2) & 3)));
+        auto vo_a = [&](int mt_) { return ((mt_ * BM + arow) * K + (tid & 7) * 8) * 2; };
+        auto vo_x = [&](int b_, int tt_) { return ((b_ * K + x_row) * P16 + tt_ * PW_BN + x_ch * 8) * 2; };
+        int voA = vo_a(mt), voX = vo_x(b, tt), voAn = voA, voXn = voX;
+        int t_lim = p.T - tt * PW_BN - x_ch * 8;            // this lane's chunk: columns e < t_lim exist
+        auto aim_next = [&]() {
+            const int vn = v + (int)gridDim.x < total ? v + (int)gridDim.x : v;
+            int b_, tt_, mt_;
+            pw_work_v(p, vn, total, b_, tt_, mt_);
+            voAn = vo_a(mt_); voXn = vo_x(b_, tt_);
+        };
+        aim_next();
+        u32x4 ra[4];
+        u32x4 rx[2][2];
+        auto load_a = [&](int kt, int i) {                   // kt >= NK: k-tile kt - NK of the next tile
+            const bool nx = kt >= NK;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, nx ? voAn : voA, (nx ? kt - NK : kt) * (BF_BK * 2) + i * stepA, 0);
+        };
+        auto load_x = [&](int kt, auto stg, int e) {
+            constexpr int SG = decltype(stg)::value;
+            const bool nx = kt >= NK;
+            rx[SG][e] = __builtin_amdgcn_raw_buffer_load_b128(rX, nx ? voXn : voX, ((nx ? kt - NK : kt) * BF_BK + 32 * e) * stepX, 0);
+        };
+        auto store_a = [&](int buf, int i) { *reinterpret_cast<u32x4*>(As + buf * A_BYTES + ldsA0 + i * 8192) = ra[i]; };
+        auto store_x = [&](int buf, auto stg, int e) {
+            constexpr int SG = decltype(stg)::value;
+            // columns past T (partial last t-tile) are staged as ZEROS: their accumulators are exactly 0 (nothing for the statistics)
+            u32x4 o = rx[SG][e];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] &= (2 * d < t_lim ? 0xffffu : 0u) | (2 * d + 1 < t_lim ? 0xffff0000u : 0u);
+            *reinterpret_cast<u32x4*>(smem + ldsX + (buf * X_BYTES + e * 8192)) = o;
+        };
+        const int wm = wave >> 1, wn = wave & 1;             // rows wm * 64 ... + 63, columns wn * 64 ... + 63
+        f32x16 acc[2][2];
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        };
+        zero_acc();
+        const int lr = lane & 31, lh = lane >> 5;
+        const int sw = (lr >> 1) & 7;
+        const int rdA0 = (wm * 64 + lr) * 128;
+        // B fragment of column block j, k-step ks (see the transposed-read form of the kernel above): address register per (j, h)
+        typedef short sl_s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) sl_s16x4 sl_lds_s16x4;
+        int trB[2][2];
+        {
+            const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = 8 * (g >> 1) + 4 * h + q4;
+                    const int ch = ((wn * 64 + j * 32 + 16 * (g & 1)) >> 3) + (pp >> 1);
+                    trB[j][h] = B_OFF + 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (pp & 1);
+                }
+        }
+        auto mfma_step = [&](int kt, int ks) {
+            const unsigned char* Ab = As + (kt & 1) * A_BYTES;
+            const unsigned char* Bb = smem + (kt & 1) * X_BYTES;
+            const int co = ((ks * 2 + lh) ^ sw) << 4;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + co);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + 32 * 128 + co);
+            bf16x8 bq[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const sl_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sl_lds_s16x4*)(Bb + trB[j][0] + ks * 4096));
+                const sl_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sl_lds_s16x4*)(Bb + trB[j][1] + ks * 4096));
+                bq[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // (operands swapped: element r of lane l = output row i * 32 + (l & 31), column j * 32 + (r & 3) + 8 (r >> 2) + 4 (l >> 5))
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[j], a0, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[j], a1, acc[1][j], 0, 0, 0);
+            }
+        };
+        // k-tile kt (static): fragments from slot kt & 1; k-tile kt + 1 (ra, rx[(kt + 1) & 1]) -> LDS slot (kt + 1) & 1 in four slices
+        // behind the k-steps' MFMAs, k-tiles kt + 2 (A) / kt + 3 (X) requested (none of it in the last k-tile)
+        auto ktile = [&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
+            constexpr bool STAGE = kt < NK - 1;
+            using SG = std::integral_constant<int, (kt + 1) & 1>;
+            constexpr int nb = (kt + 1) & 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                mfma_step(kt, ks);
+                if constexpr (STAGE) {
+                    store_a(nb, ks); load_a(kt + 2, ks);
+                    if ((ks & 1) == 0) store_x(nb, SG{}, ks >> 1);
+                    if (ks == 3) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) load_x(kt + 3, SG{}, e);
+                    }
+                }
+                if constexpr (!(PW_SL_DBG & 4)) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2b6, 2, 0); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            SL_BARRIER();
+        };
+        auto kloop = [&]() {
+            ktile(std::integral_constant<int, 0>{}); ktile(std::integral_constant<int, 1>{});
+            if constexpr (NK > 2) { ktile(std::integral_constant<int, 2>{}); ktile(std::integral_constant<int, 3>{}); }
+            if constexpr (NK > 4) { ktile(std::integral_constant<int, 4>{}); ktile(std::integral_constant<int, 5>{});
+                                    ktile(std::integral_constant<int, 6>{}); ktile(std::integral_constant<int, 7>{}); }
+            static_assert(NK == 2 || NK == 4 || NK == 8, "k-loop instantiated for K = 128, 256, 512");
+        };
+        // the first tile's k-tiles 0 and 1, then k-tile 0 -> LDS slot 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_a(0, i);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) load_x(0, S0{}, e);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) load_x(1, S1{}, e);
+        for (int it = 0;; ++it) {
+            // k-tile 0 of this tile -> LDS slot 0 (the registers hold it), k-tiles 1 (A) and 2 (X) requested
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { store_a(0, i); load_a(1, i); }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { store_x(0, S0{}, e); load_x(2, S0{}, e); }
+            __builtin_amdgcn_sched_barrier(0);
+            SL_BARRIER();                               // it == 0: the start barrier; later: the hand-over of the previous tile's accumulators
+            kloop();
+            // the finished tile -> the LDS tile (the epilogue waves are done with the previous one: they passed the last k-tile's barrier)
+            int out_row = O_OFF + (wm * 64 + lr) * 256, out_slot = (wn * 16 + lh) ^ lr;
+            asm volatile("" : "+v"(out_row), "+v"(out_slot));
+            if constexpr (PW_SL_DBG & 16) {                  // timing-only: no hand-over (keep the accumulators alive)
+                float sum_ = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum_ += acc[i][j][r];
+                if (sum_ == 12345.678f) p.stats[0] = sum_;
+            } else
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const u32x2 o2 = {pack_bf16(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack_bf16(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])};
+                        // slot (wn 16 + j 8 + 2 g + lh) ^ lr = out_slot ^ (j 8 + 2 g): one XOR + one shift-add per store, from a base that
+                        // is re-derived per tile (hoisted, the sixteen addresses would live in registers across the k-loop)
+                        *reinterpret_cast<u32x2*>(smem + out_row + i * (32 * 256) + ((out_slot ^ (j * 8 + 2 * g)) << 3)) = o2;
+                    }
+            if (it + 1 >= ntl) break;
+            zero_acc();
+            v += (int)gridDim.x;
+            pw_work_v(p, v, total, b, tt, mt);
+            voA = voAn; voX = voXn;
+            t_lim = p.T - tt * PW_BN - x_ch * 8;
+            aim_next();
+        }
+        SL_BARRIER();                                   // the last hand-over
+        return;
+    }
+    // =================================================== epilogue waves ====================================================
+    if constexpr (!(PW_SL_DBG & 2)) {
+        // The epilogue waves are the workgroup's youngest: with issue arbitrated by priority, then age, they only get the slots the
+        // matrix waves leave (measured: 11 us per tile for ~1200 instructions).  Their stream is short; at a raised priority it
+        // costs the matrix waves little and is no longer what the tile time waits for.
+        if constexpr (PW_SL_PRIO > 0) __builtin_amdgcn_s_setprio(PW_SL_PRIO);
+        const int sw4 = wave - 8;                            // rows sw4 * 64 ... + 63 of a tile, two per pass
+        const int col4 = (lane & 31) * 4, half = lane >> 5;
+        const int in_row0 = O_OFF + (sw4 * 64 + half) * 256, in_slot0 = (lane & 31) ^ half;
+        const __amdgpu_buffer_rsrc_t rS = make_rsrc(p.stats, (unsigned)((size_t)p.B * p.n_ttiles * M * 8u));
+        const __amdgpu_buffer_rsrc_t rY = make_rsrc(p.Y, (unsigned)p.B * M * P16 * 2u);
+        const __amdgpu_buffer_rsrc_t rR = make_rsrc(MASK ? p.R : p.X, MASK ? (unsigned)p.B * M * P16 * 2u : 0u);
+        const __amdgpu_buffer_rsrc_t rEa = make_rsrc(MASK ? p.ea : p.X, MASK ? (unsigned)M * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t rEb = make_rsrc(MASK ? p.eb : p.X, MASK ? (unsigned)M * 4u : 0u);
+        constexpr int PPC = 32 / NK;                         // passes between two barriers
+        const int stepP = 2 * P16 * 2;                       // bytes from one pass to the next (two rows)
+        auto tile_vo = [&](int it_, int& b_, int& tt_, int& mt_) {
+            const int v_ = (int)blockIdx.x + (it_ < ntl ? it_ : ntl - 1) * (int)gridDim.x;
+            pw_work_v(p, v_, total, b_, tt_, mt_);
+            return ((b_ * M + mt_ * BM + sw4 * 64 + half) * P16 + tt_ * PW_BN + col4) * 2;
+        };
+        u32x2 rr[MASK ? 16 : 1];                              // R pieces of the next 16 passes (half a tile, ~2.5 us, ahead)
+        float cea = 0.f, ceb = 0.f, cean = 0.f, cebn = 0.f; // lane l: (ea, eb) of row sw4 * 64 + l of the tile in hand / the next one
+        int nb_, ntt_, nmt_;
+        int nvo = tile_vo(0, nb_, ntt_, nmt_);
+        if constexpr (MASK) {
+#pragma unroll
+            for (int ps = 0; ps < 16; ++ps) rr[ps] = __builtin_amdgcn_raw_buffer_load_b64(rR, nvo, ps * stepP, 0);
+            cean = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rEa, (nmt_ * BM + sw4 * 64 + lane) * 4, 0, 0));
+            cebn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rEb, (nmt_ * BM + sw4 * 64 + lane) * 4, 0, 0));
+        }
+        // one pass: rows sw4 * 64 + 2 ps + half of the LDS tile -> Y (and the row's partial sums); MASK: R piece ps is consumed and, when
+        // MORE, re-requested for the tile after this one
+        int pb = 0, ptt = 0, pmt = 0, pvo = 0, ptl = 0, psvo = 0;      // the tile in hand
+        auto pass = [&](auto psc, auto morec) {
+            constexpr int ps = decltype(psc)::value;
+            constexpr bool MORE = decltype(morec)::value;
+            if constexpr (PW_SL_DBG & 8) return;             // timing-only: the epilogue waves only keep the barriers
+            // row sw4 64 + 2 ps + half, slot (lane & 31) ^ (row & 31) = in_slot ^ (2 ps & 31) with in_slot = (lane & 31) ^ half
+            int in_row = in_row0, in_slot = in_slot0;
+            asm volatile("" : "+v"(in_row), "+v"(in_slot));     // (not hoisted: 32 address registers otherwise)
+            u32x2 o2 = *reinterpret_cast<const u32x2*>(smem + in_row + ps * 512 + ((in_slot ^ ((2 * ps) & 31)) << 3));
+            float s0 = 0.f, s1 = 0.f;
+            if constexpr (MASK) {
+                const int e0 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, cea), 2 * ps), e1 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, cea), 2 * ps + 1);
+                const int f0 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ceb), 2 * ps), f1 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ceb), 2 * ps + 1);
+                const float ea = __builtin_bit_cast(float, half ? e1 : e0), eb = __builtin_bit_cast(float, half ? f1 : f0);
+                const u32x2 r2 = rr[ps & 15];
+                // piece ps + 16: of this tile (pvo) for the first half, of the tile after it (nvo; only when there is one) for the second
+                if constexpr (ps < 16) rr[ps & 15] = __builtin_amdgcn_raw_buffer_load_b64(rR, pvo, (ps + 16) * stepP, 0);
+                else if constexpr (MORE) rr[ps & 15] = __builtin_amdgcn_raw_buffer_load_b64(rR, nvo, (ps - 16) * stepP, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // (columns past T of a partial last t-tile: accumulators exactly 0 -- zero X --, R's row padding is whatever the
+                    //  allocation held: the median maps a NaN / Inf there to a finite value, so 0 * R stays 0)
+                    const float r = __builtin_amdgcn_fmed3f(pw_bf16_at(r2, e), -3.3895314e38f, 3.3895314e38f);
+                    const float pre = fmaf(r, ea, eb);
+                    const bool keep = pre > 0.f && pre < 6.f;
+                    const float x = keep ? pw_bf16_at(o2, e) : 0.f;
+                    if (!keep) o2[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+                    s0 += x; s1 = fmaf(x, r, s1);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float x = pw_bf16_at(o2, e); s0 += x; s1 = fmaf(x, x, s1); }
+            }
+            // (a straddling lane's 8 bytes stay inside the pitched row; a lane wholly past T aims outside the descriptor: dropped)
+            if constexpr (!(PW_SL_DBG & 32)) __builtin_amdgcn_raw_buffer_store_b64(o2, rY, ptl > 0 ? pvo : 0x7ffffff0, ps * stepP, 0);
+            else if (o2[0] == 0x12345678u) p.stats[1] = 1.f;
+            if constexpr (PW_SL_DBG & 128) { if (s0 + s1 == 12345.678f) p.stats[2] = 1.f; return; }
+            s0 = half_wave_sum_dpp(s0);
+            s1 = half_wave_sum_dpp(s1);
+            // lanes 31 and 63 hold the two rows' sums: 8 bytes each at stats[part][row][0..1]
+            const u32x2 st2 = {__builtin_bit_cast(unsigned, s0), __builtin_bit_cast(unsigned, s1)};
+            if constexpr (!(PW_SL_DBG & 64)) __builtin_amdgcn_raw_buffer_store_b64(st2, rS, (lane & 31) == 31 ? psvo : 0x7ffffff0, ps * 16, 0);
+            else if (st2[0] == 0x12345678u) p.stats[1] = 1.f;
+        };
+        auto chunk = [&](auto cc, auto morec) {
+            constexpr int c = decltype(cc)::value;
+#define SL_P(k_) if constexpr ((k_) < PPC) pass(std::integral_constant<int, c * PPC + ((k_) < PPC ? (k_) : 0)>{}, morec);
+            SL_P(0) SL_P(1) SL_P(2) SL_P(3) SL_P(4) SL_P(5) SL_P(6) SL_P(7) SL_P(8) SL_P(9) SL_P(10) SL_P(11) SL_P(12) SL_P(13) SL_P(14) SL_P(15)
+#undef SL_P
+        };
+        auto begin_tile = [&](int it_) {                   // tile it_ becomes the tile in hand; the one after it the prefetch target
+            pvo = tile_vo(it_, pb, ptt, pmt);
+            ptl = p.T - (ptt * PW_BN + col4);
+            psvo = (((pb * p.n_ttiles + ptt) * M + pmt * BM + sw4 * 64 + half) * 2) * 4;
+            cea = cean; ceb = cebn;
+            nvo = tile_vo(it_ + 1, nb_, ntt_, nmt_);
+            if constexpr (MASK) {
+                cean = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rEa, (nmt_ * BM + sw4 * 64 + lane) * 4, 0, 0));
+                cebn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rEb, (nmt_ * BM + sw4 * 64 + lane) * 4, 0, 0));
+            }
+        };
+        auto process = [&](auto morec, auto barc) {         // NK chunks, a workgroup barrier behind each when BAR
+            constexpr bool BAR = decltype(barc)::value;
+#define SL_C(c_) if constexpr ((c_) < NK) { chunk(std::integral_constant<int, ((c_) < NK ? (c_) : 0)>{}, morec); if constexpr (BAR) SL_BARRIER(); }
+            SL_C(0) SL_C(1) SL_C(2) SL_C(3) SL_C(4) SL_C(5) SL_C(6) SL_C(7)
+#undef SL_C
+        };
+        SL_BARRIER();                                   // the start barrier
+        // tile 0's k-loop: nothing to do yet
+#pragma unroll
+        for (int c = 0; c < NK; ++c) SL_BARRIER();
+        SL_BARRIER();                                   // hand-over of tile 0
+        for (int it = 1; it < ntl; ++it) {
+            begin_tile(it - 1);
+            process(std::true_type{}, std::true_type{});
+            SL_BARRIER();                               // hand-over of tile it
+        }
+        begin_tile(ntl - 1);
+        process(std::false_type{}, std::false_type{});
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2266,6 +2609,20 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
         (long)p.B * p.M * P * 2 < 0x7ffffff0L) {
         const long nt_ = (long)pb.n_mtiles * p.n_ttiles * p.B;
         const unsigned gridp = 256;                    // one workgroup per CU walks tiles v = blockIdx.x, + 256, ... (any count)
+#if PW_SL
+        if (nt_ >= gridp) {
+            if (p.epi_mode == 1 && p.io16 == (PW_IO_X | PW_IO_Y) && ((PW_SL >> (p.K == 512 ? 0 : 1)) & 1)) {
+                if (p.K == 512) V100_GGL((pw_gemm_bf16_sl_kernel<1, 8>), dim3(gridp), dim3(768), 0, st, pb);
+                else V100_GGL((pw_gemm_bf16_sl_kernel<1, 4>), dim3(gridp), dim3(768), 0, st, pb);
+                return true;
+            }
+            if (p.epi_mode == 4 && p.io16 == (PW_IO_X | PW_IO_R | PW_IO_Y) && ((PW_SL >> (p.K == 512 ? 2 : 3)) & 1)) {
+                if (p.K == 512) V100_GGL((pw_gemm_bf16_sl_kernel<4, 8>), dim3(gridp), dim3(768), 0, st, pb);
+                else V100_GGL((pw_gemm_bf16_sl_kernel<4, 4>), dim3(gridp), dim3(768), 0, st, pb);
+                return true;
+            }
+        }
+#endif
         if (nt_ >= 2 * gridp) {
             if (p.epi_mode == 1 && p.io16 == (PW_IO_X | PW_IO_Y)) {
                 if (p.K == 512) V100_GGL((pw_gemm_bf16_ov_kernel<1, (PW_IO_X | PW_IO_Y), 8>), dim3(gridp), dim3(512), 0, st, pb);

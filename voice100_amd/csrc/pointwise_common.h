@@ -54,6 +54,22 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #ifndef PW_OV_MASK
 #define PW_OV_MASK 1         /* ... and project backward-data (mask epilogue) */
 #endif
+#ifndef PW_SL
+#define PW_SL 4              /* split-role short-K GEMM (pw_gemm_bf16_sl_kernel) instead of the overlapped-epilogue one: bit 0 expand forward
+                                K = 512, bit 1 K = 256, bit 2 project backward-data K = 512, bit 3 K = 256 */
+#endif
+#ifndef PW_SL_PRIO
+#define PW_SL_PRIO 3
+#endif
+#ifndef PW_SL_RAWBAR
+#define PW_SL_RAWBAR 1
+#endif
+#ifndef PW_OV_RAWBAR
+#define PW_OV_RAWBAR 0       /* the overlapped-epilogue kernel's k-tile barrier as s_waitcnt lgkmcnt(0) + s_barrier (no vmcnt(0)) */
+#endif
+#ifndef PW_SL_DBG
+#define PW_SL_DBG 0
+#endif
 #ifndef PW_OV_XTR
 #define PW_OV_XTR 1          /* round 5: the overlapped-epilogue kernel keeps its X image [k][t] as loaded (16-byte copies) and reads the B
                                 fragments with ds_read_b64_tr_b16 (0: [t][k] image built with byte permutes + 8-byte column stores) */
