@@ -45,6 +45,16 @@ def dw_source_sha():
     return h.hexdigest()[:16]
 
 
+def csrc_sha():
+    """sha256 (16 hex) over every kernel source: profiles/step_pmc.json (HBM bytes of the whole step) is quoted only for the tree it was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "voice100_amd", "csrc", "*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def encoder_dw_bytes(B, T):
     """Algorithmic bytes of the 9 depthwise forward launches: fp32 in + out + taps + BN coeffs."""
     specs = [(256, 11, 2), (1024, 19, 1), (1024, 27, 1), (1024, 35, 1), (1024, 51, 1),
@@ -299,6 +309,13 @@ def lean_line(out):
         r.pop("traffic_per_launch", None)
         cut(r, "kernel", 90)
         cut(r, "traffic_source", 110)
+        cut(r, "note", 160)
+    rs = o.get("roofline_step")
+    if isinstance(rs, dict):
+        for k in ("note", "families_algorithmic_mb"):
+            rs.pop(k, None)
+    if isinstance(r, dict):
+        r.pop("frac_note", None)
     if isinstance(o.get("launches_per_step"), dict):
         o["launches_per_step"] = o["launches_per_step"].get("value")
     cut(o.get("dp_path_single_rank"), "what", 60)
@@ -486,7 +503,7 @@ def main():
                      "frames_per_s": round(B_PER_GPU * T_FRAMES * n_sus / total_s, 1),
                      "host_enqueue_ms_per_step": round(host_s / n_sus * 1e3, 3),
                      "under_load": mid, "before": idle}
-    kt, kt_all = {}, {}
+    kt, kt_all, kt_nom = {}, {}, {}
     if not args.no_kernel_timing:
         kt = kt_main
         # per-kernel-family breakdown: a separate pass after the timed region (it slows the step, see above)
@@ -496,6 +513,18 @@ def main():
             step(batch)
         kt_all = {k: round(v[1] / nb, 3) for k, v in sorted(N.timing_read().items())}
         N.timing_enable(False)
+        # the same pass on the NOMINAL step only (time-stretch off: every launch is the 1024-frame problem the algorithmic byte model
+        # and the PMC passes describe) -> roofline_step.kernel_ms and the depthwise forward's nominal-only fraction
+        if aug is not None:
+            keep_ts, aug.do_timestretch = aug.do_timestretch, False
+        step(batch)
+        N.timing_enable(True)
+        for _ in range(nb):
+            step(batch)
+        kt_nom = {k: (v[0] / nb, v[1] / nb, v[2] / nb) for k, v in sorted(N.timing_read().items())}
+        N.timing_enable(False)
+        if aug is not None:
+            aug.do_timestretch = keep_ts
     # fp32 line (item 2c): the same step in the reference's own default arithmetic (exact-fp32 MFMA GEMMs, fp32 storage everywhere),
     # same model / optimiser state running on.  Extra key only.
     fp32_line = None
@@ -626,6 +655,25 @@ def main():
         e1.record(); sync()
         probe_gbs = 10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
+        # ... and a copy with the depthwise kernels' OWN access pattern (v100_rows_copy_probe: 1 KB bf16 rows of a [B][C][T] tensor, one
+        # workgroup per channel, one row per wave at a time, nontemporal) at the wide layers' shape, rotating over 4 buffer sets
+        # (> 256 MB between two uses of a line: HBM, not the Infinity Cache): what this LAYOUT lets a kernel with no arithmetic reach.
+        pat_gbs = None
+        try:
+            sets = [(torch.empty(B_PER_GPU * 2048 * 512 // 2, device=device, dtype=torch.float32).normal_(),
+                     torch.empty(B_PER_GPU * 2048 * 512 // 2, device=device, dtype=torch.float32)) for _ in range(4)]
+            for a_, b_ in sets:
+                N.call("v100_rows_copy_probe", a_, b_, B_PER_GPU, 2048, 1024)
+            sync()
+            e0.record()
+            for i in range(16):
+                a_, b_ = sets[i % 4]
+                N.call("v100_rows_copy_probe", a_, b_, B_PER_GPU, 2048, 1024)
+            e1.record(); sync()
+            pat_gbs = 16 * 2 * B_PER_GPU * 2048 * 1024 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del sets
+        except Exception:                                            # noqa: BLE001
+            pat_gbs = None
         frames = B_PER_GPU * T_FRAMES * world * args.steps
         dw_bytes, _ = encoder_dw_bytes(B_PER_GPU, T_FRAMES)
         roof = None
@@ -647,7 +695,13 @@ def main():
                     "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                     "algorithmic_bytes_per_launch": round(nbytes / n), "algorithmic_bytes_nominal_step": dw_bytes,
                     "measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
-                    "copy_probe_gbs": round(probe_gbs, 1), "frac_of_copy_probe": round(achieved / probe_gbs, 4)}
+                    "copy_probe_gbs": round(probe_gbs, 1), "frac_of_copy_probe": round(achieved / probe_gbs, 4),
+                    "pattern_copy_gbs": round(pat_gbs, 1) if pat_gbs else None,
+                    "frac_of_pattern_copy": round(achieved / pat_gbs, 4) if pat_gbs else None,
+                    "note": ("ceiling of this layout: a pure copy with the kernel's own access pattern ([B][C][T] bf16 rows, one workgroup per "
+                             "channel, one row per wave, measured live = pattern_copy_gbs) reaches "
+                             + (f"{pat_gbs / HBM_PEAK_GBS:.2f}" if pat_gbs else "0.56-0.64") + " of 8 TB/s; the 0.60 target needs channel-major "
+                             "hidden tensors, which cost the K <= 512 GEMMs more than the depthwise kernels gain (profiles/r04_layout_ab.txt)")}
             # `traffic` only when the PMC file lists FETCH_SIZE / WRITE_SIZE for EVERY forward launch the nominal step dispatches
             # (one row per layer, matched by kernel size): the ratio is the bytes-weighted mean over those rows
             rows = (pmc or {}).get("launches") or []
@@ -661,6 +715,42 @@ def main():
                                           f"with its own FETCH_SIZE / WRITE_SIZE rows (rocprofv3 PMC over bench.py itself, separate passes, "
                                           f"2*FETCH_SIZE + WRITE_SIZE; profiles/{os.path.basename(PMC_FILE)})")
                 roof["traffic_per_launch"] = [{"k": k, "kernel": byk[k]["kernel"], "ratio": round(byk[k]["hbm_bytes"] / byk[k]["algorithmic_bytes"], 4)} for k in ks]
+            if "dw_fwd" in kt_nom:               # the nominal step's nine launches alone (separate pass, time-stretch off): review item 3c
+                nn, nms, nby = kt_nom["dw_fwd"]
+                roof["frac_nominal_step"] = round(nby / (nms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                roof["frac_note"] = ("frac: every forward launch of the timed region (~30 % of the seeded steps are time-stretched: longer rows on the "
+                                     "three-tile / general kernels); frac_nominal_step: the nine launches of a 1024-frame step, timed in a separate pass")
+        # Step-level roofline (round-4 review, item 2): algorithmic bytes and 1x1-GEMM flops of ONE nominal step from the shape model
+        # (tools/step_model.py: every operand read once, every result written once, in the step's storage formats), the kernel time of a
+        # nominal step measured in THIS run (HIP events in the dispatch packets of every library launch), and the HBM bytes rocprofv3's
+        # counters saw for the same step (profiles/step_pmc.json, quoted only for the kernel sources it was measured on).
+        roof_step = None
+        try:
+            from tools import step_model
+            fam = step_model.by_family(step_model.step_rows(B_PER_GPU, T_FRAMES))
+            b_alg = sum(f["bytes"] for f in fam.values())
+            fl = sum(f["flops"] for f in fam.values())
+            k_ms = sum(v[1] for v in kt_nom.values()) if kt_nom else None
+            spmc = None
+            sp = os.path.join(ROOT, "profiles", "step_pmc.json")
+            if os.path.exists(sp):
+                spmc = json.load(open(sp))
+                if spmc.get("csrc_sha") != csrc_sha():
+                    spmc = None
+            roof_step = {"bytes_algorithmic": round(b_alg), "bytes_measured": (spmc or {}).get("bytes_measured_per_step"),
+                         "kernel_ms": round(k_ms, 3) if k_ms else None,
+                         "achieved_gbs": round(b_alg / (k_ms * 1e-3) / 1e9, 1) if k_ms else None,
+                         "frac_of_8TBs": round(b_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms else None,
+                         "hbm_floor_ms": round(b_alg / (HBM_PEAK_GBS * 1e9) * 1e3, 3), "mfma_floor_ms": round(fl / 2.5e15 * 1e3, 3),
+                         "gemm_tflops": round(fl / 1e12, 3),
+                         "launches": round(sum(v[0] for v in kt_nom.values()), 1) if kt_nom else None,
+                         "note": "nominal step (B = 32 x T = 1024, time-stretch off), library launches only; bytes_algorithmic / flops: tools/step_model.py; "
+                                 "bytes_measured: rocprofv3 PMC 2*FETCH_SIZE + WRITE_SIZE over every kernel of the step (profiles/step_pmc.json, "
+                                 "null when the kernel sources changed since); kernel_ms: HIP events of every launch in this run",
+                         "families_ms": {k: round(v[1], 3) for k, v in kt_nom.items()},
+                         "families_algorithmic_mb": {k: round(f["bytes"] / 1e6, 1) for k, f in fam.items()}}
+        except Exception as e:                                       # noqa: BLE001
+            roof_step = {"error": f"{type(e).__name__}: {e}"}
         out = {
             "metric": "audio frames/sec (fwd+bwd) asr_en_base, B=32x1024-frame mel" + (" [DIAGNOSTIC: time-stretch off]" if args.diag_no_timestretch else "") + (f" [DIAGNOSTIC: stretch {args.diag_stretch_rate}% every step]" if args.diag_stretch_rate else ""),
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -688,6 +778,7 @@ def main():
             "windows_ms_per_step": ({"n": len(windows), "median": round(float(np.median(windows)), 3), "min": round(min(windows), 3),
                                      "max": round(max(windows), 3)} if windows else None),
             "roofline": roof,
+            "roofline_step": roof_step,
             "kernel_ms_per_step": kt_all,
             "sustained": sustained,
             "fp32_ms_per_step": fp32_line,

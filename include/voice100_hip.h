@@ -255,7 +255,8 @@ int v100_ln_gelu_fwd(const float* y, const float* gamma, const float* beta, floa
 int v100_ln_gelu_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* mean,
                      const float* rstd, float* dy, float* partial, int B, int C, int T, void* stream);
 
-/* ---- opt-in kernel timing (bench.py roofline): HIP events on the launch stream for the hot kernels.
+/* ---- opt-in kernel timing (bench.py roofline): HIP events on the launch stream for the hot kernels (tags 0-4) and, with tag 5
+ * ("other"), in the dispatch packet of every other launch of the library (roofline_step.kernel_ms).
  * tags: 0 depthwise fwd, 1 depthwise bwd, 2 depthwise bwd-weight (stand-alone), 3 pointwise GEMM, 4 pointwise bwd-weight.
  * The depthwise launches are timed with the dispatch packet's own start/stop timestamps (hipExtLaunchKernelGGL: no
  * marker packets, the pair reads what rocprofv3 reports as the kernel's duration); the GEMM tags bracket their launches
@@ -270,6 +271,10 @@ long long v100_launch_count(void);
 int v100_copy_probe(const void* src, void* dst, long long nbytes, void* stream);
 int v100_timing_enable(int tag_mask);
 int v100_timing_read(int tag, double* ms, long long* count, double* bytes);
+/* The depthwise streaming kernels' access pattern as a pure copy (bench.py yardstick only): dst[b][c][:] = src[b][c][:] for
+ * row_bytes-byte rows of a [B][C][row_bytes] tensor, one workgroup per channel, one row per wave at a time, nontemporal.
+ * row_bytes % 1024 == 0. */
+int v100_rows_copy_probe(const void* src, void* dst, int B, int C, int row_bytes, void* stream);
 
 /* ---- "act16": bf16 STORAGE of the big hidden tensors in bf16-operand training (csrc/block.hip) ---------------
  * In bf16 mode the reference under autocast keeps its conv activations in bf16; here the two tensors a block saves for

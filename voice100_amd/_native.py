@@ -121,7 +121,7 @@ def helper(name, *args):
     return getattr(lib, name)(*args)
 
 
-TIMING_TAGS = {"dw_fwd": 0, "dw_bwd_data": 1, "dw_wgrad": 2, "pw_gemm": 3, "pw_wgrad": 4}
+TIMING_TAGS = {"dw_fwd": 0, "dw_bwd_data": 1, "dw_wgrad": 2, "pw_gemm": 3, "pw_wgrad": 4, "other": 5}
 
 
 def launch_count() -> int:

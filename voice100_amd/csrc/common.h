@@ -22,8 +22,18 @@ typedef unsigned short u16;
 // every kernel launch of the library goes through these two: a process-wide launch counter (v100_launch_count(), read by bench.py
 // to report launches per step from THIS run rather than from a stored profile)
 #include <atomic>
+#include <hip/hip_ext.h>
 inline std::atomic<long long> g_v100_launches{0};
-#define V100_GGL(...) do { g_v100_launches.fetch_add(1, std::memory_order_relaxed); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+// ... and, when bench.py's step-level pass asks for it (v100_timing_enable with the "other" bit), every launch that is not timed under
+// a family tag of its own carries an event pair in its dispatch packet (hipExtLaunchKernelGGL), so that the step's WHOLE kernel time
+// is read inside the run (roofline_step.kernel_ms) and not from a stored profile.  Off: one relaxed load per launch.
+extern "C" int v100_timing_other(void** a, void** b);      // timing.hip: 1 and an event pair when the "other" tag is on
+#define V100_GGL(kernel, grid, block, shmem, st, ...) do {                                                                 \
+        g_v100_launches.fetch_add(1, std::memory_order_relaxed);                                                             \
+        void *ta_ = nullptr, *tb_ = nullptr;                                                                                 \
+        if (v100_timing_other(&ta_, &tb_)) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, (hipEvent_t)ta_, (hipEvent_t)tb_, 0, ##__VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, st, ##__VA_ARGS__);                                              \
+    } while (0)
 #define V100_EXT_GGL(...) do { g_v100_launches.fetch_add(1, std::memory_order_relaxed); hipExtLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 static inline int v100_launch_status() {

@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include "common.h"
-enum { V100_T_DW_FWD = 0, V100_T_DW_BWD_DATA = 1, V100_T_DW_WGRAD = 2, V100_T_PW_GEMM = 3, V100_T_PW_WGRAD = 4 };
+enum { V100_T_DW_FWD = 0, V100_T_DW_BWD_DATA = 1, V100_T_DW_WGRAD = 2, V100_T_PW_GEMM = 3, V100_T_PW_WGRAD = 4, V100_T_OTHER = 5 };
 void v100_timing_begin(int tag, hipStream_t st, int* slot, double bytes);
 void v100_timing_end(int slot, hipStream_t st);
 // A launch timed by the dispatch packet's own start/stop timestamps (hipExtLaunchKernelGGL): no marker packets in the queue,

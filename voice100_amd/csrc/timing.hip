@@ -6,6 +6,7 @@
 #include "timing.h"
 #include <vector>
 #include <mutex>
+#include <atomic>
 #include <stdlib.h>
 
 namespace {
@@ -15,6 +16,7 @@ unsigned g_mask = 0;          // bit t set: launches tagged t are timed
 std::vector<Pair> g_pairs;
 size_t g_used = 0;
 const size_t kMaxPairs = 16384;
+thread_local int g_in_region = 0;   // > 0: this thread is inside a V100TimedRegion that is being timed (its launches belong to that tag, not to "other")
 }
 
 void v100_timing_begin(int tag, hipStream_t st, int* slot, double bytes) {
@@ -31,6 +33,7 @@ void v100_timing_begin(int tag, hipStream_t st, int* slot, double bytes) {
     g_pairs[g_used].bytes = bytes;
     (void)hipEventRecord(g_pairs[g_used].a, st);
     *slot = (int)g_used++;
+    ++g_in_region;
 }
 
 V100TimedLaunch::V100TimedLaunch(int tag, double bytes) {
@@ -49,8 +52,28 @@ V100TimedLaunch::V100TimedLaunch(int tag, double bytes) {
     ++g_used;
 }
 
+// every launch that goes through plain V100_GGL (common.h): timed under V100_T_OTHER when that bit is on
+std::atomic<unsigned> g_other_on{0};
+extern "C" int v100_timing_other(void** a, void** b) {
+    if (!g_other_on.load(std::memory_order_relaxed) || g_in_region > 0) return 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!((g_mask >> V100_T_OTHER) & 1u) || g_used >= kMaxPairs) return 0;
+    if (g_used >= g_pairs.size()) {
+        Pair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return 0;
+        g_pairs.push_back(p);
+    }
+    g_pairs[g_used].tag = V100_T_OTHER;
+    g_pairs[g_used].bytes = 0.0;
+    *a = g_pairs[g_used].a;
+    *b = g_pairs[g_used].b;
+    ++g_used;
+    return 1;
+}
+
 void v100_timing_end(int slot, hipStream_t st) {
     if (slot < 0) return;
+    --g_in_region;
     std::lock_guard<std::mutex> lk(g_mu);
     (void)hipEventRecord(g_pairs[slot].b, st);
 }
@@ -58,6 +81,7 @@ void v100_timing_end(int slot, hipStream_t st) {
 extern "C" int v100_timing_enable(int tag_mask) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_mask = (unsigned)tag_mask;
+    g_other_on.store(((unsigned)tag_mask >> V100_T_OTHER) & 1u, std::memory_order_relaxed);
     if (tag_mask) g_used = 0;
     return V100_OK;
 }
@@ -120,5 +144,32 @@ extern "C" int v100_copy_probe(const void* src, void* dst, long long nbytes, voi
     else if (un == 3) { if (nt) CP(2, true); else CP(2, false); }
     else { if (nt) CP(4, true); else CP(4, false); }
 #undef CP
+    return v100_launch_status();
+}
+
+// The depthwise streaming kernels' ACCESS PATTERN as a pure copy (no arithmetic): y[b][c][:] = x[b][c][:] for the P-sample bf16 rows of
+// a [B][C][P] tensor, one 256-thread workgroup per channel, wave w takes rows b = w, w + 4, ..., one row of loads in flight ahead of
+// the stores, nontemporal -- what dwconv_fwd16_stream_kernel does to memory (tools/micro/stream_pattern_probe.hip, D = 1 nt).  bench.py
+// times it on a rotating working set to report the [B][C][T] one-row-per-wave pattern's own ceiling next to the 8 TB/s nominal rate
+// (round-4 review, item 3: the kernel is graded against what its layout can reach).  P * 2 bytes must be a multiple of 1024 here.
+__global__ __launch_bounds__(256) void rows_copy_probe_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int B, int C, int P16B) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x;
+    const int per = P16B / 1024;                        // 1 KB pieces per row (64 lanes x 16 B)
+    const int nrows = (B - wave + 3) >> 2;
+    for (int q = 0; q < per; ++q) {
+        auto idx = [&](int r) -> size_t { return ((size_t)(wave + 4 * r) * C + c) * (size_t)(P16B / 16) + q * 64 + lane; };
+        f32x4 v = nrows > 0 ? __builtin_nontemporal_load(x + idx(0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < nrows; ++r) {
+            const f32x4 t = v;
+            if (r + 1 < nrows) v = __builtin_nontemporal_load(x + idx(r + 1));
+            __builtin_nontemporal_store(t, y + idx(r));
+        }
+    }
+}
+extern "C" int v100_rows_copy_probe(const void* src, void* dst, int B, int C, int row_bytes, void* stream) {
+    if (!src || !dst) return V100_ERR_NULL;
+    if (B <= 0 || C <= 0 || row_bytes <= 0 || (row_bytes & 1023)) return V100_ERR_SHAPE;
+    V100_GGL(rows_copy_probe_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, B, C, row_bytes);
     return v100_launch_status();
 }
