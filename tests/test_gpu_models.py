@@ -108,8 +108,12 @@ def test_asr_c1_full_size(cuda):
     m = AudioToTextCTC(audio_size=64, embed_size=512, vocab_size=29, hidden_size=512)
     assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) == 11621661
     sums = np.array([float(v.double().sum()) for v in m.state_dict().values() if v.dtype.is_floating_point])
-    if not np.allclose(sums, g["weight_sums"], rtol=0, atol=1e-9):
-        pytest.skip("torch RNG/init differs from the build container: seeded weights not reproducible here")
+    # The golden logits belong to the weights torch.manual_seed(1234) produces in the build container (11.6 M parameters are not
+    # shipped as a fixture).  If a torch build ever initialises differently this test must FAIL, not skip: it is the only full-size
+    # configs[0] pin against the reference's own logits -- regenerate tests/golden/asr_c1.npz with tests/golden/make_golden.py then.
+    assert np.allclose(sums, g["weight_sums"], rtol=0, atol=1e-9), (
+        "torch's seeded initialisation differs from the one tests/golden/asr_c1.npz was generated with: the configs[0] pin cannot "
+        "be checked -- regenerate the fixture with tests/golden/make_golden.py (needs /root/reference)")
     m = m.to(cuda).eval()
     logits = m(torch.from_numpy(g["audio"]).to(cuda))
     assert rel_err(logits, g["logits"]) < 1e-4

@@ -11,6 +11,9 @@
 // and emit  scale = gamma * rstd,  shift = beta - mean * scale  for the consumer's prologue.
 #include "common.h"
 #include "depthwise_common.h"     // DwFin / dw_finalize: BatchNorm finalisation inside a producing kernel
+#ifndef BN_FIN_WPB
+#define BN_FIN_WPB 4              /* channels (= waves) per workgroup of the stand-alone BatchNorm finalisers */
+#endif
 
 __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int parts, double count,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -18,9 +21,10 @@ __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int pa
                                          long long* __restrict__ num_batches_tracked, float momentum, float eps,
                                          float* __restrict__ scale, float* __restrict__ shift,
                                          float* __restrict__ save_mean, float* __restrict__ save_rstd, int C) {
-    // one wave per channel: lanes stride over the slab rows, fixed-order butterfly in double
-    const int c = blockIdx.x;
-    const int lane = threadIdx.x;
+    // one wave per channel (BN_FIN_WPB channels per workgroup): lanes stride over the slab rows, fixed-order butterfly in double
+    const int c = blockIdx.x * BN_FIN_WPB + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
     if (c == 0 && lane == 0 && num_batches_tracked) *num_batches_tracked += 1;
     double s0 = 0.0, s1 = 0.0;
     for (int g = lane; g < parts; g += 64) {
@@ -81,8 +85,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int pa
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, float* __restrict__ p, float* __restrict__ q,
                                        float* __restrict__ r, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int frozen) {
-    const int c = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int c = blockIdx.x * BN_FIN_WPB + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
     for (int g = lane; g < parts; g += 64) {
         s0 += (double)partial[((size_t)g * C + c) * 2 + 0];
@@ -589,7 +594,7 @@ extern "C" int v100_bn_finalize_train(const float* stats, int parts, long long c
                                       float eps, float* scale, float* shift, float* save_mean, float* save_rstd, int C, void* stream) {
     if (!stats || !gamma || !beta || !scale || !shift) return V100_ERR_NULL;
     if (C <= 0 || parts <= 0 || count <= 0) return V100_ERR_SHAPE;
-    V100_GGL(bn_finalize_train_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, parts, (double)count,
+    V100_GGL(bn_finalize_train_kernel, dim3(ceil_div(C, BN_FIN_WPB)), dim3(64 * BN_FIN_WPB), 0, (hipStream_t)stream, stats, parts, (double)count,
                        gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean, save_rstd, C);
     return v100_launch_status();
 }
@@ -607,7 +612,7 @@ extern "C" int v100_bn_bwd_finalize(const float* partial, int parts, long long c
                                     const float* rstd, float* p, float* q, float* r, float* dgamma, float* dbeta, int C, void* stream) {
     if (!partial || !gamma || !mean || !rstd || !p || !q || !r) return V100_ERR_NULL;
     if (C <= 0 || parts <= 0 || count <= 0) return V100_ERR_SHAPE;
-    V100_GGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, parts, (double)count,
+    V100_GGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, BN_FIN_WPB)), dim3(64 * BN_FIN_WPB), 0, (hipStream_t)stream, partial, parts, (double)count,
                        gamma, mean, rstd, p, q, r, dgamma, dbeta, C, 0);
     return v100_launch_status();
 }
@@ -616,7 +621,7 @@ extern "C" int v100_bn_bwd_finalize_frozen(const float* partial, int parts, long
                                            const float* rstd, float* p, float* q, float* r, float* dgamma, float* dbeta, int C, void* stream) {
     if (!partial || !gamma || !mean || !rstd || !p || !q || !r) return V100_ERR_NULL;
     if (C <= 0 || parts <= 0 || count <= 0) return V100_ERR_SHAPE;
-    V100_GGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, parts, (double)count,
+    V100_GGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, BN_FIN_WPB)), dim3(64 * BN_FIN_WPB), 0, (hipStream_t)stream, partial, parts, (double)count,
                        gamma, mean, rstd, p, q, r, dgamma, dbeta, C, 1);
     return v100_launch_status();
 }
