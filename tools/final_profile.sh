@@ -1,9 +1,11 @@
 #!/bin/bash
 # Round-end evidence -> gpurun_out/final/ (copy what is to be judged into profiles/):
-#   rocprofv3 --kernel-trace --stats of the bench command (per-kernel table + per-step breakdown), PMC passes of the depthwise
-#   micro-benchmark (HBM traffic ratio for bench.py's `roofline.traffic`, tagged with the kernel sources' hash), kernel tables of
-#   config 3 (tts predict + chain) and config 5 (log-mel -> encoder -> greedy decode), and the unprofiled bench line.
-tag=${1:-r04}
+#   rocprofv3 --kernel-trace --stats of the bench command (per-kernel table + per-step breakdown), the PMC passes over bench.py's
+#   nominal step for EVERY kernel (tools/pmc_bench_step.sh -> the 1x1-GEMM counter table, the step-level roofline table and
+#   profiles/step_pmc.json, which bench.py's roofline_step.bytes_measured reads), the per-launch HBM traffic of the depthwise forward
+#   launches (nominal + stretched; profiles/dw_fwd_pmc.json for roofline.traffic), the GEMM yardstick, kernel tables of config 3 / 5,
+#   and the unprofiled bench line.
+tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/final; rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python3 bench.py --steps 30 --warmup 5 --windows 0 --host-contention 0 --sustained-seconds 0 --no-extras --no-cpu-baseline --no-other-configs > $out/${tag}_bench_line_under_rocprof.json 2> $out/prof_err.txt
@@ -16,12 +18,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1)
 python3 tools/prof_summary.py "$f" 1 40 > $out/${tag}_infer_configs_kernel_summary.txt
 rm -rf $out/prof
-# HBM traffic of the depthwise forward launches AS bench.py DISPATCHES THEM (one row per launch; round-3 review, item 2a) -> the file bench.py
-# reads for `roofline.traffic` (tagged with the depthwise sources' hash), refreshed before the unprofiled bench line below
+# every kernel of the nominal step: SQ / TCC / GRBM counters (separate passes) -> GEMM counter table, step roofline table, step_pmc.json
+tools/pmc_bench_step.sh $out/pmc_step > $out/pmc_step.log 2>&1
+python3 tools/pmc_step_table.py $out/pmc_step --gemm-out $out/${tag}_gemm_pmc.txt --step-out $out/${tag}_step_roofline.txt --json $out/step_pmc.json > /dev/null 2>> $out/prof_err.txt
+cp $out/step_pmc.json profiles/step_pmc.json
+# HBM traffic of the depthwise forward launches AS bench.py DISPATCHES THEM (one row per launch) -> the file bench.py reads for
+# `roofline.traffic` (tagged with the depthwise sources' hash), refreshed before the unprofiled bench line below
 tools/pmc_bench_dw.sh $out/pmc_dw > /dev/null 2>&1
 python3 tools/pmc_dw_json.py $out/pmc_dw --json $out/dw_fwd_pmc.json > $out/${tag}_dw_fwd_pmc_per_launch.txt 2>&1
 cp $out/dw_fwd_pmc.json profiles/dw_fwd_pmc.json
 rm -rf $out/pmc_dw/*.csv
+python3 tools/gemm_yardstick.py > $out/${tag}_gemm_yardstick.txt 2>> $out/prof_err.txt
 python3 bench.py > $out/${tag}_bench_line.json 2> $out/bench_err.txt
 cp gpurun_out/bench_details.json $out/${tag}_bench_details.json 2>/dev/null
 tail -c 600 $out/${tag}_bench_line.json

@@ -278,6 +278,7 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
         CK(v100_pw_gemm_io(pw.w3tbf, w.da3, nullptr, nullptr, nullptr, nullptr, 0, w.dz2, s2, t2, a2, 4, w.part, B, hid, cout, T2,
                            PW_IO_R | (g16 ? PW_IO_Y : 0) | (a316 ? PW_IO_X : 0), stream));
         const int G16 = v100_dw_num_groups(B, hid);
+        bool da1 = false;
         const bool pre2 = (IR_FUSE_PRE & 2) && G16 == 1;    // BatchNorm-2 backward coefficients from the GEMM's slab, by the depthwise kernel
         if (!pre2) CK(v100_bn_bwd_finalize(w.part, parts16, (long long)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], hid, stream));
         if (G16 == 1) {        // BatchNorm-1 backward coefficients by the depthwise backward kernel itself
@@ -288,8 +289,12 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
             DwPre pre{};
             if (pre2) pre = DwPre{{2, (double)B * T2, g2, m2, r2, pp, qq, rr, (float*)P[17], (float*)P[18], nullptr, nullptr, nullptr, 0.f, 0.f},
                                   w.part, parts16};
+            // Round 5: where the streaming kernel can keep a wave's rows in registers (one group, B <= 32, every hidden tensor bf16) it
+            // writes the FINISHED gradient da1 = p dz1 + q a1 + r (into the dz1 buffer) and the two consumers below read ONE plain
+            // bf16 tensor -- bit for bit the operand their on-load transform of (dz1, a1) produced.
+            da1 = g16 && !frozen && dw_bwd_da1_supported(B, hid, T, K, G16);
             CK(dw_bwd_io_fin(w.dz2, a2, wd, pp, qq, rr, a1, s1, t1, w.dz1, w.part, w.slab, (float*)P[16], G16, B, hid, T, K,
-                             g16 ? (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y) : (DW_IO_X2 | DW_IO_AUX), fin, pre, stream));
+                             g16 ? (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y) : (DW_IO_X2 | DW_IO_AUX), fin, pre, stream, da1 ? 1 : 0));
             pp = pp2; qq = qq2; rr = rr2;
         } else {
             CK(v100_dwconv_bwd_io(w.dz2, a2, wd, pp, qq, rr, a1, s1, t1, w.dz1, w.part, w.slab, (float*)P[16], G16, B, hid, T, K,
@@ -297,6 +302,14 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
             CK(v100_bn_bwd_finalize(w.part, G16, (long long)B * T, g1, m1, r1, pp, qq, rr, (float*)P[14], (float*)P[15], hid, stream));
         }
         const void* x16 = (sh[IR_ACT16] >= 4 && (sh[IR_PREPPED] & 2)) ? P[24] : nullptr;
+        if (da1) {
+            CK(v100_pw_wgrad_io(w.dz1, nullptr, nullptr, nullptr, nullptr, 0, x16 ? x16 : (const void*)x, nullptr, nullptr, 0, w.slab, (float*)P[13],
+                                v100_pw_wgrad_splits(B, hid, cin), B, hid, cin, T, WG_IO_G | (x16 ? WG_IO_X : 0), stream));
+            if (dx)
+                CK(v100_pw_gemm_io(pw.w1tbf, w.dz1, nullptr, nullptr, nullptr, nullptr, 0, dx, nullptr, nullptr, res ? dy : nullptr, res ? 5 : 0, nullptr,
+                                   B, cin, hid, T, PW_IO_X, stream));
+            return V100_OK;
+        }
         CK(v100_pw_wgrad_io(w.dz1, a1, pp, qq, rr, 2, x16 ? x16 : (const void*)x, nullptr, nullptr, 0, w.slab, (float*)P[13], v100_pw_wgrad_splits(B, hid, cin),
                             B, hid, cin, T, WG_IO_G2 | (g16 ? WG_IO_G : 0) | (x16 ? WG_IO_X : 0), stream));
         if (dx)

@@ -477,9 +477,10 @@ extern "C" int v100_dwconv_bwd_io(const void* g, const void* g2, const float* w,
 
 int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc, const void* xpre,
                   const float* xa, const float* xb, void* dxin, float* stats, float* wpartial, float* dw, int G, int B, int C, int T, int K,
-                  int io16, const DwFin& fin, const DwPre& pre, void* stream) {
+                  int io16, const DwFin& fin, const DwPre& pre, void* stream, int da1) {
     if (!g || !g2 || !w || !ga || !gb || !gc || !xpre || !xa || !xb || !dxin || !stats || !wpartial || !dw) return V100_ERR_NULL;
     if ((fin.mode != 0 || pre.f.mode != 0) && G != 1) return V100_ERR_SHAPE;
+    if (da1 && (fin.mode != 2 || !dw_bwd_da1_supported(B, C, T, K, G))) return V100_ERR_SHAPE;
     if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || (K & 1) == 0 || G <= 0 || G > B) return V100_ERR_SHAPE;
     if ((size_t)B * C * dw_pitch16(T) * 4 >= 0x7fffff00ull) return V100_ERR_SHAPE;
     const int cm = (io16 >> 4) & 1;              // DW_IO_CM (see dw_fwd_train_io_fin)
@@ -489,9 +490,11 @@ int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga
     DwParams p{(const float*)g, (const float*)g2, w, ga, gb, gc, (float*)dxin, (const float*)xpre, xa, xb, stats,
                B, C, T, T, K, 1, K - 1 - pad, 1, 1, G, DW_IN_AFFINE2, DW_OUT_MASK_STATS, wpartial, io16, fin, pre};
     p.cm = cm;
+    p.da1 = da1;
     if (cm && io16 != (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y)) return V100_ERR_SHAPE;
     const bool all16 = io16 == (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y);
     if (!all16 && io16 != (DW_IO_X2 | DW_IO_AUX)) return V100_ERR_SHAPE;
+    if (da1 && (!all16 || cm)) return V100_ERR_SHAPE;
     V100TimedLaunch timed(V100_T_DW_BWD_DATA, (all16 ? 2.0 : 3.0) * B * C * 4.0 * T + 8.0 * C * K + 8.0 * C);
     if (G == 1) p.wpartial = dw;               // one group: the kernel's "partial" IS the weight gradient
     const bool done = all16 ? dw_launch_bwd_fused16g(p, st, timed) : dw_launch_bwd_fused16(p, st, timed);

@@ -15,6 +15,16 @@ static bool dws_bwd_enabled() {
     return on;
 }
 
+// the kept-rows form of the streaming kernel (DA1, depthwise_stream16.h): one group, a wave's rows fit its 8 register slots
+bool dw_bwd_da1_supported(int B, int C, int T, int K, int G) {
+    static const bool on = [] { const char* e = getenv("V100_IR_DA1"); return !(e && e[0] == '0'); }();     // A/B switch
+    if (!on || !dws_bwd_enabled() || G != 1 || B > 32 || T > 512 || T < 1 || C < 1) return false;     // (rows of 513-768 outputs: three sub-tiles, the kept rows no longer fit the register file)
+#define X(KK) if (K == KK) return true;
+    V100_DW_SPECIALISED(X)
+#undef X
+    return false;
+}
+
 bool dw_launch_bwd_fused16g(const DwParams& p, hipStream_t st, const V100TimedLaunch& tl) {
     // rows of up to 768 outputs: the streaming kernel (V100_DW_STREAM_BWD=0: the general kernel, for A/B runs)
     if (dws_bwd_enabled() && p.stride == 1 && p.upsample == 1 && p.flip && p.Tin == p.Tout && p.Tin <= 768 &&
@@ -23,7 +33,11 @@ bool dw_launch_bwd_fused16g(const DwParams& p, hipStream_t st, const V100TimedLa
         dim3 grid(p.C, p.G);
 #define GO(KK, NTT)                                                                                                               \
     do {                                                                                                                          \
-        if (p.Tin <= 512) V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_BWD_DEPTH, DWS_NT * 2, 2>), grid, dim3(256), 0, st, p);  \
+        if (p.da1) {                                                                                                              \
+            if (p.fin.mode != 2 || p.G != 1 || p.B > 32) return false;                                                            \
+            if (p.Tin > 512) return false;                                                                                        \
+            V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, 1, DWS_NT * 2, 2, true>), grid, dim3(256), 0, st, p);          \
+        } else if (p.Tin <= 512) V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_BWD_DEPTH, DWS_NT * 2, 2>), grid, dim3(256), 0, st, p);  \
         else V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_BWD_DEPTH, DWS_NT * 2, 3>), grid, dim3(256), 0, st, p);     \
     } while (0)
 #define X(KK)                                                                                                                     \
@@ -35,6 +49,6 @@ bool dw_launch_bwd_fused16g(const DwParams& p, hipStream_t st, const V100TimedLa
 #undef X
 #undef GO
     }
-    if (p.cm) return false;               // the general kernel addresses [B][C][P] only
+    if (p.cm || p.da1) return false;      // the general kernel addresses [B][C][P] only (and has no kept-rows form)
     return dw_launch_specialised<DW_IN_AFFINE2, DW_OUT_MASK_STATS, true, DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y>(p, st, tl);
 }

@@ -73,6 +73,9 @@ struct DwParams {
     // outputs) are laid side by side in ONE LDS image, `segn` utterances per item, `segs` image positions apart (a multiple of 16, >= P +
     // pad so that the zeros between two rows are each row's own zero padding).  0 / 1: one row per item.
     int segn, segs;
+    // fused backward, streaming kernel, one group, <= 32 batch rows (dw_bwd_da1_supported): the kernel writes the FINISHED BatchNorm-1
+    // backward gradient da1 = p dz1 + q a1 + r (coefficients it finalises itself: fin.mode == 2) where it otherwise writes dz1
+    int da1;
 };
 __device__ __forceinline__ unsigned dw_row_index(const DwParams& p, int b, int c) {
     return p.cm ? (unsigned)(c * p.B + b) : (unsigned)(b * p.C + c);
@@ -142,7 +145,8 @@ int dw_fwd_eval_io(const void* h1, const float* w, const float* out_a, const flo
                    int cm = 0, int f16 = 0);
 int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc, const void* xpre,
                   const float* xa, const float* xb, void* dxin, float* stats, float* wpartial, float* dw, int G, int B, int C, int T, int K,
-                  int io16, const DwFin& fin, const DwPre& pre, void* stream);
+                  int io16, const DwFin& fin, const DwPre& pre, void* stream, int da1 = 0);
+bool dw_bwd_da1_supported(int B, int C, int T, int K, int G);      // depthwise_bwd_fused16g.hip
 __host__ __device__ __forceinline__ int dw_pitch16(int T) { return (T + 7) & ~7; }
 
 struct DwWgradParams {

@@ -255,8 +255,19 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
 // the general kernel keeps one row of the first two in flight and loads a1 at the top of the row it is needed in (a full miss on
 // the critical path of every row).  Here all three are requested D rows ahead, from kernel entry on (12 VGPRs per row in flight).
 // Same arithmetic and order of accumulation: bit-identical results (E tiles, sums, stored gradient).
-template <int K, int NT, int D, int CP = 0, int NS = 2>
-__global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p) {
+// DA1 (round 5): the kernel finalises BatchNorm 1's backward itself (one group: it owns the channel's sums after its last row), so it
+// can hand its consumers -- the expand weight gradient and the expand backward-data GEMM -- the FINISHED gradient
+// da1 = p dz1 + q a1 + r instead of dz1, which both of them re-derive today from two 67 MB tensors with a transform on load (the
+// backward-data GEMM runs 62 us so against 43 on a plain operand).  A wave keeps the up to MAXR = 8 rows it produced -- dz1 as
+// stored (bf16) and the a1 it loaded for the mask: 4 NS registers a row -- instead of storing them, and after the channel's
+// coefficients are known writes fmaf(dz1, p, fmaf(a1, q, r)) rounded to bf16: exactly the value (same operations, same order) the
+// consumers' on-load transform produced, so every downstream result is bit-identical.  The row loop is unrolled MAXR times (rows past
+// a wave's last one run as the branch-free kernel's dummy rows); B <= 4 MAXR.
+#ifndef DWS_DA1_RELOAD
+#define DWS_DA1_RELOAD 0
+#endif
+template <int K, int NT, int D, int CP = 0, int NS = 2, bool DA1 = false, int MAXR = 8>
+__global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD) ? 2 : 3) void dwconv_bwd16_stream_kernel(DwParams p) {
     using S_ = DwStreamGeom<K, NS>;
     constexpr int STEPS = S_::STEPS, WPAD = S_::WPAD, WLEN = S_::WLEN, IB = S_::IB, NL = S_::NL, XIMG = S_::XIMG;
     constexpr int IMG0 = S_::FWD_IMG > S_::BWD_IMG ? S_::FWD_IMG : S_::BWD_IMG;
@@ -362,7 +373,9 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p)
     for (int ib = 0; ib < IB; ++ib) eacc[ib] = dwm_f32x4{0.f, 0.f, 0.f, 0.f};
     float s0 = 0.f, s1 = 0.f;
 
-    auto row = [&](Row& rw, int r) {
+    dwm_u32x2 keep_o[DA1 ? MAXR : 1][NS], keep_a[(DA1 && !DWS_DA1_RELOAD) ? MAXR : 1][NS];
+    auto row = [&](Row& rw, int r, auto rconst) {
+        constexpr int RI = decltype(rconst)::value;  // DA1: the row's slot in the kept arrays (a compile-time index: registers)
         const bool ok = r < nrows;                   // rows past the end: zero coefficients -> g' = 0, xin = 0, mask 0, nothing stored
         const float ra = ok ? ca : 0.f, rb = ok ? cb : 0.f, rc = ok ? cc : 0.f, roa = ok ? oa : 0.f, rob = ok ? ob : 0.f;
         float auxv[NS][4];
@@ -424,17 +437,28 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p)
                 outv[e] = yv;
             }
             const dwm_u32x2 o2 = {dwm_pack_rne(outv[0], outv[1]), dwm_pack_rne(outv[2], outv[3])};
-            __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && in_row) ? 2 * t0 : 0x7ffffff0, (int)yb, CP);
+            if constexpr (DA1) { keep_o[RI][sub] = o2; if constexpr (!DWS_DA1_RELOAD) keep_a[RI][sub] = rw.a[sub]; }
+            else __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && in_row) ? 2 * t0 : 0x7ffffff0, (int)yb, CP);
         }
+        if constexpr (DA1) (void)yb;
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);          // rows are not interleaved: the sums of a row retire before the next row starts
     };
 
+    using R0 = std::integral_constant<int, 0>;
+    if constexpr (DA1) {
+        static_assert(D == 1, "the kept-rows form walks one row at a time");
+#define DWS_ROW(i_) if constexpr ((i_) < MAXR) row(raw[0], (i_), std::integral_constant<int, ((i_) < MAXR ? (i_) : 0)>{});
+        DWS_ROW(0) DWS_ROW(1) DWS_ROW(2) DWS_ROW(3) DWS_ROW(4) DWS_ROW(5) DWS_ROW(6) DWS_ROW(7)
+#undef DWS_ROW
+        static_assert(MAXR <= 8, "unrolled by hand up to 8 rows per wave");
+    } else {
 #pragma unroll
-    for (int d = 0; d < D; ++d) row(raw[d], d);
-    for (int r0 = D; r0 < nrows; r0 += D) {
+        for (int d = 0; d < D; ++d) row(raw[d], d, R0{});
+        for (int r0 = D; r0 < nrows; r0 += D) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) row(raw[d], r0 + d);
+            for (int d = 0; d < D; ++d) row(raw[d], r0 + d, R0{});
+        }
     }
 
     // dWf[jf] = sum over waves and rr of E[rr + jf + off][rr]; the E tiles go through LDS (over the dead images)
@@ -466,6 +490,35 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd16_stream_kernel(DwParams p)
         const float t1s = (lds_red[0][1] + lds_red[1][1]) + (lds_red[2][1] + lds_red[3][1]);
         p.stats[((size_t)g * p.C + c) * 2 + 0] = t0s;
         p.stats[((size_t)g * p.C + c) * 2 + 1] = t1s;
-        if (p.fin.mode != 0) dw_finalize(p.fin, c, t0s, t1s);
+        if constexpr (DA1) dw_finalize_d(p.fin, c, (double)t0s, (double)t1s, lds_coef);      // (p, q, r) of BatchNorm 1's backward -> LDS too
+        else if (p.fin.mode != 0) dw_finalize(p.fin, c, t0s, t1s);
+    }
+    if constexpr (DA1) {
+        __syncthreads();
+        const float pa = lds_coef[0], qb = lds_coef[1], rc = lds_coef[2];
+        // DWS_DA1_RELOAD: a1 is not kept (half the registers, three workgroups per CU stay resident) but read again here -- the rows
+        // were in this CU's hands a few microseconds ago (L2 / Infinity Cache)
+        dwm_u32x2 again[DWS_DA1_RELOAD ? MAXR : 1][NS];
+        if constexpr (DWS_DA1_RELOAD) {
+#pragma unroll
+            for (int ri = 0; ri < MAXR; ++ri)
+#pragma unroll
+                for (int sub = 0; sub < NS; ++sub)
+                    again[ri][sub] = __builtin_amdgcn_raw_buffer_load_b64(raux, ri < nrows ? vo_aux[sub] : 0x7ffffff0, (int)row_bytes(ri < nrows ? ri : 0), 0);
+        }
+#pragma unroll
+        for (int ri = 0; ri < MAXR; ++ri) {
+            const bool ok = ri < nrows;
+            const unsigned yb = row_bytes(ok ? ri : 0);
+#pragma unroll
+            for (int sub = 0; sub < NS; ++sub) {
+                const int t0 = 256 * sub + 16 * n_ + 4 * q_;
+                float dv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dv[e] = fmaf(dwm_elem(keep_o[ri][sub], e), pa, fmaf(dwm_elem(DWS_DA1_RELOAD ? again[ri][sub] : keep_a[ri][sub], e), qb, rc));
+                const dwm_u32x2 o2 = {dwm_pack_rne(dv[0], dv[1]), dwm_pack_rne(dv[2], dv[3])};
+                __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && t0 < T) ? 2 * t0 : 0x7ffffff0, (int)yb, CP);
+            }
+        }
     }
 }

@@ -2207,9 +2207,10 @@ __global__ __launch_bounds__(768) void pw_gemm_bf16_sl_kernel(PwParams p) {
 // (M % GR == 0, K % XR == 0); TAIL: T % 64 != 0, contraction indices past T are zeroed in BOTH operands (masks on the plain one).
 template <int GM, int XM, bool TAIL, int IO, int GR, int XR, int NSW>
 __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgParams p) {
-    static_assert((GM == PW_X_NONE) != (XM == PW_X_NONE), "one plain operand (256 rows), one transformed (128 rows)");
+    // (both plain -- G = the finished gradient da1, round 5 --: G takes the 128-row side and its "transform" is a copy)
+    static_assert(!(GM != PW_X_NONE && XM != PW_X_NONE), "at most one transformed operand (128 rows); the other one plain (256 rows)");
     static_assert((IO & WG_IO_G) && (IO & WG_IO_X) && (GM != PW_X_AFFINE2 || (IO & WG_IO_G2)), "bf16-stored operands only");
-    constexpr bool PG = GM == PW_X_NONE;                    // the plain operand is G
+    constexpr bool PG = GM == PW_X_NONE && XM != PW_X_NONE; // the plain 256-row operand is G
     static_assert((PG ? GR : XR) == 256 && (PG ? XR : GR) == 128, "tile shape");
     constexpr int QM = PG ? XM : GM;                        // the transform
     constexpr int NX = XR / 64;
@@ -2274,7 +2275,7 @@ __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgPara
 #pragma unroll
         for (int i = 0; i < NQP; ++i) {
             const int r = row0 + qrow + QRS * i;
-            ca[i] = pa[r]; cb[i] = pb[r];
+            ca[i] = QM != PW_X_NONE ? pa[r] : 1.f; cb[i] = QM != PW_X_NONE ? pb[r] : 0.f;
             cc[i] = QM == PW_X_AFFINE2 ? p.gc[r] : 0.f;
         }
         const int voQ = ((row0 + qrow) * P16 + ch * 8) * 2;
@@ -2320,6 +2321,11 @@ __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgPara
                 if constexpr (PW_WG_ABL & 4) {              // timing-only: raw copy, no transform
                     o[i] = rq[SG][i];
                     if constexpr (QM == PW_X_AFFINE2) o[i][0] ^= rq2[SG][i][0];
+                    continue;
+                }
+                if constexpr (QM == PW_X_NONE) {            // plain operand on the staged side: copied as loaded
+                    o[i] = rq[SG][i];
+                    if constexpr (TAIL) { if (tail) o[i] = tail_mask(o[i], tb); }
                     continue;
                 }
                 float v[8];
@@ -2649,6 +2655,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     XS(0, 4, PW_IO_X | PW_IO_R | PW_IO_Y)                               // project backward-data
     XS(0, 1, PW_IO_X | PW_IO_Y)                                         // expand forward on the bf16 shadow
     XS(0, 3, PW_IO_X)                                                   // eval-mode project (K = the hidden width): y = bn3(W3 h2) (+ x)
+    XS(0, 5, PW_IO_X) XS(0, 0, PW_IO_X)                                 // expand backward-data on the finished gradient da1 (round 5): plain bf16 X, fp32 dx (+ dy)
 #undef XS
 #endif
 #if PW_PERSIST
@@ -2690,6 +2697,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     X(0, 4, PW_IO_X | PW_IO_R | PW_IO_Y)
     X(0, 2, PW_IO_Y)                      // eval-mode expand: h1 = relu6(bn1(W1 x)) stored as bf16 (inference, block executor)
     X(0, 3, PW_IO_X)                      // eval-mode project: y = bn3(W3 h2) (+ x), h2 bf16 in
+    X(0, 5, PW_IO_X) X(0, 0, PW_IO_X)     // expand backward-data on da1 (plain bf16 X), fp32 out (+ residual gradient)
 #undef X
     return false;
 }
@@ -2725,11 +2733,14 @@ bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
     //  waves instead of four: slower)
     if constexpr (PW_WG_WS & 2) { XS(2, 0, WG_IO_G | WG_IO_G2 | WG_IO_X, 128, 256, (PW_WG_WS & 8 ? 8 : 4)) }
     if constexpr (PW_WG_WS & 1) { XS(0, 1, WG_IO_G | WG_IO_X, 256, 128, (PW_WG_WS & 4 ? 8 : 4)) }
+    if constexpr (PW_WG_WS & 2) { XS(0, 0, WG_IO_G | WG_IO_X, 128, 256, 4) }       // expand gradient on the finished gradient da1 (round 5)
 #undef XS
 #endif
     XW(2, 0, WG_IO_G | WG_IO_G2 | WG_IO_X, 128, 256, 2)      // ... X = bf16 shadow of the block input: copied as loaded, 32 registers a stage
     XW(2, 0, WG_IO_G | WG_IO_G2, 128, 256, PW_WG_EXPAND_NST)      // expand: G = affine2(dz1, a1), X = block input (plain fp32)
     XW(0, 1, WG_IO_G | WG_IO_X, 256, 128, 2)       // project: G = da3 (plain bf16, copied), X = relu6(bn2(a2))
+    XW(0, 0, WG_IO_G | WG_IO_X, 128, 256, 2)       // expand on da1: both operands plain bf16, copied as loaded
+    XW(0, 0, WG_IO_G, 128, 256, 1)                 // ... X = the block input in fp32 (no shadow)
 #undef XW
 #endif
 #define X(GM, XM, IOV)                                                                                                              \
@@ -2743,6 +2754,7 @@ bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
     X(2, 0, WG_IO_G | WG_IO_G2)           // ... with dz1 stored as bf16
     X(2, 0, WG_IO_G | WG_IO_G2 | WG_IO_X) // ... and X = bf16 shadow of the block input
     X(0, 1, WG_IO_G | WG_IO_X)            // ... with da3 stored as bf16
+    X(0, 0, WG_IO_G | WG_IO_X) X(0, 0, WG_IO_G)      // expand gradient on the finished gradient da1 (bf16), X = bf16 shadow / fp32
 #undef X
     return false;
 }
