@@ -233,3 +233,48 @@ def test_frozen_statistics_block_matches_torch_autograd(cuda, precision, tol, gt
             assert rel_err(blk(x.detach()), yr.detach()) < tol
     finally:
         F_.set_matmul_precision("fp32")
+
+
+_DA1_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from voice100_amd import functional as F_
+from voice100_amd.layers import InvertedResidual
+F_.set_matmul_precision("bf16")
+torch.manual_seed(5)
+dev = torch.device("cuda:0")
+net = torch.nn.Sequential(InvertedResidual(256, 256, kernel_size=19), InvertedResidual(256, 512, kernel_size=51, use_residual=False),
+                          InvertedResidual(512, 512, kernel_size=83)).to(dev).train()
+out = {}
+for T in (200, 333, 512, 600):               # one sub-tile rows, a ragged length, the bench length, a length past the kept-rows form
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(8, 256, T, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(8, 512, T, generator=g).to(dev)
+    for p in net.parameters():
+        p.grad = None
+    y = F_.ir_stack_train(list(net), x)
+    (y * gy).sum().backward()
+    out[T] = [y.detach().cpu(), x.grad.cpu()] + [p.grad.cpu() for p in net.parameters()]
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_finished_gradient_path_is_bit_identical(cuda, tmp_path):
+    """Round 5: where it can, the fused depthwise backward writes the FINISHED BatchNorm-1-backward gradient da1 = p dz1 + q a1 + r
+    (block.hip, dw_bwd_da1_supported) and the expand weight gradient / backward-data GEMM read one plain bf16 operand instead of
+    transforming (dz1, a1) on load.  The claim is bit-identity of every result: the same stack is run in two child processes, with
+    the path on (default) and off (V100_IR_DA1=0 -- the switch is read once per process), and every output / gradient compared."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "da1.py"
+    script.write_text(_DA1_SCRIPT)
+    res = {}
+    for v in ("1", "0"):
+        env = dict(os.environ, V100_IR_DA1=v)
+        subprocess.run([sys.executable, str(script), root, str(tmp_path / f"out{v}.pt")], check=True, env=env, timeout=600)
+        res[v] = torch.load(tmp_path / f"out{v}.pt")
+    for T in res["1"]:
+        for a, b in zip(res["1"][T], res["0"][T]):
+            assert torch.equal(a, b), T
