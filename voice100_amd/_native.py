@@ -88,7 +88,14 @@ def _ptr(x):
     return x
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """torch's CURRENT stream on the current device as a raw hipStream_t (an int).  The private accessor is one C call; the
+    public torch.cuda.current_stream().cuda_stream builds a Stream object per call (10 us x ~10 library calls a step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -106,7 +113,7 @@ def call(name, *args):
                              bool(params) and params[-1][1] == "stream", len(params))
     fn, is_ptr, wants_stream, nparams = ent
     if wants_stream and len(args) == nparams - 1:
-        args = args + (torch.cuda.current_stream().cuda_stream,)
+        args = args + (stream_ptr(),)
     if len(args) != nparams:
         raise TypeError(f"{name}: expected {nparams} arguments, got {len(args)}")
     conv = [(_ptr(a) if (p and a is not None and not isinstance(a, int)) else a) for a, p in zip(args, is_ptr)]

@@ -263,11 +263,17 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
 // coefficients are known writes fmaf(dz1, p, fmaf(a1, q, r)) rounded to bf16: exactly the value (same operations, same order) the
 // consumers' on-load transform produced, so every downstream result is bit-identical.  The row loop is unrolled MAXR times (rows past
 // a wave's last one run as the branch-free kernel's dummy rows); B <= 4 MAXR.
+#ifndef DWS_BWD_MINW
+#define DWS_BWD_MINW 3        /* A/B: 2 = the plain fused backward at the kept-rows form's occupancy */
+#endif
+#ifndef DWS_BWD_PADLDS
+#define DWS_BWD_PADLDS 0
+#endif
 #ifndef DWS_DA1_RELOAD
 #define DWS_DA1_RELOAD 0
 #endif
 template <int K, int NT, int D, int CP = 0, int NS = 2, bool DA1 = false, int MAXR = 8>
-__global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD) ? 2 : 3) void dwconv_bwd16_stream_kernel(DwParams p) {
+__global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD) ? 2 : DWS_BWD_MINW) void dwconv_bwd16_stream_kernel(DwParams p) {
     using S_ = DwStreamGeom<K, NS>;
     constexpr int STEPS = S_::STEPS, WPAD = S_::WPAD, WLEN = S_::WLEN, IB = S_::IB, NL = S_::NL, XIMG = S_::XIMG;
     constexpr int IMG0 = S_::FWD_IMG > S_::BWD_IMG ? S_::FWD_IMG : S_::BWD_IMG;
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD) ? 2 : 3) void dwconv_
     constexpr int WAVE_U16 = IMGP + XIMG;
     constexpr int E_FLOATS = 16 * IB * 16;
     constexpr int LDS_BYTES = (4 * WAVE_U16 * 2 > 4 * E_FLOATS * 4) ? 4 * WAVE_U16 * 2 : 4 * E_FLOATS * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES + DWS_BWD_PADLDS];      // (DWS_BWD_PADLDS: A/B of the occupancy alone)
     __shared__ float lds_w[256];
     __shared__ float lds_red[4][2];
 
@@ -380,9 +386,11 @@ __global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD) ? 2 : 3) void dwconv_
         const float ra = ok ? ca : 0.f, rb = ok ? cb : 0.f, rc = ok ? cc : 0.f, roa = ok ? oa : 0.f, rob = ok ? ob : 0.f;
         float auxv[NS][4];
 #pragma unroll
-        for (int sub = 0; sub < NS; ++sub)
+        for (int sub = 0; sub < NS; ++sub) {
+            if constexpr (DA1 && !DWS_DA1_RELOAD) keep_a[RI][sub] = rw.a[sub];      // (before issue() below re-uses rw for the next row)
 #pragma unroll
             for (int e = 0; e < 4; ++e) auxv[sub][e] = dwm_elem(rw.a[sub], e);
+        }
 #pragma unroll
         for (int v = 0; v < NL; ++v) {
             float vals[8];
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD) ? 2 : 3) void dwconv_
                 outv[e] = yv;
             }
             const dwm_u32x2 o2 = {dwm_pack_rne(outv[0], outv[1]), dwm_pack_rne(outv[2], outv[3])};
-            if constexpr (DA1) { keep_o[RI][sub] = o2; if constexpr (!DWS_DA1_RELOAD) keep_a[RI][sub] = rw.a[sub]; }
+            if constexpr (DA1) keep_o[RI][sub] = o2;
             else __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && in_row) ? 2 * t0 : 0x7ffffff0, (int)yb, CP);
         }
         if constexpr (DA1) (void)yb;

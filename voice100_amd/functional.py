@@ -406,6 +406,7 @@ class IRStackTrainFn(torch.autograd.Function):
         # (plain attributes, not save_for_backward: y is a view of the blob, and the fused optimiser updates parameters through raw
         # pointers anyway -- tensor version counters say nothing here)
         ctx.blob, ctx.x, ctx.x16, ctx.params, ctx.desc, ctx.totals, ctx.cfgs = blob, x, x16, params, desc, totals, cfgs
+        ctx.ptab = ptab                                   # the same 18 n pointers serve this forward's backward (same step, same storages)
         ctx.y_shape = y.shape
         return y, y16
 
@@ -426,8 +427,7 @@ class IRStackTrainFn(torch.autograd.Function):
             grads = _f32(totals[2], like=x)
         ws = torch.empty(totals[1], dtype=torch.uint8, device=x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        ptab = (ctypes.c_void_p * (18 * n))(*[t.data_ptr() for t in params])
-        N.call("v100_ir_stack_bwd", ctx.desc, ptab, x, ctx.x16, ctx.blob, dy, dx, grads, ws)
+        N.call("v100_ir_stack_bwd", ctx.desc, ctx.ptab, x, ctx.x16, ctx.blob, dy, dx, grads, ws)
         ctx.blob = None                                   # the activations are dead: free them before the rest of backward runs
         out, off = [], 0
         for i, (cin, hid, cout, k, _, _) in enumerate(cfgs):
