@@ -142,6 +142,14 @@ int v100_augment_fused(const float* x, const int* len, const float* uniform, flo
                        int F, int stretch_rate, float pitch_rate, float amp, int n_tmask, const int* tm_s,
                        const int* tm_e, const float* tm_a, int fm_on, int fm_s, int fm_e, float fm_a, int noise_on,
                        float noise_low, float noise_high, float noise_std, int mix, float log_offset, void* stream);
+/* The same pass fed the lengths BEFORE the stretch (len_raw, int32, device): it derives len * stretch_rate / 100 (audio.py:58)
+ * itself and also writes it to len_out [B] and (len_out + 1) / 2 -- ConvVoiceEncoder.output_length, asr.py:80-81 -- to half_out [B]
+ * (either may be null): the integer tensor ops of a training step folded into the pass that reads the lengths anyway. */
+int v100_augment_fused_len(const float* x, const int* len_raw, int* len_out, int* half_out, const float* uniform, float* y,
+                           int B, int Tin, int Tout, int F, int stretch_rate, float pitch_rate, float amp, int n_tmask,
+                           const int* tm_s, const int* tm_e, const float* tm_a, int fm_on, int fm_s, int fm_e, float fm_a,
+                           int noise_on, float noise_low, float noise_high, float noise_std, int mix, float log_offset,
+                           void* stream);
 
 /* ---- K4 / K7 / K9 glue (csrc/features.hip) -------------------------------------------------
  * shift_copy: out[b][out_coff+c][u*out_mul+out_add] (=|+=) in[b][in_coff+c][u*in_mul+in_add] (0 when that

@@ -609,3 +609,38 @@ def test_streaming_config5_full_size_vs_oracle(cuda, precision):
     for b in range(32):
         if clear[b]:
             assert ids[b, :int(n[b])].cpu().tolist() == intops.merge_repeated_ids(ref_logits[b].argmax(-1).tolist())
+
+
+def test_augment_side_lengths_and_unit_root_gradient(cuda):
+    """The augmentation pass writes the stretched lengths and the encoder's (len + 1) // 2 itself (bit-exact integers, every input
+    form), and TrainStep's cached unit root gradient gives the gradients loss.backward() gives."""
+    from voice100_amd import functional as F_
+    from voice100_amd.audio import BatchSpectrogramAugumentation, AugmentDecisions
+    aug = BatchSpectrogramAugumentation()
+    g = torch.Generator().manual_seed(5)
+    audio = torch.randn(7, 211, 64, generator=g).to(cuda)
+    lens = torch.tensor([211, 1, 0, 210, 77, 150, 3])
+    for rate in (0, 50, 99, 100, 149):
+        for form in (lens, lens.to(torch.int32).to(cuda), lens.to(cuda)):
+            d = AugmentDecisions(); d.stretch_rate = rate
+            out, ln = aug(audio, form, decisions=d)
+            want = torch.div(lens * rate, 100, rounding_mode="trunc") if rate else lens
+            assert ln.dtype == form.dtype and ln.device == form.device
+            assert torch.equal(ln.cpu().long(), want)
+            half = F_.half_length(ln)
+            assert half is not None and half.dtype == torch.int32 and half.is_cuda
+            assert torch.equal(half.cpu().long(), torch.div(want + 1, 2, rounding_mode="trunc"))
+            if ln.is_cuda:
+                ln.add_(1)                                  # a written-to lengths tensor drops its tag
+                assert F_.half_length(ln) is None
+    # unit root gradient == loss.backward()
+    logits = torch.randn(4, 50, 29, device=cuda, requires_grad=True)
+    tgt = torch.randint(1, 29, (4, 12), device=cuda)
+    il = torch.tensor([50, 40, 33, 50], dtype=torch.int32, device=cuda); tl = torch.tensor([12, 3, 7, 9], dtype=torch.int32, device=cuda)
+    loss = F_.ctc_loss(logits, tgt, il, tl)
+    (g0,) = torch.autograd.grad(loss, logits)
+    loss = F_.ctc_loss(logits, tgt, il, tl)
+    (g1,) = torch.autograd.grad(loss, logits, grad_outputs=F_.unit_grad(loss))
+    loss = F_.ctc_loss(logits, tgt, il, tl)
+    (g2,) = torch.autograd.grad(loss, logits, grad_outputs=torch.full((), 2.0, device=cuda))
+    assert torch.equal(g0, g1) and torch.allclose(g2, 2 * g0)

@@ -99,10 +99,14 @@ def main():
             ("expand bwd-data   Y[C x N] = W1^T[C x hid] X[hid x N]", C, hid,
              L(lambda s: torch.matmul(W1t, s["xh"], out=s["yc"])), L(lambda s: torch.matmul(W1t, s["fh"], out=s["ofc"])),
              L(lambda s: G(W1t, s["xh"], None, None, None, None, 0, s["yc32"], cc[0], cc[1], None, 3, None, B, C, hid, T, 1)),
-             L(lambda s: G(W1t, s["xh"], s["xh2"], ch[0], ch[1], ch[2], 2, s["yc32"], None, None, s["x32"], 5, None, B, C, hid, T, 3)), "BN-bwd affine of two tensors on load, +residual, fp32 out (plain: the eval-mode kernel)"),
+             L(lambda s: G(W1t, s["xh"], None, None, None, None, 0, s["yc32"], None, None, s["x32"], 5, None, B, C, hid, T, 1)), "round 5: plain bf16 X = the finished gradient da1 (written by the depthwise backward), +residual, fp32 out"),
+            ("  ... round 4's form: BN-bwd affine of (dz1, a1) on load", C, hid, None, None, None,
+             L(lambda s: G(W1t, s["xh"], s["xh2"], ch[0], ch[1], ch[2], 2, s["yc32"], None, None, s["x32"], 5, None, B, C, hid, T, 3)), "BN-bwd affine of two tensors on load, +residual, fp32 out"),
             ("expand wgrad      dW1[hid x C] = G[hid x N] X[C x N]^T", hid, C,
              None, L(lambda s: torch.matmul(s["fh"], s["fc"].t(), out=dW1b)),
              None,
+             L(lambda s: WG(s["xh"], None, None, None, None, 0, s["xc"], None, None, 0, p1, dW1, S1, B, hid, C, T, 5)), "round 5: plain bf16 G = da1 (+ slab reduce launch)"),
+            ("  ... round 4's form: BN-bwd affine on G", hid, C, None, None, None,
              L(lambda s: WG(s["xh"], s["xh2"], ch[0], ch[1], ch[2], 2, s["xc"], None, None, 0, p1, dW1, S1, B, hid, C, T, 7)), "BN-bwd affine on G (+ slab reduce launch)"),
             ("project wgrad     dW2[C x hid] = G[C x N] X[hid x N]^T", C, hid,
              None, L(lambda s: torch.matmul(s["fc"], s["fh"].t(), out=dW2b)),
@@ -114,13 +118,15 @@ def main():
         tot = [0.0, 0.0, 0.0, 0.0]
         for name, M, K, yb, yf, op, oi, mode in rows:
             cells = []
+            extra = name.startswith("  ...")                 # a second form of the row above: shown, not summed
             for j, fns in enumerate((yb, yf, op, oi)):
                 if fns is None:
                     cells.append(f"{'-':>16s}")
                     continue
                 try:
                     dt = timeit(fns, args.iters)
-                    tot[j] += dt
+                    if not extra:
+                        tot[j] += dt
                     cells.append(f"{dt*1e6:7.1f} us {fl/dt/2.5e15:5.2f}")
                 except Exception as ex:                                      # noqa: BLE001
                     cells.append(f"{'ERR ' + type(ex).__name__:>16s}")

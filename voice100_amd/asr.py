@@ -43,6 +43,9 @@ class ConvVoiceEncoder(nn.Module):
         return self.layers(embed)
 
     def output_length(self, embed_len: torch.Tensor) -> torch.Tensor:
+        half = F_.half_length(embed_len)          # the augmentation pass already wrote (len + 1) // 2 next to the lengths
+        if half is not None:
+            return half
         return torch.div(embed_len + 1, 2, rounding_mode="trunc")
 
 

@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from . import _native as N
+from . import functional as F_
 
 __all__ = ["BatchSpectrogramAugumentation"]
 
@@ -89,10 +90,12 @@ class BatchSpectrogramAugumentation(nn.Module):
         Tout = Tin
         if d.stretch_rate:
             Tout = Tin * d.stretch_rate // 100
-            audio_len = torch.div(audio_len * d.stretch_rate, 100, rounding_mode="trunc")
         if Tout <= 0:
             raise RuntimeError("timestretch produced an empty batch")
-        len_dev = audio_len.to(device=audio.device, dtype=torch.int32).contiguous()
+        # the kernel takes the lengths BEFORE the stretch and derives len * rate // 100 (audio.py:58) itself; it also writes them
+        # and the encoder's (len + 1) // 2 as side outputs, so the step spends no integer tensor ops on either
+        len_raw = audio_len.to(device=audio.device, dtype=torch.int32).contiguous()
+        len_pair = torch.empty((2, B), dtype=torch.int32, device=audio.device)
         n = len(d.tmask)
         tm_s, tm_e, tm_a = (ctypes.c_int * 3)(), (ctypes.c_int * 3)(), (ctypes.c_float * 3)()
         for i, (t, hw, a) in enumerate(d.tmask):
@@ -111,7 +114,12 @@ class BatchSpectrogramAugumentation(nn.Module):
                 uniform = torch.rand((B, Tout, F), device=audio.device)
             uniform = uniform.to(audio.device).contiguous()
         out = torch.empty((B, Tout, F), dtype=torch.float32, device=audio.device)
-        N.call("v100_augment_fused", audio, len_dev, uniform, out, B, Tin, Tout, F, int(d.stretch_rate), float(d.pitch_rate),
-               float(d.amp), n, tm_s, tm_e, tm_a, fm_on, fm_s, fm_e, float(fm_a), int(d.noise is not None),
-               float(low), float(high), float(std), int(d.mix), float(self.log_offset))
-        return out, audio_len
+        N.call("v100_augment_fused_len", audio, len_raw, len_pair[0], len_pair[1], uniform, out, B, Tin, Tout, F,
+               int(d.stretch_rate), float(d.pitch_rate), float(d.amp), n, tm_s, tm_e, tm_a, fm_on, fm_s, fm_e, float(fm_a),
+               int(d.noise is not None), float(low), float(high), float(std), int(d.mix), float(self.log_offset))
+        if audio_len.device != audio.device:      # host lengths stay host lengths, computed there as the reference does (no sync)
+            out_len = torch.div(audio_len * d.stretch_rate, 100, rounding_mode="trunc") if d.stretch_rate else audio_len.clone()
+        else:
+            out_len = len_pair[0] if audio_len.dtype == torch.int32 else len_pair[0].to(audio_len.dtype)
+        F_.tag_half_length(out_len, len_pair[1])
+        return out, out_len

@@ -269,11 +269,14 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
 #ifndef DWS_BWD_PADLDS
 #define DWS_BWD_PADLDS 0
 #endif
+#ifndef DWS_DA1_K3
+#define DWS_DA1_K3 0          /* kept-rows form: kernel sizes up to this keep three workgroups per CU (168 registers) */
+#endif
 #ifndef DWS_DA1_RELOAD
 #define DWS_DA1_RELOAD 0
 #endif
 template <int K, int NT, int D, int CP = 0, int NS = 2, bool DA1 = false, int MAXR = 8>
-__global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD) ? 2 : DWS_BWD_MINW) void dwconv_bwd16_stream_kernel(DwParams p) {
+__global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD && K > DWS_DA1_K3) ? 2 : DWS_BWD_MINW) void dwconv_bwd16_stream_kernel(DwParams p) {
     using S_ = DwStreamGeom<K, NS>;
     constexpr int STEPS = S_::STEPS, WPAD = S_::WPAD, WLEN = S_::WLEN, IB = S_::IB, NL = S_::NL, XIMG = S_::XIMG;
     constexpr int IMG0 = S_::FWD_IMG > S_::BWD_IMG ? S_::FWD_IMG : S_::BWD_IMG;
@@ -382,7 +385,11 @@ __global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD) ? 2 : DWS_BWD_MINW) v
     dwm_u32x2 keep_o[DA1 ? MAXR : 1][NS], keep_a[(DA1 && !DWS_DA1_RELOAD) ? MAXR : 1][NS];
     auto row = [&](Row& rw, int r, auto rconst) {
         constexpr int RI = decltype(rconst)::value;  // DA1: the row's slot in the kept arrays (a compile-time index: registers)
-        const bool ok = r < nrows;                   // rows past the end: zero coefficients -> g' = 0, xin = 0, mask 0, nothing stored
+        // (DA1: r is a constant in each of the eight unrolled copies, so `ok` and the five coefficient selects below would be hoisted
+        //  out of all of them and live across the whole loop: 40 registers.  An opaque copy of nrows keeps them inside their row.)
+        int nrows_l = nrows;
+        if constexpr (DA1) asm volatile("" : "+s"(nrows_l));
+        const bool ok = r < nrows_l;                 // rows past the end: zero coefficients -> g' = 0, xin = 0, mask 0, nothing stored
         const float ra = ok ? ca : 0.f, rb = ok ? cb : 0.f, rc = ok ? cc : 0.f, roa = ok ? oa : 0.f, rob = ok ? ob : 0.f;
         float auxv[NS][4];
 #pragma unroll

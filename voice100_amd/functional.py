@@ -1282,7 +1282,40 @@ class CTCLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         (grad,) = ctx.saved_tensors
+        if is_unit_grad(gout):           # the root gradient TrainStep hands to backward(): the factor is exactly 1, no pass over grad
+            return grad, None, None, None, None
         return grad * gout, None, None, None, None
+
+
+_UNIT_GRADS = {}
+
+
+def unit_grad(like: torch.Tensor) -> torch.Tensor:
+    """A cached scalar 1 of `like`'s device and dtype: the root gradient of loss.backward() without the ones_like launch per step
+    (TrainStep passes it; CTCLossFn.backward recognises it by address and skips its multiply).  Nothing may write to it."""
+    key = (like.device, like.dtype)
+    one = _UNIT_GRADS.get(key)
+    if one is None:
+        one = _UNIT_GRADS[key] = torch.ones((), device=like.device, dtype=like.dtype)
+    return one
+
+
+def is_unit_grad(g: torch.Tensor) -> bool:
+    one = _UNIT_GRADS.get((g.device, g.dtype))
+    return one is not None and g.dim() == 0 and g.data_ptr() == one.data_ptr()
+
+
+def tag_half_length(lengths: torch.Tensor, half: torch.Tensor) -> None:
+    """Attach (lengths + 1) // 2, already computed on the device by the augmentation pass, to the lengths tensor it belongs to;
+    half_length() returns it instead of launching the two integer ops -- as long as `lengths` has not been written to since."""
+    lengths._v100_half = (half, lengths._version)
+
+
+def half_length(lengths: torch.Tensor):
+    tag = getattr(lengths, "_v100_half", None)
+    if tag is not None and tag[1] == lengths._version:
+        return tag[0]
+    return None
 
 
 def ctc_loss(logits_btv, targets, input_lengths, target_lengths, blank: int = 0):

@@ -11,6 +11,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from . import functional as F_
 from .dist import FlatGradBuckets, broadcast_module_state
 
 
@@ -83,7 +84,10 @@ class TrainStep:
         loss = self.model.training_step(batch, self.step_idx)
         if isinstance(loss, dict):
             loss = loss["loss"]
-        loss.backward()
+        if loss.dim() == 0 and loss.is_cuda:
+            torch.autograd.backward(loss, grad_tensors=F_.unit_grad(loss))      # (no ones_like launch; the CTC head sees the factor is 1)
+        else:
+            loss.backward()
         self.buckets.finish_step()
         self.optimizer.step()
         self.step_idx += 1
