@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One inference workload, a few iterations, for rocprofv3 --kernel-trace --stats (kernel tables of the inference configs):
-    python tools/prof_eval.py asr32 bf16 | stream256 fp16 | predict16 bf16 | chainwave bf16     [--iters 10]"""
+    python tools/prof_eval.py asr32 bf16 | stream256 fp16 | stream32 bf16 | asr2 bf16 | predict16 bf16 | chainwave bf16     [--iters 10]"""
 import os
 import sys
 
@@ -31,6 +31,15 @@ def main():
             mel = MelSpectrogramAudioTransform().to(dev)
             wav = torch.rand(256, 16000, device=dev) * 2 - 1
             fn = lambda: ctc_greedy_decode(m(mel(wav)))
+        elif what in ("stream32", "stream32nd"):        # configs[4] at B = 32: 1-second chunks, 101 frames -> 51
+            m = AudioToTextCTC(64, 512, 29, 512).to(dev).eval()
+            mel = MelSpectrogramAudioTransform().to(dev)
+            wav = torch.rand(32, 16000, device=dev) * 2 - 1
+            fn = (lambda: ctc_greedy_decode(m(mel(wav)))) if what == "stream32" else (lambda: m(mel(wav)))
+        elif what == "asr2":                            # configs[0]: B = 2 x 256 frames
+            m = AudioToTextCTC(64, 512, 29, 512).to(dev).eval()
+            x = torch.rand(2, 256, 64, device=dev)
+            fn = lambda: m(x)
         elif what == "predict16":
             t = AlignTextToAudioModel(vocab_size=29, hidden_size=512, use_mcep=False).to(dev).eval()
             at = torch.randint(0, 29, (16, 512), device=dev)

@@ -95,7 +95,7 @@ class BatchSpectrogramAugumentation(nn.Module):
         # the kernel takes the lengths BEFORE the stretch and derives len * rate // 100 (audio.py:58) itself; it also writes them
         # and the encoder's (len + 1) // 2 as side outputs, so the step spends no integer tensor ops on either
         len_raw = audio_len.to(device=audio.device, dtype=torch.int32).contiguous()
-        len_pair = torch.empty((2, B), dtype=torch.int32, device=audio.device)
+        len_pair = torch.empty((2, (B + 3) & ~3), dtype=torch.int32, device=audio.device)[:, :B]     # (rows 16-byte aligned)
         n = len(d.tmask)
         tm_s, tm_e, tm_a = (ctypes.c_int * 3)(), (ctypes.c_int * 3)(), (ctypes.c_float * 3)()
         for i, (t, hw, a) in enumerate(d.tmask):

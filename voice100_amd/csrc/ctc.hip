@@ -138,9 +138,17 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const float* __restric
 // go through LDS, into a ring slot per frame, and the waves run SKEWED: wave w may start frame q as soon as wave w-1 has
 // published frame q-1 (a progress word per wave; no workgroup barrier in the recursion).  Emission log-probabilities are
 // gathered straight from global memory eight frames ahead.
+// (Round 5, measured at B = 32, T' = 512, 100-token targets, whole head 134 us: timing-only ablations (CTC_ABL) put 62 us on the
+//  handshake, 37 us on the four transcendentals per frame, 10-12 us each on the lattice store and the emission gathers; the same
+//  pipeline in LOCKSTEP -- fixed skew of two frames, one s_barrier per frame, no progress words -- was built and measured SLOWER,
+//  143 us: a four-wave s_barrier costs more per frame (~75 ns) than the polling it replaces.  DESIGN.md section 8.)
 // log2-domain log-sum-exp of three terms on the raw v_exp_f32 / v_log_f32 (no range scaling: the sum lies in [1, 3] or is exactly
 // 0), branch-free: an all -inf input gives mm + log2(0) = -inf, never inf - inf
+#ifndef CTC_ABL
+#define CTC_ABL 0      /* timing-only ablations (wrong results): 1 no lattice store, 2 no transcendentals, 4 no handshake, 8 no emission loads */
+#endif
 __device__ __forceinline__ float ctc_lse3_log2(float a, float b, float c) {
+    if constexpr (CTC_ABL & 2) return (a + b + c) * 0.3f;
     const float mm = fmaxf(fmaxf(fmaxf(a, b), c), -1e30f);
     const float sum = __builtin_amdgcn_exp2f(a - mm) + __builtin_amdgcn_exp2f(b - mm) + __builtin_amdgcn_exp2f(c - mm);
     return mm + __builtin_amdgcn_logf(sum);
@@ -192,6 +200,7 @@ __global__ __launch_bounds__(1024) void ctc_lattice_skew_kernel(const float* __r
     auto emission = [&](int q) -> float {
         const int qq = q < Tb ? q : Tb - 1;
         const int t = dir == 0 ? qq : Tb - 1 - qq;
+        if constexpr (CTC_ABL & 8) return -3.f - 0.001f * (float)t;
         return (lg[(size_t)t * V] - ls[t]) * 1.44269504088896340736f;       // log2 units: the recursion runs on exp2 / log2 directly
     };
     float cur[CTC_PF], nxt[CTC_PF];
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(1024) void ctc_lattice_skew_kernel(const float* __r
         asm volatile("" ::: "memory");       // program order only: LDS performs one wave's writes in the order they were issued
         if (lane == 0) __hip_atomic_store(&progress[w], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         a_prev = v;
-        if (active) *lrow = v * 0.69314718055994530942f;      // the lattice is stored in natural-log units
+        if (!(CTC_ABL & 1)) if (active) *lrow = v * 0.69314718055994530942f;      // the lattice is stored in natural-log units
         lrow += lstep;
     };
     auto run = [&](auto up_t, auto down_t) {
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(1024) void ctc_lattice_skew_kernel(const float* __r
             for (int j = 0; j < CTC_PF; ++j) cur[j] = nxt[j];
         }
     };
-    const bool has_up = w > 0, has_down = w < NW - 1;
+    const bool has_up = !(CTC_ABL & 4) && w > 0, has_down = !(CTC_ABL & 4) && w < NW - 1;
     if (has_up && has_down) run(std::true_type{}, std::true_type{});
     else if (has_up) run(std::true_type{}, std::false_type{});
     else if (has_down) run(std::false_type{}, std::true_type{});
