@@ -2577,10 +2577,209 @@ void pw_launch_wgrad_bf16(const WgParams& p, dim3 grid, hipStream_t st) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the LATENCY form of the two inference GEMMs (channel-major eval blocks, block.hip v100_ir_fwd_eval: ONE matrix
+// Y [M][N] = epi(W [M][K] X [K][N]), N = B * pitch(T)).  At the configs' own sizes (configs[4] at B = 32: N = 1792; configs[0]: N = 256) the
+// throughput kernels above launch 4-112 workgroups of 256 x 128 and each walks its k-tiles with two register stages in flight: the
+// k-loop is a chain of memory latencies (30 us for K = 2048 whatever N is; profiles/r05_infer_small_chains.txt), on a chip that is
+// 90 % idle.  Here: 64 x 64 tiles (4 waves, one 32 x 32 accumulator each) so that even N = 256 gives 32-128 workgroups, and
+// PW_LAT_NSTG (6) k-tiles of loads in flight per workgroup -- 16-24 registers a stage -- so a workgroup waits for memory about once,
+// not once per k-tile.  Same LDS images, fragment reads, MFMA order (k ascending) and epilogue arithmetic as the kernels above.
+// EPI 2 (expand): X fp32 -> Y 16-bit = relu6(ea acc + eb);  EPI 3 (project): X 16-bit -> Y fp32 = ea acc + eb (+ R).
+template <int EPI, bool F16>
+__global__ __launch_bounds__(256) void pw_gemm_lat_kernel(PwParams p) {
+    static_assert(EPI == PW_EPI_AFFINE_RELU6 || EPI == PW_EPI_AFFINE_RES, "inference epilogues only");
+    constexpr bool XB = EPI == PW_EPI_AFFINE_RES;                   // project: 16-bit X;  expand: fp32 X
+    using XReg = std::conditional_t<XB, u32x2, u32x4>;
+    constexpr int EX = XB ? 2 : 4;
+    constexpr int NSTG = PW_LAT_NSTG;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192];     // As[2][64][64] | Bs[2][64][64] bf16; epilogue: [64][68] fp32
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + 2 * 8192;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_mt = p.M >> 6;
+    const int mt = blockIdx.x % n_mt, tt = blockIdx.x / n_mt;
+    const int m0 = mt * 64, t0 = tt * 64;
+    const int K = p.K, N = p.T;
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.Abf, (unsigned)p.M * K * 2u);
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.X, (unsigned)K * N * EX);
+    int voA[2], ldsA[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = tid + 256 * i, row = piece >> 3, ch = piece & 7;
+        voA[i] = ((m0 + row) * K + ch * 8) * 2;
+        ldsA[i] = bf_off(row, ch);
+    }
+    const int b_tq = (tid & 15) * 4, b_kg = tid >> 4;               // X patch: columns b_tq .. +3 of rows 4 b_kg .. +3
+    int voX[4], ldsB[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) voX[e] = ((4 * b_kg + e) * N + t0 + b_tq) * EX;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ldsB[q] = bf_off(b_tq + q, b_kg >> 1) + (b_kg & 1) * 8;
+    const int nk = K >> 6;
+    u32x4 ra[NSTG][2];
+    XReg rb[NSTG][4];
+    auto load = [&](int kt, auto stg) {                             // (past the end: the last k-tile again -- unconditional, see the kernels above)
+        constexpr int SG = decltype(stg)::value;
+        const int k0 = min(kt, nk - 1) * BF_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[SG][i] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA[i], k0 * 2, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (XB) rb[SG][e] = __builtin_amdgcn_raw_buffer_load_b64(rX, voX[e], k0 * N * EX, 0);
+            else rb[SG][e] = __builtin_amdgcn_raw_buffer_load_b128(rX, voX[e], k0 * N * EX, 0);
+        }
+    };
+    auto store = [&](int buf, auto stg) {
+        constexpr int SG = decltype(stg)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(As + buf * 8192 + ldsA[i]) = ra[SG][i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint2 o;
+            if constexpr (XB) {                                     // [k][t] -> [t][k]: a byte shuffle of the loaded words
+                const unsigned sel = (q & 1) ? 0x07060302u : 0x05040100u;
+                o.x = __builtin_amdgcn_perm(rb[SG][1][q >> 1], rb[SG][0][q >> 1], sel);
+                o.y = __builtin_amdgcn_perm(rb[SG][3][q >> 1], rb[SG][2][q >> 1], sel);
+            } else {
+                o.x = pack16<F16>(__builtin_bit_cast(f32x4, rb[SG][0])[q], __builtin_bit_cast(f32x4, rb[SG][1])[q]);
+                o.y = pack16<F16>(__builtin_bit_cast(f32x4, rb[SG][2])[q], __builtin_bit_cast(f32x4, rb[SG][3])[q]);
+            }
+            *reinterpret_cast<uint2*>(Bs + buf * 8192 + ldsB[q]) = o;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lr = lane & 31, lh = lane >> 5, sw = (lr >> 1) & 7;
+    const int rdA0 = (wm * 32 + lr) * 128, rdB0 = (wn * 32 + lr) * 128;
+    auto mfma_block = [&](int buf) {                                // all eight fragment reads first: one LDS latency per k-tile, not four
+        bf16x8 a[BF_BK / 16], b[BF_BK / 16];
+#pragma unroll
+        for (int ks = 0; ks < BF_BK / 16; ++ks) {
+            const int co = ((ks * 2 + lh) ^ sw) << 4;
+            a[ks] = *reinterpret_cast<const bf16x8*>(As + buf * 8192 + rdA0 + co);
+            b[ks] = *reinterpret_cast<const bf16x8*>(Bs + buf * 8192 + rdB0 + co);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < BF_BK / 16; ++ks) acc = mfma16<F16>(a[ks], b[ks], acc);
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1 % NSTG>;
+    using S2 = std::integral_constant<int, 2 % NSTG>; using S3 = std::integral_constant<int, 3 % NSTG>;
+    using S4 = std::integral_constant<int, 4 % NSTG>; using S5 = std::integral_constant<int, 5 % NSTG>;
+    static_assert(NSTG == 2 || NSTG == 4 || NSTG == 6, "register stages");
+    // (the requests stay in stage order -- sched_barrier -- so that the wait at a stage's use counts the YOUNGER stages, in the loop's
+    //  first trip as in every later one; reordered, hipcc's merge at the loop head degenerates into vmcnt(0) once per trip)
+#define LAT_SB() __builtin_amdgcn_sched_barrier(0)
+    load(0, S0{}); LAT_SB(); load(1, S1{}); LAT_SB();
+    if constexpr (NSTG >= 4) { load(2, S2{}); LAT_SB(); load(3, S3{}); LAT_SB(); }
+    if constexpr (NSTG >= 6) { load(4, S4{}); LAT_SB(); load(5, S5{}); LAT_SB(); }
+    int kt = 0;
+    // k-tile kt: registers of stage kt % NSTG -> LDS buffer kt & 1, the request NSTG tiles ahead into the same registers, ONE barrier
+    // (buffer kt & 1 was last read by the MFMAs of tile kt - 2, which every wave finished before the barrier of tile kt - 1)
+#define LAT_STEP(SG)                                                                                                              \
+    {                                                                                                                             \
+        store(kt & 1, SG{});                                                                                                      \
+        LAT_SB();                                                                                                                 \
+        load(kt + NSTG, SG{});                                                                                                    \
+        LAT_SB();                                                                                                                 \
+        __syncthreads();                                                                                                          \
+        mfma_block(kt & 1);                                                                                                       \
+        ++kt;                                                                                                                     \
+    }
+    // whole trips without exits (an exit inside the trip makes every `break` a predecessor of the loop head, and hipcc's wait at the
+    // head then covers the path on which stage 0 was requested LAST: vmcnt(0) once per trip), then the last nk % NSTG tiles straight-line
+    for (; kt + NSTG <= nk;) {
+        LAT_STEP(S0) LAT_STEP(S1)
+        if constexpr (NSTG >= 4) { LAT_STEP(S2) LAT_STEP(S3) }
+        if constexpr (NSTG >= 6) { LAT_STEP(S4) LAT_STEP(S5) }
+    }
+    if (kt < nk) LAT_STEP(S0)
+    if (kt < nk) LAT_STEP(S1)
+    if constexpr (NSTG >= 4) {
+        if (kt < nk) LAT_STEP(S2)
+        if (kt < nk) LAT_STEP(S3)
+    }
+    if constexpr (NSTG >= 6) {
+        if (kt < nk) LAT_STEP(S4)
+    }
+#undef LAT_STEP
+#undef LAT_SB
+    // epilogue through LDS: the 64 x 64 fp32 tile (row pitch 68), then 16 consecutive columns of one row per thread
+    __syncthreads();
+    float* tile = reinterpret_cast<float*>(smem);
+    {
+        const int col = wn * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + col] = acc[r];
+    }
+    __syncthreads();
+    const int row = tid >> 2, cg = (tid & 3) * 16;
+    const int m = m0 + row;
+    const float ea = p.ea[m], eb = p.eb[m];
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(tile + row * 68 + cg + 4 * j);
+    if constexpr (EPI == PW_EPI_AFFINE_RES) {
+        float* y = p.Y + (size_t)m * N;
+        const float* rr = p.R ? p.R + (size_t)m * N : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + cg + 4 * j;
+            if (t >= N) continue;
+            f32x4 o;
+            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+            if (rr) rv = *reinterpret_cast<const f32x4*>(rr + t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(v[j][e], ea, eb) + rv[e];
+            *reinterpret_cast<f32x4*>(y + t) = o;
+        }
+    } else {
+        u16* y = reinterpret_cast<u16*>(p.Y) + (size_t)m * N;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = t0 + cg + 8 * h;
+            if (t >= N) continue;
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 2 * h + (e >> 1), c = (e & 1) * 2;
+                o[e] = pack16<F16>(relu6f(fmaf(v[j][c], ea, eb)), relu6f(fmaf(v[j][c + 1], ea, eb)));
+            }
+            *reinterpret_cast<u32x4*>(y + t) = o;
+        }
+    }
+}
+
+static bool pw_launch_gemm_lat(const PwParams& p, hipStream_t st) {
+    if (!PW_LAT || p.B != 1 || p.x_mode != 0 || p.bias || (p.M & 63) || (p.K & 63) || (p.T & 7) || p.K < 64) return false;
+    if ((long)p.K * p.T * 4 >= 0x7fffffffL || (long)p.M * p.T * 4 >= 0x7fffffffL || (long)p.M * p.K * 2 >= 0x7fffffffL) return false;
+    const long big_tiles = (long)((p.M + 255) / 256) * ((p.T + PW_BN - 1) / PW_BN);
+    static const long max_tiles = [] { const char* e = getenv("V100_PW_LAT_MAXTILES"); return e ? atol(e) : (long)PW_LAT_MAXTILES; }();
+    if (big_tiles > max_tiles) return false;
+    const dim3 grid((unsigned)((p.M >> 6) * ((p.T + 63) >> 6)));
+    const int f16 = p.io16 & PW_IO_F16, io = p.io16 & ~PW_IO_F16;
+    if ((p.fmt == 2) != (f16 != 0)) return false;
+    if (p.epi_mode == PW_EPI_AFFINE_RELU6 && io == PW_IO_Y) {
+        if (f16) V100_GGL((pw_gemm_lat_kernel<PW_EPI_AFFINE_RELU6, true>), grid, dim3(256), 0, st, p);
+        else V100_GGL((pw_gemm_lat_kernel<PW_EPI_AFFINE_RELU6, false>), grid, dim3(256), 0, st, p);
+        return true;
+    }
+    if (p.epi_mode == PW_EPI_AFFINE_RES && io == PW_IO_X) {
+        if (f16) V100_GGL((pw_gemm_lat_kernel<PW_EPI_AFFINE_RES, true>), grid, dim3(256), 0, st, p);
+        else V100_GGL((pw_gemm_lat_kernel<PW_EPI_AFFINE_RES, false>), grid, dim3(256), 0, st, p);
+        return true;
+    }
+    return false;
+}
+
 // 16-bit activation storage (PwParams::io16 / WgParams::io16): the combinations the block executor issues in "act16" mode.
 // false = no instantiation for this (modes, mask) or the shape does not fit the buffer-addressed kernels.
 bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     const int P = pw_pitch16(p.T);
+    if (pw_launch_gemm_lat(p, st)) return true;
     if (p.io16 & PW_IO_F16) {
         // inference at precision "fp16" with fp16-stored hidden tensors: the two eval-mode GEMMs of a block (256-row tiles; 128 for M < 256)
         if (!((p.K & 1) == 0 && (long)(p.K + 64) * P * 4 < 0x7fffffffL && (long)(p.M + 128) * p.K * 2 < 0x7fffffffL &&

@@ -34,6 +34,15 @@ enum { PW_EPI_STORE = 0, PW_EPI_STATS = 1, PW_EPI_AFFINE_RELU6 = 2, PW_EPI_AFFIN
 #ifndef PW_EPI_FAST
 #define PW_EPI_FAST 2      /* 1: lean epilogue for interior tiles; 2: also for the partial last t-tile (PT) */
 #endif
+#ifndef PW_LAT
+#define PW_LAT 1             /* latency form of the inference GEMMs when the matrix has too few 256 x 128 tiles to fill the chip */
+#endif
+#ifndef PW_LAT_MAXTILES
+#define PW_LAT_MAXTILES 64
+#endif
+#ifndef PW_LAT_NSTG
+#define PW_LAT_NSTG 4
+#endif
 #ifndef PW_PERSIST
 #define PW_PERSIST 1         /* persistent workgroups with cross-tile prefetch for the short-K training GEMMs */
 #endif
