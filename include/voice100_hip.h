@@ -363,6 +363,10 @@ long long v100_ir_fwd_workspace_bytes(const int* shape);
 long long v100_ir_eval_cache_bytes(const int* shape);
 int v100_ir_eval_prep(const int* shape, const void* const* ptrs, void* stream);
 int v100_ir_fwd_eval(const int* shape, const void* const* ptrs, void* stream);
+/* n eval-mode blocks back to back in ONE host call (inference at the configs' own sizes is bound by the host's per-call cost, not by
+ * the GPU): shapes = n x 11 ints, ptrs = n x 8 pointers, each block's in v100_ir_fwd_eval's order (block i's y is block i+1's x:
+ * the caller lays the buffers out).  HOST arrays.  Stops at the first block that fails and returns its code. */
+int v100_ir_stack_fwd_eval(int n, const int* shapes, const void* const* ptrs, void* stream);
 int v100_ir_prep_batched(const int* shapes, const void* const* w1s, const void* const* w3s, void* const* preps, int n, void* stream);
 int v100_ir_fwd_train(const int* shape, const void* const* ptrs, void* stream);
 long long v100_ir_bwd_workspace_bytes(const int* shape);

@@ -97,13 +97,13 @@ def test_asr_eval_channel_major_model(cuda):
                 with torch.no_grad():
                     F_.EVAL_CM = True
                     calls = []
-                    orig = F_.inverted_residual_eval_cm
-                    F_.inverted_residual_eval_cm = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+                    orig = F_.ir_stack_eval_cm              # (the eight stride-1 blocks go through ONE stack call)
+                    F_.ir_stack_eval_cm = lambda blocks, *a, **k: (calls.append(len(blocks)), orig(blocks, *a, **k))[1]
                     try:
                         outs[prec, True] = m(audio)
                     finally:
-                        F_.inverted_residual_eval_cm = orig
-                    assert len(calls) == 8, "the channel-major path was not taken"
+                        F_.ir_stack_eval_cm = orig
+                    assert calls == [8], "the channel-major path was not taken"
                     F_.EVAL_CM = False
                     outs[prec, False] = m(audio)
             finally:
@@ -193,5 +193,46 @@ def test_graphed_forward_replays_the_eager_result(cuda):
             want = t.predict(at2)
         got = gp(at2)
         assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+    finally:
+        F_.set_matmul_precision("fp32")
+
+
+def test_stack_call_equals_block_calls_and_follows_weight_updates(cuda):
+    """ir_stack_eval_cm (one library call for a run of blocks, plan cached on the first block) == the blocks one call each, bit for
+    bit; the plan is rebuilt when a parameter is written in place, replaced, or the batch / length changes."""
+    from voice100_amd import functional as F_
+
+    def same(a, b, B, T):          # the valid columns (padding columns T .. P-1 hold whatever the buffers held)
+        return torch.equal(F_.cm_to_btc(a, B, T), F_.cm_to_btc(b, B, T))
+
+    blocks = [_block(cuda, 64, 64, k, True, 70 + k) for k in (19, 27, 35)]
+    F_.set_matmul_precision("bf16")
+    try:
+        with torch.no_grad():
+            for B, T in ((3, 51), (2, 128), (3, 51)):
+                g = torch.Generator().manual_seed(B * 100 + T)
+                xc = F_.bct_to_cm(torch.randn(B, 64, T, generator=g).to(cuda))
+                want = xc
+                for blk in blocks:
+                    want = F_.inverted_residual_eval_cm(blk, want, B, T)
+                got = F_.ir_stack_eval_cm(blocks, xc, B, T)
+                assert same(got, want, B, T)
+                plan = blocks[0].__dict__["_v100_eval_stack_plan"]
+                assert same(F_.ir_stack_eval_cm(blocks, xc, B, T), want, B, T)
+                assert blocks[0].__dict__["_v100_eval_stack_plan"] is plan               # unchanged inputs: the plan is reused
+            B, T = 3, 51
+            before = F_.ir_stack_eval_cm(blocks, xc, B, T).clone()
+            blocks[1].conv[3].running_mean.add_(0.25)                                    # in place: the version moves
+            after = F_.ir_stack_eval_cm(blocks, xc, B, T)
+            want = xc
+            for blk in blocks:
+                want = F_.inverted_residual_eval_cm(blk, want, B, T)
+            assert same(after, want, B, T) and not same(after, before, B, T)
+            blocks[2].conv[2].weight = torch.nn.Parameter(blocks[2].conv[2].weight.detach() * 0.5)      # replaced: the object moves
+            after2 = F_.ir_stack_eval_cm(blocks, xc, B, T)
+            want = xc
+            for blk in blocks:
+                want = F_.inverted_residual_eval_cm(blk, want, B, T)
+            assert same(after2, want, B, T) and not same(after2, after, B, T)
     finally:
         F_.set_matmul_precision("fp32")

@@ -30,11 +30,17 @@ def main():
     for prec in ("bf16", "fp32"):
         F_.set_matmul_precision(prec)
         m = AudioToTextCTC(64, 512, 29, 512).to(dev).eval()
-        for B, T in ((2, 256), (1, 100), (8, 512), (32, 1024)):
+        for B, T in ((2, 256), (32, 101), (1, 100), (8, 512), (32, 1024)):
             x = torch.rand(B, T, 64, device=dev)
             with torch.no_grad():
                 ref = m(x).clone()
                 te = timeit(lambda: m(x))
+                torch.cuda.synchronize()
+                h0 = time.perf_counter()
+                for _ in range(50):
+                    m(x)
+                th = (time.perf_counter() - h0) / 50          # host enqueue alone (the queue is empty at the start, 50 calls deep at the end)
+                torch.cuda.synchronize()
             g = GraphedForward(m, x)
             out = g(x)
             same = torch.equal(out, ref)
@@ -43,7 +49,7 @@ def main():
                 ref2 = m(x2).clone()
             same2 = torch.equal(g(x2), ref2)
             tg = timeit(lambda: g(x))
-            print(f"asr eval {prec} B={B} T={T}: eager {te*1e3:.3f} ms, graph {tg*1e3:.3f} ms, identical {same and same2}")
+            print(f"asr eval {prec} B={B} T={T}: eager {te*1e3:.3f} ms (host enqueue {th*1e3:.3f}), graph {tg*1e3:.3f} ms, identical {same and same2}")
         t = AlignTextToAudioModel(vocab_size=29, hidden_size=512, use_mcep=True).to(dev).eval()
         for B, L in ((1, 64), (16, 512)):
             at = torch.randint(0, 29, (B, L), device=dev)

@@ -115,8 +115,7 @@ class AudioToTextCTC(Voice100ModelBase):
         with torch.no_grad():
             y = layers[0](x)                     # the stride-2 opener: batch-major (its depthwise kernel is the register-window one)
             xc = F_.bct_to_cm(y)
-            for blk in layers[1:]:
-                xc = F_.inverted_residual_eval_cm(blk, xc, B, T1)
+            xc = F_.ir_stack_eval_cm(layers[1:], xc, B, T1)      # the eight stride-1 blocks: one call into the library
             logits = F_.pointwise_conv1d_cm(xc, conv.weight, conv.bias)
             return F_.cm_to_btc(logits, B, T1)
 

@@ -419,6 +419,16 @@ extern "C" int v100_ir_fwd_eval(const int* sh, const void* const* P, void* strea
     return V100_OK;
 }
 
+extern "C" int v100_ir_stack_fwd_eval(int n, const int* shapes, const void* const* ptrs, void* stream) {
+    if (!shapes || !ptrs) return V100_ERR_NULL;
+    if (n < 0) return V100_ERR_SHAPE;
+    for (int i = 0; i < n; ++i) {
+        const int rc = v100_ir_fwd_eval(shapes + (size_t)i * IR_NSHAPE, ptrs + (size_t)i * 8, stream);
+        if (rc != V100_OK) return rc;
+    }
+    return V100_OK;
+}
+
 // Prepared weights of n blocks in ONE launch (the per-block pair of weight_prep launches costs ~13 us a block, mostly
 // launch latency).  shapes: n x IR_NSHAPE ints; w1s / w3s: the fp32 weights; preps: each block's prep buffer.  HOST arrays.
 struct PrepBatch {

@@ -677,6 +677,71 @@ def inverted_residual_eval_cm(blk, x: torch.Tensor, B: int, T: int, precision: O
     return y
 
 
+class _EvalStackPlan:
+    __slots__ = ("key", "n", "shapes", "ptrs", "caches", "hid_max", "cout_max", "cout_last", "keep")
+
+
+def ir_stack_eval_cm(blocks, x: torch.Tensor, B: int, T: int, precision: Optional[str] = None) -> torch.Tensor:
+    """A run of eval-mode stride-1 InvertedResidual blocks on a channel-major activation x [cin, B * P]: inverted_residual_eval_cm
+    block after block, as ONE call into the library (v100_ir_stack_fwd_eval).  At the configs' own sizes (1-second chunks, B = 2 x 256
+    frames) the forward is bound by the host's cost per block -- parameter lookups through nn.Module, two allocations, a pointer table,
+    a ctypes call: ~28 us a block against ~20 us of GPU work -- so the shapes, folded-BatchNorm caches and the constant pointers live
+    in a plan that is rebuilt only when a parameter or buffer object, its version, the batch, the length or the precision changes."""
+    fmt = _fmt(precision)
+    n = len(blocks)
+    P = (T + 7) & ~7
+    tens = [_block_tensors(b) for b in blocks]
+    key = (fmt, B, T, x.device.index) + tuple((id(t), t._version) for bt in tens for t in bt)
+    holder = blocks[0].__dict__
+    plan = holder.get("_v100_eval_stack_plan")
+    if plan is None or plan.key != key:
+        plan = _EvalStackPlan()
+        plan.key, plan.n = key, n
+        plan.shapes = (ctypes.c_int * (11 * n))()
+        plan.ptrs = (ctypes.c_void_p * (8 * n))()
+        plan.caches, plan.keep = [], []
+        plan.hid_max = plan.cout_max = 0
+        cin_prev = x.shape[0]
+        for i, (blk, bt) in enumerate(zip(blocks, tens)):
+            (w1, g1, b1, rm1, rv1, _n1, wd, g2, b2, rm2, rv2, _n2, w3, g3, b3, rm3, rv3, _n3) = bt
+            hid, cin, cout, k = w1.shape[0], w1.shape[1], w3.shape[0], int(blk.kernel_size)
+            if cin != cin_prev or int(blk.stride) != 1:
+                raise RuntimeError("ir_stack_eval_cm: blocks must chain (cin == previous cout) at stride 1")
+            cin_prev = cout
+            params = (w1, g1, b1, rm1, rv1, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3)
+            for t in params + (wd,):
+                if not t.is_cuda or not t.is_contiguous():
+                    raise RuntimeError("InvertedResidual: parameters and buffers must be contiguous CUDA tensors (no CPU fallback)")
+            shape = (ctypes.c_int * 11)(B, cin, hid, cout, T, k, 1, int(bool(blk.use_residual)), int(fmt), 0, 0)
+            cache = torch.empty(N.helper("v100_ir_eval_cache_bytes", shape), dtype=torch.uint8, device=x.device)
+            N.call("v100_ir_eval_prep", shape, _ptr_table(tuple(t.detach() for t in params) + (cache,)))
+            shape[10] = 2
+            for j in range(11):
+                plan.shapes[11 * i + j] = shape[j]
+            plan.ptrs[8 * i + 1], plan.ptrs[8 * i + 2], plan.ptrs[8 * i + 3] = w1.data_ptr(), wd.data_ptr(), w3.data_ptr()
+            plan.ptrs[8 * i + 4] = cache.data_ptr()
+            plan.caches.append(cache)
+            plan.keep.append((w1, wd, w3))
+            plan.hid_max, plan.cout_max = max(plan.hid_max, hid), max(plan.cout_max, cout)
+            plan.cout_last = cout
+        holder["_v100_eval_stack_plan"] = plan
+    if x.shape != (plan.shapes[1], B * P):
+        raise RuntimeError("ir_stack_eval_cm: x must be [cin, B * pitch(T)]")
+    cols = B * P
+    h = torch.empty((2, plan.hid_max, cols), dtype=torch.float16 if fmt == 2 else torch.bfloat16, device=x.device)
+    out = _f32(plan.cout_last, cols, like=x)
+    tmp = _f32(2, plan.cout_max, cols, like=x) if n > 1 else None
+    h0, h1 = h.data_ptr(), h[1].data_ptr()
+    cur = x.data_ptr()
+    ptrs = plan.ptrs
+    for i in range(n):
+        y = out.data_ptr() if i == n - 1 else tmp[i & 1].data_ptr()
+        ptrs[8 * i], ptrs[8 * i + 5], ptrs[8 * i + 6], ptrs[8 * i + 7] = cur, h0, h1, y
+        cur = y
+    N.call("v100_ir_stack_fwd_eval", n, plan.shapes, ptrs)
+    return out
+
+
 def pointwise_conv1d_cm(x: torch.Tensor, w: torch.Tensor, bias, precision: Optional[str] = None) -> torch.Tensor:
     """nn.Conv1d(kernel_size=1) on a channel-major activation [cin, N] -> [cout, N] (inference): one GEMM over all columns."""
     cout, cin = w.shape[0], w.shape[1]
