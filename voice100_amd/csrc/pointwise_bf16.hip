@@ -674,21 +674,36 @@ __global__ __launch_bounds__(768) void pw_gemm_bf16_ws_kernel(PwParams p) {
         // body is a path on which the registers of the next one are the youngest loads, and hipcc then waits vmcnt(0) everywhere);
         // the stores are unconditional (a tile past the last is zeros, lands in the slot nobody reads, before the barrier that
         // precedes the epilogue's use of the LDS).
-        for (int kt = 0;; kt += NSX) {
-            if (kt >= nk) break;
+        // (Round 5: WHOLE trips without exits, then the last nk % NSX tiles straight-line.  With an exit behind every tile each `break`
+        //  is a predecessor of the loop head -- hipcc's structurizer routes them through the latch -- and the wait at the head then
+        //  covers the path on which stage 1 was requested LAST: the first tile of EVERY trip waited vmcnt(0), i.e. drained the three
+        //  younger stages it exists to keep in flight, one exposed memory latency per NSX tiles.)
+        int kt = 0;
+        for (; kt + NSX <= nk; kt += NSX) {
             stage(kt + 1, S1{});
             __syncthreads();
-            if (kt + 1 >= nk) break;
             stage(kt + 2, S2{});
             __syncthreads();
-            if (kt + 2 >= nk) break;
             if constexpr (NSX == 4) {
                 stage(kt + 3, S3{});
                 __syncthreads();
-                if (kt + 3 >= nk) break;
             }
             stage(kt + NSX, S0{});
             __syncthreads();
+        }
+        if (kt < nk) {
+            stage(kt + 1, S1{});
+            __syncthreads();
+            if (kt + 1 < nk) {
+                stage(kt + 2, S2{});
+                __syncthreads();
+                if constexpr (NSX == 4) {
+                    if (kt + 2 < nk) {
+                        stage(kt + 3, S3{});
+                        __syncthreads();
+                    }
+                }
+            }
         }
 #undef WS_SB
         __syncthreads();                                   // the epilogue's one barrier (accumulators parked in LDS)
@@ -2366,21 +2381,34 @@ __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgPara
         __syncthreads();                                   // step 0 is in LDS
         // NSQ steps per trip with EXITS, not skipped bodies (pw_gemm_bf16_ws_kernel); the stores are unconditional (a step past the
         // last re-stages the last tile into the slot nobody reads)
-        for (int st = 0;; st += NSQ) {
-            if (st >= nsteps) break;
+        // (Round 5: whole trips WITHOUT exits, then the last nsteps % NSQ steps straight-line -- with an exit behind every step the first
+        //  step of every trip waited vmcnt(0): see the staging waves of pw_gemm_bf16_ws_kernel)
+        int st = 0;
+        for (; st + NSQ <= nsteps; st += NSQ) {
             stage(st + 1, S1{});
             __syncthreads();
-            if (st + 1 >= nsteps) break;
             stage(st + 2, S2{});
             __syncthreads();
-            if (st + 2 >= nsteps) break;
             if constexpr (NSQ == 4) {
                 stage(st + 3, S3{});
                 __syncthreads();
-                if (st + 3 >= nsteps) break;
             }
             stage(st + NSQ, S0{});
             __syncthreads();
+        }
+        if (st < nsteps) {
+            stage(st + 1, S1{});
+            __syncthreads();
+            if (st + 1 < nsteps) {
+                stage(st + 2, S2{});
+                __syncthreads();
+                if constexpr (NSQ == 4) {
+                    if (st + 2 < nsteps) {
+                        stage(st + 3, S3{});
+                        __syncthreads();
+                    }
+                }
+            }
         }
 #undef WS_SB
         return;
