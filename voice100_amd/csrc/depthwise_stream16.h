@@ -272,11 +272,16 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
 #ifndef DWS_DA1_K3
 #define DWS_DA1_K3 0          /* kept-rows form: kernel sizes up to this keep three workgroups per CU (168 registers) */
 #endif
-#ifndef DWS_DA1_RELOAD
-#define DWS_DA1_RELOAD 0
+// DWS_DA1_KEEP 0 (A/B): the rows are NOT kept -- the plain form (rolled row loop, dz1 stored as produced, three workgroups per CU), then each
+// wave reads its own rows back (dz1 it wrote, a1 it read: L2 / Infinity Cache) and overwrites dz1 with the finished gradient.  Bit-identical
+// (the stored bf16 dz1 IS what the kept register held) but measured SLOWER in the step: this kernel 0.498 ms against 0.448 kept-rows and
+// 0.374 without DA1 (step 3.36 / 3.33 / 3.36 ms): the second pass costs more than the occupancy returns.
+#ifndef DWS_DA1_KEEP
+#define DWS_DA1_KEEP 1
 #endif
 template <int K, int NT, int D, int CP = 0, int NS = 2, bool DA1 = false, int MAXR = 8>
-__global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD && K > DWS_DA1_K3) ? 2 : DWS_BWD_MINW) void dwconv_bwd16_stream_kernel(DwParams p) {
+__global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : DWS_BWD_MINW) void dwconv_bwd16_stream_kernel(DwParams p) {
+    constexpr bool KEEP = DA1 && DWS_DA1_KEEP;
     using S_ = DwStreamGeom<K, NS>;
     constexpr int STEPS = S_::STEPS, WPAD = S_::WPAD, WLEN = S_::WLEN, IB = S_::IB, NL = S_::NL, XIMG = S_::XIMG;
     constexpr int IMG0 = S_::FWD_IMG > S_::BWD_IMG ? S_::FWD_IMG : S_::BWD_IMG;
@@ -382,19 +387,19 @@ __global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD && K > DWS_DA1_K3) ? 2
     for (int ib = 0; ib < IB; ++ib) eacc[ib] = dwm_f32x4{0.f, 0.f, 0.f, 0.f};
     float s0 = 0.f, s1 = 0.f;
 
-    dwm_u32x2 keep_o[DA1 ? MAXR : 1][NS], keep_a[(DA1 && !DWS_DA1_RELOAD) ? MAXR : 1][NS];
+    dwm_u32x2 keep_o[KEEP ? MAXR : 1][NS], keep_a[KEEP ? MAXR : 1][NS];
     auto row = [&](Row& rw, int r, auto rconst) {
         constexpr int RI = decltype(rconst)::value;  // DA1: the row's slot in the kept arrays (a compile-time index: registers)
         // (DA1: r is a constant in each of the eight unrolled copies, so `ok` and the five coefficient selects below would be hoisted
         //  out of all of them and live across the whole loop: 40 registers.  An opaque copy of nrows keeps them inside their row.)
         int nrows_l = nrows;
-        if constexpr (DA1) asm volatile("" : "+s"(nrows_l));
+        if constexpr (KEEP) asm volatile("" : "+s"(nrows_l));
         const bool ok = r < nrows_l;                 // rows past the end: zero coefficients -> g' = 0, xin = 0, mask 0, nothing stored
         const float ra = ok ? ca : 0.f, rb = ok ? cb : 0.f, rc = ok ? cc : 0.f, roa = ok ? oa : 0.f, rob = ok ? ob : 0.f;
         float auxv[NS][4];
 #pragma unroll
         for (int sub = 0; sub < NS; ++sub) {
-            if constexpr (DA1 && !DWS_DA1_RELOAD) keep_a[RI][sub] = rw.a[sub];      // (before issue() below re-uses rw for the next row)
+            if constexpr (KEEP) keep_a[RI][sub] = rw.a[sub];      // (before issue() below re-uses rw for the next row)
 #pragma unroll
             for (int e = 0; e < 4; ++e) auxv[sub][e] = dwm_elem(rw.a[sub], e);
         }
@@ -452,16 +457,16 @@ __global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD && K > DWS_DA1_K3) ? 2
                 outv[e] = yv;
             }
             const dwm_u32x2 o2 = {dwm_pack_rne(outv[0], outv[1]), dwm_pack_rne(outv[2], outv[3])};
-            if constexpr (DA1) keep_o[RI][sub] = o2;
+            if constexpr (KEEP) keep_o[RI][sub] = o2;
             else __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && in_row) ? 2 * t0 : 0x7ffffff0, (int)yb, CP);
         }
-        if constexpr (DA1) (void)yb;
+        if constexpr (KEEP) (void)yb;
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);          // rows are not interleaved: the sums of a row retire before the next row starts
     };
 
     using R0 = std::integral_constant<int, 0>;
-    if constexpr (DA1) {
+    if constexpr (KEEP) {
         static_assert(D == 1, "the kept-rows form walks one row at a time");
 #define DWS_ROW(i_) if constexpr ((i_) < MAXR) row(raw[0], (i_), std::integral_constant<int, ((i_) < MAXR ? (i_) : 0)>{});
         DWS_ROW(0) DWS_ROW(1) DWS_ROW(2) DWS_ROW(3) DWS_ROW(4) DWS_ROW(5) DWS_ROW(6) DWS_ROW(7)
@@ -511,28 +516,52 @@ __global__ __launch_bounds__(256, (DA1 && !DWS_DA1_RELOAD && K > DWS_DA1_K3) ? 2
     if constexpr (DA1) {
         __syncthreads();
         const float pa = lds_coef[0], qb = lds_coef[1], rc = lds_coef[2];
-        // DWS_DA1_RELOAD: a1 is not kept (half the registers, three workgroups per CU stay resident) but read again here -- the rows
-        // were in this CU's hands a few microseconds ago (L2 / Infinity Cache)
-        dwm_u32x2 again[DWS_DA1_RELOAD ? MAXR : 1][NS];
-        if constexpr (DWS_DA1_RELOAD) {
+        if constexpr (KEEP) {
 #pragma unroll
-            for (int ri = 0; ri < MAXR; ++ri)
+            for (int ri = 0; ri < MAXR; ++ri) {
+                const bool ok = ri < nrows;
+                const unsigned yb = row_bytes(ok ? ri : 0);
 #pragma unroll
-                for (int sub = 0; sub < NS; ++sub)
-                    again[ri][sub] = __builtin_amdgcn_raw_buffer_load_b64(raux, ri < nrows ? vo_aux[sub] : 0x7ffffff0, (int)row_bytes(ri < nrows ? ri : 0), 0);
-        }
+                for (int sub = 0; sub < NS; ++sub) {
+                    const int t0 = 256 * sub + 16 * n_ + 4 * q_;
+                    float dv[4];
 #pragma unroll
-        for (int ri = 0; ri < MAXR; ++ri) {
-            const bool ok = ri < nrows;
-            const unsigned yb = row_bytes(ok ? ri : 0);
+                    for (int e = 0; e < 4; ++e) dv[e] = fmaf(dwm_elem(keep_o[ri][sub], e), pa, fmaf(dwm_elem(keep_a[ri][sub], e), qb, rc));
+                    const dwm_u32x2 o2 = {dwm_pack_rne(dv[0], dv[1]), dwm_pack_rne(dv[2], dv[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && t0 < T) ? 2 * t0 : 0x7ffffff0, (int)yb, CP);
+                }
+            }
+        } else {
+            // the wave's own rows again, four at a time: 4 NS loads of dz1 (as stored above by this wave: the stores are older in its
+            // memory queue) and of a1 in flight, then the finished rows over the unfinished ones
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int r0 = 0; r0 < nrows; r0 += 4) {
+                dwm_u32x2 go[4][NS], ga[4][NS];
 #pragma unroll
-            for (int sub = 0; sub < NS; ++sub) {
-                const int t0 = 256 * sub + 16 * n_ + 4 * q_;
-                float dv[4];
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = r0 + i < nrows;
+                    const unsigned yb = row_bytes(ok ? r0 + i : 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dv[e] = fmaf(dwm_elem(keep_o[ri][sub], e), pa, fmaf(dwm_elem(DWS_DA1_RELOAD ? again[ri][sub] : keep_a[ri][sub], e), qb, rc));
-                const dwm_u32x2 o2 = {dwm_pack_rne(dv[0], dv[1]), dwm_pack_rne(dv[2], dv[3])};
-                __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && t0 < T) ? 2 * t0 : 0x7ffffff0, (int)yb, CP);
+                    for (int sub = 0; sub < NS; ++sub) {
+                        const int t0 = 256 * sub + 16 * n_ + 4 * q_;
+                        go[i][sub] = __builtin_amdgcn_raw_buffer_load_b64(ry, (ok && t0 < T) ? 2 * t0 : 0x7ffffff0, (int)yb, 0);
+                        ga[i][sub] = __builtin_amdgcn_raw_buffer_load_b64(raux, ok ? vo_aux[sub] : 0x7ffffff0, (int)yb, 0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = r0 + i < nrows;
+                    const unsigned yb = row_bytes(ok ? r0 + i : 0);
+#pragma unroll
+                    for (int sub = 0; sub < NS; ++sub) {
+                        const int t0 = 256 * sub + 16 * n_ + 4 * q_;
+                        float dv[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dv[e] = fmaf(dwm_elem(go[i][sub], e), pa, fmaf(dwm_elem(ga[i][sub], e), qb, rc));
+                        const dwm_u32x2 o2 = {dwm_pack_rne(dv[0], dv[1]), dwm_pack_rne(dv[2], dv[3])};
+                        __builtin_amdgcn_raw_buffer_store_b64(o2, ry, (ok && t0 < T) ? 2 * t0 : 0x7ffffff0, (int)yb, CP);
+                    }
+                }
             }
         }
     }
