@@ -303,13 +303,15 @@ def lean_line(out):
     cfg = o.get("config") or {}
     if isinstance(cfg.get("workload"), str):
         cfg["workload"] = cfg["workload"].split(" (0 fp32 everywhere")[0]
-        cut(cfg, "workload", 330)
+        cut(cfg, "workload", 220)
     r = o.get("roofline")
     if isinstance(r, dict):
         r.pop("traffic_per_launch", None)
-        cut(r, "kernel", 90)
-        cut(r, "traffic_source", 110)
+        cut(r, "kernel", 60)
+        cut(r, "traffic_source", 60)
         cut(r, "note", 160)
+        for k in ("measured_copy_gbs", "frac_of_measured_copy", "copy_probe_gbs", "frac_of_copy_probe", "algorithmic_bytes_nominal_step"):
+            r.pop(k, None)                # (the plain-copy yardsticks stay in the details record; the line keeps the pattern copy)
     rs = o.get("roofline_step")
     if isinstance(rs, dict):
         for k in ("note", "families_algorithmic_mb"):
@@ -318,7 +320,10 @@ def lean_line(out):
         r.pop("frac_note", None)
     if isinstance(o.get("launches_per_step"), dict):
         o["launches_per_step"] = o["launches_per_step"].get("value")
-    cut(o.get("dp_path_single_rank"), "what", 60)
+    cut(o.get("dp_path_single_rank"), "what", 40)
+    cut(o, "kernel_ms_method", 100)
+    if o.get("launch_graph_diagnostic") is None:
+        o.pop("launch_graph_diagnostic", None)
     cb = o.get("cpu_baseline")
     if isinstance(cb, dict):
         cut(cb, "sample", 150)
@@ -508,8 +513,8 @@ def main():
         kt = kt_main
         # per-kernel-family breakdown: a separate pass after the timed region (it slows the step, see above)
         FAM = ["dw_fwd", "dw_bwd_data", "dw_wgrad", "pw_gemm", "pw_wgrad"]
-        N.timing_enable(FAM)                                # (the family tags only, as in every earlier round: comparable figures)
-        nb = max(2, min(5, args.steps))
+        N.timing_enable(FAM)                                # (round 5: dispatch-packet timestamps for the GEMM families too; r04 and before bracketed them with event markers, ~+0.2 ms)
+        nb = max(2, min(10, args.steps))
         for _ in range(nb):
             step(batch)
         kt_all = {k: round(v[1] / nb, 3) for k, v in sorted(N.timing_read().items())}
@@ -519,15 +524,13 @@ def main():
         if aug is not None:
             keep_ts, aug.do_timestretch = aug.do_timestretch, False
         step(batch)
-        # two sub-passes: the family tags (event brackets / dispatch-packet events of the hot kernels), then the "other" tag alone:
-        # with no family tag on, every library launch takes the plain path and carries an event pair in its dispatch packet, i.e.
-        # that pass times the WHOLE step one way (timed together the two mechanisms inflate each other by ~7 %)
-        for tags in (FAM, ["other"]):
-            N.timing_enable(tags)
-            for _ in range(nb):
-                step(batch)
-            kt_nom.update({k: (v[0] / nb, v[1] / nb, v[2] / nb) for k, v in sorted(N.timing_read().items())})
-            N.timing_enable(False)
+        # one pass with every tag on: since round 5 the GEMM families are timed like everything else, by their dispatch packets' own
+        # timestamps (csrc/timing.hip) -- no marker packets, so the tags no longer disturb each other and the sum IS the step's kernel time
+        N.timing_enable(FAM + ["other"])
+        for _ in range(nb):
+            step(batch)
+        kt_nom.update({k: (v[0] / nb, v[1] / nb, v[2] / nb) for k, v in sorted(N.timing_read().items())})
+        N.timing_enable(False)
         if aug is not None:
             aug.do_timestretch = keep_ts
     # fp32 line (item 2c): the same step in the reference's own default arithmetic (exact-fp32 MFMA GEMMs, fp32 storage everywhere),
@@ -735,12 +738,8 @@ def main():
             fam = step_model.by_family(step_model.step_rows(B_PER_GPU, T_FRAMES))
             b_alg = sum(f["bytes"] for f in fam.values())
             fl = sum(f["flops"] for f in fam.values())
-            # (the second sub-pass had no family tag on, so EVERY library launch carried a dispatch-packet event pair under "other":
-            #  that pass alone is the step's kernel time; the family figures come from the first sub-pass)
-            k_ms = kt_nom["other"][1] if "other" in kt_nom else None
-            fam_ms = {k: v[1] for k, v in kt_nom.items() if k != "other"}
-            if k_ms:
-                fam_ms["other"] = k_ms - sum(fam_ms.values())
+            k_ms = sum(v[1] for v in kt_nom.values()) if kt_nom else None
+            fam_ms = {k: v[1] for k, v in kt_nom.items()}
             spmc = None
             sp = os.path.join(ROOT, "profiles", "step_pmc.json")
             if os.path.exists(sp):
@@ -753,7 +752,7 @@ def main():
                          "frac_of_8TBs": round(b_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms else None,
                          "hbm_floor_ms": round(b_alg / (HBM_PEAK_GBS * 1e9) * 1e3, 3), "mfma_floor_ms": round(fl / 2.5e15 * 1e3, 3),
                          "gemm_tflops": round(fl / 1e12, 3),
-                         "launches": round(kt_nom["other"][0], 1) if "other" in kt_nom else None,
+                         "launches": round(sum(v[0] for v in kt_nom.values()), 1) if kt_nom else None,
                          "note": "nominal step (B = 32 x T = 1024, time-stretch off), library launches only; bytes_algorithmic / flops: tools/step_model.py; "
                                  "bytes_measured: rocprofv3 PMC 2*FETCH_SIZE + WRITE_SIZE over every kernel of the step (profiles/step_pmc.json, "
                                  "null when the kernel sources changed since); kernel_ms: HIP events of every launch in this run",
@@ -790,6 +789,8 @@ def main():
             "roofline": roof,
             "roofline_step": roof_step,
             "kernel_ms_per_step": kt_all,
+            "kernel_ms_method": "dispatch-packet timestamps, all timed launches of 10 steps of the seeded sequence (r04 and earlier: event markers "
+                                "around each 1x1-GEMM call, ~+0.2 ms on pw_*)",
             "sustained": sustained,
             "fp32_ms_per_step": fp32_line,
             "dp_path_single_rank": dp_line,
