@@ -303,7 +303,7 @@ def lean_line(out):
     cfg = o.get("config") or {}
     if isinstance(cfg.get("workload"), str):
         cfg["workload"] = cfg["workload"].split(" (0 fp32 everywhere")[0]
-        cut(cfg, "workload", 220)
+        cut(cfg, "workload", 180)
     r = o.get("roofline")
     if isinstance(r, dict):
         r.pop("traffic_per_launch", None)
@@ -320,24 +320,25 @@ def lean_line(out):
         r.pop("frac_note", None)
     if isinstance(o.get("launches_per_step"), dict):
         o["launches_per_step"] = o["launches_per_step"].get("value")
-    cut(o.get("dp_path_single_rank"), "what", 40)
-    cut(o, "kernel_ms_method", 100)
+    if isinstance(o.get("dp_path_single_rank"), dict):
+        o["dp_path_single_rank"].pop("what", None)
+    cut(o, "kernel_ms_method", 60)
     if o.get("launch_graph_diagnostic") is None:
         o.pop("launch_graph_diagnostic", None)
     cb = o.get("cpu_baseline")
     if isinstance(cb, dict):
-        cut(cb, "sample", 150)
+        cut(cb, "sample", 110)
         for k in [k for k in cb if k.startswith("config")]:
             cb.pop(k)
     oc = o.get("other_configs")
     if isinstance(oc, dict):
-        keep = ("ms", "frames_per_s", "world_frames_per_s", "tokens_per_s", "chunks_per_s", "x_realtime", "error")
+        keep = ("ms", "chunks_per_s", "x_realtime", "error")
         for k, v in list(oc.items()):
             if isinstance(v, dict):
                 oc[k] = {kk: vv for kk, vv in v.items() if kk in keep}
     su = o.get("sustained")
     if isinstance(su, dict):
-        for k in ("before",):
+        for k in ("before", "steps"):
             su.pop(k, None)
         if isinstance(su.get("under_load"), dict):
             su["under_load"] = {k: v for k, v in su["under_load"].items() if k in ("sclk_mhz", "power_w")}
