@@ -721,7 +721,7 @@ def ir_stack_eval_cm(blocks, x: torch.Tensor, B: int, T: int, precision: Optiona
             plan.ptrs[8 * i + 1], plan.ptrs[8 * i + 2], plan.ptrs[8 * i + 3] = w1.data_ptr(), wd.data_ptr(), w3.data_ptr()
             plan.ptrs[8 * i + 4] = cache.data_ptr()
             plan.caches.append(cache)
-            plan.keep.append((w1, wd, w3))
+            plan.keep.append(bt)        # every keyed tensor stays alive with the plan: id() of a replaced parameter can then never be reused by its successor
             plan.hid_max, plan.cout_max = max(plan.hid_max, hid), max(plan.cout_max, cout)
             plan.cout_last = cout
         holder["_v100_eval_stack_plan"] = plan
