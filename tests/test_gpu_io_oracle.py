@@ -267,3 +267,64 @@ def test_dwconv_io_vs_float64(cuda, B, C, T, K):
         s = st.sum(0).double()
         assert float((s[:, 0] - dz1r.sum((0, 2))).abs().max()) <= 2e-4 * max(1.0, float(dz1r.abs().sum((0, 2)).max()))
         assert float((s[:, 1] - (dz1r * a1s).sum((0, 2))).abs().max()) <= 2e-4 * max(1.0, float((dz1r * a1s).abs().sum((0, 2)).max()))
+
+
+# (M, K, N): one-matrix GEMMs of the channel-major inference path -- small enough in 256 x 128 tiles for the LATENCY form
+# (pw_gemm_lat_kernel: 64 x 64 tiles, four k-tiles of loads in flight): one k-tile, k-tile counts that are and are not multiples of its
+# register stages, a last column tile that is partly / wholly past N, the models' own widths
+EVAL_CM_SHAPES = [(64, 64, 8), (128, 320, 200), (256, 64, 56), (192, 448, 136), (512, 2048, 256), (2048, 512, 264), (256, 1024, 1792)]
+
+
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,K,N", EVAL_CM_SHAPES)
+def test_eval_gemms_one_matrix_vs_float64_and_vs_batched(cuda, M, K, N, fmt):
+    """The two eval-mode GEMMs (epilogue 2: relu6(ea acc + eb) stored 16-bit from an fp32 X; epilogue 3: ea acc + eb (+ R) in fp32 from a
+    16-bit X) called as ONE matrix (B = 1, T = N: what v100_ir_fwd_eval issues on channel-major activations): elementwise against float64
+    on the rounded operands, and BIT FOR BIT against the same columns issued as two utterances (B = 2, T = N / 2 -- that call takes the
+    throughput kernels whatever the size, so the latency form must accumulate and round exactly as they do)."""
+    N_ = _native()
+    f16 = fmt == "fp16"
+    dt = torch.float16 if f16 else torch.bfloat16
+    F16 = 16
+    g = torch.Generator().manual_seed(M + 3 * K + 7 * N)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(cuda)
+    A = (rnd(M, K) / K ** 0.5).to(dt)
+    Ad = A.double()
+    x = rnd(1, K, N)
+    ea, eb = torch.rand(M, generator=g).to(cuda) + 0.5, rnd(M)
+    r = rnd(1, M, N) * 2
+    half = N // 2 if (N // 2) % 8 == 0 else None          # the two-utterance split needs a pitch equal to the row length
+
+    def split(t):            # [1, C, N] -> [2, C, N / 2]: the same columns as two utterances
+        return torch.stack((t[0, :, :half], t[0, :, half:]), 0).contiguous()
+
+    def join(t):
+        return torch.cat((t[0], t[1]), -1)[None]
+
+    # expand: X fp32 -> h1 16-bit
+    def expand(xin, B, T):
+        y = torch.full((B, M, T), float("nan"), dtype=dt, device=cuda)
+        N_.call("v100_pw_gemm_io", A, xin, None, None, None, None, 0, y, ea, eb, None, 2, None, B, M, K, T, Y | (F16 if f16 else 0))
+        return y
+    y1 = expand(x, 1, N)
+    ref = torch.clamp(fma32(torch.einsum("mk,bkt->bmt", Ad, x.to(dt).double()).float().double(), col(ea), col(eb)), 0, 6)
+    got, refd = y1.double(), ref
+    assert torch.isfinite(got).all()
+    ulp = 2.0 ** (-10 if f16 else -8)
+    err = (got - refd).abs() - refd.abs() * ulp
+    assert float(err.max()) <= 2e-4 * max(1.0, float(refd.abs().max())), ("expand", float(err.max()))
+    if half:
+        assert torch.equal(y1, join(expand(split(x), 2, half))), "expand: latency form != throughput kernels"
+    # project: X 16-bit -> y fp32 (+ residual)
+    x16 = x.to(dt).contiguous()
+
+    def project(xin, rin, B, T):
+        y = torch.full((B, M, T), float("nan"), device=cuda)
+        N_.call("v100_pw_gemm_io", A, xin, None, None, None, None, 0, y, ea, eb, rin, 3, None, B, M, K, T, X | (F16 if f16 else 0))
+        return y
+    for res in (None, r):
+        y3 = project(x16, res, 1, N)
+        ref = fma32(torch.einsum("mk,bkt->bmt", Ad, x16.double()).float().double(), col(ea), col(eb)) + (res.double() if res is not None else 0)
+        close(y3, ref, "project eval")
+        if half:
+            assert torch.equal(y3, join(project(split(x16), split(res) if res is not None else None, 2, half))), "project: latency form != throughput kernels"
