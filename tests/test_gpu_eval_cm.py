@@ -236,3 +236,33 @@ def test_stack_call_equals_block_calls_and_follows_weight_updates(cuda):
             assert same(after2, want, B, T) and not same(after2, after, B, T)
     finally:
         F_.set_matmul_precision("fp32")
+
+
+def test_asr_eval_small_shapes_fuzz(cuda):
+    """The shapes the latency GEMMs and the one-call stack serve (few columns: short chunks, small batches) and those just past their
+    limits: channel-major forward == per-module forward, bit for bit at bf16, over a seeded spread of (B, T)."""
+    from voice100_amd.asr import AudioToTextCTC
+    from voice100_amd import functional as F_
+    torch.manual_seed(11)
+    m = AudioToTextCTC(audio_size=64, embed_size=256, vocab_size=29, hidden_size=256).to(cuda).eval()
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_((torch.randn(mod.running_mean.shape, generator=g) * 0.1).to(cuda))
+                mod.running_var.copy_((torch.rand(mod.running_var.shape, generator=g) + 0.5).to(cuda))
+    shapes = [(1, 16), (1, 101), (2, 256), (3, 33), (5, 77), (8, 101), (13, 64), (32, 101), (40, 50), (64, 128), (7, 511), (96, 101)]
+    F_.set_matmul_precision("bf16")
+    try:
+        with torch.no_grad():
+            for B, T in shapes:
+                audio = (torch.randn(B, T, 64, generator=g) * 2 - 4).to(cuda)
+                F_.EVAL_CM = True
+                a = m(audio)
+                F_.EVAL_CM = False
+                b = m(audio)
+                assert a.shape == b.shape == (B, (T + 1) // 2, 29)
+                assert torch.equal(a, b), (B, T, float((a - b).abs().max()))
+    finally:
+        F_.EVAL_CM = True
+        F_.set_matmul_precision("fp32")
