@@ -249,3 +249,27 @@ def test_derived_tensor_cache_follows_versions_and_lifetimes():
     del w
     gc.collect()
     assert len(F_._DERIVED) == n - 2                   # both tags of the dead parameter are gone
+
+
+def test_bench_line_stays_under_3kb():
+    """bench.py prints ONE JSON line for the driver; the full record goes to stderr / gpurun_out.  The printed form of the last committed
+    record (profiles/r05_bench_details.json) must keep every contract key and stay under 3 KB."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    rec = os.path.join(root, "profiles", "r05_bench_details.json")
+    if not os.path.exists(rec):
+        pytest.skip("no committed bench record")
+    line = bench.lean_line(json.load(open(rec)))
+    text = json.dumps(line)
+    assert len(text) < 3072, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
