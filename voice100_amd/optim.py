@@ -89,11 +89,14 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             ps = t["params"]
             grads = [p.grad for p in ps]
-            if any(g is None for g in grads):
-                raise RuntimeError("FusedAdam: every parameter needs a gradient each step (the reference's models produce one)")
-            for i, g in enumerate(grads):
-                if g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous():
-                    grads[i] = ps[i].grad = g.to(torch.float32).contiguous()
+            f32 = torch.float32
+            try:
+                # one pass: a gradient that is not a contiguous fp32 CUDA tensor (None included) takes the slow path below
+                bad = [i for i, g in enumerate(grads) if g.dtype is not f32 or not g.is_contiguous() or not g.is_cuda]
+            except AttributeError:
+                raise RuntimeError("FusedAdam: every parameter needs a gradient each step (the reference's models produce one)") from None
+            for i in bad:
+                grads[i] = ps[i].grad = grads[i].to(device=ps[i].device, dtype=f32).contiguous()
             ptrs = [g.data_ptr() for g in grads]
             if [p.data_ptr() for p in ps] != t["p_ptrs"]:        # every step: far cheaper than a write into freed memory
                 raise RuntimeError("FusedAdam: a parameter's storage moved since the optimizer was built (re-create the optimizer)")
@@ -117,7 +120,13 @@ class FusedAdam(torch.optim.Optimizer):
             # the kernel wrote the parameters through raw pointers: advance their version counters (host-side metadata), or everything
             # keyed on them -- the eval-mode caches of folded coefficients / 16-bit weight copies -- would keep serving the old weights
             torch.autograd.graph.increment_version(ps)
-            t["step_tensor"] = torch.tensor(float(t["step"]))
-            for p in ps:
-                self.state[p]["step"] = t["step_tensor"]
+            # state[p]["step"]: ONE host tensor shared by the group's parameters (attached once, advanced in place) -- what torch's
+            # Adam keeps per parameter, without 170 dictionary writes a step
+            st = t.get("step_tensor")
+            if st is None or any(self.state[p].get("step") is not st for p in ps[:1]):
+                st = t["step_tensor"] = torch.tensor(float(t["step"]))
+                for p in ps:
+                    self.state[p]["step"] = st
+            else:
+                st.fill_(float(t["step"]))
         return loss
