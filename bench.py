@@ -346,6 +346,9 @@ def lean_line(out):
 
 
 def main():
+    if os.environ.get("V100_BENCH_WATCHDOG"):          # diagnostic: dump every thread's Python stack (and exit) after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["V100_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -561,11 +564,13 @@ def main():
             with socket.socket() as so:
                 so.bind(("127.0.0.1", 0))
                 port = so.getsockname()[1]
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ["MASTER_PORT"] = str(port)
             created = False
             if not dist.is_initialized():
-                dist.init_process_group("nccl", rank=0, world_size=1)
+                # an explicit store of our own: under torchrun (a one-rank launch leaves the group uninitialised here) both the env:// and
+                # the tcp:// rendezvous handlers act as CLIENTS of the launcher's agent store (TORCHELASTIC_USE_AGENT_STORE) and wait for ever
+                # for a server on a port that has none
+                own_store = dist.TCPStore("127.0.0.1", port, 1, True)
+                dist.init_process_group("nccl", store=own_store, rank=0, world_size=1)
                 created = True
             try:
                 step.buckets.remove_hooks()
