@@ -512,7 +512,7 @@ def main():
                      "frames_per_s": round(B_PER_GPU * T_FRAMES * n_sus / total_s, 1),
                      "host_enqueue_ms_per_step": round(host_s / n_sus * 1e3, 3),
                      "under_load": mid, "before": idle}
-    kt, kt_all, kt_nom = {}, {}, {}
+    kt, kt_all, kt_nom, kt_all_raw = {}, {}, {}, {}
     if not args.no_kernel_timing:
         kt = kt_main
         # per-kernel-family breakdown: a separate pass after the timed region (it slows the step, see above)
@@ -521,7 +521,8 @@ def main():
         nb = max(2, min(10, args.steps))
         for _ in range(nb):
             step(batch)
-        kt_all = {k: round(v[1] / nb, 3) for k, v in sorted(N.timing_read().items())}
+        kt_all_raw = dict(N.timing_read())
+        kt_all = {k: round(v[1] / nb, 3) for k, v in sorted(kt_all_raw.items())}
         N.timing_enable(False)
         # the same pass on the NOMINAL step only (time-stretch off: every launch is the 1024-frame problem the algorithmic byte model
         # and the PMC passes describe) -> roofline_step.kernel_ms and the depthwise forward's nominal-only fraction
@@ -732,8 +733,22 @@ def main():
             if "dw_fwd" in kt_nom:               # the nominal step's nine launches alone (separate pass, time-stretch off): review item 3c
                 nn, nms, nby = kt_nom["dw_fwd"]
                 roof["frac_nominal_step"] = round(nby / (nms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                # the depthwise FAMILY (round-5 review, item 1d): forward + fused backward (backward-data + the weight gradient inside
+                # it; the stride-2 opener's separate kernels included), algorithmic bytes of both directions / their summed time
+                def _fam(t):
+                    keys = [k for k in ("dw_fwd", "dw_bwd_data", "dw_wgrad") if k in t]
+                    ms_ = sum(t[k][1] for k in keys)
+                    return (sum(t[k][2] for k in keys) / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_ > 0 and "dw_bwd_data" in t else None
+                ff, ffn = _fam(kt_all_raw), _fam(kt_nom)
+                roof["frac_family"] = round(ff, 4) if ff else None
+                roof["frac_family_nominal_step"] = round(ffn, 4) if ffn else None
+                if "dw_bwd_data" in kt_nom:
+                    bn_, bms_, bby_ = kt_nom["dw_bwd_data"]
+                    roof["frac_bwd_nominal_step"] = round(bby_ / (bms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 roof["frac_note"] = ("frac: every forward launch of the timed region (~30 % of the seeded steps are time-stretched: longer rows on the "
-                                     "three-tile / general kernels); frac_nominal_step: the nine launches of a 1024-frame step, timed in a separate pass")
+                                     "three-tile / general kernels); frac_nominal_step: the nine launches of a 1024-frame step, timed in a separate pass; "
+                                     "frac_family: forward + backward depthwise launches together (algorithmic bytes of both / their time) over the seeded "
+                                     "sequence, frac_family_nominal_step: on the 1024-frame step")
         # Step-level roofline (round-4 review, item 2): algorithmic bytes and 1x1-GEMM flops of ONE nominal step from the shape model
         # (tools/step_model.py: every operand read once, every result written once, in the step's storage formats), the kernel time of a
         # nominal step measured in THIS run (HIP events in the dispatch packets of every library launch), and the HBM bytes rocprofv3's

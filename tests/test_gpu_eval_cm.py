@@ -217,9 +217,9 @@ def test_stack_call_equals_block_calls_and_follows_weight_updates(cuda):
                     want = F_.inverted_residual_eval_cm(blk, want, B, T)
                 got = F_.ir_stack_eval_cm(blocks, xc, B, T)
                 assert same(got, want, B, T)
-                plan = blocks[0].__dict__["_v100_eval_stack_plan"]
+                plan = F_._EVAL_STACK_PLANS[blocks[0]]
                 assert same(F_.ir_stack_eval_cm(blocks, xc, B, T), want, B, T)
-                assert blocks[0].__dict__["_v100_eval_stack_plan"] is plan               # unchanged inputs: the plan is reused
+                assert F_._EVAL_STACK_PLANS[blocks[0]] is plan                           # unchanged inputs: the plan is reused
             B, T = 3, 51
             before = F_.ir_stack_eval_cm(blocks, xc, B, T).clone()
             blocks[1].conv[3].running_mean.add_(0.25)                                    # in place: the version moves
@@ -234,6 +234,45 @@ def test_stack_call_equals_block_calls_and_follows_weight_updates(cuda):
             for blk in blocks:
                 want = F_.inverted_residual_eval_cm(blk, want, B, T)
             assert same(after2, want, B, T) and not same(after2, after, B, T)
+            # `p.data = other` (EMA / SWA swaps, checkpoint assignment) keeps the object AND its version, only the storage moves:
+            # the plan bakes pointers and folded coefficients, so the key must see data_ptr() (round-5 advisor finding)
+            w = blocks[0].conv[0][0].weight
+            ident = (id(w), w._version)
+            w.data = w.data.clone() * 2
+            assert (id(w), w._version) == ident
+            g1 = blocks[1].conv[0][1].weight
+            g1.data = g1.data.clone() * 0.5
+            after3 = F_.ir_stack_eval_cm(blocks, xc, B, T)
+            want = xc
+            for blk in blocks:
+                want = F_.inverted_residual_eval_cm(blk, want, B, T)
+            assert same(after3, want, B, T) and not same(after3, after2, B, T)
+    finally:
+        F_.set_matmul_precision("fp32")
+
+
+def test_modules_stay_copyable_and_picklable_after_an_eval_forward(cuda):
+    """The eval-stack plan holds ctypes pointer arrays (neither picklable nor deep-copyable): it must not live in the module's
+    __dict__.  After an eval forward copy.deepcopy / pickle / torch.save of the blocks work and the copy computes the same."""
+    import copy
+    import io
+    import pickle
+    from voice100_amd import functional as F_
+    blocks = torch.nn.ModuleList([_block(cuda, 64, 64, k, True, 90 + k) for k in (19, 27)])
+    F_.set_matmul_precision("bf16")
+    try:
+        with torch.no_grad():
+            B, T = 2, 64
+            xc = F_.bct_to_cm(torch.randn(B, 64, T, generator=torch.Generator().manual_seed(5)).to(cuda))
+            want = F_.cm_to_btc(F_.ir_stack_eval_cm(list(blocks), xc, B, T), B, T).clone()
+            twin = copy.deepcopy(blocks)
+            pickle.dumps(blocks)
+            buf = io.BytesIO()
+            torch.save(blocks, buf)
+            assert "_v100_eval_stack_plan" not in blocks[0].__dict__
+            got = F_.cm_to_btc(F_.ir_stack_eval_cm(list(twin), xc, B, T), B, T)
+            assert torch.equal(got, want)
+            assert twin[0] in F_._EVAL_STACK_PLANS and F_._EVAL_STACK_PLANS[twin[0]] is not F_._EVAL_STACK_PLANS[blocks[0]]
     finally:
         F_.set_matmul_precision("fp32")
 

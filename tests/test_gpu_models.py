@@ -628,8 +628,11 @@ def test_augment_side_lengths_and_unit_root_gradient(cuda):
             assert ln.dtype == form.dtype and ln.device == form.device
             assert torch.equal(ln.cpu().long(), want)
             half = F_.half_length(ln)
-            assert half is not None and half.dtype == torch.int32 and half.is_cuda
-            assert torch.equal(half.cpu().long(), torch.div(want + 1, 2, rounding_mode="trunc"))
+            if ln.is_cuda:      # the tag follows the reference's output_length contract (asr.py:81-82): the argument's device and dtype
+                assert half is not None and half.dtype == ln.dtype and half.is_cuda
+                assert torch.equal(half.cpu().long(), torch.div(want + 1, 2, rounding_mode="trunc"))
+            else:               # host lengths carry no device tag: output_length computes on the host, like the reference
+                assert half is None
             if ln.is_cuda:
                 ln.add_(1)                                  # a written-to lengths tensor drops its tag
                 assert F_.half_length(ln) is None
@@ -644,3 +647,13 @@ def test_augment_side_lengths_and_unit_root_gradient(cuda):
     loss = F_.ctc_loss(logits, tgt, il, tl)
     (g2,) = torch.autograd.grad(loss, logits, grad_outputs=torch.full((), 2.0, device=cuda))
     assert torch.equal(g0, g1) and torch.allclose(g2, 2 * g0)
+    # the shortcut hands the saved buffer itself downstream: a second backward through the same node must refuse, not reuse it
+    loss = F_.ctc_loss(logits, tgt, il, tl)
+    torch.autograd.grad(loss, logits, grad_outputs=F_.unit_grad(loss), retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        torch.autograd.grad(loss, logits, grad_outputs=F_.unit_grad(loss))
+    loss = F_.ctc_loss(logits, tgt, il, tl)                 # an explicit gradient tensor may be replayed under retain_graph
+    one = torch.ones((), device=cuda)
+    (g3,) = torch.autograd.grad(loss, logits, grad_outputs=one, retain_graph=True)
+    (g4,) = torch.autograd.grad(loss, logits, grad_outputs=one)
+    assert torch.equal(g3, g0) and torch.equal(g4, g0)

@@ -121,5 +121,6 @@ class BatchSpectrogramAugumentation(nn.Module):
             out_len = torch.div(audio_len * d.stretch_rate, 100, rounding_mode="trunc") if d.stretch_rate else audio_len.clone()
         else:
             out_len = len_pair[0] if audio_len.dtype == torch.int32 else len_pair[0].to(audio_len.dtype)
-        F_.tag_half_length(out_len, len_pair[1])
+        if out_len.device == len_pair[1].device:  # host lengths get no device tag: output_length() then computes on the host like the reference
+            F_.tag_half_length(out_len, len_pair[1])
         return out, out_len

@@ -136,9 +136,11 @@ class FlatGradBuckets:
             self._pending[i] = len(members)
         self._next = 0
         self._handles = []
+        self.launch_order = []     # bucket indices in the order this step put them on the wire (every rank must show the same list)
 
     def _launch(self, b):
         s, e, members = self.buckets[b]
+        self.launch_order.append(b)
         views, grads = [], []
         for p in members:
             v = self.flat[self._view[p][0]:self._view[p][1]].view_as(p)

@@ -681,6 +681,11 @@ class _EvalStackPlan:
     __slots__ = ("key", "n", "shapes", "ptrs", "caches", "hid_max", "cout_max", "cout_last", "keep")
 
 
+# Plans live beside the modules, not inside them: a plan holds ctypes pointer arrays, which can be neither pickled nor
+# deep-copied, and a module must stay copy.deepcopy()-able / torch.save()-able after an eval forward.
+_EVAL_STACK_PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
 def ir_stack_eval_cm(blocks, x: torch.Tensor, B: int, T: int, precision: Optional[str] = None) -> torch.Tensor:
     """A run of eval-mode stride-1 InvertedResidual blocks on a channel-major activation x [cin, B * P]: inverted_residual_eval_cm
     block after block, as ONE call into the library (v100_ir_stack_fwd_eval).  At the configs' own sizes (1-second chunks, B = 2 x 256
@@ -691,9 +696,9 @@ def ir_stack_eval_cm(blocks, x: torch.Tensor, B: int, T: int, precision: Optiona
     n = len(blocks)
     P = (T + 7) & ~7
     tens = [_block_tensors(b) for b in blocks]
-    key = (fmt, B, T, x.device.index) + tuple((id(t), t._version) for bt in tens for t in bt)
-    holder = blocks[0].__dict__
-    plan = holder.get("_v100_eval_stack_plan")
+    # data_ptr() is part of the key: `p.data = other` keeps id() and _version but moves the storage the plan's pointers name
+    key = (fmt, B, T, x.device.index, n) + tuple((id(t), t.data_ptr(), t._version) for bt in tens for t in bt)
+    plan = _EVAL_STACK_PLANS.get(blocks[0])
     if plan is None or plan.key != key:
         plan = _EvalStackPlan()
         plan.key, plan.n = key, n
@@ -724,7 +729,7 @@ def ir_stack_eval_cm(blocks, x: torch.Tensor, B: int, T: int, precision: Optiona
             plan.keep.append(bt)        # every keyed tensor stays alive with the plan: id() of a replaced parameter can then never be reused by its successor
             plan.hid_max, plan.cout_max = max(plan.hid_max, hid), max(plan.cout_max, cout)
             plan.cout_last = cout
-        holder["_v100_eval_stack_plan"] = plan
+        _EVAL_STACK_PLANS[blocks[0]] = plan
     if x.shape != (plan.shapes[1], B * P):
         raise RuntimeError("ir_stack_eval_cm: x must be [cin, B * pitch(T)]")
     cols = B * P
@@ -1342,12 +1347,19 @@ class CTCLossFn(torch.autograd.Function):
         # the 'mean' reduction (finite utterances, / target length, / B) and its factor on the gradient happen in the library
         N.call("v100_ctc_loss_mean", logits, targets, il, tl, ws, nll, loss, grad, B, T, V, lmax, int(blank))
         ctx.save_for_backward(grad)
+        ctx.handed_out = False
         return loss[0]
 
     @staticmethod
     def backward(ctx, gout):
         (grad,) = ctx.saved_tensors
+        if ctx.handed_out:
+            # the unit-gradient shortcut below gave the SAVED buffer itself downstream (it may since have become a leaf's .grad or been
+            # written in place): a second backward through this node (retain_graph=True) can no longer trust it
+            raise RuntimeError("ctc_loss: second backward after the unit-root-gradient shortcut handed out the saved gradient; "
+                               "call backward() with an explicit gradient tensor (not functional.unit_grad) when retaining the graph")
         if is_unit_grad(gout):           # the root gradient TrainStep hands to backward(): the factor is exactly 1, no pass over grad
+            ctx.handed_out = True
             return grad, None, None, None, None
         return grad * gout, None, None, None, None
 
@@ -1378,8 +1390,9 @@ def tag_half_length(lengths: torch.Tensor, half: torch.Tensor) -> None:
 
 def half_length(lengths: torch.Tensor):
     tag = getattr(lengths, "_v100_half", None)
-    if tag is not None and tag[1] == lengths._version:
-        return tag[0]
+    if tag is not None and tag[1] == lengths._version and tag[0].device == lengths.device:
+        # the public output_length() keeps the reference's contract (asr.py:81-82): same device and dtype as its argument
+        return tag[0] if tag[0].dtype == lengths.dtype else tag[0].to(lengths.dtype)
     return None
 
 
