@@ -307,6 +307,15 @@ int v100_dwconv_fwd_train_io(const void* a1, const float* w, const float* in_a, 
 int v100_dwconv_bwd_io(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc,
                        const void* xpre, const float* xa, const float* xb, void* dxin, float* stats, float* wpartial,
                        float* dw, int G, int B, int C, int T, int K, int io16, void* stream);
+/* v100_dwconv_bwd_io with every tensor bf16-stored, ONE group, finishing BatchNorm 1's backward itself: the kernel owns the channel's
+ * sums (stats [C][2] = sum dz1, sum dz1*a1) after its last row, forms (p, q, r) -> pqr [3][C] and (dgamma, dbeta) from the saved mean /
+ * rstd / gamma of BatchNorm 1 and writes the FINISHED gradient da1 = p*dz1 + q*a1 + r (bf16, rounded once) where v100_dwconv_bwd_io
+ * writes dz1 -- the operand the expand weight gradient and the expand backward-data GEMM consume (autograd of asr.py:45-49).
+ * B <= 32, T <= 512, specialised K only; 1 otherwise (no fallback). */
+int v100_dwconv_bwd_da1_io(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc,
+                           const void* xpre, const float* xa, const float* xb, void* da1_out, float* stats, float* dw,
+                           const float* bn1_gamma, const float* bn1_mean, const float* bn1_rstd, float* pqr, float* dgamma,
+                           float* dbeta, int B, int C, int T, int K, void* stream);
 /* the two block-boundary passes with a bf16-stored operand: io16 of v100_chan_reduce2_io: 2 = v is bf16 (sums of dy, dy*a3);
  * of v100_chan_affine2_io: 1 = u is bf16 (y = s3*a3 + t3 (+ x)), 6 = v and out are bf16 (da3 = p*dy + q*a3 + r) */
 int v100_chan_reduce2_io(const void* u, const void* v, float* partial, int G, int B, int C, int T, int io16, void* stream);

@@ -269,6 +269,64 @@ def test_dwconv_io_vs_float64(cuda, B, C, T, K):
         assert float((s[:, 1] - (dz1r * a1s).sum((0, 2))).abs().max()) <= 2e-4 * max(1.0, float((dz1r * a1s).abs().sum((0, 2)).max()))
 
 
+@pytest.mark.parametrize("B,C,T,K", [(2, 8, 48, 19), (3, 6, 133, 83), (32, 64, 512, 59), (32, 16, 512, 83), (9, 3, 379, 75), (7, 5, 257, 11),
+                                     (32, 8, 500, 35), (1, 2, 5, 7), (29, 4, 64, 67)])
+def test_dwconv_bwd_da1_vs_float64(cuda, B, C, T, K):
+    """The fused depthwise backward in its FINISHED-GRADIENT form (v100_dwconv_bwd_da1_io: what the 16-bit training step runs on every
+    stride-1 block, autograd of asr.py:45-49): the kernel finalises BatchNorm 1's backward from its own sums and writes
+    da1 = p dz1 + q a1 + r.  Elementwise against float64 on the operands as the kernels define them: the sums, (p, q, r), dgamma / dbeta,
+    the weight gradient, and da1 formed from the kernel's OWN (p, q, r) and the bf16-rounded dz1 (the value its consumers used to
+    re-derive on load), rounded once."""
+    import torch.nn.functional as F
+    N = _native()
+    g = torch.Generator().manual_seed(C * 11 + T + K)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(cuda)
+    pad = (K - 1) // 2
+    a116, a1s = store16(rnd(B, C, T) * 2)
+    w = rnd(C, K) * 0.2
+    s1, t1 = torch.rand(C, generator=g).to(cuda) + 0.5, rnd(C)
+    pre = fma32(a1s, col(s1), col(t1))
+    xin = bf(torch.clamp(pre, 0, 6).float()).double()
+    dz216, dz2s = store16(rnd(B, C, T))
+    a216, a2s = store16(rnd(B, C, T))
+    ga, gb, gc = torch.rand(C, generator=g).to(cuda) + 0.5, rnd(C) * 0.3, rnd(C) * 0.1
+    gp = bf(affine2(dz2s, a2s, ga, gb, gc).float()).double()
+    xv, wv = xin.clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+    (F.conv1d(xv, wv[:, None, :], padding=pad, groups=C) * gp).sum().backward()
+    mask = ((pre > 0) & (pre < 6)).double()
+    dz1r = xv.grad * mask
+    gamma, mean, rstd = torch.rand(C, generator=g).to(cuda) + 0.5, rnd(C) * 0.3, torch.rand(C, generator=g).to(cuda) + 0.5
+    da1 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    st = torch.zeros(1, C, 2, device=cuda)
+    dw = torch.empty(C, K, device=cuda)
+    pqr = torch.empty(3, C, device=cuda)
+    dga, dbe = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    N.call("v100_dwconv_bwd_da1_io", dz216, a216, w, ga, gb, gc, a116, s1, t1, da1, st, dw, gamma, mean, rstd, pqr, dga, dbe, B, C, T, K)
+    close(dw, wv.grad, "depthwise wgrad (da1 form)", tol=3e-4)
+    s = st[0].double()
+    S0, S1 = dz1r.sum((0, 2)), (dz1r * a1s).sum((0, 2))
+    assert float((s[:, 0] - S0).abs().max()) <= 2e-4 * max(1.0, float(dz1r.abs().sum((0, 2)).max()))
+    assert float((s[:, 1] - S1).abs().max()) <= 2e-4 * max(1.0, float((dz1r * a1s).abs().sum((0, 2)).max()))
+    # BatchNorm backward from the kernel's own sums (float64 like the kernel: voice100_amd/csrc/depthwise_common.h dw_finalize_bwd_pre)
+    n = float(B * T)
+    mu, rs, gm = mean.double(), rstd.double(), gamma.double()
+    dg = rs * (s[:, 1] - mu * s[:, 0])
+    pp = gm * rs
+    qq = -gm * rs * rs * dg / n
+    rr = -pp * s[:, 0] / n - qq * mu
+    for got, ref, what in ((pqr[0], pp, "p"), (pqr[1], qq, "q"), (pqr[2], rr, "r"), (dga, dg, "dgamma"), (dbe, s[:, 0], "dbeta")):
+        assert float((got.double() - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max())), what
+    # da1 = fmaf(dz1, p, fmaf(a1, q, r)) on the STORED (bf16) dz1 and the kernel's fp32 coefficients, rounded once to bf16
+    dz1_16 = bf(dz1r.float()).double()
+    ref_da1 = fma32(dz1_16, col(pqr[0]), fma32(a1s, col(pqr[1]), col(pqr[2])))
+    got = da1[:, :, :T].double()
+    assert torch.isfinite(got).all()
+    # a dz1 that sits on a bf16 rounding tie (fp32 accumulation order) may round the other way: one bf16 ulp of dz1, times |p|
+    slack = (dz1r.abs() * 2.0 ** -7) * col(pqr[0]).abs() + ref_da1.abs() * 2.0 ** -8 + 2e-4 * max(1.0, float(ref_da1.abs().max()))
+    bad = ((got - ref_da1).abs() > slack)
+    assert not bool(bad.any()), f"da1: {int(bad.sum())} elements off, worst {float((got - ref_da1).abs().max()):.3e}"
+
+
 # (M, K, N): one-matrix GEMMs of the channel-major inference path -- small enough in 256 x 128 tiles for the LATENCY form
 # (pw_gemm_lat_kernel: 64 x 64 tiles, four k-tiles of loads in flight): one k-tile, k-tile counts that are and are not multiples of its
 # register stages, a last column tile that is partly / wholly past N, the models' own widths

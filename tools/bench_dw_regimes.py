@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--T", type=int, default=512)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--bwd", action="store_true", help="also the fused backward kernel")
+    ap.add_argument("--da1", action="store_true", help="... and its finished-gradient form (v100_dwconv_bwd_da1_io: what the 16-bit training step runs)")
+    ap.add_argument("--only", default="", help="comma list of the columns to run (resident,rotating,produced,bwd resident,bwd rotating,da1 rotating)")
     ap.add_argument("--layers", default="", help="comma list of kernel sizes (default all)")
     ap.add_argument("--cm", action="store_true", help="channel-major tensors [C][B][P]")
     args = ap.parse_args()
@@ -67,6 +69,14 @@ def main():
             j = (i + S // 2) % S
             N.call("v100_dwconv_bwd_io", ys[i], ys[j], w, a, b, c, xs[i], a, b, xs[j], st, part, dwg, G, B, hid, T, k, 15 | cmb)
 
+        pqr = torch.empty(3, hid, device=dev)
+        dga, dbe = torch.empty(hid, device=dev), torch.empty(hid, device=dev)
+        rstd = torch.rand(hid, device=dev) + 0.5
+
+        def bwd_da1(i):
+            j = (i + S // 2) % S
+            N.call("v100_dwconv_bwd_da1_io", ys[i], ys[j], w, a, b, c, xs[i], a, b, xs[j], st, dwg, a, b, rstd, pqr, dga, dbe, B, hid, T, k)
+
         def produce(i):
             if args.cm:
                 N.call("v100_pw_gemm_io", w1, x_in[i], None, None, None, None, 0, xs[i], None, None, None, 1, st, 1, hid, cin, B * P, 1 | 4)
@@ -84,10 +94,14 @@ def main():
             N.timing_enable(False)
             return ms / n * 1e3
 
-        rows = [("resident", timed("dw_fwd", lambda i: fwd(0)), nb_f), ("rotating", timed("dw_fwd", fwd), nb_f),
-                ("produced", timed("dw_fwd", lambda i: (produce(i), fwd(i))), nb_f)]
+        only = {x for x in args.only.split(",") if x}
+        cols = [("resident", "dw_fwd", lambda i: fwd(0), nb_f), ("rotating", "dw_fwd", fwd, nb_f),
+                ("produced", "dw_fwd", lambda i: (produce(i), fwd(i)), nb_f)]
         if args.bwd:
-            rows += [("bwd resident", timed("dw_bwd_data", lambda i: bwd(0)), nb_b), ("bwd rotating", timed("dw_bwd_data", bwd), nb_b)]
+            cols += [("bwd resident", "dw_bwd_data", lambda i: bwd(0), nb_b), ("bwd rotating", "dw_bwd_data", bwd, nb_b)]
+        if args.da1:
+            cols += [("da1 rotating", "dw_bwd_data", bwd_da1, nb_b)]
+        rows = [(name, timed(tag, body), nb) for name, tag, body, nb in cols if not only or name in only]
         line = f"C={hid:5d} k={k:3d}:"
         for name, us, nb in rows:
             line += f"  {name} {us:6.1f} us {nb / us / 8e6 * 100:5.1f}%"

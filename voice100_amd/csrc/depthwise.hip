@@ -475,6 +475,22 @@ extern "C" int v100_dwconv_bwd_io(const void* g, const void* g2, const float* w,
     return dw_bwd_io_fin(g, g2, w, ga, gb, gc, xpre, xa, xb, dxin, stats, wpartial, dw, G, B, C, T, K, io16, DwFin{}, DwPre{}, stream);
 }
 
+// The same pass finishing BatchNorm 1's backward itself (one group) and writing the FINISHED gradient da1 = p dz1 + q a1 + r (bf16)
+// instead of dz1: what the block executor issues for the 16-bit training step (block.hip), exposed for the kernel tests / benchmarks.
+extern "C" int v100_dwconv_bwd_da1_io(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc,
+                                      const void* xpre, const float* xa, const float* xb, void* da1_out, float* stats, float* dw,
+                                      const float* bn1_gamma, const float* bn1_mean, const float* bn1_rstd, float* pqr, float* dgamma,
+                                      float* dbeta, int B, int C, int T, int K, void* stream) {
+    if (!bn1_gamma || !bn1_mean || !bn1_rstd || !pqr || !dgamma || !dbeta) return V100_ERR_NULL;
+    DwFin fin{};
+    fin.mode = 2;
+    fin.count = (double)B * T;
+    fin.gamma = bn1_gamma; fin.a = bn1_mean; fin.b = bn1_rstd;
+    fin.o0 = pqr; fin.o1 = pqr + C; fin.o2 = pqr + 2 * (size_t)C; fin.o3 = dgamma; fin.o4 = dbeta;
+    return dw_bwd_io_fin(g, g2, w, ga, gb, gc, xpre, xa, xb, da1_out, stats, dw, dw, 1, B, C, T, K,
+                         DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y, fin, DwPre{}, stream, 1);
+}
+
 int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc, const void* xpre,
                   const float* xa, const float* xb, void* dxin, float* stats, float* wpartial, float* dw, int G, int B, int C, int T, int K,
                   int io16, const DwFin& fin, const DwPre& pre, void* stream, int da1) {

@@ -9,6 +9,15 @@
 #ifndef DWS_NT
 #define DWS_NT 1
 #endif
+#ifndef DWS_BWD_DEPTH3
+#define DWS_BWD_DEPTH3 DWS_BWD_DEPTH     /* ... in the 768-position form (time-stretched rows) */
+#endif
+// rows of loads in flight per wave in the kept-rows (DA1) form.  Round 6, 8 layers on a rotating working set (profiles/r06_dw_ab.txt):
+// 1 -> 2: 407 -> 366 us.  That form holds two workgroups per CU (its kept rows fill the register file), and unlike the plain form --
+// which a depth of 2 never helped -- it has too few bytes in flight at one row per wave; the extra row costs no occupancy here.
+#ifndef DWS_KEEP_DEPTH
+#define DWS_KEEP_DEPTH 2
+#endif
 
 static bool dws_bwd_enabled() {
     static const bool on = [] { const char* e = getenv("V100_DW_STREAM_BWD"); return !(e && e[0] == '0'); }();
@@ -36,9 +45,9 @@ bool dw_launch_bwd_fused16g(const DwParams& p, hipStream_t st, const V100TimedLa
         if (p.da1) {                                                                                                              \
             if (p.fin.mode != 2 || p.G != 1 || p.B > 32) return false;                                                            \
             if (p.Tin > 512) return false;                                                                                        \
-            V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, 1, DWS_NT * 2, 2, true>), grid, dim3(256), 0, st, p);          \
+            V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_KEEP_DEPTH, DWS_NT * 2, 2, true>), grid, dim3(256), 0, st, p);          \
         } else if (p.Tin <= 512) V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_BWD_DEPTH, DWS_NT * 2, 2>), grid, dim3(256), 0, st, p);  \
-        else V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_BWD_DEPTH, DWS_NT * 2, 3>), grid, dim3(256), 0, st, p);     \
+        else V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_BWD_DEPTH3, DWS_NT * 2, 3>), grid, dim3(256), 0, st, p);     \
     } while (0)
 #define X(KK)                                                                                                                     \
     if (p.K == KK) {                                                                                                              \

@@ -84,37 +84,51 @@ enum { DW_IO_X = 1, DW_IO_X2 = 2, DW_IO_AUX = 4, DW_IO_Y = 8 };
 
 // one lane, with the channel's complete sums in double: the arithmetic of bn_finalize_train_kernel / bn_bwd_finalize_kernel.
 // coef (may be null) receives the three per-channel coefficients the consumer applies: mode 1 (scale, shift, 0), mode 2 (p, q, r).
+// BatchNorm backward (mode 2) from the channel's sums s0 = sum(dz), s1 = sum(dz * x) with the three per-channel inputs already in hand
+// (saved mean, rstd, gamma): the ONE place that arithmetic lives -- dw_finalize_d loads them and calls this; a kernel that has to store
+// data behind the result (the fused depthwise backward's finished gradient) fetches them at its start instead of at its end.
+__device__ __forceinline__ void dw_finalize_bwd_pre(const DwFin& f, int c, double s0, double s1, float mu_f, float rs_f, float ga_f, float* coef) {
+    const double mu = mu_f, rs = rs_f, ga = ga_f;
+    const double dg = rs * (s1 - mu * s0);
+    const double pp = ga * rs;
+    const double qq = -ga * rs * rs * dg / f.count;
+    const double rr = -pp * s0 / f.count - qq * mu;
+    f.o0[c] = (float)pp;
+    f.o1[c] = (float)qq;
+    f.o2[c] = (float)rr;
+    if (f.o3) f.o3[c] = (float)dg;
+    if (f.o4) f.o4[c] = (float)s0;
+    if (coef) { coef[0] = (float)pp; coef[1] = (float)qq; coef[2] = (float)rr; }
+}
+
+// BatchNorm training statistics (mode 1) from the channel's sums with gamma, beta and the running statistics already in hand (see
+// dw_finalize_bwd_pre: same reason -- a consumer that finalises in front of its first row requests them at kernel entry)
+__device__ __forceinline__ void dw_finalize_fwd_pre(const DwFin& f, int c, double s0, double s1, float ga_f, float be_f, float rm_f, float rv_f,
+                                                    float* coef) {
+    if (c == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
+    const double mean = s0 / f.count;
+    double var = s1 / f.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float sc = ga_f * rstd;
+    const float sh = be_f - (float)mean * sc;
+    f.o0[c] = sc;
+    f.o1[c] = sh;
+    if (f.o3) f.o3[c] = (float)mean;
+    if (f.o4) f.o4[c] = rstd;
+    if (f.running_mean) {
+        const double unbiased = f.count > 1.0 ? var * (f.count / (f.count - 1.0)) : var;
+        f.running_mean[c] = (1.f - f.momentum) * rm_f + f.momentum * (float)mean;
+        f.running_var[c] = (1.f - f.momentum) * rv_f + f.momentum * (float)unbiased;
+    }
+    if (coef) { coef[0] = sc; coef[1] = sh; coef[2] = 0.f; }
+}
+
 __device__ __forceinline__ void dw_finalize_d(const DwFin& f, int c, double s0, double s1, float* coef) {
     if (f.mode == 1) {
-        if (c == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
-        const double mean = s0 / f.count;
-        double var = s1 / f.count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
-        const float sc = f.gamma[c] * rstd;
-        const float sh = f.a[c] - (float)mean * sc;
-        f.o0[c] = sc;
-        f.o1[c] = sh;
-        if (f.o3) f.o3[c] = (float)mean;
-        if (f.o4) f.o4[c] = rstd;
-        if (f.running_mean) {
-            const double unbiased = f.count > 1.0 ? var * (f.count / (f.count - 1.0)) : var;
-            f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
-            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
-        }
-        if (coef) { coef[0] = sc; coef[1] = sh; coef[2] = 0.f; }
+        dw_finalize_fwd_pre(f, c, s0, s1, f.gamma[c], f.a[c], f.running_mean ? f.running_mean[c] : 0.f, f.running_mean ? f.running_var[c] : 0.f, coef);
     } else if (f.mode == 2) {
-        const double mu = f.a[c], rs = f.b[c], ga = f.gamma[c];
-        const double dg = rs * (s1 - mu * s0);
-        const double pp = ga * rs;
-        const double qq = -ga * rs * rs * dg / f.count;
-        const double rr = -pp * s0 / f.count - qq * mu;
-        f.o0[c] = (float)pp;
-        f.o1[c] = (float)qq;
-        f.o2[c] = (float)rr;
-        if (f.o3) f.o3[c] = (float)dg;
-        if (f.o4) f.o4[c] = (float)s0;
-        if (coef) { coef[0] = (float)pp; coef[1] = (float)qq; coef[2] = (float)rr; }
+        dw_finalize_bwd_pre(f, c, s0, s1, f.a[c], f.b[c], f.gamma[c], coef);
     }
 }
 // thread 0 of the workgroup of channel c, with the channel's complete sums (G == 1)
@@ -132,6 +146,45 @@ __device__ __forceinline__ void dw_finalize_parts(const DwPre& pre, int C, int c
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
     if (lane == 0) dw_finalize_d(pre.f, c, s0, s1, coef);
+}
+
+// dw_finalize_parts with its loads issued AHEAD (streaming depthwise kernels, round 6).  Inside the kernel the finalisation used to sit
+// behind the row requests: its slab reads and per-channel parameter reads were YOUNGER than the wave's first rows, vmcnt retires in
+// order, so wave 0 waited a full HBM round trip for rows it did not need yet and three waves waited for wave 0 at the barrier
+// (IR_FUSE_PRE cost the forward kernel 10 %).  dw_pre_issue requests everything at kernel entry, in front of the rows, with no branch
+// (inactive waves / modes load through an out-of-range buffer offset -- no bytes move -- or from a harmless valid address);
+// dw_pre_finish is pure arithmetic on those registers: same values, same order of summation as dw_finalize_parts (parts past the slab
+// read as 0.0 and add nothing), so the coefficients are bit-identical.  Up to DW_PRE_MAXPARTS partial sums (4 per lane).
+#define DW_PRE_MAXPARTS 256
+struct DwPreRegs { float s[4][2]; float ga, a, b, rm, rv; };
+__device__ __forceinline__ void dw_pre_issue(const DwPre& pre, int C, int c, int lane, bool active, const float* safe, DwPreRegs& r) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pre.stats), 0,
+                                                                        active ? (int)((size_t)pre.parts * C * 8) : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = lane + 64 * i;
+        const unsigned off = (unsigned)(((size_t)g * C + c) * 8);
+        const f32x2_ v = __builtin_bit_cast(f32x2_, __builtin_amdgcn_raw_buffer_load_b64(rs, (active && g < pre.parts) ? (int)off : 0x7ffffff0, 0, 0));
+        r.s[i][0] = v[0]; r.s[i][1] = v[1];
+    }
+    const DwFin& f = pre.f;
+    r.ga = *((active && f.gamma) ? f.gamma + c : safe);
+    r.a = *((active && f.a) ? f.a + c : safe);
+    r.b = *((active && f.b) ? f.b + c : safe);
+    r.rm = *((active && f.running_mean) ? f.running_mean + c : safe);
+    r.rv = *((active && f.running_var) ? f.running_var + c : safe);
+}
+__device__ __forceinline__ void dw_pre_finish(const DwPre& pre, int c, int lane, const DwPreRegs& r, float* coef) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s0 += (double)r.s[i][0]; s1 += (double)r.s[i][1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+    if (lane == 0) {
+        if (pre.f.mode == 1) dw_finalize_fwd_pre(pre.f, c, s0, s1, r.ga, r.a, r.rm, r.rv, coef);
+        else dw_finalize_bwd_pre(pre.f, c, s0, s1, r.a, r.b, r.ga, coef);
+    }
 }
 
 int chan_affine2_fin(const void* u, const void* v, float* out, void* shadow, int B, int C, int T, int u_bf16, const DwPre& pre, void* stream,

@@ -8,6 +8,9 @@
 #ifndef DWS_DEPTH
 #define DWS_DEPTH 1
 #endif
+#ifndef DWS_DEPTH3
+#define DWS_DEPTH3 DWS_DEPTH      /* rows of loads in flight per wave in the 768-position form (time-stretched rows of 513 .. 768 outputs) */
+#endif
 #ifndef DWS_NT
 #define DWS_NT 1
 #endif
@@ -25,7 +28,7 @@ bool dw_launch_fwd_train16(const DwParams& p, hipStream_t st, const V100TimedLau
 #define GO(KK, NTT)                                                                                                               \
     do {                                                                                                                          \
         if (p.Tin <= 512) V100_LAUNCH(tl, (dwconv_fwd16_stream_kernel<KK, NTT, DWS_DEPTH, DWS_NT * 2, 2>), grid, dim3(256), 0, st, p);  \
-        else V100_LAUNCH(tl, (dwconv_fwd16_stream_kernel<KK, NTT, DWS_DEPTH, DWS_NT * 2, 3>), grid, dim3(256), 0, st, p);         \
+        else V100_LAUNCH(tl, (dwconv_fwd16_stream_kernel<KK, NTT, DWS_DEPTH3, DWS_NT * 2, 3>), grid, dim3(256), 0, st, p);         \
     } while (0)
 #define X(KK)                                                                                                                     \
     if (p.K == KK) {                                                                                                              \

@@ -37,6 +37,13 @@ typedef unsigned int dwm_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int dwm_u32x2 __attribute__((ext_vector_type(2)));
 typedef short dwm_s16x4 __attribute__((ext_vector_type(4)));
 
+// Row stride (floats) of the E tiles' exchange buffer.  Thread jf sums the diagonal E[r + jf + off][r]: with 16-float rows the lanes of a
+// ds_read_b32 sit 16 dwords apart -- two banks for 32 lanes, a 16-way conflict on every one of the 64 reads per thread (round 6: this
+// was most of the fused backward's 39-49 % SQ_LDS_BANK_CONFLICT) -- with 17 they walk the banks.
+#ifndef DWM_EP
+#define DWM_EP 17
+#endif
+
 // 8 bf16 of one MFMA operand fragment as two transposing LDS reads (rows 4G..4G+3 and 16+4G..16+4G+3 of a [32 x 16] tile,
 // G = lane >> 4, column lane & 15); `tile` points at element 0 of the tile, 8-byte aligned.  EXEC must be all ones.
 __device__ __forceinline__ dwm_bf16x8 dwm_tr_fragment(const unsigned short* tile, int lane) {
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
     // per wave: NT digit images of the staged span (+ NT digit images of xin over the tile when WG); the E tiles of the
     // fused backward-weight are spilled over the same bytes at the very end
     constexpr int WAVE_U16 = NX * IMGP + (WG ? NX * TILE : 0);
-    constexpr int E_FLOATS = WG ? 16 * IB * 16 : 0;
+    constexpr int E_FLOATS = WG ? 16 * IB * DWM_EP : 0;
     constexpr int LDS_BYTES = (4 * WAVE_U16 * 2 > 4 * E_FLOATS * 4) ? 4 * WAVE_U16 * 2 : 4 * E_FLOATS * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     __shared__ float lds_w[WLEN];
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
 #pragma unroll
         for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ebuf[(wave * 16 * IB + 16 * ib + 4 * q_ + r) * 16 + n_] = eacc[ib][r];
+            for (int r = 0; r < 4; ++r) ebuf[(wave * 16 * IB + 16 * ib + 4 * q_ + r) * DWM_EP + n_] = eacc[ib][r];
         __syncthreads();
         for (int jf = threadIdx.x; jf < K; jf += 256) {
             float sum = 0.f;
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
             for (int w = 0; w < 4; ++w) {
                 float sw = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sw += ebuf[(w * 16 * IB + r + jf + off) * 16 + r];
+                for (int r = 0; r < 16; ++r) sw += ebuf[(w * 16 * IB + r + jf + off) * DWM_EP + r];
                 sum += sw;
             }
             p.wpartial[((size_t)g * p.C + c) * K + (K - 1 - jf)] = sum;      // flipped taps here = forward taps K-1-jf

@@ -30,6 +30,53 @@
 // instead of two tiles (same values, a different order of the fp32 partial sums).
 #pragma once
 
+// Round-6 knobs of the streaming kernels (A/B builds: tools/ab_variants.sh; the defaults are what ships)
+#ifndef DWS_XSWZ
+#define DWS_XSWZ 1            /* xin image of the fused backward stored with an XOR swizzle of its 8-byte chunks (see dws_xoff) */
+#endif
+#ifndef DWS_TAIL
+#define DWS_TAIL 1            /* DA1: finish BatchNorm 1's backward and store the kept rows BEFORE the weight-gradient tiles go through LDS */
+#endif
+#ifndef DWS_XCD
+#define DWS_XCD 0             /* 1: consecutive channels on ONE XCD (blockIdx -> channel remap), so neighbours in memory share an L2 */
+#endif
+
+// blockIdx.x -> channel.  Workgroups are dealt to the 8 XCDs round-robin; with DWS_XCD the channels c, c + 1, ... (adjacent 1 KB rows
+// of every utterance) go to the same XCD: rows whose pitch is not a whole number of 128-byte lines then share their boundary lines in
+// ONE L2 instead of fetching them twice.
+__device__ __forceinline__ int dws_chan(int bid, int C) {
+#if DWS_XCD
+    return (C & 7) == 0 ? (bid & 7) * (C >> 3) + (bid >> 3) : bid;
+#else
+    (void)C;
+    return bid;
+#endif
+}
+
+// Element offset, inside a 256-position half of the xin image, of the 4-sample chunk q of tile row n (row-major [16 x 16] bf16 tiles,
+// 32-byte rows).  Plain: 16 n + 4 q.  A ds_write_b64 is served in four groups of 16 consecutive lanes on 32 banks: with q fixed in a
+// group the plain addresses are 8 dwords apart -- 4 lanes per bank, a 4-way conflict on both stores of every row.  XOR-ing the chunk
+// index with bits 2..3 of the row spreads each group over all 32 banks; the transposing read supplies one address per (row, chunk), so
+// it simply asks for the swizzled chunk (dws_tr_fragment_x) and still covers 256 contiguous bytes per 32 lanes: conflict-free both ways.
+__device__ __forceinline__ int dws_xoff(int n, int q) {
+#if DWS_XSWZ
+    return 16 * n + 4 * (q ^ ((n >> 2) & 3));
+#else
+    return 16 * n + 4 * q;
+#endif
+}
+__device__ __forceinline__ dwm_bf16x8 dws_tr_fragment_x(const unsigned short* tile, int lane) {
+#if DWS_XSWZ
+    typedef __attribute__((address_space(3))) dwm_s16x4 lds_s16x4;
+    const int o = dws_xoff(lane >> 2, lane & 3);
+    const dwm_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o));
+    const dwm_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + 256 + o));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#else
+    return dwm_tr_fragment(tile, lane);
+#endif
+}
+
 template <int K, int NS>
 struct DwStreamGeom {
     using G_ = DwMfmaGeom<K, 7>;
@@ -57,7 +104,7 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     __shared__ float lds_w[256];                             // WLEN used; every thread stores one slot (no lane-masked branch)
     __shared__ float lds_red[4][2];
 
-    const int c = blockIdx.x, g = blockIdx.y;
+    const int c = dws_chan(blockIdx.x, p.C), g = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_ = lane & 15, q_ = lane >> 4;
@@ -98,6 +145,10 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     static_assert(WLEN <= 256, "one tap slot per thread");
     const int tj = (int)threadIdx.x - WPAD;
     const float tapv = p.w[(size_t)c * K + min(max(tj, 0), K - 1)];      // unconditional (clamped) load, selected below
+    // BatchNorm 1 finalised HERE (DwPre, one group): its slab and parameter reads go out in front of the rows (dw_pre_issue)
+    DwPreRegs prer;
+    const bool pre_fast = !EV && p.pre.f.mode != 0 && p.pre.parts <= DW_PRE_MAXPARTS;
+    if constexpr (!EV) dw_pre_issue(p.pre, p.C, c, lane, pre_fast && wave == 0, p.w, prer);
     __builtin_amdgcn_sched_barrier(0);
     Row raw[D];
 #pragma unroll
@@ -117,7 +168,12 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     // consumer of channel c), finalised HERE from the expand GEMM's slab of partial sums by the first wave (DwPre), under the latency
     // of the row requests above: one dependent launch less per block
     __shared__ float lds_coef[3];
-    if (!EV && p.pre.f.mode != 0 && wave == 0) dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
+    if constexpr (!EV) {
+        if (p.pre.f.mode != 0 && wave == 0) {
+            if (pre_fast) dw_pre_finish(p.pre, c, lane, prer, lds_coef);
+            else dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
+        }
+    }
     __syncthreads();
     float ca = 1.f, cb = 0.f, oa = 1.f, ob = 0.f;
     if constexpr (EV) { oa = p.out_a[c]; ob = p.out_b[c]; }
@@ -287,13 +343,14 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
     constexpr int IMG0 = S_::FWD_IMG > S_::BWD_IMG ? S_::FWD_IMG : S_::BWD_IMG;
     constexpr int IMGP = IMG0 > 512 * NL + 64 ? IMG0 : 512 * NL + 64;
     constexpr int WAVE_U16 = IMGP + XIMG;
-    constexpr int E_FLOATS = 16 * IB * 16;
+    constexpr int E_FLOATS = 16 * IB * DWM_EP;
     constexpr int LDS_BYTES = (4 * WAVE_U16 * 2 > 4 * E_FLOATS * 4) ? 4 * WAVE_U16 * 2 : 4 * E_FLOATS * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES + DWS_BWD_PADLDS];      // (DWS_BWD_PADLDS: A/B of the occupancy alone)
     __shared__ float lds_w[256];
     __shared__ float lds_red[4][2];
+    __shared__ float lds_fin[4];
 
-    const int c = blockIdx.x, g = blockIdx.y;
+    const int c = dws_chan(blockIdx.x, p.C), g = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_ = lane & 15, q_ = lane >> 4;
@@ -332,6 +389,15 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
     const int tj = (int)threadIdx.x - WPAD;
     const int tjc = min(max(tj, 0), K - 1);
     const float tapv = p.w[(size_t)c * K + (p.flip ? (K - 1 - tjc) : tjc)];       // taps first (vmcnt retires in order)
+    // DA1: the three per-channel inputs of BatchNorm 1's backward finalisation (saved mean, rstd, gamma) are requested HERE, with the
+    // taps, and parked in LDS: fetched by thread 0 at the end of the kernel they were three dependent misses between the channel's last
+    // row and the stores of all its kept rows
+    float fmu = 0.f, frs = 0.f, fga = 0.f;
+    if constexpr (DA1 && DWS_TAIL) { fmu = p.fin.a[c]; frs = p.fin.b[c]; fga = p.fin.gamma[c]; }
+    // BatchNorm-2 backward finalised HERE (DwPre, one group): its slab and parameter reads go out in front of the rows
+    DwPreRegs prer;
+    const bool pre_fast = p.pre.f.mode != 0 && p.pre.parts <= DW_PRE_MAXPARTS;
+    dw_pre_issue(p.pre, p.C, c, lane, pre_fast && wave == 0, p.w, prer);
     __builtin_amdgcn_sched_barrier(0);
     Row raw[D];
 #pragma unroll
@@ -339,6 +405,7 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
     __builtin_amdgcn_sched_barrier(0);
 
     lds_w[threadIdx.x] = (tj >= 0 && tj < K) ? tapv : 0.f;
+    if constexpr (DA1 && DWS_TAIL) { lds_fin[0] = fmu; lds_fin[1] = frs; lds_fin[2] = fga; }      // (every thread, the same values: no branch)
     const int off = (-p.pad) & 7;
     const int in0a = (-p.pad) & ~7;
     const int lpad = -in0a;
@@ -351,7 +418,10 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
     // BatchNorm-2 backward coefficients (p, q, r): from the finaliser launch, or finalised here from the project backward-data GEMM's
     // slab by the first wave (DwPre; one group only), under the latency of the row requests
     __shared__ float lds_coef[3];
-    if (p.pre.f.mode != 0 && wave == 0) dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
+    if (p.pre.f.mode != 0 && wave == 0) {
+        if (pre_fast) dw_pre_finish(p.pre, c, lane, prer, lds_coef);
+        else dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
+    }
     __syncthreads();
     const bool pre_on = p.pre.f.mode != 0;
     const float ca = pre_on ? lds_coef[0] : p.in_a[c], cb = pre_on ? lds_coef[1] : p.in_b[c], cc = pre_on ? lds_coef[2] : p.in_c[c];
@@ -420,7 +490,7 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[e] = (t0 + e < T) ? relu6f(fmaf(auxv[sub][e], roa, rob)) : 0.f;
             const dwm_u32x2 w2 = {dwm_pack_rne(xv[0], xv[1]), dwm_pack_rne(xv[2], xv[3])};
-            *reinterpret_cast<dwm_u32x2*>(ximg + t0) = w2;
+            *reinterpret_cast<dwm_u32x2*>(ximg + 256 * sub + dws_xoff(n_, q_)) = w2;
         }
         asm volatile("" ::: "memory");
         issue(r + D, rw);
@@ -428,7 +498,7 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
 #pragma unroll
         for (int h = 0; h < NL; ++h) {
             dwm_bf16x8 xfr[1];
-            xfr[0] = dwm_tr_fragment(ximg + 512 * h, lane);
+            xfr[0] = dws_tr_fragment_x(ximg + 512 * h, lane);
 #pragma unroll
             for (int ib = 0; ib < IB; ++ib) {
                 dwm_bf16x8 gfr[1];
@@ -467,8 +537,8 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
 
     using R0 = std::integral_constant<int, 0>;
     if constexpr (KEEP) {
-        static_assert(D == 1, "the kept-rows form walks one row at a time");
-#define DWS_ROW(i_) if constexpr ((i_) < MAXR) row(raw[0], (i_), std::integral_constant<int, ((i_) < MAXR ? (i_) : 0)>{});
+        static_assert(D >= 1 && D <= 4, "the kept-rows form keeps one to four rows of loads in flight");
+#define DWS_ROW(i_) if constexpr ((i_) < MAXR) row(raw[(i_) % D], (i_), std::integral_constant<int, ((i_) < MAXR ? (i_) : 0)>{});
         DWS_ROW(0) DWS_ROW(1) DWS_ROW(2) DWS_ROW(3) DWS_ROW(4) DWS_ROW(5) DWS_ROW(6) DWS_ROW(7)
 #undef DWS_ROW
         static_assert(MAXR <= 8, "unrolled by hand up to 8 rows per wave");
@@ -482,25 +552,31 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
     }
 
     // dWf[jf] = sum over waves and rr of E[rr + jf + off][rr]; the E tiles go through LDS (over the dead images)
-    __syncthreads();
-    float* ebuf = reinterpret_cast<float*>(lds_raw);
+    auto e_exchange = [&]() {
+        float* ebuf = reinterpret_cast<float*>(lds_raw);
 #pragma unroll
-    for (int ib = 0; ib < IB; ++ib)
+        for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ebuf[(wave * 16 * IB + 16 * ib + 4 * q_ + e) * 16 + n_] = eacc[ib][e];
-    __syncthreads();
-    for (int jf = threadIdx.x; jf < K; jf += 256) {
-        float sum = 0.f;
+            for (int e = 0; e < 4; ++e) ebuf[(wave * 16 * IB + 16 * ib + 4 * q_ + e) * DWM_EP + n_] = eacc[ib][e];
+        __syncthreads();
+        for (int jf = threadIdx.x; jf < K; jf += 256) {
+            float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            float sw = 0.f;
+            for (int w = 0; w < 4; ++w) {
+                float sw = 0.f;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) sw += ebuf[(w * 16 * IB + rr + jf + off) * 16 + rr];
-            sum += sw;
+                for (int rr = 0; rr < 16; ++rr) sw += ebuf[(w * 16 * IB + rr + jf + off) * DWM_EP + rr];
+                sum += sw;
+            }
+            p.wpartial[((size_t)g * p.C + c) * K + (K - 1 - jf)] = sum;
         }
-        p.wpartial[((size_t)g * p.C + c) * K + (K - 1 - jf)] = sum;
-    }
+    };
+    constexpr bool TAIL_FIRST = DA1 && DWS_TAIL;      // the kept rows leave first; the weight-gradient tiles follow under their stores
     __syncthreads();
+    if constexpr (!TAIL_FIRST) {
+        e_exchange();
+        __syncthreads();
+    }
     s0 = wave_sum(s0);
     s1 = wave_sum(s1);
     if (lane == 0) { lds_red[wave][0] = s0; lds_red[wave][1] = s1; }
@@ -510,7 +586,8 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
         const float t1s = (lds_red[0][1] + lds_red[1][1]) + (lds_red[2][1] + lds_red[3][1]);
         p.stats[((size_t)g * p.C + c) * 2 + 0] = t0s;
         p.stats[((size_t)g * p.C + c) * 2 + 1] = t1s;
-        if constexpr (DA1) dw_finalize_d(p.fin, c, (double)t0s, (double)t1s, lds_coef);      // (p, q, r) of BatchNorm 1's backward -> LDS too
+        if constexpr (TAIL_FIRST) dw_finalize_bwd_pre(p.fin, c, (double)t0s, (double)t1s, lds_fin[0], lds_fin[1], lds_fin[2], lds_coef);
+        else if constexpr (DA1) dw_finalize_d(p.fin, c, (double)t0s, (double)t1s, lds_coef);      // (p, q, r) of BatchNorm 1's backward -> LDS too
         else if (p.fin.mode != 0) dw_finalize(p.fin, c, t0s, t1s);
     }
     if constexpr (DA1) {
@@ -565,4 +642,5 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
             }
         }
     }
+    if constexpr (TAIL_FIRST) e_exchange();           // (every wave passed two barriers since its last image read: the images are dead)
 }
