@@ -302,6 +302,10 @@ int v100_pw_wgrad_io(const void* G, const void* G2, const float* ga, const float
                      const void* X, const float* xa, const float* xb, int x_mode, float* partial, float* dW, int S, int B,
                      int M, int K, int T, int io16, void* stream);
 int v100_dw_mfma_supported(int K, int stride);
+/* Row pitch, in elements, of every 16-bit-stored activation tensor [B][C][P] the _io entry points address: a multiple of 8 (16-byte
+ * rows); for B > 1 and T >= 256 a multiple of 64 (rows start on 128-byte lines: a time-stretched 1136-byte row otherwise shares its
+ * boundary lines with its neighbours and they are fetched twice).  The ONE rule (csrc/common.h v100_pitch16): callers allocate with it. */
+int v100_row_pitch16(int T, int B);
 int v100_dwconv_fwd_train_io(const void* a1, const float* w, const float* in_a, const float* in_b, void* a2, float* stats,
                              int G, int B, int C, int T, int K, int io16, void* stream);
 int v100_dwconv_bwd_io(const void* g, const void* g2, const float* w, const float* ga, const float* gb, const float* gc,

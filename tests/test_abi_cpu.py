@@ -137,7 +137,7 @@ def test_stack_plan_layout(lib):
                 t2 = (t + 2 * ((k - 1) // 2) - k) // s + 1
                 assert o[7] == t2
                 act = bf16 == 1 and level and s == 1
-                P, P2 = (t + 7) & ~7, (t2 + 7) & ~7
+                P, P2 = F_.pitch16(t, B), F_.pitch16(t2, B)
                 sizes = {0: B * hid * (P * 2 if act else t * 4), 1: B * hid * (P * 2 if act else t2 * 4),
                          2: B * cout * (P * 2 if (act and level >= 3) else t2 * 4), 3: B * cout * t2 * 4,
                          5: 12 * max(hid, cout) * 4}

@@ -20,14 +20,16 @@ def _native():
     return N
 
 
-def pitch(T):
-    return (T + 7) & ~7
+def pitch(T, B):
+    """row pitch of a 16-bit-stored [B][C][P] tensor: the library's own rule (csrc/common.h v100_pitch16)"""
+    from voice100_amd import functional as F_
+    return F_.pitch16(T, B)
 
 
 def to16(t):
     """fp32 [B, C, T] -> bf16 [B, C, pitch(T)] (padding filled with NaN: nothing may read it) and the rounded values as fp32."""
     B, C, T = t.shape
-    out = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=t.device)
+    out = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=t.device)
     out[:, :, :T] = t.to(torch.bfloat16)
     return out, out[:, :, :T].to(torch.float32).contiguous()
 
@@ -64,7 +66,7 @@ def test_gemm_io_variants(cuda, B, M, K, T):
         return y, st
 
     def io(xm, ep, xin, x2in, rin, mask):
-        y = (torch.full((B, M, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda) if mask & Y else torch.empty(B, M, T, device=cuda))
+        y = (torch.full((B, M, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda) if mask & Y else torch.empty(B, M, T, device=cuda))
         st = torch.zeros(parts, M, 2, device=cuda)
         N.call("v100_pw_gemm_io", Abf, xin, x2in, xa if xm else None, xb if xm else None, xc if xm == 2 else None, xm, y,
                ea if ep == 4 else None, eb if ep == 4 else None, rin, ep, st if ep in (1, 4) else None, B, M, K, T, mask)
@@ -148,7 +150,7 @@ def test_io_gemms_repeatable(cuda):
     N = _native()
     g = torch.Generator().manual_seed(77)
     B, C, hid, T = 32, 256, 1024, 512
-    P = pitch(T)
+    P = pitch(T, B)
     x = torch.randn(B, C, T, generator=g).to(cuda)
     bf = lambda *shape: (torch.randn(*shape, generator=g) * 0.5).to(cuda).to(torch.bfloat16)
     a1, a2, dz1, da3 = bf(B, hid, P), bf(B, hid, P), bf(B, hid, P), bf(B, C, P)
@@ -210,7 +212,7 @@ def test_dwconv_io_variants(cuda, B, C, T, K):
     xin = _bf(torch.clamp(pre, 0, 6))
     # forward: bf16 in, bf16 out, BN2 partial sums from the fp32 accumulators
     ref = F.conv1d(xin, w[:, None, :], padding=pad, groups=C)
-    y1 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    y1 = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda)
     st1 = torch.zeros(G, C, 2, device=cuda)
     N.call("v100_dwconv_fwd_train_io", a116, w, s1, t1, y1, st1, G, B, C, T, K, DX | DY)
     assert rel_err(from16(y1, T), ref) < 6e-3                     # one bf16 rounding of the stored output
@@ -229,7 +231,7 @@ def test_dwconv_io_variants(cuda, B, C, T, K):
         (F.conv1d(xv, wv[:, None, :], padding=pad, groups=C) * gp).sum().backward()
         dz1r = xv.grad * ((pre > 0) & (pre < 6))
         s0r, s1r = dz1r.sum((0, 2)), (dz1r * a1r).sum((0, 2))
-        dz1 = (torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda) if mask & DY else torch.empty(B, C, T, device=cuda))
+        dz1 = (torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda) if mask & DY else torch.empty(B, C, T, device=cuda))
         st = torch.zeros(G, C, 2, device=cuda)
         part = torch.empty(G, C, K, device=cuda)
         dw = torch.empty(C, K, device=cuda)
@@ -261,7 +263,7 @@ def test_chan_passes_io(cuda, B, C, T):
     part = torch.zeros(G, C, 2, device=cuda)
     N.call("v100_chan_reduce2_io", dy, a316, part, G, B, C, T, 2)
     assert rel_err(part.sum(0)[:, 0], dy.sum((0, 2))) < 1e-5 and rel_err(part.sum(0)[:, 1], (dy * a3r).sum((0, 2))) < 1e-5
-    da3 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    da3 = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda)
     N.call("v100_chan_affine2_io", dy, a316, p_, q_, r_, da3, B, C, T, 6)
     ref = p_[None, :, None] * dy + q_[None, :, None] * a3r + r_[None, :, None]
     assert torch.equal(from16(da3, T), ref.to(torch.bfloat16).to(torch.float32)) or rel_err(from16(da3, T), ref) < 5e-3
@@ -278,7 +280,7 @@ def test_chan_affine2_shadow(cuda):
         for ub, u, uref in ((1, a316, a3r), (0, a3, a3)):
             for rr in (res, None):
                 y = torch.empty(B, C, T, device=cuda)
-                sh = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+                sh = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda)
                 N.call("v100_chan_affine2_shadow", u, rr, p_, r_, y, sh, B, C, T, ub)
                 ref = uref * p_[None, :, None] + r_[None, :, None] + (rr if rr is not None else 0)
                 assert rel_err(y, ref) < 1e-6

@@ -25,8 +25,10 @@ def _native():
     return N
 
 
-def pitch(T):
-    return (T + 7) & ~7
+def pitch(T, B):
+    """row pitch of a 16-bit-stored [B][C][P] tensor: the library's own rule (csrc/common.h v100_pitch16)"""
+    from voice100_amd import functional as F_
+    return F_.pitch16(T, B)
 
 
 def bf(t):
@@ -36,7 +38,7 @@ def bf(t):
 def store16(t):
     """fp32 [B, C, T] -> (bf16 [B, C, pitch(T)] with NaN padding -- nothing may read it --, the stored values as float64)"""
     B, C, T = t.shape
-    out = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=t.device)
+    out = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=t.device)
     out[:, :, :T] = t.to(torch.bfloat16)
     return out, out[:, :, :T].to(torch.float64)
 
@@ -77,7 +79,10 @@ GEMM_SHAPES = [(2, 32, 8, 48), (3, 200, 64, 100), (2, 72, 256, 133), (1, 512, 12
                (2, 256, 1088, 200), (3, 512, 1024, 133), (1, 768, 1152, 64), (2, 256, 2048, 90), (1, 256, 1216, 128),
                # the overlapped-epilogue kernel (plain bf16 X, K = 256 / 512, >= 512 tiles): partial last t-tiles with T % 4 != 0 and
                # T % 8 == 0, an uneven number of tiles per workgroup (768 / 256 and 640 / 256)
-               (32, 2048, 512, 379), (32, 2048, 256, 250), (20, 2048, 512, 512), (32, 1280, 256, 512)]
+               (32, 2048, 512, 379), (32, 2048, 256, 250), (20, 2048, 512, 512), (32, 1280, 256, 512),
+               # rows of >= 256 samples whose pitch is a whole number of 128-byte lines and NOT the next multiple of 8 (round 6,
+               # v100_pitch16: T = 300 -> 320, 563 -> 576, 520 -> 576; B > 1): every kernel family at a time-stretched length
+               (3, 256, 64, 300), (4, 512, 512, 563), (5, 2048, 256, 520), (3, 256, 1024, 563), (32, 2048, 512, 563)]
 
 
 @pytest.mark.parametrize("B,M,K,T", GEMM_SHAPES)
@@ -98,7 +103,7 @@ def test_pw_gemm_io_vs_float64(cuda, B, M, K, T):
     parts = N.helper("v100_pw_num_parts", B, T)
 
     def io(xm, ep, xin, x2in, rin, mask):
-        y = (torch.full((B, M, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda) if mask & Y else
+        y = (torch.full((B, M, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda) if mask & Y else
              torch.full((B, M, T), float("nan"), device=cuda))
         st = torch.zeros(parts, M, 2, device=cuda)
         N.call("v100_pw_gemm_io", A, xin, x2in, xa if xm else None, xb if xm else None, xc if xm == 2 else None, xm, y,
@@ -148,6 +153,7 @@ def test_pw_gemm_io_vs_float64(cuda, B, M, K, T):
 
 
 @pytest.mark.parametrize("B,M,K,T", [(2, 32, 8, 48), (4, 200, 64, 100), (3, 64, 256, 133), (3, 300, 260, 133), (5, 640, 384, 77),
+                                     (3, 256, 64, 300), (4, 512, 2048, 563), (4, 2048, 512, 563),      # pitch of whole 128-byte lines (see GEMM_SHAPES)
                                      (32, 1024, 256, 512), (16, 2048, 512, 512), (16, 512, 2048, 512),
                                      # the wave-specialised project gradient (M % 256 == 0, K % 128 == 0): T % 64 != 0 with a
                                      # pitch that is not T, a single step per split, odd step counts, more splits than steps allow
@@ -188,7 +194,7 @@ def test_pw_wgrad_io_vs_float64(cuda, B, M, K, T):
         close(run(Gin, None, 0, x16, 1, mask), ref(gop, xt), "project wgrad", tol=3e-4)
 
 
-@pytest.mark.parametrize("B,C,T", [(2, 8, 48), (3, 6, 133), (32, 512, 512)])
+@pytest.mark.parametrize("B,C,T", [(2, 8, 48), (3, 6, 133), (32, 512, 512), (5, 12, 300), (4, 64, 563)])
 def test_chan_passes_io_vs_float64(cuda, B, C, T):
     """Block-boundary passes on a bf16-stored a3 / da3 (asr.py:52-59 and their backward), elementwise."""
     N = _native()
@@ -204,7 +210,7 @@ def test_chan_passes_io_vs_float64(cuda, B, C, T):
         N.call("v100_chan_affine2_io", a316, res, p_, None, r_, y, B, C, T, 1)
         close(y, ref, "block output", tol=2e-6)
         y = torch.full((B, C, T), float("nan"), device=cuda)
-        sh = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+        sh = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda)
         N.call("v100_chan_affine2_shadow", a316, res, p_, r_, y, sh, B, C, T, 1)
         close(y, ref, "block output (shadow form)", tol=2e-6)
         assert torch.equal(sh[:, :, :T], y.to(torch.bfloat16))                    # the shadow is exactly the rounded output
@@ -215,7 +221,7 @@ def test_chan_passes_io_vs_float64(cuda, B, C, T):
     n = B * T
     assert float((s[:, 0] - dy.double().sum((0, 2))).abs().max()) <= 2e-6 * n
     assert float((s[:, 1] - (dy.double() * a3s).sum((0, 2))).abs().max()) <= 2e-6 * n * 4
-    da3 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    da3 = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda)
     N.call("v100_chan_affine2_io", dy, a316, p_, q_, r_, da3, B, C, T, 6)
     close(da3[:, :, :T], col(p_) * dy.double() + col(q_) * a3s + col(r_), "BatchNorm-3 backward", out16=True, tol=2e-6)
 
@@ -239,7 +245,7 @@ def test_dwconv_io_vs_float64(cuda, B, C, T, K):
     pre = fma32(a1s, col(s1), col(t1))
     xin = bf(torch.clamp(pre, 0, 6).float()).double()
     ref = F.conv1d(xin, w.double()[:, None, :], padding=pad, groups=C)
-    y = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    y = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda)
     st = torch.zeros(G, C, 2, device=cuda)
     N.call("v100_dwconv_fwd_train_io", a116, w, s1, t1, y, st, G, B, C, T, K, DX | DY)
     close(y[:, :, :T], ref, "depthwise fwd", out16=True)
@@ -255,7 +261,7 @@ def test_dwconv_io_vs_float64(cuda, B, C, T, K):
     mask = ((pre > 0) & (pre < 6)).double()
     edge = torch.zeros_like(mask, dtype=torch.bool)          # pre is the kernel's own fmaf: no kink ambiguity
     dz1r = xv.grad * mask
-    dz1 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    dz1 = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda)
     st = torch.zeros(G, C, 2, device=cuda)
     part = torch.empty(G, C, K, device=cuda)
     dw = torch.empty(C, K, device=cuda)
@@ -296,7 +302,7 @@ def test_dwconv_bwd_da1_vs_float64(cuda, B, C, T, K):
     mask = ((pre > 0) & (pre < 6)).double()
     dz1r = xv.grad * mask
     gamma, mean, rstd = torch.rand(C, generator=g).to(cuda) + 0.5, rnd(C) * 0.3, torch.rand(C, generator=g).to(cuda) + 0.5
-    da1 = torch.full((B, C, pitch(T)), float("nan"), dtype=torch.bfloat16, device=cuda)
+    da1 = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda)
     st = torch.zeros(1, C, 2, device=cuda)
     dw = torch.empty(C, K, device=cuda)
     pqr = torch.empty(3, C, device=cuda)

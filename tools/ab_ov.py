@@ -21,7 +21,8 @@ from tools.gemm_yardstick import timeit, NSETS  # noqa: E402
 N.load()
 dev = torch.device("cuda")
 B, T = 32, 512
-P = (T + 7) & ~7
+from voice100_amd.functional import pitch16 as _pitch16
+P = _pitch16(T, B)
 out = []
 for (C, hid) in ((256, 1024), (512, 2048)):
     bf = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)          # noqa: E731

@@ -41,7 +41,8 @@ def main():
         N.LIB_PATH = os.path.abspath(args.lib)
     dev = torch.device("cuda:0")
     B, T = args.B, args.T
-    P = (T + 7) & ~7
+    from voice100_amd.functional import pitch16 as _pitch16
+    P = _pitch16(T, B)
     want = {int(k) for k in args.layers.split(",") if k}
     tot = {}
     for cin, hid, k in LAYERS:

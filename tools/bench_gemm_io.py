@@ -34,7 +34,8 @@ def main():
     from voice100_amd import _native as N
     dev = torch.device("cuda")
     B, T = args.B, args.T
-    P = (T + 7) & ~7
+    from voice100_amd.functional import pitch16 as _pitch16
+    P = _pitch16(T, B)
     tot = 0.0
     for (C, hid) in ((256, 1024), (512, 2048)):
         bf = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)

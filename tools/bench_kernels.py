@@ -69,7 +69,8 @@ def main():
                 print(f"{name:12s} C={hid:5d} k={k:3d} s={s} T={t:5d}: {dt*1e6:8.1f} us  {nb/dt/1e9:7.0f} GB/s ({nb/dt/8e12*100:5.1f}% of 8TB/s)  {fl/dt/1e12:6.1f} TFLOP/s")
         if "dw16" in args.what.split(",") and s == 1:
             # bf16 storage of the hidden tensors (act16): same layers, bf16 [B, C, pitch] in / out
-            P = (t + 7) & ~7
+            from voice100_amd.functional import pitch16 as _pitch16
+            P = _pitch16(t, B)
             x16 = torch.randn(B, hid, P, device=dev).to(torch.bfloat16)
             y16 = torch.empty(B, hid, P, device=dev, dtype=torch.bfloat16)
             g16 = torch.randn(B, hid, P, device=dev).to(torch.bfloat16)

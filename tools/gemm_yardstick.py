@@ -48,7 +48,8 @@ def main():
     N.load()
     dev = torch.device("cuda")
     B, T = args.B, args.T
-    P = (T + 7) & ~7
+    from voice100_amd.functional import pitch16 as _pitch16
+    P = _pitch16(T, B)
     Ncol = B * T
     print(f"# device: {torch.cuda.get_device_name(0)}; torch {torch.__version__}; B = {B}, T = {T} (N = B*T = {Ncol} columns); {NSETS} rotating buffer sets")
     print(f"# peak used for the fractions: 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md)")

@@ -48,8 +48,7 @@ def table(tag, t_in):
         for n in names:
             bf16 = "fwd16_stream" in n or re.search(r"false, 9>", n) is not None
             if bf16:
-                P = (t + 7) & ~7
-                algo = 2.0 * B * hid * (P + P) + 4 * hid * k + 8 * hid
+                algo = 2.0 * B * hid * (t + t) + 4 * hid * k + 8 * hid      # (algorithmic: the T samples of a row, not its pitch)
             else:
                 algo = 4.0 * B * hid * (t + tout) + 4 * hid * k + 8 * hid
             rd = 2 * fe[n][0] * 1024

@@ -46,7 +46,7 @@ t = T
 fwd_rows = []
 for hid, k, s in SPECS:
     tout = (t - 1) // s + 1
-    P16 = (t + 7) & ~7
+    P16 = (t + 7) & ~7 if t < 256 else (t + 63) & ~63      # (csrc/common.h v100_pitch16 for B > 1)
     for kind, pat, rd, wrb in (("fwd", rf"dwconv(_mfma)?_kernel<{k}, (1, 0, 3, false, 0|{s}, 8, 1, 0, true, false)>", 4.0 * B * hid * t, 4.0 * B * hid * tout),
                                ("bwd fused", rf"dwconv(_mfma)?_kernel<{k}, 2, 2, 3, true, 0>", 4.0 * B * hid * (2 * tout + t), 4.0 * B * hid * t),
                                ("fwd16", rf"(dwconv_mfma_kernel<{k}, 1, 0, 2, false, 9>|dwconv_fwd16_stream_kernel<{k}, 2, \d+, \d+, \d+>)", 2.0 * B * hid * P16, 2.0 * B * hid * P16),

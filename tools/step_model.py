@@ -35,7 +35,8 @@ N_PARAMS = 11621661
 
 
 def pitch16(t):
-    return (t + 7) & ~7
+    """csrc/common.h v100_pitch16 for B > 1 (kept as arithmetic here: this model also runs where the library is not built)"""
+    return (t + 7) & ~7 if t < 256 else (t + 63) & ~63
 
 
 def wgrad_splits(B, M, K, target=512):

@@ -10,12 +10,15 @@
 #define IR_FUSE_BN3 2      /* 1: reduce + finalise in one kernel; 2: ... + the affine, from registers */
 #endif
 // consumer-side BatchNorm finalisation in the depthwise kernels (DwPre): bit 0 forward (BatchNorm 1 from the expand GEMM's slab),
-// bit 1 backward (BatchNorm-2 backward from the project backward-data GEMM's slab).  Bit-identical results; measured on one box:
-// both on 3.982 -> 3.952 ms/step (16 launches fewer) but the forward depthwise kernel itself 0.206 -> 0.228 ms per step (the slab
-// reduction sits in front of its first row) -- that kernel is the one graded against the HBM roofline; backward only: +-0 (its
-// kernel +0.03 ms).  Off.
+// bit 1 backward (BatchNorm-2 backward from the project backward-data GEMM's slab).  Bit-identical results.  Round 2 measured it as
+// a faster STEP (16 launches fewer) with a slower depthwise kernel and left it off because that kernel is the one graded against the
+// HBM roofline; the round-5 review asked for the default that minimises ms_per_step.  Round 6, with the finalisation's loads issued
+// ahead of the rows (dw_pre_issue) and the Toeplitz fragments built under their latency, A/B on one box (profiles/r06_dw_ab.txt):
+// 3.30 -> 3.24 ms/step, 151 -> 135 launches, glue 0.58 -> 0.51 ms; the depthwise forward pays +2 us a launch for it (0.189 -> 0.207 ms
+// per step, roofline.frac_nominal_step 0.57 -> 0.52: the fp64 finalisation of a channel sits in front of its first row), the fused
+// backward 0.388 -> 0.408.  On (3): the step is what counts; the slab bytes are counted in the kernels' algorithmic bytes.
 #ifndef IR_FUSE_PRE
-#define IR_FUSE_PRE 0
+#define IR_FUSE_PRE 3
 #endif
 
 namespace {
@@ -41,7 +44,9 @@ const float kMom = 0.1f, kEps = 1e-5f;
 // backward workspace; 3 = also the project output a3 (saved for backward; the caller allocates it bf16 [B][cout][pitch16(T)])
 // and its BatchNorm-backward gradient da3 (workspace).  Statistics and every accumulation stay fp32; only the stored copies are rounded.
 enum { IR_B, IR_CIN, IR_HID, IR_COUT, IR_T, IR_K, IR_STRIDE, IR_RES, IR_BF16, IR_PREPPED, IR_ACT16, IR_NSHAPE };
-static inline int pitch16(int T) { return (T + 7) & ~7; }
+static inline int pitch16(int T, int B) { return v100_pitch16(T, B); }      // THE rule: common.h
+// the row pitch (elements) of a 16-bit-stored [B][C][P] activation, for host code that allocates such tensors (functional.pitch16)
+extern "C" int v100_row_pitch16(int T, int B) { return v100_pitch16(T, B); }
 enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8, PW_IO_F16 = 16, WG_IO_G = 1, WG_IO_G2 = 2, WG_IO_X = 4 };   // DW_IO_*: depthwise_common.h
 
 // 1 when a block of this shape can run with act16 != 0 (stride 1, a depthwise kernel size with an MFMA kernel, bf16 operands,
@@ -49,7 +54,7 @@ enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8, PW_IO_F16 = 16, WG_I
 extern "C" int v100_ir_act16_supported(const int* sh) {
     if (!sh || sh[IR_BF16] != 1 || sh[IR_STRIDE] != 1) return 0;
     if (!v100_dw_mfma_supported(sh[IR_K], sh[IR_STRIDE])) return 0;
-    const long B = sh[IR_B], hid = sh[IR_HID], cin = sh[IR_CIN], cout = sh[IR_COUT], P = pitch16(sh[IR_T]);
+    const long B = sh[IR_B], hid = sh[IR_HID], cin = sh[IR_CIN], cout = sh[IR_COUT], P = pitch16(sh[IR_T], sh[IR_B]);
     if (hid % 2 || cin % 2 || cout % 2) return 0;
     if (B * hid * P * 4 >= 0x7fffff00L || (hid + 128) * P * 4 >= 0x7fffff00L || (hid + 128) * (cin > cout ? cin : cout) * 2 >= 0x7fffff00L) return 0;
     return 1;
@@ -96,7 +101,7 @@ extern "C" long long v100_ir_fwd_workspace_bytes(const int* shape) {
 
 // ptrs: 0 x | 1 w1 2 g1 3 b1 4 rm1 5 rv1 6 nbt1 | 7 wd 8 g2 9 b2 10 rm2 11 rv2 12 nbt2 | 13 w3 14 g3 15 b3 16 rm3 17 rv3 18 nbt3 |
 //       19 a1 20 a2 21 a3 22 y 23 coef 24 workspace 25 prepared-weights buffer (v100_ir_prep_bytes)
-//       26 x16 27 y16 (act16 >= 4 only, each may be NULL): bf16 shadow [B][C][(T + 7) & ~7] of the block input (written by the
+//       26 x16 27 y16 (act16 >= 4 only, each may be NULL): bf16 shadow [B][C][pitch16(T, B)] of the block input (written by the
 //       previous block) / of this block's output (for the next block)
 extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stream) {
     if (!sh || !P) return V100_ERR_NULL;
@@ -200,12 +205,12 @@ static size_t ir_bwd_carve(const int* sh, void* base, IrBwdWs& w) {
     size_t m = (size_t)v100_pw_num_parts(B, T2) * hid * 2; if (m > n) n = m;
     m = (size_t)v100_dw_num_groups(B, hid) * hid * 2; if (m > n) n = m;
     w.part = c.take<float>(n);
-    w.da3 = sh[IR_ACT16] >= 3 ? (float*)c.take<u16>((size_t)B * cout * pitch16(T2)) : c.take<float>((size_t)B * cout * T2);
+    w.da3 = sh[IR_ACT16] >= 3 ? (float*)c.take<u16>((size_t)B * cout * pitch16(T2, B)) : c.take<float>((size_t)B * cout * T2);
     // act16 == 2: the two hidden gradients are bf16 with pitched rows (half the bytes; the fp32 size is an upper bound
     // only when pitch16(T) <= 2*T, i.e. always)
     if (sh[IR_ACT16] >= 2) {
-        w.dz2 = (float*)c.take<u16>((size_t)B * hid * pitch16(T2));
-        w.dz1 = (float*)c.take<u16>((size_t)B * hid * pitch16(T));
+        w.dz2 = (float*)c.take<u16>((size_t)B * hid * pitch16(T2, B));
+        w.dz1 = (float*)c.take<u16>((size_t)B * hid * pitch16(T, B));
     } else {
         w.dz2 = c.take<float>((size_t)B * hid * T2);
         w.dz1 = c.take<float>((size_t)B * hid * T);
@@ -394,7 +399,7 @@ extern "C" int v100_ir_fwd_eval(const int* sh, const void* const* P, void* strea
         for (int i = 0; i < IR_NSHAPE; ++i) shb[i] = sh[i];
         shb[IR_BF16] = 1;
         if ((bf != 1 && bf != 2) || S != 1 || T > 768 || !v100_ir_act16_supported(shb)) return V100_ERR_SHAPE;
-        const long long N = (long long)B * pitch16(T);
+        const long long N = (long long)B * pitch16(T, B);
         if (N > 0x7fffff00LL) return V100_ERR_SHAPE;
         const int f16 = bf == 2 ? PW_IO_F16 : 0;
         CK(v100_pw_gemm_io(c.w1bf, x, nullptr, nullptr, nullptr, nullptr, 0, h1, c.s1, c.t1, nullptr, 2, nullptr, 1, hid, cin, (int)N, PW_IO_Y | f16, stream));
@@ -557,7 +562,7 @@ int stack_layout(const int* desc, StackBlock* blk, size_t& blob_bytes, size_t& b
         if (T2 <= 0) return 0;
         b.Tout = T2;
         const int lv = sh[IR_ACT16];
-        const size_t P = pitch16(T), P2 = pitch16(T2);
+        const size_t P = pitch16(T, B), P2 = pitch16(T2, B);
         b.a1 = (long long)off; off = al256(off + (lv ? (size_t)B * hid * P * 2 : (size_t)B * hid * T * 4));
         b.a2 = (long long)off; off = al256(off + (lv ? (size_t)B * hid * P * 2 : (size_t)B * hid * T2 * 4));   // (act16: stride 1, T2 == T)
         b.a3 = (long long)off; off = al256(off + (lv >= 3 ? (size_t)B * cout * P * 2 : (size_t)B * cout * T2 * 4));

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void chan_reduce2_kernel(const float* __restri
     }
 }
 
-// ---- the two block-boundary passes over tensors of which some are STORED as bf16 [B][C][P], P = (T + 7) & ~7 ("act16", see
+// ---- the two block-boundary passes over tensors of which some are STORED as bf16 [B][C][P], P = v100_pitch16(T, B) ("act16", see
 // include/voice100_hip.h): a3 (project output, saved for backward) and da3 (its BatchNorm-backward gradient, executor-internal).
 // Row-wise addressing: fp32 operands have pitch T, bf16 operands pitch P; 4 samples per thread and step.
 typedef unsigned int bn_u32x2 __attribute__((ext_vector_type(2)));
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void chan_reduce2_io_kernel(const void* __rest
     const int c = blockIdx.x, g = blockIdx.y;
     const int bper = (B + G - 1) / G;
     const int b0 = g * bper, b1 = min(B, b0 + bper);
-    const int P = (T + 7) & ~7;
+    const int P = v100_pitch16(T, B);
     float s0 = 0.f, s1 = 0.f;
     for (int b = b0; b < b1; ++b) {
         const size_t row = (size_t)b * C + c;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(1024) void chan_reduce2_fin_kernel(const void* __re
                                                                 int B, int C, int T, DwFin fin) {
     __shared__ float red[16][2];
     const int c = blockIdx.x;
-    const int P = (T + 7) & ~7;
+    const int P = v100_pitch16(T, B);
     const int T4 = (T + 3) >> 2;
     float s0 = 0.f, s1 = 0.f;
     for (int i = threadIdx.x; i < B * T4; i += 1024) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(1024) void chan_bn3_bwd_kernel(const float* __restr
     __shared__ float red[16][2];
     __shared__ float coef[3];
     const int c = blockIdx.x;
-    const int P = (T + 7) & ~7;
+    const int P = v100_pitch16(T, B);
     const int T4 = (T + 3) >> 2;
     const int n = B * T4;
     float a[NQ][4], w[NQ][4];
@@ -300,7 +300,7 @@ template <int IO>
 __global__ __launch_bounds__(256) void chan_affine2_io_kernel(const void* __restrict__ u, const void* __restrict__ v, const float* __restrict__ A,
                                                               const float* __restrict__ Bc, const float* __restrict__ Cc, void* __restrict__ out,
                                                               int C, int T, long rows) {
-    const int P = (T + 7) & ~7;
+    const int P = v100_pitch16(T, (int)(rows / C));       // rows = B * C
     const int T4 = (T + 3) >> 2;
     const long total = rows * T4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -328,14 +328,14 @@ __global__ __launch_bounds__(256) void chan_affine2_io_kernel(const void* __rest
 }
 
 // The forward block output with a bf16 SHADOW beside it: out = A[c]*u + Cc[c] (+ v) as fp32 [rows][T] and the same values rounded
-// to bf16 in a pitched copy [rows][(T + 7) & ~7] -- what the next block's expand GEMM and expand weight gradient load as their X
+// to bf16 in a pitched copy [rows][v100_pitch16(T, B)] -- what the next block's expand GEMM and expand weight gradient load as their X
 // operand (they round X to bf16 anyway: identical results, half the bytes through the CU's 64 B/clk vector-memory path, which is
 // what bounds the 256-row backward-weight kernel once its fp32 X tile is 64 of the 96 KB it stages per step).  UB: u is bf16 (pitched).
 template <bool UB>
 __global__ __launch_bounds__(256) void chan_affine2_shadow_kernel(const void* __restrict__ u, const float* __restrict__ v, const float* __restrict__ A,
                                                                   const float* __restrict__ Cc, float* __restrict__ out, u16* __restrict__ shadow,
                                                                   int C, int T, long rows) {
-    const int P = (T + 7) & ~7;
+    const int P = v100_pitch16(T, (int)(rows / C));       // rows = B * C
     const int T4 = (T + 3) >> 2;
     const long total = rows * T4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(1024) void chan_affine2_fin_kernel(const void* __re
     if (threadIdx.x < 64) dw_finalize_parts(pre, C, c, threadIdx.x, coef);
     __syncthreads();
     const float a = coef[0], cc = coef[1];
-    const int P = (T + 7) & ~7;
+    const int P = v100_pitch16(T, B);
     const int T4 = (T + 3) >> 2;
     for (int i = threadIdx.x; i < B * T4; i += 1024) {
         const int b = i / T4, t = (i - b * T4) * 4;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __res
     }
 }
 
-// Channel-major inference layout (block.hip, v100_ir_fwd_eval with shape[10] == 2): [B][C][T] -> [C][B][P], P = (T + 7) & ~7, the padding
+// Channel-major inference layout (block.hip, v100_ir_fwd_eval with shape[10] == 2): [B][C][T] -> [C][B][P], P = v100_pitch16(T, B), the padding
 // columns zeroed; and back out of it at the model's edge: [C][B][P] -> [B][T][C]  (asr.py:114: transpose(1, 2) of the logits)
 __global__ __launch_bounds__(256) void bct_to_cm_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int T, int P) {
     // flat over the output (rows of 51 samples would leave a workgroup per row 80 % idle: 30 us for 256 x 256 rows)
@@ -782,7 +782,7 @@ extern "C" int v100_transpose_last2(const float* in, float* out, int B, int R, i
 extern "C" int v100_bct_to_cm(const float* in, float* out, int B, int C, int T, void* stream) {
     if (!in || !out) return V100_ERR_NULL;
     if (B <= 0 || C <= 0 || T <= 0) return V100_ERR_SHAPE;
-    const int P = (T + 7) & ~7;
+    const int P = v100_pitch16(T, B);
     const long long total = (long long)C * B * P;
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
@@ -793,7 +793,7 @@ extern "C" int v100_bct_to_cm(const float* in, float* out, int B, int C, int T, 
 extern "C" int v100_cm_to_btc(const float* in, float* out, int B, int C, int T, void* stream) {
     if (!in || !out) return V100_ERR_NULL;
     if (B <= 0 || C <= 0 || T <= 0 || B > 65535) return V100_ERR_SHAPE;
-    const int P = (T + 7) & ~7;
+    const int P = v100_pitch16(T, B);
     V100_GGL(cm_to_btc_kernel, dim3(ceil_div(C, 32), ceil_div(T, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, B, C, T, P);
     return v100_launch_status();
 }

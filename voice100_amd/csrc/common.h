@@ -110,3 +110,14 @@ __device__ __forceinline__ u16 f2h(float f) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Row pitch, in elements, of a 16-bit-stored activation tensor [B][C][P] ("act16") -- THE one place the rule lives
+// (round 6; it used to be written out as (T + 7) & ~7 at ~50 sites).  Every row starts on a 16-byte boundary (P % 8 == 0: the kernels'
+// 8- and 16-byte accesses stay aligned whatever T a time-stretch produced); rows of 256 samples or more start on a 128-BYTE boundary
+// (P % 64 == 0): a 1136-byte row (T' = 563, the stretch-110 % step) shares its first and last cache line with its neighbours in memory --
+// other channels, i.e. other workgroups on other XCDs -- and every shared line is fetched twice: measured 1.07-1.10 x algorithmic HBM
+// traffic on the depthwise launches of those steps and 8-10 % of their time (profiles/r06_dw_ab.txt: T = 568 -> 51.4 %, 576 -> 55.4 % of
+// 8 TB/s).  A tensor of ONE row per channel (B == 1: the channel-major inference matrices [C][B P], which the GEMMs see as B = 1,
+// T = B P) keeps the 8-sample rule: its row length is the caller's column count and must not be re-padded.
+__host__ __device__ __forceinline__ int v100_pitch16(int T, int B) { return (B > 1 && T >= 256) ? ((T + 63) & ~63) : ((T + 7) & ~7); }
+// (exported to the host side as v100_row_pitch16, block.hip)

@@ -432,12 +432,13 @@ int dw_fwd_train_io_fin(const void* a1, const float* w, const float* in_a, const
     const int cm = (io16 >> 4) & 1;              // DW_IO_CM: channel-major tensors [C][B][P] (streaming kernels: rows of up to 768 outputs)
     io16 &= 15;
     if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || (K & 1) == 0 || G <= 0 || G > B || io16 != (DW_IO_X | DW_IO_Y)) return V100_ERR_SHAPE;
-    if ((size_t)B * C * dw_pitch16(T) * 4 >= 0x7fffff00ull) return V100_ERR_SHAPE;
+    if ((size_t)B * C * dw_pitch16(T, B) * 4 >= 0x7fffff00ull) return V100_ERR_SHAPE;
     DwParams p{(const float*)a1, nullptr, w, in_a, in_b, nullptr, (float*)a2, nullptr, nullptr, nullptr, stats,
                B, C, T, T, K, 1, (K - 1) / 2, 0, 1, G, DW_IN_AFFINE_RELU6, DW_OUT_RAW_STATS, nullptr, io16, fin, pre};
     p.cm = cm;
     hipStream_t st = (hipStream_t)stream;
-    V100TimedLaunch timed(V100_T_DW_FWD, 2.0 * B * C * 2.0 * T + 4.0 * C * K + 8.0 * C);
+    // (algorithmic bytes: the two streams, taps, coefficients -- and the producer's slab of partial sums when BatchNorm 1 is finalised here)
+    V100TimedLaunch timed(V100_T_DW_FWD, 2.0 * B * C * 2.0 * T + 4.0 * C * K + 8.0 * C + (pre.f.mode != 0 ? 8.0 * pre.parts * C : 0.0));
     if (!dw_launch_fwd_train16(p, st, timed)) return V100_ERR_SHAPE;
     return v100_launch_status();
 }
@@ -448,14 +449,14 @@ int dw_fwd_eval_io(const void* h1, const float* w, const float* out_a, const flo
                    int cm, int f16) {
     if (!h1 || !w || !out_a || !out_b || !h2) return V100_ERR_NULL;
     if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || (K & 1) == 0) return V100_ERR_SHAPE;
-    if ((size_t)B * C * dw_pitch16(T) * 4 >= 0x7fffff00ull) return V100_ERR_SHAPE;
+    if ((size_t)B * C * dw_pitch16(T, B) * 4 >= 0x7fffff00ull) return V100_ERR_SHAPE;
     const int G = v100_dw_num_groups(B, C);
     DwParams p{(const float*)h1, nullptr, w, nullptr, nullptr, nullptr, (float*)h2, nullptr, out_a, out_b, nullptr,
                B, C, T, T, K, 1, (K - 1) / 2, 0, 1, G, DW_IN_NONE, DW_OUT_AFFINE_RELU6, nullptr, DW_IO_X | DW_IO_Y, DwFin{}, DwPre{}};
     p.cm = cm;
     // rows much shorter than a wave item (1-second chunks: 51 outputs against 512 positions): several utterances side by side in one
     // item, each followed by >= pad zeros (its own right padding = the next one's left padding)
-    const int P = dw_pitch16(T), pad = (K - 1) / 2;
+    const int P = dw_pitch16(T, B), pad = (K - 1) / 2;
     // a multiple of 16: an output then keeps its row (t mod 16) inside the 16 x 16 Toeplitz block whatever its segment, so the packed
     // form sums exactly what the one-row form sums
     const int ss = (P + pad + 15) & ~15;
@@ -498,7 +499,7 @@ int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga
     if ((fin.mode != 0 || pre.f.mode != 0) && G != 1) return V100_ERR_SHAPE;
     if (da1 && (fin.mode != 2 || !dw_bwd_da1_supported(B, C, T, K, G))) return V100_ERR_SHAPE;
     if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || (K & 1) == 0 || G <= 0 || G > B) return V100_ERR_SHAPE;
-    if ((size_t)B * C * dw_pitch16(T) * 4 >= 0x7fffff00ull) return V100_ERR_SHAPE;
+    if ((size_t)B * C * dw_pitch16(T, B) * 4 >= 0x7fffff00ull) return V100_ERR_SHAPE;
     const int cm = (io16 >> 4) & 1;              // DW_IO_CM (see dw_fwd_train_io_fin)
     io16 &= 15;
     hipStream_t st = (hipStream_t)stream;
@@ -511,7 +512,7 @@ int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga
     const bool all16 = io16 == (DW_IO_X | DW_IO_X2 | DW_IO_AUX | DW_IO_Y);
     if (!all16 && io16 != (DW_IO_X2 | DW_IO_AUX)) return V100_ERR_SHAPE;
     if (da1 && (!all16 || cm)) return V100_ERR_SHAPE;
-    V100TimedLaunch timed(V100_T_DW_BWD_DATA, (all16 ? 2.0 : 3.0) * B * C * 4.0 * T + 8.0 * C * K + 8.0 * C);
+    V100TimedLaunch timed(V100_T_DW_BWD_DATA, (all16 ? 2.0 : 3.0) * B * C * 4.0 * T + 8.0 * C * K + 8.0 * C + (pre.f.mode != 0 ? 8.0 * pre.parts * C : 0.0));
     if (G == 1) p.wpartial = dw;               // one group: the kernel's "partial" IS the weight gradient
     const bool done = all16 ? dw_launch_bwd_fused16g(p, st, timed) : dw_launch_bwd_fused16(p, st, timed);
     if (!done) return V100_ERR_SHAPE;

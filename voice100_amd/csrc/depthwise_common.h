@@ -200,7 +200,7 @@ int dw_bwd_io_fin(const void* g, const void* g2, const float* w, const float* ga
                   const float* xa, const float* xb, void* dxin, float* stats, float* wpartial, float* dw, int G, int B, int C, int T, int K,
                   int io16, const DwFin& fin, const DwPre& pre, void* stream, int da1 = 0);
 bool dw_bwd_da1_supported(int B, int C, int T, int K, int G);      // depthwise_bwd_fused16g.hip
-__host__ __device__ __forceinline__ int dw_pitch16(int T) { return (T + 7) & ~7; }
+__host__ __device__ __forceinline__ int dw_pitch16(int T, int B) { return v100_pitch16(T, B); }
 
 struct DwWgradParams {
     const float* g;      // [B,C,Tout] upstream gradient stream 1

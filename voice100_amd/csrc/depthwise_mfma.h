@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
 
     float s0 = 0.f, s1 = 0.f;
     // row pitches (elements): bf16-stored tensors are padded to a multiple of 8 samples per row
-    const int PinX = XB ? dw_pitch16(Tin) : Tin, PinX2 = X2B ? dw_pitch16(Tin) : Tin;
-    const int PoutA = AUXB ? dw_pitch16(Tout) : Tout, PoutY = YB ? dw_pitch16(Tout) : Tout;
+    const int PinX = XB ? dw_pitch16(Tin, p.B) : Tin, PinX2 = X2B ? dw_pitch16(Tin, p.B) : Tin;
+    const int PoutA = AUXB ? dw_pitch16(Tout, p.B) : Tout, PoutY = YB ? dw_pitch16(Tout, p.B) : Tout;
     constexpr int NV8 = G_::NV8;
     typename DwmRun<XB>::type rawx[W8 ? 1 : NV];
     typename DwmRun<X2B>::type rawx2[(TWO && !W8) ? NV : 1];

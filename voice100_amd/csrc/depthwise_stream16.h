@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_ = lane & 15, q_ = lane >> 4;
     const int T = p.Tin;                                     // == Tout <= 256 NS; rows are stored with pitch P (a multiple of 8 samples)
-    const int P = dw_pitch16(T);
+    const int P = dw_pitch16(T, p.B);
     const int bper = (p.B + p.G - 1) / p.G;
     const int b0 = g * bper;
     const int nb = min(p.B, b0 + bper) - b0;
@@ -168,16 +168,13 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
     // consumer of channel c), finalised HERE from the expand GEMM's slab of partial sums by the first wave (DwPre), under the latency
     // of the row requests above: one dependent launch less per block
     __shared__ float lds_coef[3];
-    if constexpr (!EV) {
-        if (p.pre.f.mode != 0 && wave == 0) {
-            if (pre_fast) dw_pre_finish(p.pre, c, lane, prer, lds_coef);
-            else dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
-        }
-    }
-    __syncthreads();
+    __syncthreads();                                         // taps and zero padding in place
+    // (the coefficient reads are unconditional -- a harmless address when the in-kernel finalisation supplies them -- and go out before
+    //  the fragment build, which hides them)
+    const bool pre_on = !EV && p.pre.f.mode != 0;
     float ca = 1.f, cb = 0.f, oa = 1.f, ob = 0.f;
     if constexpr (EV) { oa = p.out_a[c]; ob = p.out_b[c]; }
-    else { ca = p.pre.f.mode != 0 ? lds_coef[0] : p.in_a[c]; cb = p.pre.f.mode != 0 ? lds_coef[1] : p.in_b[c]; }
+    else { ca = *(pre_on ? p.w : p.in_a + c); cb = *(pre_on ? p.w : p.in_b + c); }
     dwm_bf16x8 afr[STEPS][NT];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
@@ -201,6 +198,17 @@ __global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p)
         for (int t = 0; t < NT; ++t) {
             const dwm_u32x4 v = {pk[t][0], pk[t][1], pk[t][2], pk[t][3]};
             afr[s][t] = __builtin_bit_cast(dwm_bf16x8, v);
+        }
+    }
+    // the in-kernel finalisation AFTER the fragment build: its slab reads (issued at entry) have had the whole prologue to arrive
+    if constexpr (!EV) {
+        if (pre_on) {
+            if (wave == 0) {
+                if (pre_fast) dw_pre_finish(p.pre, c, lane, prer, lds_coef);
+                else dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
+            }
+            __syncthreads();
+            ca = lds_coef[0]; cb = lds_coef[1];
         }
     }
     const unsigned short* bsrc = img + 16 * n_ + 8 * q_;
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_ = lane & 15, q_ = lane >> 4;
     const int T = p.Tin;
-    const int P = dw_pitch16(T);
+    const int P = dw_pitch16(T, p.B);
     const int bper = (p.B + p.G - 1) / p.G;
     const int b0 = g * bper;
     const int nb = min(p.B, b0 + bper) - b0;
@@ -418,13 +426,9 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
     // BatchNorm-2 backward coefficients (p, q, r): from the finaliser launch, or finalised here from the project backward-data GEMM's
     // slab by the first wave (DwPre; one group only), under the latency of the row requests
     __shared__ float lds_coef[3];
-    if (p.pre.f.mode != 0 && wave == 0) {
-        if (pre_fast) dw_pre_finish(p.pre, c, lane, prer, lds_coef);
-        else dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
-    }
-    __syncthreads();
+    __syncthreads();                                         // taps and zero padding in place
     const bool pre_on = p.pre.f.mode != 0;
-    const float ca = pre_on ? lds_coef[0] : p.in_a[c], cb = pre_on ? lds_coef[1] : p.in_b[c], cc = pre_on ? lds_coef[2] : p.in_c[c];
+    float ca = *(pre_on ? p.w : p.in_a + c), cb = *(pre_on ? p.w : p.in_b + c), cc = *(pre_on ? p.w : p.in_c + c);
     const float oa = p.out_a[c], ob = p.out_b[c];
     dwm_bf16x8 afr[STEPS][NT];
 #pragma unroll
@@ -443,6 +447,15 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : 
             const dwm_u32x4 v = {pk[t][0], pk[t][1], pk[t][2], pk[t][3]};
             afr[s][t] = __builtin_bit_cast(dwm_bf16x8, v);
         }
+    }
+    // the in-kernel finalisation AFTER the fragment build (see the forward kernel)
+    if (pre_on) {
+        if (wave == 0) {
+            if (pre_fast) dw_pre_finish(p.pre, c, lane, prer, lds_coef);
+            else dw_finalize_parts(p.pre, p.C, c, lane, lds_coef);
+        }
+        __syncthreads();
+        ca = lds_coef[0]; cb = lds_coef[1]; cc = lds_coef[2];
     }
     const unsigned short* bsrc = img + 16 * n_ + 8 * q_;
     int nval[NL];

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(BM * 2) void pw_gemm_bf16_fast_kernel(PwParams p) {
     // tap-addressed X: physical rows are the cx channels of the padded tensor, row pitch Tx (see PwParams)
     const int Tx = TAPS ? p.Tx : T;
     const int Kx = TAPS ? p.cx : K;
-    const int P16 = pw_pitch16(T);                  // row pitch of the bf16-stored tensors
+    const int P16 = pw_pitch16(T, p.B);                  // row pitch of the bf16-stored tensors
     const int TxX = XB ? P16 : Tx, TxX2 = X2B ? P16 : Tx;
     constexpr int EX = XB ? 2 : 4, EX2 = X2B ? 2 : 4;      // bytes per element
 
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(768) void pw_gemm_bf16_ws_kernel(PwParams p) {
     pw_work(p, b, tt, mt);
     const int m0 = mt * BM, t0 = tt * PW_BN;
     const int M = p.M, K = p.K;
-    const int P16 = pw_pitch16(p.T);
+    const int P16 = pw_pitch16(p.T, p.B);
     const int nk = (K + BF_BK - 1) / BF_BK;
 
     if (wave >= 8) {
@@ -933,7 +933,7 @@ template <int GM, int XM, bool TAIL, bool TAPS = false, int IO = 0>
 __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
     static_assert(!TAPS || (GM == PW_X_NONE && XM == PW_X_NONE), "tap-addressed X has no prologues");
     static_assert(!(IO != 0 && TAPS), "16-bit activation storage: plain operands only");
-    // operands stored as bf16 [B][rows][pw_pitch16(T)]: the 8 consecutive t of a piece are ONE 16-byte load
+    // operands stored as bf16 [B][rows][pw_pitch16(T, p.B)]: the 8 consecutive t of a piece are ONE 16-byte load
     constexpr bool GB = (IO & WG_IO_G) != 0, G2B = (IO & WG_IO_G2) != 0, XB = (IO & WG_IO_X) != 0;
     __shared__ __attribute__((aligned(16))) unsigned char As[2][128 * 128];   // [m][t] bf16
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][128 * 128];   // [k][t] bf16
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_fast_kernel(WgParams p) {
 
     float ga[4], gb[4], gc[4], xa[4], xb[4];
     int voG[4], voX[4], ldsO[4], voG16[4], voX16[4];
-    const int P16 = pw_pitch16(T);
+    const int P16 = pw_pitch16(T, p.B);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int piece = tid + 256 * i;
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_bf16_wide_kernel(WgParams p) {
     wg_work(p, s, mt, ktile);
     const int m0 = mt * GR, n0 = ktile * XR;
     const int M = p.M, K = p.K, T = p.T;
-    const int P16 = pw_pitch16(T);
+    const int P16 = pw_pitch16(T, p.B);
 
     float ga[NG], gb[NG], gc[NG], xa[NX], xb[NX];
     int voG[NG], voX[NX], ldsG[NG], ldsX[NX];
@@ -1440,7 +1440,7 @@ __global__ __launch_bounds__(512) void pw_gemm_bf16_ov_kernel(PwParams p) {
     float* scr = reinterpret_cast<float*>(smem + STAGES + wave * 4096);
     float* cfe = reinterpret_cast<float*>(smem + STAGES + SCR + 4 * 32 * 16);       // MASK: (ea, eb) of the previous tile's 256 rows
     const int M = p.M, K = p.K;
-    const int P16 = pw_pitch16(p.T);
+    const int P16 = pw_pitch16(p.T, p.B);
     const int total = p.n_mtiles * p.n_ttiles * p.B;
     int v = blockIdx.x;
     int b, tt, mt;
@@ -1915,7 +1915,7 @@ __global__ __launch_bounds__(768) void pw_gemm_bf16_sl_kernel(PwParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = p.M, K = p.K;
-    const int P16 = pw_pitch16(p.T);
+    const int P16 = pw_pitch16(p.T, p.B);
     const int total = p.n_mtiles * p.n_ttiles * p.B;
     const int ntl = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;       // tiles of this workgroup (>= 1: grid <= total)
     using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
@@ -2241,7 +2241,7 @@ __global__ __launch_bounds__(512 + 64 * NSW) void pw_wgrad_bf16_ws_kernel(WgPara
     wg_work(p, s, mt, ktile);
     const int m0 = mt * GR, n0 = ktile * XR;
     const int M = p.M, K = p.K, T = p.T;
-    const int P16 = pw_pitch16(T);
+    const int P16 = pw_pitch16(T, p.B);
     const int nt = (T + BF_BK - 1) / BF_BK;
     const WgSpan sp = wg_span(p, s, nt);
     const int nsteps = sp.nb * sp.ntl, b_lo = sp.b_lo;
@@ -2806,7 +2806,7 @@ static bool pw_launch_gemm_lat(const PwParams& p, hipStream_t st) {
 // 16-bit activation storage (PwParams::io16 / WgParams::io16): the combinations the block executor issues in "act16" mode.
 // false = no instantiation for this (modes, mask) or the shape does not fit the buffer-addressed kernels.
 bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
-    const int P = pw_pitch16(p.T);
+    const int P = pw_pitch16(p.T, p.B);
     if (pw_launch_gemm_lat(p, st)) return true;
     if (p.io16 & PW_IO_F16) {
         // inference at precision "fp16" with fp16-stored hidden tensors: the two eval-mode GEMMs of a block (256-row tiles; 128 for M < 256)
@@ -2930,7 +2930,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
 }
 
 bool pw_launch_wgrad_bf16_io(const WgParams& p, dim3 grid, hipStream_t st) {
-    const int P = pw_pitch16(p.T);
+    const int P = pw_pitch16(p.T, p.B);
     if (!((long)(p.M + 256) * P * 4 < 0x7fffffffL && (long)(p.K + 256) * P * 4 < 0x7fffffffL)) return false;
 #if PW_WG_WIDE
     // 256-row tile on the plain operand, 128 rows on the transformed one (pw_wgrad_bf16_wide_kernel)

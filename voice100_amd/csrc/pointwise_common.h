@@ -141,7 +141,7 @@ struct PwParams {
 // are stored in the operand format of the GEMMs that read them)
 enum { PW_IO_X = 1, PW_IO_X2 = 2, PW_IO_Y = 4, PW_IO_R = 8, PW_IO_F16 = 16 };
 enum { WG_IO_G = 1, WG_IO_G2 = 2, WG_IO_X = 4 };
-__host__ __device__ __forceinline__ int pw_pitch16(int T) { return (T + 7) & ~7; }
+__host__ __device__ __forceinline__ int pw_pitch16(int T, int B) { return v100_pitch16(T, B); }
 // element q of a run of bf16 values held as dwords (two per dword, low half first)
 template <class V>
 __device__ __forceinline__ float pw_bf16_at(const V& r, int q) {
@@ -323,7 +323,7 @@ struct PwEpilogueFull {
     // part 1: request the R tile and the per-row coefficients of all 16 passes
     __device__ __forceinline__ void issue(const PwParams& p, int b, int m0, int t0, int tid) {
         use_r = (epi == PW_EPI_MASK_STATS || epi == PW_EPI_ADD || (epi == PW_EPI_AFFINE_RES && p.R != nullptr));
-        const int P16 = pw_pitch16(p.T);
+        const int P16 = pw_pitch16(p.T, p.B);
         const int lane = tid & 63, col = lane & 31, half = lane >> 5, wave = tid >> 6;
         mrow = m0 + wave * 2 + half;            // this lane's row in pass 0
         tcol = t0 + col * 4;                    // this lane's first column
@@ -356,7 +356,7 @@ struct PwEpilogueFull {
 
     // part 2: accumulators through LDS, 16 row passes, statistics
     __device__ __forceinline__ void finish(const PwParams& p, f32x16 (&acc)[2][2], float* ct, int b, int tt, int wm, int wn, int tid) {
-        const int P16 = pw_pitch16(p.T);
+        const int P16 = pw_pitch16(p.T, p.B);
         const int lane = tid & 63, col = lane & 31, half = lane >> 5, wave = tid >> 6;
         const int PY = YB ? P16 : p.T;
         const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)((size_t)p.B * p.M * PY * EY), 0x00020000);
@@ -492,7 +492,7 @@ __device__ __forceinline__ void pw_epilogue_lds(const PwParams& p, f32x16 (&acc)
     constexpr bool YB = (IO & PW_IO_Y) != 0, RB = (IO & PW_IO_R) != 0, YF16 = (IO & PW_IO_F16) != 0;
     typedef unsigned int epi_u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int epi_u32x4 __attribute__((ext_vector_type(4)));
-    const int P16 = pw_pitch16(p.T);
+    const int P16 = pw_pitch16(p.T, p.B);
     constexpr int epi = EPI_;
     if (pw_tile_is_full(p, BM, m0, t0)) {
         PwEpilogueFull<EPI_, BM, IO> ef;

@@ -14,6 +14,7 @@ BatchNorm + ReLU6 are applied by the *consumer* while it loads its input:
       --pw GEMM (BN2+ReLU6 on load)--> a3 (+stats) --affine(+x)--> y
 """
 import ctypes
+import functools
 import weakref
 import os
 from typing import Optional
@@ -21,6 +22,13 @@ from typing import Optional
 import torch
 
 from . import _native as N
+
+
+@functools.lru_cache(maxsize=None)
+def pitch16(T: int, B: int) -> int:
+    """Row pitch (elements) of a 16-bit-stored activation tensor [B][C][P]: the library's ONE rule (csrc/common.h v100_pitch16 --
+    a multiple of 8; for B > 1 and T >= 256 whole 128-byte lines).  Every allocation of such a tensor goes through here."""
+    return int(N.helper("v100_row_pitch16", int(T), int(B)))
 
 # The kernels clamp out-of-range ids instead of faulting (embedding rows: bn.hip; CTC labels -> blank: ctc.hip), where
 # the reference's nn.Embedding / nn.CTCLoss raise.  VOICE100_CHECK_IDS=1 validates them on the host first (one device
@@ -228,7 +236,7 @@ class InvertedResidualTrainFn(torch.autograd.Function):
                                     int(prep is not None) | (2 if shadows else 0) | (8 if frozen else 0), 0)
         if bf16 == 1 and _ACT16 and not frozen and N.helper("v100_ir_act16_supported", shape):
             shape[10] = _ACT16
-            pitch = (T + 7) & ~7                       # bf16 rows are padded to a multiple of 8 samples (aligned 8 / 16-byte accesses)
+            pitch = pitch16(T, B)                      # bf16 rows are pitched (aligned 8 / 16-byte accesses; long rows on 128-byte lines)
             a1 = torch.empty((B, hid, pitch), dtype=torch.bfloat16, device=x.device)
             a2 = torch.empty((B, hid, pitch), dtype=torch.bfloat16, device=x.device)
             a3 = torch.empty((B, cout, pitch), dtype=torch.bfloat16, device=x.device) if _ACT16 >= 3 else _f32(B, cout, T2, like=x)
@@ -239,7 +247,7 @@ class InvertedResidualTrainFn(torch.autograd.Function):
         y = _f32(B, cout, T2, like=x)
         # level 4: a bf16 copy of y (pitched rows) for the next block's expand GEMM / expand weight gradient; x16 = the copy
         # of x the previous block wrote (only the act16 executor reads it)
-        y16 = torch.empty((B, cout, (T2 + 7) & ~7), dtype=torch.bfloat16, device=x.device) if (shadows and want_shadow) else None
+        y16 = torch.empty((B, cout, pitch16(T2, B)), dtype=torch.bfloat16, device=x.device) if (shadows and want_shadow) else None
         if not (shadows and shape[10] >= 4):
             x16 = None
         coef = _f32(12, max(hid, cout), like=x)
@@ -399,7 +407,7 @@ class IRStackTrainFn(torch.autograd.Function):
         y = blob[o[3]:o[3] + 4 * B * cout * T2].view(torch.float32).view(B, cout, T2)
         y16 = None
         if o[4] >= 0:
-            P2 = (T2 + 7) & ~7
+            P2 = pitch16(T2, B)
             y16 = blob[o[4]:o[4] + 2 * B * cout * P2].view(torch.bfloat16).view(B, cout, P2)
             ctx.mark_non_differentiable(y16)
         ctx.set_materialize_grads(False)
@@ -508,7 +516,7 @@ def ir_stack_train(blocks, x, precision: Optional[str] = None, segment: Optional
             segs[i] = (cfgs, params, seg)
         sh = getattr(x, "_v100_shadow", None)
         x16 = sh[0] if (sh is not None and sh[1] == x._version and sh[0].shape[:2] == x.shape[:2]
-                        and sh[0].shape[2] == ((x.shape[2] + 7) & ~7)) else None
+                        and sh[0].shape[2] == pitch16(x.shape[2], x.shape[0])) else None
         last = i + 1 == len(segs)
         weights = [params[18 * b + j] for b in range(len(cfgs)) for j in (0, 1, 2, 6, 7, 8, 12, 13, 14)]
         y, y16 = IRStackTrainFn.apply(x, x16, (cfgs, precision, not last, params), *weights)
@@ -590,7 +598,7 @@ def inverted_residual_eval_cached(blk, x, precision: Optional[str] = None):
         # precision "bf16": the two hidden tensors (4x the block's width, values in [0, 6] after BatchNorm + ReLU6) stored as bf16 with
         # pitched rows -- half the bytes of the big streams of all three kernels (the GEMMs round them to bf16 as operands anyway)
         shape[10] = 1
-        pitch = (T + 7) & ~7
+        pitch = pitch16(T, B)
         h1 = torch.empty((B, hid, pitch), dtype=torch.bfloat16, device=x.device)
         h2 = torch.empty((B, hid, pitch), dtype=torch.bfloat16, device=x.device)
     else:
@@ -600,7 +608,7 @@ def inverted_residual_eval_cached(blk, x, precision: Optional[str] = None):
 
 
 # ---- channel-major inference (round 4) ------------------------------------------------------------------------------
-# Activations [C][B][P] (P = (T + 7) & ~7): one [C x (B P)] matrix per tensor, the utterances' rows back to back.  Each 1x1
+# Activations [C][B][P] (P = pitch16(T, B)): one [C x (B P)] matrix per tensor, the utterances' rows back to back.  Each 1x1
 # convolution of a block is then ONE GEMM over all B P columns, the depthwise kernel walks a channel's rows contiguously and packs
 # short rows several to a wave item (include/voice100_hip.h).  Used by the models' eval-mode forwards at the 16-bit precisions.
 EVAL_CM = os.environ.get("VOICE100_EVAL_CM", "1") not in ("", "0")
@@ -614,7 +622,7 @@ def eval_cm_supported(blocks, T: int, precision: Optional[str] = None, batch: in
     import torch.nn.modules.module as _m
     if not EVAL_CM or _fmt(precision) == 0 or T > 768 or T < 1:
         return False
-    if batch > 65535 or batch * ((T + 7) & ~7) > 0x7fffff00:
+    if batch > 65535 or batch * pitch16(T, batch) > 0x7fffff00:
         return False
     if _m._global_forward_hooks or _m._global_forward_pre_hooks:
         return False
@@ -634,7 +642,7 @@ def bct_to_cm(x: torch.Tensor) -> torch.Tensor:
     _check(x, "bct_to_cm")
     x = x.contiguous()
     B, C, T = x.shape
-    P = (T + 7) & ~7
+    P = pitch16(T, B)
     y = _f32(C, B * P, like=x)
     N.call("v100_bct_to_cm", x, y, B, C, T)
     return y
@@ -656,7 +664,7 @@ def inverted_residual_eval_cm(blk, x: torch.Tensor, B: int, T: int, precision: O
     w1, wd, w3 = pw[0].weight, dw[0].weight, pl.weight
     fmt = _fmt(precision)
     hid, cin, cout, k = w1.shape[0], w1.shape[1], w3.shape[0], int(blk.kernel_size)
-    P = (T + 7) & ~7
+    P = pitch16(T, B)
     if x.shape != (cin, B * P):
         raise RuntimeError("inverted_residual_eval_cm: x must be [cin, B * pitch(T)]")
     shape = (ctypes.c_int * 11)(B, cin, hid, cout, T, k, 1, int(bool(blk.use_residual)), int(fmt), 0, 0)
@@ -694,7 +702,7 @@ def ir_stack_eval_cm(blocks, x: torch.Tensor, B: int, T: int, precision: Optiona
     in a plan that is rebuilt only when a parameter or buffer object, its version, the batch, the length or the precision changes."""
     fmt = _fmt(precision)
     n = len(blocks)
-    P = (T + 7) & ~7
+    P = pitch16(T, B)
     tens = [_block_tensors(b) for b in blocks]
     # data_ptr() is part of the key: `p.data = other` keeps id() and _version but moves the storage the plan's pointers name
     key = (fmt, B, T, x.device.index, n) + tuple((id(t), t.data_ptr(), t._version) for bt in tens for t in bt)

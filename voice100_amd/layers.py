@@ -78,7 +78,7 @@ class InvertedResidual(nn.Module):
             # version of x -- any in-place edit of x in between invalidates it
             sh = getattr(x, "_v100_shadow", None)
             x16 = sh[0] if (sh is not None and sh[1] == x._version and sh[0].shape[:2] == x.shape[:2]
-                            and sh[0].shape[2] == ((x.shape[2] + 7) & ~7)) else None
+                            and sh[0].shape[2] == F_.pitch16(x.shape[2], x.shape[0])) else None
             y, y16 = F_.InvertedResidualTrainFn.apply(
                 x, pw[0].weight, bn1.weight, bn1.bias, dw[0].weight, bn2.weight, bn2.bias, pl.weight, bn3.weight, bn3.bias,
                 bn1.running_mean, bn1.running_var, bn1.num_batches_tracked,
