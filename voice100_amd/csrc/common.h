@@ -119,5 +119,10 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // traffic on the depthwise launches of those steps and 8-10 % of their time (profiles/r06_dw_ab.txt: T = 568 -> 51.4 %, 576 -> 55.4 % of
 // 8 TB/s).  A tensor of ONE row per channel (B == 1: the channel-major inference matrices [C][B P], which the GEMMs see as B = 1,
 // T = B P) keeps the 8-sample rule: its row length is the caller's column count and must not be re-padded.
-__host__ __device__ __forceinline__ int v100_pitch16(int T, int B) { return (B > 1 && T >= 256) ? ((T + 63) & ~63) : ((T + 7) & ~7); }
+#ifndef V100_PITCH_LINES
+#define V100_PITCH_LINES 1     /* 0: the rounds 2-5 rule, (T + 7) & ~7 everywhere (A/B builds) */
+#endif
+__host__ __device__ __forceinline__ int v100_pitch16(int T, int B) {
+    return (V100_PITCH_LINES && B > 1 && T >= 256) ? ((T + 63) & ~63) : ((T + 7) & ~7);
+}
 // (exported to the host side as v100_row_pitch16, block.hip)
