@@ -351,7 +351,11 @@ def test_block_act16_matches_fp32_storage(cuda, level, cin):                    
 
 
 @pytest.mark.parametrize("cin,k,B,T", [(320, 19, 2, 133), (256, 51, 3, 512), (64, 27, 32, 2048), (512, 83, 2, 640), (384, 35, 2, 77),
-                                       (256, 19, 4, 302)])
+                                       (256, 19, 4, 302),
+                                       # round 6: one group with the consumer-side BatchNorm finalisation (IR_FUSE_PRE) on a
+                                       # time-stretched length whose pitch is whole 128-byte lines (563 -> 576), and with more partial
+                                       # sums than the ahead-of-the-rows form holds (48 x 6 t-tiles = 288 > 256: the in-branch form)
+                                       (256, 27, 6, 563), (256, 19, 48, 700)])
 def test_block_act16_wide_shapes(cuda, cin, k, B, T):
     """Level-3 bf16 storage against fp32 storage (both with bf16 GEMM operands) on shapes that reach the kernels the small
     cases do not: 256-row backward-weight tiles with ragged rows and T tails, persistent expand GEMM (512 block tiles), one

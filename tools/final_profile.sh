@@ -29,6 +29,10 @@ python3 tools/pmc_dw_json.py $out/pmc_dw --json $out/dw_fwd_pmc.json > $out/${ta
 cp $out/dw_fwd_pmc.json profiles/dw_fwd_pmc.json
 rm -rf $out/pmc_dw/*.csv
 python3 tools/gemm_yardstick.py > $out/${tag}_gemm_yardstick.txt 2>> $out/prof_err.txt
+# per-kernel table of a step with EVERY batch stretched to 110 % (T' = 563: the 768-position depthwise forms, five 128-column GEMM tiles)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python3 bench.py --steps 20 --warmup 5 --windows 0 --host-contention 0 --sustained-seconds 0 --no-extras --no-cpu-baseline --no-other-configs --diag-stretch-rate 110 > $out/${tag}_stretch110_line_under_rocprof.json 2>> $out/prof_err.txt
+python3 tools/prof_summary.py "$(find $out/prof -name '*kernel_stats.csv' | head -1)" 26 40 > $out/${tag}_stretch110_kernel_summary.txt
+rm -rf $out/prof
 python3 bench.py > $out/${tag}_bench_line.json 2> $out/bench_err.txt
 cp gpurun_out/bench_details.json $out/${tag}_bench_details.json 2>/dev/null
 tail -c 600 $out/${tag}_bench_line.json

@@ -94,13 +94,19 @@ struct DwStreamGeom {
 // with the folded BatchNorm-2 coefficients, no statistics -- ConvBNActivate's "dw" stage with frozen statistics (asr.py:27-37, 49)
 // F16 (EV only): the stored tensors hold IEEE fp16 (inference at precision "fp16"): the loaded words ARE the matrix operand -- no
 // conversion while staging --, the taps are split into fp16 digits, the output is rounded to fp16
+#ifndef DWS_FWD_MINW
+#define DWS_FWD_MINW 4        /* A/B: workgroups per CU the register allocation must allow (8: all 2048 channels of a wide layer resident at once) */
+#endif
+#ifndef DWS_FWD_PADLDS
+#define DWS_FWD_PADLDS 0      /* A/B: bytes of unused LDS per workgroup (caps the workgroups per CU: 26000 -> 4, 18000 -> 5) */
+#endif
 template <int K, int NT, int D, int CP = 0, int NS = 2, bool EV = false, bool F16 = false>
-__global__ __launch_bounds__(256, 4) void dwconv_fwd16_stream_kernel(DwParams p) {
+__global__ __launch_bounds__(256, (NS == 2 && !EV) ? DWS_FWD_MINW : 4) void dwconv_fwd16_stream_kernel(DwParams p) {
     static_assert(!F16 || EV, "fp16 storage: inference only");
     using S_ = DwStreamGeom<K, NS>;
     constexpr int STEPS = S_::STEPS, WPAD = S_::WPAD, WLEN = S_::WLEN, NL = S_::NL;
     constexpr int IMGP = S_::FWD_IMG > 512 * NL + 64 ? S_::FWD_IMG : 512 * NL + 64;   // + the staged runs of lanes past the row
-    __shared__ __attribute__((aligned(16))) unsigned short lds_img[4 * IMGP];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_img[4 * IMGP + ((NS == 2 && !EV) ? DWS_FWD_PADLDS / 2 : 0)];
     __shared__ float lds_w[256];                             // WLEN used; every thread stores one slot (no lane-masked branch)
     __shared__ float lds_red[4][2];
 
