@@ -290,7 +290,8 @@ def test_asr_eval_small_shapes_fuzz(cuda):
             if isinstance(mod, torch.nn.BatchNorm1d):
                 mod.running_mean.copy_((torch.randn(mod.running_mean.shape, generator=g) * 0.1).to(cuda))
                 mod.running_var.copy_((torch.rand(mod.running_var.shape, generator=g) + 0.5).to(cuda))
-    shapes = [(1, 16), (1, 101), (2, 256), (3, 33), (5, 77), (8, 101), (13, 64), (32, 101), (40, 50), (64, 128), (7, 511), (96, 101)]
+    shapes = [(1, 16), (1, 101), (2, 256), (3, 33), (5, 77), (8, 101), (13, 64), (32, 101), (40, 50), (64, 128), (7, 511), (96, 101),
+              (3, 601), (2, 1101), (5, 640)]      # rows of >= 256 output frames: pitch of whole 128-byte lines (301 -> 320, 551 -> 576)
     F_.set_matmul_precision("bf16")
     try:
         with torch.no_grad():

@@ -11,6 +11,9 @@
 // and emit  scale = gamma * rstd,  shift = beta - mean * scale  for the consumer's prologue.
 #include "common.h"
 #include "depthwise_common.h"     // DwFin / dw_finalize: BatchNorm finalisation inside a producing kernel
+#ifndef BN_XCD
+#define BN_XCD 1      /* (step 3.218 -> 3.208 ms, A/B on one box) the one-workgroup-per-channel boundary passes: blockIdx -> channel in groups of 16 per XCD (v100_chan_of_block) */
+#endif
 #ifndef BN_FIN_WPB
 #define BN_FIN_WPB 4              /* channels (= waves) per workgroup of the stand-alone BatchNorm finalisers */
 #endif
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(1024) void chan_bn3_bwd_kernel(const float* __restr
                                                             void* __restrict__ out, int B, int C, int T, DwFin fin) {
     __shared__ float red[16][2];
     __shared__ float coef[3];
-    const int c = blockIdx.x;
+    const int c = BN_XCD ? v100_chan_of_block<16>(blockIdx.x, C) : (int)blockIdx.x;
     const int P = v100_pitch16(T, B);
     const int T4 = (T + 3) >> 2;
     const int n = B * T4;
@@ -369,7 +372,7 @@ template <bool UB, bool SH, bool VB = false>
 __global__ __launch_bounds__(1024) void chan_affine2_fin_kernel(const void* __restrict__ u, const void* __restrict__ v, float* __restrict__ out,
                                                                 u16* __restrict__ shadow, int B, int C, int T, DwPre pre) {
     __shared__ float coef[3];
-    const int c = blockIdx.x;
+    const int c = BN_XCD ? v100_chan_of_block<16>(blockIdx.x, C) : (int)blockIdx.x;
     if (threadIdx.x < 64) dw_finalize_parts(pre, C, c, threadIdx.x, coef);
     __syncthreads();
     const float a = coef[0], cc = coef[1];

@@ -27,7 +27,12 @@ static bool dws_bwd_enabled() {
 // the kept-rows form of the streaming kernel (DA1, depthwise_stream16.h): one group, a wave's rows fit its 8 register slots
 bool dw_bwd_da1_supported(int B, int C, int T, int K, int G) {
     static const bool on = [] { const char* e = getenv("V100_IR_DA1"); return !(e && e[0] == '0'); }();     // A/B switch
-    if (!on || !dws_bwd_enabled() || G != 1 || B > 32 || T > 512 || T < 1 || C < 1) return false;     // (rows of 513-768 outputs: three sub-tiles, the kept rows no longer fit the register file)
+    // Rows of 513 .. 768 outputs (time-stretched steps) cannot keep their rows (12 registers a row: the file is full); their read-back
+    // form exists (depthwise_stream16.h, V100_IR_DA1_TMAX=768) and was measured in round 6 on a step with every batch stretched to 110 %:
+    // the two expand GEMMs gain 0.19 ms (1.704 + 0.822 -> 1.580 + 0.756) and this kernel loses 0.19 (0.416 -> 0.610): no net gain, so
+    // those rows keep dz1 + the consumers' transform on load.
+    static const int tmax = [] { const char* e = getenv("V100_IR_DA1_TMAX"); return e ? atoi(e) : 512; }();
+    if (!on || !dws_bwd_enabled() || G != 1 || B > 32 || T > tmax || T > 768 || T < 1 || C < 1) return false;
 #define X(KK) if (K == KK) return true;
     V100_DW_SPECIALISED(X)
 #undef X
@@ -44,8 +49,8 @@ bool dw_launch_bwd_fused16g(const DwParams& p, hipStream_t st, const V100TimedLa
     do {                                                                                                                          \
         if (p.da1) {                                                                                                              \
             if (p.fin.mode != 2 || p.G != 1 || p.B > 32) return false;                                                            \
-            if (p.Tin > 512) return false;                                                                                        \
-            V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_KEEP_DEPTH, DWS_NT * 2, 2, true>), grid, dim3(256), 0, st, p);          \
+            if (p.Tin > 512) V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_BWD_DEPTH3, DWS_NT * 2, 3, true>), grid, dim3(256), 0, st, p);  \
+            else V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_KEEP_DEPTH, DWS_NT * 2, 2, true>), grid, dim3(256), 0, st, p);          \
         } else if (p.Tin <= 512) V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_BWD_DEPTH, DWS_NT * 2, 2>), grid, dim3(256), 0, st, p);  \
         else V100_LAUNCH(tl, (dwconv_bwd16_stream_kernel<KK, NTT, DWS_BWD_DEPTH3, DWS_NT * 2, 3>), grid, dim3(256), 0, st, p);     \
     } while (0)

@@ -148,6 +148,17 @@ __device__ __forceinline__ void dw_finalize_parts(const DwPre& pre, int C, int c
     if (lane == 0) dw_finalize_d(pre.f, c, s0, s1, coef);
 }
 
+// blockIdx -> channel for kernels that run ONE workgroup per channel over [B][C][T] rows: workgroups are dealt to the 8 XCDs round-robin;
+// groups of GR consecutive channels go to one XCD (the groups round-robin), so an XCD sweeps GR-row runs of every utterance and the
+// channels that share a 128-byte line of a per-channel array ([parts][C][2] slabs, BatchNorm parameters) share an L2.  Identity when
+// C is not a multiple of 8 GR.  (Round 6: depthwise_stream16.h dws_chan, measured there; bn.hip's block-boundary passes.)
+template <int GR>
+__device__ __forceinline__ int v100_chan_of_block(int bid, int C) {
+    if (C & (8 * GR - 1)) return bid;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return ((idx / GR) * 8 + xcd) * GR + (idx & (GR - 1));
+}
+
 // dw_finalize_parts with its loads issued AHEAD (streaming depthwise kernels, round 6).  Inside the kernel the finalisation used to sit
 // behind the row requests: its slab reads and per-channel parameter reads were YOUNGER than the wave's first rows, vmcnt retires in
 // order, so wave 0 waited a full HBM round trip for rows it did not need yet and three waves waited for wave 0 at the barrier

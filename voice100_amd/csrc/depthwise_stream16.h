@@ -38,15 +38,30 @@
 #define DWS_TAIL 1            /* DA1: finish BatchNorm 1's backward and store the kept rows BEFORE the weight-gradient tiles go through LDS */
 #endif
 #ifndef DWS_XCD
-#define DWS_XCD 0             /* 1: consecutive channels on ONE XCD (blockIdx -> channel remap), so neighbours in memory share an L2 */
+#define DWS_XCD 2             /* blockIdx -> channel: 0 identity, 1 C/8 consecutive channels per XCD, 2 groups of DWS_XCD_GROUP channels per XCD */
+#endif
+#ifndef DWS_XCD_GROUP
+#define DWS_XCD_GROUP 16      /* a power of two */
 #endif
 
 // blockIdx.x -> channel.  Workgroups are dealt to the 8 XCDs round-robin; with DWS_XCD the channels c, c + 1, ... (adjacent 1 KB rows
 // of every utterance) go to the same XCD: rows whose pitch is not a whole number of 128-byte lines then share their boundary lines in
 // ONE L2 instead of fetching them twice.
 __device__ __forceinline__ int dws_chan(int bid, int C) {
-#if DWS_XCD
+#if DWS_XCD == 1
     return (C & 7) == 0 ? (bid & 7) * (C >> 3) + (bid >> 3) : bid;
+#elif DWS_XCD == 2
+    // groups of 16 consecutive channels per XCD, the groups dealt round-robin: the 16 channels whose partial sums share one 128-byte
+    // line of a producer's slab [parts][C][2] (and whose BatchNorm parameters share a line) then run on ONE XCD, back to back, so the
+    // consumer-side finalisation (dw_pre_issue) fetches each slab line into one L2 once instead of into all eight (measured: +9 / +18 MB
+    // of reads per 1024- / 2048-channel launch, 1.14 x the algorithmic bytes)
+    // (round 6, 8 layers on a rotating working set: forward 177 -> 170 us, plain fused backward 326 -> 301, kept-rows form 366 -> 340 --
+    // the remap pays without any finalisation in the kernel too: an XCD's 32 CUs sweep 16 KB runs of each utterance instead of every
+    // eighth 1 KB row; HBM bytes of the forward launches 1.132 -> 1.018 x algorithmic with the finalisation on)
+    constexpr int GR = DWS_XCD_GROUP;
+    if (C & (8 * GR - 1)) return bid;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return ((idx / GR) * 8 + xcd) * GR + (idx & (GR - 1));
 #else
     (void)C;
     return bid;
@@ -350,8 +365,12 @@ __global__ __launch_bounds__(256, (NS == 2 && !EV) ? DWS_FWD_MINW : 4) void dwco
 #define DWS_DA1_KEEP 1
 #endif
 template <int K, int NT, int D, int CP = 0, int NS = 2, bool DA1 = false, int MAXR = 8>
-__global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && K > DWS_DA1_K3) ? 2 : DWS_BWD_MINW) void dwconv_bwd16_stream_kernel(DwParams p) {
-    constexpr bool KEEP = DA1 && DWS_DA1_KEEP;
+__global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && NS == 2 && K > DWS_DA1_K3) ? 2 : DWS_BWD_MINW) void dwconv_bwd16_stream_kernel(DwParams p) {
+    // rows of up to 512 outputs: the wave KEEPS its rows in registers; rows of 513 .. 768 (NS = 3: 12 registers a row, the file is full)
+    // take the read-back form -- dz1 stored as produced, then each wave reads its own rows of dz1 and a1 back (L2 / Infinity Cache) and
+    // overwrites dz1 with the finished gradient.  Measured (round 6, stretch-110 step): this kernel 0.416 -> 0.610 ms, the two expand
+    // GEMMs -0.19 ms: no net gain -- off by default (V100_IR_DA1_TMAX, depthwise_bwd_fused16g.hip)
+    constexpr bool KEEP = DA1 && DWS_DA1_KEEP && NS == 2;
     using S_ = DwStreamGeom<K, NS>;
     constexpr int STEPS = S_::STEPS, WPAD = S_::WPAD, WLEN = S_::WLEN, IB = S_::IB, NL = S_::NL, XIMG = S_::XIMG;
     constexpr int IMG0 = S_::FWD_IMG > S_::BWD_IMG ? S_::FWD_IMG : S_::BWD_IMG;

@@ -4,6 +4,7 @@
 // pairs from Python cost ~10 us each and distorted the step).  Off by default; no effect on results.
 #include "common.h"
 #include "timing.h"
+#include "depthwise_common.h"     // v100_chan_of_block
 #include <vector>
 #include <mutex>
 #include <atomic>
@@ -155,7 +156,7 @@ extern "C" int v100_copy_probe(const void* src, void* dst, long long nbytes, voi
 // (round-4 review, item 3: the kernel is graded against what its layout can reach).  P * 2 bytes must be a multiple of 1024 here.
 __global__ __launch_bounds__(256) void rows_copy_probe_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int B, int C, int P16B) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x;
+    const int c = v100_chan_of_block<16>(blockIdx.x, C);      // the streaming kernels' own blockIdx -> channel order (round 6)
     const int per = P16B / 1024;                        // 1 KB pieces per row (64 lanes x 16 B)
     const int nrows = (B - wave + 3) >> 2;
     for (int q = 0; q < per; ++q) {
