@@ -298,12 +298,6 @@ int v100_rows_copy_probe(const void* src, void* dst, int B, int C, int row_bytes
 int v100_pw_gemm_io(const void* A_bf16, const void* X, const void* X2, const float* xa, const float* xb, const float* xc,
                     int x_mode, void* Y, const float* ea, const float* eb, const void* R, int epi_mode, float* stats,
                     int B, int M, int K, int T, int io16, void* stream);
-/* Slab reductions beside the stream (V100_SLAB_SIDE=1): between v100_slab_defer(1, stream) and v100_slab_defer(0, stream) the partial-slab
- * sums of v100_pw_wgrad* run on a second stream of the library (events order them behind their weight-gradient kernel; the next
- * v100_pw_wgrad* call and the closing v100_slab_defer(0) make `stream` wait for them).  v100_slab_join: make `stream` wait now.  Used by
- * the block executor around one block's backward; results are bit-identical (same kernel, same summation order). */
-int v100_slab_defer(int on, void* stream);
-int v100_slab_join(void* stream);
 int v100_pw_wgrad_io(const void* G, const void* G2, const float* ga, const float* gb, const float* gc, int g_mode,
                      const void* X, const float* xa, const float* xb, int x_mode, float* partial, float* dW, int S, int B,
                      int M, int K, int T, int io16, void* stream);

@@ -231,20 +231,9 @@ extern "C" long long v100_ir_bwd_workspace_bytes(const int* shape) {
 // ptrs: 0 x 1 a1 2 a2 3 a3 | 4 w1 5 wd 6 w3 | 7 g1 8 g2 9 g3 | 10 coef | 11 dy | 12 dx (may be NULL) |
 //       13 dW1 14 dg1 15 db1 16 dWd 17 dg2 18 db2 19 dW3 20 dg3 21 db3 | 22 workspace | 23 prepared weights (from forward)
 //       24 x16 (act16 >= 4 only, may be NULL): the bf16 shadow of x the forward read
-namespace {
-// weight-gradient slab reductions beside the stream for the length of one block's backward (pointwise.hip, V100_SLAB_SIDE)
-struct SlabGuard {
-    void* st; bool on;
-    SlabGuard(void* s, bool o) : st(s), on(o) { if (on) v100_slab_defer(1, st); }
-    ~SlabGuard() { if (on) v100_slab_defer(0, st); }
-};
-}
-
 extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     if (!sh || !P) return V100_ERR_NULL;
     const int B = sh[IR_B], cin = sh[IR_CIN], hid = sh[IR_HID], cout = sh[IR_COUT], T = sh[IR_T], K = sh[IR_K], S = sh[IR_STRIDE];
-    // (one depthwise group only: with more, the depthwise weight gradient's partial sums share the slab buffer)
-    SlabGuard slab_guard(stream, sh[IR_ACT16] != 0 && v100_dw_num_groups(B, hid) == 1);
     const int res = sh[IR_RES], bf = sh[IR_BF16];
     const int pad = (K - 1) / 2, T2 = conv_out(T, K, S);
     const float *x = (const float*)P[0], *a1 = (const float*)P[1], *a2 = (const float*)P[2], *a3 = (const float*)P[3];

@@ -57,50 +57,9 @@ __global__ __launch_bounds__(256) void pw_slab_reduce4_kernel(const f32x4* __res
     for (; g < S; ++g) s += __builtin_nontemporal_load(partial + (size_t)g * n4 + i);
     out[i] = s;
 }
-// Slab reductions BESIDE the main stream (round 6, V100_SLAB_SIDE=1; block executor only).  A weight gradient is consumed by nothing in
-// the backward pass -- only the optimiser / the gradient exchange read it -- but its partial slabs had to be summed by a launch of
-// their own that sat IN the dependent chain between the weight-gradient kernel and the data-gradient GEMM (7.6 us + a kernel boundary
-// behind 33 MB of dirty partials, 19 times a step).  Inside v100_ir_bwd the reduction goes to a second stream instead: event after the
-// weight-gradient kernel -> side stream waits -> reduce -> event; the main stream waits for that event only before the slab buffer is
-// written again (the block's next weight gradient) and at the end of the block.  Same kernel, same summation order: bit-identical.
-static struct { hipStream_t side; hipEvent_t wg, red; bool ready, pending; int defer; } g_slab = {nullptr, nullptr, nullptr, false, false, 0};
-static bool slab_side_ready() {
-    if (!g_slab.ready) {
-        if (hipStreamCreateWithFlags(&g_slab.side, hipStreamNonBlocking) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&g_slab.wg, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&g_slab.red, hipEventDisableTiming) != hipSuccess) return false;
-        g_slab.ready = true;
-    }
-    return true;
-}
-// the main stream may touch the slab buffer again / the block is over: wait for the reduction in flight on the side stream
-extern "C" int v100_slab_join(void* stream) {
-    if (g_slab.pending) {
-        g_slab.pending = false;
-        if (hipStreamWaitEvent((hipStream_t)stream, g_slab.red, 0) != hipSuccess) return V100_ERR_LAUNCH;
-    }
-    return V100_OK;
-}
-// on != 0: until the matching v100_slab_defer(0, stream) the slab reductions of v100_pw_wgrad* run beside `stream`; off joins first
-extern "C" int v100_slab_defer(int on, void* stream) {
-    static const bool enabled = [] { const char* e = getenv("V100_SLAB_SIDE"); return e && e[0] == '1'; }();
-    if (!on) { g_slab.defer = 0; return v100_slab_join(stream); }
-    g_slab.defer = (enabled && slab_side_ready()) ? 1 : 0;
-    return V100_OK;
-}
 static void pw_slab_reduce(const float* partial, float* out, int S, long n, hipStream_t st) {
-    hipStream_t rs = st;
-    if (g_slab.defer) {
-        (void)hipEventRecord(g_slab.wg, st);
-        (void)hipStreamWaitEvent(g_slab.side, g_slab.wg, 0);
-        rs = g_slab.side;
-    }
-    if ((n & 3) == 0 && ((((size_t)partial) | ((size_t)out)) & 15) == 0) V100_GGL(pw_slab_reduce4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, rs, (const f32x4*)partial, (f32x4*)out, S, n / 4);
-    else V100_GGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, rs, partial, out, S, n);
-    if (g_slab.defer) {
-        (void)hipEventRecord(g_slab.red, g_slab.side);
-        g_slab.pending = true;
-    }
+    if ((n & 3) == 0 && ((((size_t)partial) | ((size_t)out)) & 15) == 0) V100_GGL(pw_slab_reduce4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (const f32x4*)partial, (f32x4*)out, S, n / 4);
+    else V100_GGL(pw_slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, out, S, n);
 }
 
 // fp32 [rows][cols] -> bf16 [rows][cols] and/or transposed copies (weights are tiny: <= 1M elements)
@@ -256,7 +215,6 @@ extern "C" int v100_pw_wgrad(const float* G, const float* G2, const float* ga, c
     WgParams p{G, G2, ga, gb, gc, X, xa, xb, partial, B, M, K, T, S, g_mode, x_mode, nmt, nkt};
     dim3 grid((unsigned)(nmt * nkt * S));
     hipStream_t st = (hipStream_t)stream;
-    if (v100_slab_join(stream) != V100_OK) return V100_ERR_LAUNCH;      // (a reduction beside the stream may still be reading the slab)
     V100TimedRegion timed(V100_T_PW_WGRAD, st);
     if (use_bf16) pw_launch_wgrad_bf16(p, grid, st);
     else pw_launch_wgrad_f32(p, grid, st);
@@ -300,7 +258,6 @@ extern "C" int v100_pw_wgrad_io(const void* G, const void* G2, const float* ga, 
                0, 0, 0, 0, 0, 0u, io16};
     dim3 grid((unsigned)(nmt * nkt * S));
     hipStream_t st = (hipStream_t)stream;
-    if (v100_slab_join(stream) != V100_OK) return V100_ERR_LAUNCH;      // (a reduction beside the stream may still be reading the slab)
     V100TimedRegion timed(V100_T_PW_WGRAD, st);
     if (!pw_launch_wgrad_bf16_io(p, grid, st)) return V100_ERR_SHAPE;
     const long n = (long)M * K;
@@ -396,7 +353,6 @@ extern "C" int v100_pw_wgrad_taps(const float* G, int Tg, int g_off, const float
                ntap, cx, Tx, Tg, g_off, packed};
     dim3 grid((unsigned)(nmt * nkt * S));
     hipStream_t st = (hipStream_t)stream;
-    if (v100_slab_join(stream) != V100_OK) return V100_ERR_LAUNCH;
     V100TimedRegion timed(V100_T_PW_WGRAD, st);
     if (use_bf16) { if (!pw_launch_wgrad_taps_bf16(p, grid, st)) return V100_ERR_SHAPE; }
     else pw_launch_wgrad_taps_f32(p, grid, st);
