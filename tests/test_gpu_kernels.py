@@ -258,7 +258,8 @@ def test_errors_are_loud(cuda):
 
 @pytest.mark.parametrize("B,T,V,L", [(3, 40, 29, 7), (4, 130, 71, 30), (2, 9, 5, 6), (5, 64, 29, 1),
                                      (3, 700, 29, 300), (2, 1300, 71, 600), (2, 2500, 29, 1200),    # L > 255: 4 / 8 / 16 states per thread
-                                     (2, 1100, 29, 505)])                                           # 1011 states: the 16-wave pipeline
+                                     (2, 1100, 29, 505),                                            # 1011 states: the 16-wave pipeline
+                                     (32, 512, 29, 100), (3, 700, 29, 127), (6, 300, 128, 90), (2, 777, 5, 64)])   # <= 127 tokens: the linear-domain fp64 pair (round 6); the bench shape
 def test_ctc_loss_fused(cuda, B, T, V, L):
     """Fused log_softmax + CTC (value and gradient) vs torch's CPU F.ctc_loss, ragged lengths, repeated labels,
     an infeasible utterance (zero_infinity) and an empty target."""
@@ -286,6 +287,35 @@ def test_ctc_loss_fused(cuda, B, T, V, L):
     # lattice values grow with T (|alpha + beta| ~ 1e3 at T = 700: one fp32 ulp there is 6e-5 in the log domain, and the
     # occupancy exp(alpha + beta + nll - logp) inherits it), so the long cases compare at a wider fp32 bar
     assert rel_err(x.grad, ref_in.grad.float()) < (2e-4 if T <= 200 else 5e-3)
+
+
+def test_ctc_linear_domain_falls_back_when_mass_is_flushed(cuda):
+    """The linear-domain fp64 lattices (transcripts <= 127 tokens) are EXACT only while no state that carries final probability sits
+    more than 2^-1022 below its frame's largest one; the gradient kernel checks every frame's mass against P and hands flagged
+    utterances to the log-domain kernels.  Utterance 0: class 1 is 25 nats less likely than the rest at every frame and is every
+    second token of a 60-token transcript -- the states behind its 29th occurrence are 2^-1046 below the leading ones and flush to
+    zero in the alpha lattice (its per-frame class spread stays far inside fp32's exp range, which the log-domain gradient kernel
+    needs).  The result must still be the float64 reference's.  Utterances 1 and 2 are ordinary (fast path)."""
+    from voice100_amd import functional as F_
+    g = torch.Generator().manual_seed(77)
+    B, T, V, L = 3, 220, 29, 60
+    logits = torch.randn(B, T, V, generator=g) * 2
+    logits[0, :, 1] -= 25.0
+    targets = torch.randint(2, V, (B, L), generator=g)
+    targets[0, 0::2] = 1                                  # 1, x, 1, x, ... (x != 1: no repeated neighbours)
+    in_len = torch.tensor([220, 200, 215], dtype=torch.int32)
+    tgt_len = torch.tensor([60, 41, 33], dtype=torch.int32)
+    ref_in = logits.double().clone().requires_grad_(True)
+    ref = F.ctc_loss(F.log_softmax(ref_in.transpose(0, 1), dim=-1), targets, in_len, tgt_len, blank=0, reduction="mean", zero_infinity=True)
+    ref.backward()
+    x = logits.to(cuda).requires_grad_(True)
+    loss = F_.ctc_loss(x, targets.to(cuda), in_len.to(cuda), tgt_len.to(cuda))
+    loss.backward()
+    assert torch.isfinite(loss) and abs(float(loss.detach()) - float(ref.detach())) < 1e-4 * abs(float(ref.detach()))
+    gref = ref_in.grad.float()
+    assert torch.isfinite(x.grad).all()
+    for b in range(B):
+        assert rel_err(x.grad[b], gref[b]) < 2e-3, b
 
 
 @pytest.mark.parametrize("B,C,T,K,S", [(5, 12, 130, 19, 1), (3, 8, 77, 83, 1), (2, 6, 40, 9, 1), (4, 10, 61, 11, 2), (2, 4, 600, 51, 1)])
