@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 // cumulative exponent stored per frame beside the lattice row.
 // Cost per frame: ~16 fp64 VALU + 4 DPP + 4 ds_read_b64 + 2 stores for the four states = ~130 issue cycles for a lone wave.
 #define CTCL_MAXS 256
-#define CTCL_RESCALE 16
+#define CTCL_ROW (CTCL_MAXS + 64)      /* 4-byte words per lattice row: 256 state floats + 64 lane exponents */
+#define CTCL_RESCALE 4
 #ifndef CTC_LIN
 #define CTC_LIN 1
 #endif
@@ -448,12 +449,12 @@ __device__ __forceinline__ unsigned ctcl_wave_max_u32(unsigned v) {
 // their global-load latency -- was 31 of the kernel's 99 us (timing-only ablations, CTCL_ABL).  One workgroup barrier per chunk.
 __global__ __launch_bounds__(256) void ctc_lattice_lin_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
                                                               const long long* __restrict__ targets, const int* __restrict__ in_len,
-                                                              const int* __restrict__ tgt_len, double* __restrict__ lat,
-                                                              int* __restrict__ ecum, float* __restrict__ nll, double* __restrict__ ll2d,
+                                                              const int* __restrict__ tgt_len, float* __restrict__ lat,
+                                                              float* __restrict__ nll, double* __restrict__ ll2d,
                                                               int* __restrict__ bad, int B, int T, int V, int Lmax, int blank, int chunk) {
     extern __shared__ double pe_all[];               // [2][chunk + 1][V + 1]: p_t(c); column V is 0.0 (inactive states)
     __shared__ double fin[CTCL_MAXS];
-    (void)ecum;
+    __shared__ int fine[64];
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int Tb = in_len[b];
@@ -523,32 +524,46 @@ __global__ __launch_bounds__(256) void ctc_lattice_lin_kernel(const float* __res
         cidx[j] = u < S ? cls : V;
         skipm[j] = skip ? 1.0 : 0.0;
     }
-    // lattice row of frame q: rows are CTCL_MAXS doubles; S <= 255 always (2 L + 1 <= 256), so element 255 -- lane 63's fourth state --
-    // is never a state: it carries the row's cumulative exponent (as a double), and every lane stores unconditionally (no lane-masked
-    // branch, no separate exponent array in the frame loop)
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    double* lptr = lat + ((size_t)(dir * B + b) * T + (dir == 0 ? 0 : Tb - 1)) * CTCL_MAXS + 4 * lane;
-    const long lstep = dir == 0 ? (long)CTCL_MAXS : -(long)CTCL_MAXS;
+    // Lattice row of frame q: CTCL_ROW 4-byte words -- 256 floats (the lane's four states relative to ITS exponent) + 64 ints (the
+    // lanes' exponents): true value of state 4 l + j = row[4 l + j] * 2^-rowe[l].  One 16-byte and one 4-byte store per lane and frame.
+    float* lptr = lat + ((size_t)(dir * B + b) * T + (dir == 0 ? 0 : Tb - 1)) * CTCL_ROW;
+    const long lstep = dir == 0 ? (long)CTCL_ROW : -(long)CTCL_ROW;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int ec = 0;
+    int ecl = 0;                                       // this lane's exponent: true = a * 2^-ecl
     auto store_row = [&]() {
-        d2* dst = reinterpret_cast<d2*>(lptr);
         if (!(CTCL_ABL & 1)) {
-            dst[0] = d2{a0, a1};
-            dst[1] = d2{a2, lane == 63 ? (double)ec : a3};
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<f4*>(lptr + 4 * lane) = f4{(float)a0, (float)a1, (float)a2, (float)a3};
+            reinterpret_cast<int*>(lptr)[CTCL_MAXS + lane] = ecl;
         }
         lptr += lstep;
     };
+    // Per-LANE renormalisation (every CTCL_RESCALE frames): bring the lane's largest state to [1, 2).  One scale per wave is not
+    // enough for real networks: a blank-collapsed model (every CTC run passes through that phase) has the all-blank states 2^-13 per
+    // label above the states that carry the alignment -- 2^-1300 at 100 tokens, beyond fp64 -- while four ADJACENT states never
+    // differ by more than a few label probabilities.  Lanes the lattice's front has not reached yet (all zero) take the exponent of
+    // the front lane, so that the front's values arrive in range.
     auto rescale = [&]() {
         const unsigned h = max(max((unsigned)(__builtin_bit_cast(unsigned long long, a0) >> 32), (unsigned)(__builtin_bit_cast(unsigned long long, a1) >> 32)),
                                max((unsigned)(__builtin_bit_cast(unsigned long long, a2) >> 32), (unsigned)(__builtin_bit_cast(unsigned long long, a3) >> 32)));
-        const unsigned hm = ctcl_wave_max_u32(h);
-        const int ex = (int)((hm >> 20) & 0x7ff);              // biased exponent of the wave's largest state (0: all zero / denormal)
-        if (ex != 0 && ex != 0x7ff) {                          // (wave-uniform)
-            const int k = 1023 - ex;                           // bring the largest state to [1, 2)
-            a0 = ldexp(a0, k); a1 = ldexp(a1, k); a2 = ldexp(a2, k); a3 = ldexp(a3, k);
-            ec += k;
+        const int ex = (int)((h >> 20) & 0x7ff);               // biased exponent of the lane's largest state (0: all zero / denormal)
+        const bool live = ex != 0;
+        const int k = (live && ex != 0x7ff) ? 1023 - ex : 0;
+        a0 = ldexp(a0, k); a1 = ldexp(a1, k); a2 = ldexp(a2, k); a3 = ldexp(a3, k);
+        ecl += k;
+        const unsigned long long m = __ballot(live);
+        if (m != 0ull) {                                       // (wave-uniform)
+            const int front = 63 - __builtin_clzll(m);
+            const int ecf = __builtin_amdgcn_readlane(ecl, front);
+            if (!live) ecl = ecf;
         }
+    };
+    // lane l-1's last two states, brought to THIS lane's exponent (lane 0 has no predecessor: zeros)
+    auto incoming = [&](double& p3, double& p2) {
+        const int ecp = __builtin_amdgcn_update_dpp(ecl, ecl, 0x138, 0xf, 0xf, false);      // lane l-1's exponent (lane 0: its own)
+        const int sh = min(ecl - ecp, 900);                    // (a clamped shift under-scales: the mass check then flags the utterance)
+        p3 = ldexp(ctcl_shr1(a3), sh);
+        p2 = ldexp(ctcl_shr1(a2), sh);
     };
     int kbuf = 0;
     for (int c0 = 0; c0 < Tb; c0 += chunk, kbuf ^= 1) {
@@ -571,7 +586,8 @@ __global__ __launch_bounds__(256) void ctc_lattice_lin_kernel(const float* __res
             for (; tt < cn; ++tt) {
                 row += VP;
                 const double f0 = row[cidx[0]], f1 = row[cidx[1]], f2 = row[cidx[2]], f3 = row[cidx[3]];      // the NEXT frame's (used a frame later)
-                const double p3 = ctcl_shr1(a3), p2 = ctcl_shr1(a2);
+                double p3, p2;
+                incoming(p3, p2);
                 const double n0 = fma(skipm[0], p2, a0 + p3);
                 const double n1 = fma(skipm[1], p3, a1 + a0);
                 const double n2 = fma(skipm[2], a0, a2 + a1);
@@ -586,12 +602,15 @@ __global__ __launch_bounds__(256) void ctc_lattice_lin_kernel(const float* __res
     }
     if (dir == 0 && wave == 0) {
         fin[4 * lane + 0] = a0; fin[4 * lane + 1] = a1; fin[4 * lane + 2] = a2; fin[4 * lane + 3] = a3;
+        fine[lane] = ecl;
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) {
-            const double tot = fin[S - 1] + (S >= 2 ? fin[S - 2] : 0.0);
-            // log2 P = log2(tot) - ec ; tot == 0 -> +inf nll (infeasible, or everything flushed: the gradient kernel's check then flags it)
-            const double l2 = tot > 0.0 ? log2(tot) - (double)ec : -INFINITY;          // kept in double for the gradient kernel's check
+            const int e1 = fine[(S - 1) >> 2], e2 = S >= 2 ? fine[(S - 2) >> 2] : e1;
+            const int E = min(e1, e2);
+            const double tot = ldexp(fin[S - 1], E - e1) + (S >= 2 ? ldexp(fin[S - 2], E - e2) : 0.0);
+            // log2 P = log2(tot) - E ; tot == 0 -> +inf nll (infeasible, or flushed: the gradient kernel's check then flags it)
+            const double l2 = tot > 0.0 ? log2(tot) - (double)E : -INFINITY;           // kept in double for the gradient kernel's check
             ll2d[b] = l2;
             nll[b] = tot > 0.0 ? (float)(-l2 * 0.69314718055994530942) : INFINITY;
         }
@@ -601,8 +620,8 @@ __global__ __launch_bounds__(256) void ctc_lattice_lin_kernel(const float* __res
 // one wave per (b, t): gradient from the linear lattices, and the per-frame mass check (see above)
 __global__ __launch_bounds__(256) void ctc_grad_lin_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
                                                            const long long* __restrict__ targets, const int* __restrict__ in_len,
-                                                           const int* __restrict__ tgt_len, const double* __restrict__ lat,
-                                                           const int* __restrict__ ecum, const float* __restrict__ nll,
+                                                           const int* __restrict__ tgt_len, const float* __restrict__ lat,
+                                                           const float* __restrict__ nll,
                                                            const double* __restrict__ ll2d, float* __restrict__ grad, int* __restrict__ bad,
                                                            int B, int T, int V, int Lmax, int blank, int mean_scale) {
     __shared__ double bins[4][CTC_MAXV];
@@ -621,22 +640,44 @@ __global__ __launch_bounds__(256) void ctc_grad_lin_kernel(const float* __restri
     int L = tgt_len[b];
     if (L > Lmax) L = Lmax;
     const int S = 2 * L + 1;
-    const double* al = lat + ((size_t)(0 * B + b) * T + t) * CTCL_MAXS;
-    const double* be = lat + ((size_t)(1 * B + b) * T + t) * CTCL_MAXS;
+    const float* al = lat + ((size_t)(0 * B + b) * T + t) * CTCL_ROW;
+    const float* be = lat + ((size_t)(1 * B + b) * T + t) * CTCL_ROW;
+    const int* ale = reinterpret_cast<const int*>(al) + CTCL_MAXS;
+    const int* bee = reinterpret_cast<const int*>(be) + CTCL_MAXS;
     const long long* tg = targets + (size_t)b * Lmax;
     for (int c = lane; c < V; c += 64) bins[wave][c] = 0.0;
+    // alpha_t(s) beta_t(s) = prod 2^-e per state, each with its own exponent (the two lanes' exponents): first the smallest exponent
+    // (largest scale) over the states with a non-zero product, then the per-class sums relative to it (down-shifts only)
+    double prod[4];
+    int pe_[4], pc_[4];
+    int emin = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = lane + 64 * i;
+        prod[i] = 0.0; pe_[i] = 0; pc_[i] = blank;
+        if (s < S) {
+            const int ub = S - 1 - s;
+            prod[i] = (double)al[s] * (double)be[ub];
+            pe_[i] = ale[s >> 2] + bee[ub >> 2];
+            int c = (s & 1) ? (int)tg[s >> 1] : blank;
+            if (c < 0 || c >= V) c = blank;
+            pc_[i] = c;
+            if (prod[i] > 0.0) emin = min(emin, pe_[i]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) emin = min(emin, __shfl_xor(emin, off, 64));
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
-    for (int s = lane; s < S; s += 64) {
-        int c = (s & 1) ? (int)tg[s >> 1] : blank;
-        if (c < 0 || c >= V) c = blank;
-        atomicAdd(&bins[wave][c], al[s] * be[S - 1 - s]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (prod[i] != 0.0 || prod[i] != prod[i]) atomicAdd(&bins[wave][pc_[i]], ldexp(prod[i], max(emin - pe_[i], -2000)));
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
     const float z = lse[(size_t)b * T + t];
     const float* lg = logits + ((size_t)b * T + t) * V;
-    const int esum = (int)al[CTCL_MAXS - 1] + (int)be[CTCL_MAXS - 1];       // the rows' cumulative exponents ride in element 255
+    const int esum = emin == 0x7fffffff ? 0 : emin;
     const double ll2 = ll2d[b];                        // log2 P from the alpha lattice, in double
     // sum over classes of (sum_{s in c} alpha beta) / p_t(c) = P for every frame: the check, relative to P
     double tot = 0.0;
@@ -651,7 +692,7 @@ __global__ __launch_bounds__(256) void ctc_grad_lin_kernel(const float* __restri
                 int ex;
                 const double mant = frexp(acc, &ex);                            // acc = mant 2^ex, mant in [0.5, 1)
                 const double l2 = (double)(ex - esum) - (double)lp2 - ll2;        // log2 of the share, without the mantissa: O(1) for real shares
-                const double share = l2 > -1000.0 ? ldexp(mant, 0) * exp2(l2) : 0.0;
+                const double share = l2 > -1000.0 ? mant * exp2(l2) : 0.0;
                 tot += share;
                 occ[i] = (float)share;
             } else if (acc != acc) {
@@ -662,8 +703,8 @@ __global__ __launch_bounds__(256) void ctc_grad_lin_kernel(const float* __restri
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
     const bool feasible = n < INFINITY;
-    // a frame whose mass is not P (within 1e-5 relative), or an utterance whose alpha came out empty although it is not OBVIOUSLY
-    // infeasible, goes to the exact log-domain kernels (NaN fails the comparison and is flagged too)
+    // a frame whose mass is not P (the states are stored as floats: within 1e-5 relative), or an utterance whose alpha came out empty
+    // although it is not OBVIOUSLY infeasible, goes to the exact log-domain kernels (NaN fails the comparison and is flagged too)
     const bool ok = feasible ? (fabs(tot - 1.0) <= 1e-5) : (Tb < L);
     if (!ok && lane == 0) bad[b] = 1;
     const float gs = mean_scale ? 1.f / ((float)max(tgt_len[b], 1) * (float)B) : 1.f;
@@ -684,7 +725,7 @@ static bool ctc_lin_enabled() {
 // floats of the log-domain part (alpha + beta + lse + stall flags), and of the linear-domain part behind it (lattices as doubles,
 // log2 P per utterance as a double, cumulative exponents and the "flagged" words as ints; 2 floats of slack for the 8-byte alignment)
 static long ctc_ws_log(int B, int T, int Lmax) { return 2L * B * T * (2 * Lmax + 1) + (long)B * T + B; }
-static long ctc_ws_lin(int B, int T) { return 2L * (2L * B * T * CTCL_MAXS + B) + 2L * B * T + B + 2; }
+static long ctc_ws_lin(int B, int T) { return 2L * B * T * CTCL_ROW + 2L * B + B + 8; }
 extern "C" int v100_ctc_workspace_floats(int B, int T, int Lmax) {
     long n = ctc_ws_log(B, T, Lmax);
     if (ctc_lin_enabled() && 2 * Lmax + 1 <= CTCL_MAXS) n += ctc_ws_lin(B, T);
@@ -730,10 +771,10 @@ static int ctc_run(const float* logits, const long long* targets, const int* in_
     const int* only = nullptr;
     if (ctc_lin_enabled() && Smax <= CTCL_MAXS) {
         float* tail = workspace + ctc_ws_log(B, T, Lmax);
-        double* lat = (double*)(((size_t)tail + 7) & ~(size_t)7);
-        double* ll2d = lat + 2 * (size_t)B * T * CTCL_MAXS;
-        int* ecum = (int*)(ll2d + B);
-        int* bad = ecum + 2 * (size_t)B * T;
+        double* ll2d = (double*)(((size_t)tail + 7) & ~(size_t)7);
+        float* lat = (float*)(ll2d + B);                              // (16-byte aligned rows: CTCL_ROW * 4 bytes is a multiple of 16)
+        lat = (float*)(((size_t)lat + 15) & ~(size_t)15);
+        int* bad = (int*)(lat + 2 * (size_t)B * T * CTCL_ROW);
         int chunk = (int)(49152 / ((size_t)(V + 1) * sizeof(double))) - 1;        // two buffers of <= 48 KB (+ one spare row each)
         if (chunk > 128) chunk = 128;                                             // (short first chunk: its staging is not hidden)
         if (chunk > T) chunk = T;
@@ -743,9 +784,9 @@ static int ctc_run(const float* logits, const long long* targets, const int* in_
             static bool raised = false;
             if (!raised) { (void)hipFuncSetAttribute((const void*)ctc_lattice_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 49152 + 4096); raised = true; }
         }
-        V100_GGL(ctc_lattice_lin_kernel, dim3(B, 2), dim3(256), lds, st, logits, lse, targets, in_len, tgt_len, lat, ecum, nll, ll2d, bad,
+        V100_GGL(ctc_lattice_lin_kernel, dim3(B, 2), dim3(256), lds, st, logits, lse, targets, in_len, tgt_len, lat, nll, ll2d, bad,
                  B, T, V, Lmax, blank, chunk);
-        V100_GGL(ctc_grad_lin_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len, lat, ecum,
+        V100_GGL(ctc_grad_lin_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len, lat,
                  nll, ll2d, grad, bad, B, T, V, Lmax, blank, loss ? 1 : 0);
         only = bad;
     }
