@@ -164,12 +164,11 @@ __global__ __launch_bounds__(1024) void ctc_lattice_skew_kernel(const float* __r
                                                                 const long long* __restrict__ targets, const int* __restrict__ in_len,
                                                                 const int* __restrict__ tgt_len, float* __restrict__ alpha,
                                                                 float* __restrict__ beta, float* __restrict__ nll, int T, int V, int Lmax,
-                                                                int Smax, int blank, int* __restrict__ stall, const int* __restrict__ only) {
+                                                                int Smax, int blank, int* __restrict__ stall) {
     __shared__ float bnd[16][CTC_RING][2];
     __shared__ int progress[16];
     __shared__ float fin[2];
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
-    if (only && !only[b]) return;            // fallback launch behind the linear-domain kernels: only the utterances they flagged
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, NW = blockDim.x >> 6;
     int Tb = in_len[b];
     if (Tb > T) Tb = T;
@@ -315,9 +314,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                                                        const int* __restrict__ tgt_len, const float* __restrict__ alpha,
                                                        const float* __restrict__ beta, float* nll,
                                                        float* __restrict__ grad, int B, int T, int V, int Lmax, int Smax, int blank,
-                                                       int mean_scale, const int* __restrict__ stall, float* __restrict__ loss,
-                                                       const int* __restrict__ only) {
-    __shared__ float bins[4][CTC_MAXV];
+                                                       int mean_scale, const int* __restrict__ stall, float* __restrict__ loss) {
+    __shared__ float bins[8][CTC_MAXV];       // [0..3]: per-wave class sums; [4..7]: per-wave class references (as unsigned)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long w = (long)blockIdx.x * 4 + wave;
     if (loss && blockIdx.x == 0 && wave == 0) {
@@ -331,12 +329,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         s = wave_sum(s);
         if (lane == 0) loss[0] = s / (float)B;
     }
-    // `only` (the fallback launch behind the linear-domain pair): a SMALL grid -- one wave per frame index, looping over the flagged
-    // utterances (normally none: 128 workgroups that read B flags and leave, instead of B T / 4 workgroups that each leave)
-    if (only) {
-        if (w >= T) return;
-    } else if (w >= (long)B * T) return;
-    auto frame = [&](const int b, const int t) {
+    if (w >= (long)B * T) return;
+    const int b = (int)(w / T), t = (int)(w % T);
     float* g = grad + ((size_t)b * T + t) * V;
     if (stall[b]) {                                   // see ctc_lattice_skew_kernel: poison instead of a silently wrong result
         for (int c = lane; c < V; c += 64) g[c] = __builtin_nanf("");
@@ -356,7 +350,14 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     const float* al = alpha + ((size_t)b * T + t) * Smax;
     const float* be = beta + ((size_t)b * T + t) * Smax;
     const long long* tg = targets + (size_t)b * Lmax;
-    for (int c = lane; c < V; c += 64) bins[wave][c] = 0.f;
+    // Per-CLASS normalisation (round 6).  The sums of exp(alpha + beta) were taken relative to the frame's largest alpha + beta over
+    // ALL states; a class whose log-probability sits more than ~87 nats below the frame's best class then underflowed to an occupancy
+    // of exactly 0 although the lattice forces it (found with a transcript whose label has logit -400: the loss was right, that label's
+    // gradient 100 % wrong; a diverged model -- the benchmark's own after ~40 steps on noise -- is in that regime at every frame).
+    // Now each class has its own reference: dmin[c] = min over its states of (m - (alpha + beta)) (non-negative floats order like their
+    // bit patterns: an LDS atomicMin on unsigned), the sums are relative to it, and it goes back into the exponent.
+    unsigned* dmin = reinterpret_cast<unsigned*>(&bins[wave][0]) + 4 * CTC_MAXV;      // (bins is [8][CTC_MAXV]: rows 4 .. 7 hold the references)
+    for (int c = lane; c < V; c += 64) { bins[wave][c] = 0.f; dmin[c] = 0x7f800000u; }
     float m = NEG_INF;
     for (int s = lane; s < S; s += 64) m = fmaxf(m, al[s] + be[s]);
 #pragma unroll
@@ -367,7 +368,17 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         for (int s = lane; s < S; s += 64) {
             int c = (s & 1) ? (int)tg[s >> 1] : blank;
             if (c < 0 || c >= V) c = blank;
-            atomicAdd(&bins[wave][c], expf(al[s] + be[s] - m));
+            const float d = m - (al[s] + be[s]);                 // >= 0 (+inf for an unreachable state; NaN is left out: it reaches the sum below)
+            if (d >= 0.f) atomicMin(&dmin[c], __builtin_bit_cast(unsigned, d));
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        for (int s = lane; s < S; s += 64) {
+            int c = (s & 1) ? (int)tg[s >> 1] : blank;
+            if (c < 0 || c >= V) c = blank;
+            const float dm = __builtin_bit_cast(float, dmin[c]);
+            const float x = al[s] + be[s];
+            if (dm < INFINITY || x != x) atomicAdd(&bins[wave][c], expf((x - m) + dm));      // exp(x - (m - dm)) <= 1
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -379,356 +390,15 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     for (int c = lane; c < V; c += 64) {
         const float lpc = lg[c] - z;
         const float acc = bins[wave][c];
-        const float occ = (acc > 0.f) ? expf(m + logf(acc) + n - lpc) : 0.f;
+        const float dm = __builtin_bit_cast(float, dmin[c]);
+        // log occupancy = (m - dm) + log(acc) + n - lpc, summed so that the two large terms (m - dm ~ -n + lpc) meet first
+        const float occ = (acc > 0.f) ? expf(((m - dm) + n - lpc) + logf(acc)) : (acc != acc ? acc : 0.f);
         g[c] = (expf(lpc) - occ) * gs;
     }
-    };
-    if (only) {
-        for (int b = 0; b < B; ++b)
-            if (only[b]) {
-                frame(b, (int)w);
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("" ::: "memory");       // bins[wave] is reused by the next flagged utterance
-            }
-    } else {
-        frame((int)(w / T), (int)(w % T));
-    }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// Round 6: the lattices in the LINEAR domain, fp64, one wave per (utterance, direction), four states per lane.
-//
-// Why.  The wave pipeline above spends 106 us on T' = 512 frames: ~210 cycles of dependent log-sum-exp arithmetic per frame (three
-// v_exp_f32 + one v_log_f32 on the chain) plus a cross-wave hand-over per frame (62 of the head's 134 us, round 5).  In the linear
-// domain a frame is a_t(u) = (a(u) + a(u-1) + skip(u) a(u-2)) p_t(class(u)): two adds and a multiply.  Round 2 tried that in fp32
-// with one power-of-two scale per frame and lost paths that sit more than 2^-126 below the frame's maximum but still carry the
-// final probability.  fp64 moves that limit to 2^-1022, and a CHECK makes the result exact regardless: the gradient kernel forms,
-// for every frame, sum_s alpha_t(s) beta_t(s) / p_t(class(s)) ... which must equal P for every t (each path passes exactly one
-// state per frame); if any frame of an utterance disagrees with the utterance's P by more than 1e-5 in log2 units -- mass was
-// flushed somewhere, in either direction -- the utterance is flagged and the two log-domain kernels above run for it behind this
-// pair (they run for nobody otherwise: two near-empty launches).  256 states (transcripts of up to 127 tokens) fit one wave at four
-// per lane: the neighbours u-1 / u-2 are registers of the same lane, only a lane's first two states need lane-1's last two (two
-// 64-bit DPP moves), there is no hand-over at all.  Emission probabilities are staged per chunk of frames into LDS as doubles
-// (mantissa by v_exp_f32 of the fractional part of log2 p, exponent by ldexp: exact to fp32's exp2, any magnitude); the common scale
-// is renewed every 16 frames from the exponent of the wave's largest state (a 32-bit DPP max over the high dwords) and its
-// cumulative exponent stored per frame beside the lattice row.
-// Cost per frame: ~16 fp64 VALU + 4 DPP + 4 ds_read_b64 + 2 stores for the four states = ~130 issue cycles for a lone wave.
-#define CTCL_MAXS 256
-#define CTCL_ROW (CTCL_MAXS + 64)      /* 4-byte words per lattice row: 256 state floats + 64 lane exponents */
-#define CTCL_RESCALE 4
-#ifndef CTC_LIN
-#define CTC_LIN 1
-#endif
-#ifndef CTCL_ABL
-#define CTCL_ABL 0      /* timing-only ablations of the linear lattice (wrong results): 1 no lattice stores, 2 no rescale, 4 no staging */
-#endif
-__device__ __forceinline__ double ctcl_shr1(double v) {       // lane l gets v of lane l-1; lane 0 gets 0.0
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x138, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x138, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-// largest high dword over the wave (non-negative doubles order like their high dwords) on the DPP path -- six VALU max steps, no LDS
-// crossbar round trips (a __shfl_xor is a ds_bpermute) -- returned wave-uniform
-__device__ __forceinline__ unsigned ctcl_wave_max_u32(unsigned v) {
-#define CTCL_MAX_STEP(CTRL, ROWS) v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, true))
-    CTCL_MAX_STEP(0xB1, 0xf);       // quad_perm [1,0,3,2]
-    CTCL_MAX_STEP(0x4E, 0xf);       // quad_perm [2,3,0,1]
-    CTCL_MAX_STEP(0x141, 0xf);      // row_half_mirror
-    CTCL_MAX_STEP(0x140, 0xf);      // row_mirror
-    CTCL_MAX_STEP(0x142, 0xa);      // row_bcast:15 into rows 1, 3
-    CTCL_MAX_STEP(0x143, 0xc);      // row_bcast:31 into rows 2, 3
-#undef CTCL_MAX_STEP
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-// lat [2][B][T][CTCL_MAXS] doubles in DIRECTION order (alpha: u = s; beta: u = S-1-s), ecum [2][B][T] ints: true value = lat * 2^-ecum
-// Four waves per (utterance, direction): wave 0 runs the recursion of chunk k out of one LDS buffer while waves 1 - 3 stage chunk
-// k + 1 into the other (all four stage chunk 0): with ONE wave doing both, the staging -- 116 elements per lane and chunk behind
-// their global-load latency -- was 31 of the kernel's 99 us (timing-only ablations, CTCL_ABL).  One workgroup barrier per chunk.
-__global__ __launch_bounds__(256) void ctc_lattice_lin_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
-                                                              const long long* __restrict__ targets, const int* __restrict__ in_len,
-                                                              const int* __restrict__ tgt_len, float* __restrict__ lat,
-                                                              float* __restrict__ nll, double* __restrict__ ll2d,
-                                                              int* __restrict__ bad, int B, int T, int V, int Lmax, int blank, int chunk) {
-    extern __shared__ double pe_all[];               // [2][chunk + 1][V + 1]: p_t(c); column V is 0.0 (inactive states)
-    __shared__ double fin[CTCL_MAXS];
-    __shared__ int fine[64];
-    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int Tb = in_len[b];
-    if (Tb > T) Tb = T;
-    int L = tgt_len[b];
-    if (L > Lmax) L = Lmax;
-    const int S = 2 * L + 1;
-    if (dir == 0 && tid == 0) bad[b] = 0;
-    if (Tb <= 0) { if (dir == 0 && tid == 0) { nll[b] = INFINITY; ll2d[b] = -INFINITY; } return; }
-    const int VP = V + 1;
-    const size_t bufn = (size_t)(chunk + 1) * VP;
-    // ---- staging of frames [c0, c0 + cn) of this direction into `pe` by threads `id` of `nth` (coalesced: the chunk is a contiguous
-    //      run of cn * V logits, ascending t for alpha, descending for beta; eight loads per thread in flight; the spare row keeps
-    //      whatever it holds except for its zero column -- it is read into registers and never used) ----
-    auto stage = [&](double* pe, int c0, int id, int nth) {
-        const int cn = min(chunk, Tb - c0);
-        if (cn <= 0) return;
-        const int t_lo = dir == 0 ? c0 : Tb - c0 - cn;
-        const float* lg0 = logits + ((size_t)b * T + t_lo) * V;
-        const float* ls0 = lse + (size_t)b * T + t_lo;
-        const int n = cn * V;
-        const float rv = 1.f / (float)V;
-        for (int base = 0; base < ((CTCL_ABL & 4) ? 8 * nth : n); base += 8 * nth) {
-            float lv[8], zv[8];
-            int tl[8], cc[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int ii = min(base + id + nth * u, n - 1);
-                int q_ = (int)(((float)ii + 0.5f) * rv);             // ii / V without the integer division (exact after the fix-up)
-                int c_ = ii - q_ * V;
-                if (c_ < 0) { c_ += V; --q_; } else if (c_ >= V) { c_ -= V; ++q_; }
-                tl[u] = q_; cc[u] = c_;
-                lv[u] = lg0[ii];
-                zv[u] = ls0[q_];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float lp2 = (lv[u] - zv[u]) * 1.44269504088896340736f;
-                const float fl = floorf(lp2);
-                double p = 0.0;
-                if (lp2 > -3000.f) p = ldexp((double)__builtin_amdgcn_exp2f(lp2 - fl), (int)fl);
-                else if (lp2 != lp2) p = (double)lp2;                          // NaN logits stay NaN (the check then flags the utterance)
-                const int tt = dir == 0 ? tl[u] : cn - 1 - tl[u];
-                if (base + id + nth * u < n) pe[tt * VP + cc[u]] = p;
-            }
-        }
-        for (int tt = id; tt <= cn; tt += nth) pe[tt * VP + V] = 0.0;          // the zero column (inactive states), spare row included
-    };
-    stage(pe_all, 0, tid, 256);
-    __syncthreads();
-
-    const long long* tg = targets + (size_t)b * Lmax;
-    int cidx[4];
-    double skipm[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int u = 4 * lane + j;
-        const int sidx = dir == 0 ? u : S - 1 - u;
-        int cls = blank;
-        bool skip = false;
-        if (u < S && (sidx & 1)) {
-            cls = (int)tg[sidx >> 1];
-            if (dir == 0) skip = sidx >= 2 && tg[sidx >> 1] != tg[(sidx >> 1) - 1];
-            else skip = sidx + 2 < S && tg[sidx >> 1] != tg[(sidx >> 1) + 1];
-        }
-        if (cls < 0 || cls >= V) cls = blank;
-        cidx[j] = u < S ? cls : V;
-        skipm[j] = skip ? 1.0 : 0.0;
-    }
-    // Lattice row of frame q: CTCL_ROW 4-byte words -- 256 floats (the lane's four states relative to ITS exponent) + 64 ints (the
-    // lanes' exponents): true value of state 4 l + j = row[4 l + j] * 2^-rowe[l].  One 16-byte and one 4-byte store per lane and frame.
-    float* lptr = lat + ((size_t)(dir * B + b) * T + (dir == 0 ? 0 : Tb - 1)) * CTCL_ROW;
-    const long lstep = dir == 0 ? (long)CTCL_ROW : -(long)CTCL_ROW;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int ecl = 0;                                       // this lane's exponent: true = a * 2^-ecl
-    auto store_row = [&]() {
-        if (!(CTCL_ABL & 1)) {
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<f4*>(lptr + 4 * lane) = f4{(float)a0, (float)a1, (float)a2, (float)a3};
-            reinterpret_cast<int*>(lptr)[CTCL_MAXS + lane] = ecl;
-        }
-        lptr += lstep;
-    };
-    // Per-LANE renormalisation (every CTCL_RESCALE frames): bring the lane's largest state to [1, 2).  One scale per wave is not
-    // enough for real networks: a blank-collapsed model (every CTC run passes through that phase) has the all-blank states 2^-13 per
-    // label above the states that carry the alignment -- 2^-1300 at 100 tokens, beyond fp64 -- while four ADJACENT states never
-    // differ by more than a few label probabilities.  Lanes the lattice's front has not reached yet (all zero) take the exponent of
-    // the front lane, so that the front's values arrive in range.
-    auto rescale = [&]() {
-        const unsigned h = max(max((unsigned)(__builtin_bit_cast(unsigned long long, a0) >> 32), (unsigned)(__builtin_bit_cast(unsigned long long, a1) >> 32)),
-                               max((unsigned)(__builtin_bit_cast(unsigned long long, a2) >> 32), (unsigned)(__builtin_bit_cast(unsigned long long, a3) >> 32)));
-        const int ex = (int)((h >> 20) & 0x7ff);               // biased exponent of the lane's largest state (0: all zero / denormal)
-        const bool live = ex != 0;
-        const int k = (live && ex != 0x7ff) ? 1023 - ex : 0;
-        a0 = ldexp(a0, k); a1 = ldexp(a1, k); a2 = ldexp(a2, k); a3 = ldexp(a3, k);
-        ecl += k;
-        const unsigned long long m = __ballot(live);
-        if (m != 0ull) {                                       // (wave-uniform)
-            const int front = 63 - __builtin_clzll(m);
-            const int ecf = __builtin_amdgcn_readlane(ecl, front);
-            if (!live) ecl = ecf;
-        }
-    };
-    // lane l-1's last two states, brought to THIS lane's exponent (lane 0 has no predecessor: zeros)
-    auto incoming = [&](double& p3, double& p2) {
-        const int ecp = __builtin_amdgcn_update_dpp(ecl, ecl, 0x138, 0xf, 0xf, false);      // lane l-1's exponent (lane 0: its own)
-        const int sh = min(ecl - ecp, 900);                    // (a clamped shift under-scales: the mass check then flags the utterance)
-        p3 = ldexp(ctcl_shr1(a3), sh);
-        p2 = ldexp(ctcl_shr1(a2), sh);
-    };
-    int kbuf = 0;
-    for (int c0 = 0; c0 < Tb; c0 += chunk, kbuf ^= 1) {
-        const int cn = min(chunk, Tb - c0);
-        if (wave != 0) {
-            stage(pe_all + (kbuf ^ 1) * bufn, c0 + chunk, tid - 64, 192);     // the NEXT chunk, beside the recursion
-        } else {
-            const double* row = pe_all + kbuf * bufn;
-            double e0 = row[cidx[0]], e1 = row[cidx[1]], e2 = row[cidx[2]], e3 = row[cidx[3]];
-            int tt = 0;
-            if (c0 == 0) {                                     // frame 0: states 0 and 1 start the lattice
-                a0 = lane == 0 ? e0 : 0.0;
-                a1 = lane == 0 ? e1 : 0.0;
-                a2 = 0.0; a3 = 0.0;
-                store_row();
-                row += VP;
-                e0 = row[cidx[0]]; e1 = row[cidx[1]]; e2 = row[cidx[2]]; e3 = row[cidx[3]];
-                tt = 1;
-            }
-            for (; tt < cn; ++tt) {
-                row += VP;
-                const double f0 = row[cidx[0]], f1 = row[cidx[1]], f2 = row[cidx[2]], f3 = row[cidx[3]];      // the NEXT frame's (used a frame later)
-                double p3, p2;
-                incoming(p3, p2);
-                const double n0 = fma(skipm[0], p2, a0 + p3);
-                const double n1 = fma(skipm[1], p3, a1 + a0);
-                const double n2 = fma(skipm[2], a0, a2 + a1);
-                const double n3 = fma(skipm[3], a1, a3 + a2);
-                a0 = n0 * e0; a1 = n1 * e1; a2 = n2 * e2; a3 = n3 * e3;
-                if (!(CTCL_ABL & 2) && ((c0 + tt) & (CTCL_RESCALE - 1)) == CTCL_RESCALE - 1) rescale();
-                store_row();
-                e0 = f0; e1 = f1; e2 = f2; e3 = f3;
-            }
-        }
-        __syncthreads();
-    }
-    if (dir == 0 && wave == 0) {
-        fin[4 * lane + 0] = a0; fin[4 * lane + 1] = a1; fin[4 * lane + 2] = a2; fin[4 * lane + 3] = a3;
-        fine[lane] = ecl;
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            const int e1 = fine[(S - 1) >> 2], e2 = S >= 2 ? fine[(S - 2) >> 2] : e1;
-            const int E = min(e1, e2);
-            const double tot = ldexp(fin[S - 1], E - e1) + (S >= 2 ? ldexp(fin[S - 2], E - e2) : 0.0);
-            // log2 P = log2(tot) - E ; tot == 0 -> +inf nll (infeasible, or flushed: the gradient kernel's check then flags it)
-            const double l2 = tot > 0.0 ? log2(tot) - (double)E : -INFINITY;           // kept in double for the gradient kernel's check
-            ll2d[b] = l2;
-            nll[b] = tot > 0.0 ? (float)(-l2 * 0.69314718055994530942) : INFINITY;
-        }
-    }
-}
-
-// one wave per (b, t): gradient from the linear lattices, and the per-frame mass check (see above)
-__global__ __launch_bounds__(256) void ctc_grad_lin_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
-                                                           const long long* __restrict__ targets, const int* __restrict__ in_len,
-                                                           const int* __restrict__ tgt_len, const float* __restrict__ lat,
-                                                           const float* __restrict__ nll,
-                                                           const double* __restrict__ ll2d, float* __restrict__ grad, int* __restrict__ bad,
-                                                           int B, int T, int V, int Lmax, int blank, int mean_scale) {
-    __shared__ double bins[4][CTC_MAXV];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long w = (long)blockIdx.x * 4 + wave;
-    if (w >= (long)B * T) return;
-    const int b = (int)(w / T), t = (int)(w % T);
-    float* g = grad + ((size_t)b * T + t) * V;
-    const float n = nll[b];
-    int Tb = in_len[b];
-    if (Tb > T) Tb = T;
-    if (t >= Tb) {                                    // padded frame
-        for (int c = lane; c < V; c += 64) g[c] = 0.f;
-        return;
-    }
-    int L = tgt_len[b];
-    if (L > Lmax) L = Lmax;
-    const int S = 2 * L + 1;
-    const float* al = lat + ((size_t)(0 * B + b) * T + t) * CTCL_ROW;
-    const float* be = lat + ((size_t)(1 * B + b) * T + t) * CTCL_ROW;
-    const int* ale = reinterpret_cast<const int*>(al) + CTCL_MAXS;
-    const int* bee = reinterpret_cast<const int*>(be) + CTCL_MAXS;
-    const long long* tg = targets + (size_t)b * Lmax;
-    for (int c = lane; c < V; c += 64) bins[wave][c] = 0.0;
-    // alpha_t(s) beta_t(s) = prod 2^-e per state, each with its own exponent (the two lanes' exponents): first the smallest exponent
-    // (largest scale) over the states with a non-zero product, then the per-class sums relative to it (down-shifts only)
-    double prod[4];
-    int pe_[4], pc_[4];
-    int emin = 0x7fffffff;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int s = lane + 64 * i;
-        prod[i] = 0.0; pe_[i] = 0; pc_[i] = blank;
-        if (s < S) {
-            const int ub = S - 1 - s;
-            prod[i] = (double)al[s] * (double)be[ub];
-            pe_[i] = ale[s >> 2] + bee[ub >> 2];
-            int c = (s & 1) ? (int)tg[s >> 1] : blank;
-            if (c < 0 || c >= V) c = blank;
-            pc_[i] = c;
-            if (prod[i] > 0.0) emin = min(emin, pe_[i]);
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) emin = min(emin, __shfl_xor(emin, off, 64));
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (prod[i] != 0.0 || prod[i] != prod[i]) atomicAdd(&bins[wave][pc_[i]], ldexp(prod[i], max(emin - pe_[i], -2000)));
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-    const float z = lse[(size_t)b * T + t];
-    const float* lg = logits + ((size_t)b * T + t) * V;
-    const int esum = emin == 0x7fffffff ? 0 : emin;
-    const double ll2 = ll2d[b];                        // log2 P from the alpha lattice, in double
-    // sum over classes of (sum_{s in c} alpha beta) / p_t(c) = P for every frame: the check, relative to P
-    double tot = 0.0;
-    float occ[2] = {0.f, 0.f};                         // alpha beta / (P p_t(c)) for this lane's (up to two) classes
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = lane + 64 * i;
-        if (c < V) {
-            const double acc = bins[wave][c];
-            const float lp2 = (lg[c] - z) * 1.44269504088896340736f;          // the value the lattice kernel staged
-            if (acc > 0.0 && ll2 > -INFINITY) {
-                int ex;
-                const double mant = frexp(acc, &ex);                            // acc = mant 2^ex, mant in [0.5, 1)
-                const double l2 = (double)(ex - esum) - (double)lp2 - ll2;        // log2 of the share, without the mantissa: O(1) for real shares
-                const double share = l2 > -1000.0 ? mant * exp2(l2) : 0.0;
-                tot += share;
-                occ[i] = (float)share;
-            } else if (acc != acc) {
-                tot = acc;                                                      // NaN propagates into the check
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
-    const bool feasible = n < INFINITY;
-    // a frame whose mass is not P (the states are stored as floats: within 1e-5 relative), or an utterance whose alpha came out empty
-    // although it is not OBVIOUSLY infeasible, goes to the exact log-domain kernels (NaN fails the comparison and is flagged too)
-    const bool ok = feasible ? (fabs(tot - 1.0) <= 1e-5) : (Tb < L);
-    if (!ok && lane == 0) bad[b] = 1;
-    const float gs = mean_scale ? 1.f / ((float)max(tgt_len[b], 1) * (float)B) : 1.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = lane + 64 * i;
-        if (c < V) {
-            const float lpc = lg[c] - z;
-            g[c] = feasible ? (expf(lpc) - occ[i]) * gs : 0.f;
-        }
-    }
-}
-
-static bool ctc_lin_enabled() {
-    static const bool on = [] { const char* e = getenv("V100_CTC_LIN"); return CTC_LIN && !(e && e[0] == '0'); }();
-    return on;
-}
-// floats of the log-domain part (alpha + beta + lse + stall flags), and of the linear-domain part behind it (lattices as doubles,
-// log2 P per utterance as a double, cumulative exponents and the "flagged" words as ints; 2 floats of slack for the 8-byte alignment)
-static long ctc_ws_log(int B, int T, int Lmax) { return 2L * B * T * (2 * Lmax + 1) + (long)B * T + B; }
-static long ctc_ws_lin(int B, int T) { return 2L * B * T * CTCL_ROW + 2L * B + B + 8; }
-extern "C" int v100_ctc_workspace_floats(int B, int T, int Lmax) {
-    long n = ctc_ws_log(B, T, Lmax);
-    if (ctc_lin_enabled() && 2 * Lmax + 1 <= CTCL_MAXS) n += ctc_ws_lin(B, T);
+extern "C" int v100_ctc_workspace_floats(int B, int T, int Lmax) {      // alpha + beta + lse + stall flags
+    const long n = 2L * B * T * (2 * Lmax + 1) + (long)B * T + B;
     return n > 0x7fffffffL ? -1 : (int)n;
 }
 
@@ -766,40 +436,16 @@ static int ctc_run(const float* logits, const long long* targets, const int* in_
         (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);       \
     V100_GGL(ctc_lattice_kernel<NS_>, dim3(B, 2), dim3(256), shmem, st, logits, lse, targets, in_len, tgt_len, alpha, beta, \
                        nll, T, V, Lmax, Smax, blank)
-    // Round 6: transcripts of up to 127 tokens take the linear-domain fp64 pair first; the log-domain pair behind it then runs only for
-    // the utterances whose per-frame mass check failed (`only`), and forms the 'mean'
-    const int* only = nullptr;
-    if (ctc_lin_enabled() && Smax <= CTCL_MAXS) {
-        float* tail = workspace + ctc_ws_log(B, T, Lmax);
-        double* ll2d = (double*)(((size_t)tail + 7) & ~(size_t)7);
-        float* lat = (float*)(ll2d + B);                              // (16-byte aligned rows: CTCL_ROW * 4 bytes is a multiple of 16)
-        lat = (float*)(((size_t)lat + 15) & ~(size_t)15);
-        int* bad = (int*)(lat + 2 * (size_t)B * T * CTCL_ROW);
-        int chunk = (int)(49152 / ((size_t)(V + 1) * sizeof(double))) - 1;        // two buffers of <= 48 KB (+ one spare row each)
-        if (chunk > 128) chunk = 128;                                             // (short first chunk: its staging is not hidden)
-        if (chunk > T) chunk = T;
-        if (chunk < 1) return V100_ERR_SHAPE;
-        const size_t lds = 2 * (size_t)(chunk + 1) * (V + 1) * sizeof(double);
-        if (lds > 65536) {
-            static bool raised = false;
-            if (!raised) { (void)hipFuncSetAttribute((const void*)ctc_lattice_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 49152 + 4096); raised = true; }
-        }
-        V100_GGL(ctc_lattice_lin_kernel, dim3(B, 2), dim3(256), lds, st, logits, lse, targets, in_len, tgt_len, lat, nll, ll2d, bad,
-                 B, T, V, Lmax, blank, chunk);
-        V100_GGL(ctc_grad_lin_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len, lat,
-                 nll, ll2d, grad, bad, B, T, V, Lmax, blank, loss ? 1 : 0);
-        only = bad;
-    }
     if (CTC_SKEW && Smax <= 1024) {
         const int nw = (Smax + 63) / 64;
         V100_GGL(ctc_lattice_skew_kernel, dim3(B, 2), dim3(64 * nw), 0, st, logits, lse, targets, in_len, tgt_len, alpha, beta,
-                           nll, T, V, Lmax, Smax, blank, stall, only);
+                           nll, T, V, Lmax, Smax, blank, stall);
     } else if (Smax <= 512) { CTC_LATTICE(2); }
     else if (Smax <= 1024) { CTC_LATTICE(4); }
     else if (Smax <= 2048) { CTC_LATTICE(8); }
     else { CTC_LATTICE(16); }
 #undef CTC_LATTICE
-    V100_GGL(ctc_grad_kernel, dim3((unsigned)(((only ? (long)T : rows) + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len,
-                       alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank, loss ? 1 : 0, stall, loss, only);     // (the 'mean' reduction rides in block 0)
+    V100_GGL(ctc_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len,
+                       alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank, loss ? 1 : 0, stall, loss);     // (the 'mean' reduction rides in block 0)
     return v100_launch_status();
 }
