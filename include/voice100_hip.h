@@ -77,6 +77,12 @@ int v100_pw_gemm(const float* A, const void* A_bf16, const float* X, const float
                  const float* xb, const float* xc, int x_mode, float* Y, const float* bias, const float* ea,
                  const float* eb, const float* R, int epi_mode, float* stats, int B, int M, int K, int T,
                  int use_bf16, void* stream);
+/* The data gradient of Dropout(p) -> Conv1d(k=1) (asr.py:85-94) in one kernel: Y[b][m][t] = keep[b][m][t] ? (sum_k A[m][k] X[b][k][t]) / (1 - p) : 0
+ * with keep the byte mask v100_dropout_fwd wrote.  The small-K form only (K <= 32: the vocabulary head's 29 classes; M >= 64, T % 4 == 0):
+ * v100_pw_gemm_dropmask_supported tells, anything else returns the shape status.  use_bf16 as v100_pw_gemm (0 / 1). */
+int v100_pw_gemm_dropmask_supported(int B, int M, int K, int T, int use_bf16);
+int v100_pw_gemm_dropmask(const float* A, const void* A_bf16, const float* X, float* Y, const void* keep, float p, int B, int M, int K,
+                          int T, int use_bf16, void* stream);
 
 /* dW[m][k] = sum_{b,t} g'[b][m][t] * x'[b][k][t]   (weight gradient of the same 1x1 conv).
  * partial: [S][M][K] workspace, S = v100_pw_wgrad_splits(B, M, K): S <= B splits the batch, S = B * TS (small weight matrices)
@@ -150,6 +156,13 @@ int v100_augment_fused_len(const float* x, const int* len_raw, int* len_out, int
                            const int* tm_s, const int* tm_e, const float* tm_a, int fm_on, int fm_s, int fm_e, float fm_a,
                            int noise_on, float noise_low, float noise_high, float noise_std, int mix, float log_offset,
                            void* stream);
+/* ... and, for F == 64, the same values TRANSPOSED into yt [B, 64, Tout] by the same pass (null: not written): the layout the encoder
+ * takes (torch.transpose(audio, 1, 2), asr.py:111), which otherwise costs a launch that reads y back. */
+int v100_augment_fused_len_t(const float* x, const int* len_raw, int* len_out, int* half_out, const float* uniform, float* y,
+                             float* yt, int B, int Tin, int Tout, int F, int stretch_rate, float pitch_rate, float amp, int n_tmask,
+                             const int* tm_s, const int* tm_e, const float* tm_a, int fm_on, int fm_s, int fm_e, float fm_a,
+                             int noise_on, float noise_low, float noise_high, float noise_std, int mix, float log_offset,
+                             void* stream);
 
 /* ---- K4 / K7 / K9 glue (csrc/features.hip) -------------------------------------------------
  * shift_copy: out[b][out_coff+c][u*out_mul+out_add] (=|+=) in[b][in_coff+c][u*in_mul+in_add] (0 when that
@@ -357,6 +370,10 @@ int v100_ctc_loss_mean(const float* logits, const long long* targets, const int*
                        float* nll, float* loss, float* grad, int B, int T, int V, int Lmax, int blank, void* stream);
 int v100_ctc_loss(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace,
                   float* nll, float* grad, int B, int T, int V, int Lmax, int blank, void* stream);
+/* v100_ctc_loss_mean with the gradient laid out [B, V, T] when grad_bvt != 0 (the logits stay [B, T, V]): the layout of the tensor
+ * the reference transposes the logits FROM (asr.py:114), so the backward of that transpose needs no pass over the gradient. */
+int v100_ctc_loss_mean_t(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace,
+                         float* nll, float* loss, float* grad, int grad_bvt, int B, int T, int V, int Lmax, int blank, void* stream);
 
 /* ---- block executor (csrc/block.hip): the whole kernel chain of one InvertedResidual block (asr.py:40-59) per call.
  * shape = {B, Cin, hid, Cout, T, K, stride, residual, bf16, prepped, act16} (11 ints; act16: see "act16" above -- then the

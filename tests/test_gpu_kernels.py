@@ -507,3 +507,67 @@ def test_fused_adam_matches_torch(cuda):
     for a, b in zip(pa, pb):
         assert rel_err(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) < 1e-5
         assert rel_err(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) < 1e-5
+
+
+@pytest.mark.parametrize("B,cin,cout,T,prec", [(3, 64, 29, 52, "fp32"), (2, 512, 29, 128, "bf16"), (4, 96, 32, 260, "bf16"),
+                                               (2, 64, 29, 51, "fp32"), (2, 48, 29, 64, "bf16"), (2, 128, 40, 64, "fp32")])
+def test_dropout_pointwise_node_equals_the_pair(cuda, B, cin, cout, T, prec):
+    """Dropout -> Conv1d(k=1) as one autograd node (LinearCharDecoder's training forward) against the two separate nodes on the same
+    seed: output, data gradient (keep mask applied in the small-K GEMM's epilogue where that kernel applies: the first three shapes;
+    the others take the two-kernel route), weight and bias gradients -- all bit for bit."""
+    from voice100_amd import functional as F_
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B, cin, T, generator=g).to(cuda)
+    w = (torch.randn(cout, cin, 1, generator=g) * 0.1).to(cuda)
+    b = torch.randn(cout, generator=g).to(cuda)
+    gy = torch.randn(B, cout, T, generator=g).to(cuda)
+    res = []
+    for fused in (True, False):
+        xi, wi, bi = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        torch.manual_seed(77)
+        if fused:
+            y = F_.dropout_pointwise_conv1d(xi, wi, bi, 0.2, precision=prec)
+        else:
+            y = F_.pointwise_conv1d(F_.dropout(xi, 0.2, True), wi, bi, precision=prec)
+        y.backward(gy)
+        res.append((y.detach(), xi.grad, wi.grad, bi.grad))
+    for a, c in zip(*res):
+        assert torch.equal(a, c)
+    assert 0.7 < float((res[0][1] != 0).float().mean()) < 0.9
+
+
+def test_ctc_gradient_in_the_transposed_layout(cuda):
+    """Logits that are transpose_last2() of a [B, V, T] tensor (asr.py:114): ctc_loss writes its gradient in THAT layout and the
+    transpose's backward hands the buffer on without a launch; same values as the plain route, with the unit root gradient and with
+    a scaled one, ragged lengths, an infeasible and an empty utterance."""
+    from voice100_amd import functional as F_
+    import voice100_amd._native as N
+    g = torch.Generator().manual_seed(9)
+    B, V, T, L = 5, 29, 70, 12
+    src = (torch.randn(B, V, T, generator=g) * 2).to(cuda)
+    tgt = torch.randint(1, V, (B, L), generator=g).to(cuda)
+    il = torch.tensor([70, 5, 33, 70, 41], dtype=torch.int32, device=cuda)
+    tl = torch.tensor([12, 9, 0, 7, 12], dtype=torch.int32, device=cuda)        # utterance 1: too short (zero_infinity); 2: empty target
+    a = src.clone().requires_grad_(True)
+    loss_a = F_.ctc_loss(a.transpose(1, 2).contiguous(), tgt, il, tl)            # plain route: torch's transpose, [B, T, V] gradient
+    loss_a.backward()
+    for scale in (None, 2.5):
+        b = src.clone().requires_grad_(True)
+        logits = F_.transpose_last2(b)
+        assert getattr(logits, "_v100_grad_T", False)
+        loss_b = F_.ctc_loss(logits, tgt, il, tl)
+        n0 = N.launch_count()
+        if scale is None:
+            loss_b.backward(F_.unit_grad(loss_b))
+            assert N.launch_count() == n0                                         # gradient computed with the loss; no transpose launch
+            assert torch.equal(loss_a.detach(), loss_b.detach()) and torch.equal(a.grad, b.grad)
+        else:
+            loss_b.backward(torch.full((), scale, device=cuda))
+            assert N.launch_count() == n0
+            assert torch.allclose(b.grad, a.grad * scale, rtol=1e-6, atol=0)
+        assert b.grad.is_contiguous()
+    c = src.clone().requires_grad_(True)                                          # a consumer in between: the tag does not travel
+    mid = F_.transpose_last2(c) * 1.0
+    assert not getattr(mid, "_v100_grad_T", False)
+    F_.ctc_loss(mid, tgt, il, tl).backward()
+    assert torch.equal(c.grad, a.grad)

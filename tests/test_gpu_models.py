@@ -657,3 +657,54 @@ def test_augment_side_lengths_and_unit_root_gradient(cuda):
     (g3,) = torch.autograd.grad(loss, logits, grad_outputs=one, retain_graph=True)
     (g4,) = torch.autograd.grad(loss, logits, grad_outputs=one)
     assert torch.equal(g3, g0) and torch.equal(g4, g0)
+
+
+def test_augment_row_form_equals_element_form_and_writes_the_transposed_twin(cuda, monkeypatch):
+    """The 64-bin row form of the augmentation pass (a wave per frame) gives the element form's values bit for bit under every
+    decision, ragged frame counts included; its transposed twin is exactly transpose(1, 2), transpose_last2() hands it out while the
+    batch is untouched and no gradient is wanted through it, and launches otherwise."""
+    from voice100_amd import functional as F_
+    from voice100_amd.audio import BatchSpectrogramAugumentation, AugmentDecisions
+    import voice100_amd._native as N
+    g = torch.Generator().manual_seed(11)
+
+    def decisions(T):
+        out = []
+        for rate in (0, 57, 110, 149):
+            for k in range(3):
+                d = AugmentDecisions(); d.stretch_rate = rate
+                Ts = T * rate // 100 if rate else T
+                if k >= 1:
+                    d.pitch_rate = 1.13; d.amp = 2.5
+                    d.tmask = [(Ts // 3, 2, -7.0), (Ts - 1, 3, -6.0)]
+                    d.fmask = (60, 9, -8.0)
+                if k == 2:
+                    d.noise = (-4.0, -1.5, 2.0, torch.rand(5, Ts, 64, generator=g)); d.mix = True
+                out.append(d)
+        return out
+
+    for T in (211, 64, 1, 130):
+        audio = (torch.randn(5, T, 64, generator=g) * 2 - 3).to(cuda)
+        lens = torch.tensor([T, 1, 0, max(T - 1, 0), T // 2], dtype=torch.int32, device=cuda)
+        for d in decisions(T):
+            if d.stretch_rate and T * d.stretch_rate // 100 <= 0:
+                continue
+            aug = BatchSpectrogramAugumentation(); aug.emit_transposed = True
+            y, ln = aug(audio, lens, decisions=d)
+            yt = F_.transpose_last2(y)
+            n0 = N.launch_count()
+            assert F_.transpose_last2(y) is yt and N.launch_count() == n0           # the twin: no launch
+            assert torch.equal(yt, y.transpose(1, 2).contiguous())
+            monkeypatch.setenv("V100_AUG_ROWS", "0")
+            plain = BatchSpectrogramAugumentation()
+            y0, ln0 = plain(audio, lens, decisions=d)
+            monkeypatch.delenv("V100_AUG_ROWS")
+            assert torch.equal(y, y0) and torch.equal(ln, ln0)
+            assert getattr(y0, "_v100_T", None) is None
+            y.add_(1.0)                                                                # written to: the twin is stale
+            yt2 = F_.transpose_last2(y)
+            assert yt2 is not yt and torch.equal(yt2, y.transpose(1, 2).contiguous())
+    y, _ = aug(audio, lens, decisions=AugmentDecisions())
+    y.requires_grad_(True)                                                             # a gradient through the batch: the autograd op
+    z = F_.transpose_last2(y)
+    assert z.requires_grad and z.grad_fn is not None

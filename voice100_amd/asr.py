@@ -61,6 +61,11 @@ class LinearCharDecoder(nn.Module):
         drop, conv = self.layers[0], self.layers[1]
         if tracing():
             return conv(drop(enc_out))
+        if (self.training and 0.0 < drop.p < 1.0 and self._keep_mask is None and type(conv) is PointwiseConv1d
+                and not (conv._forward_hooks or conv._forward_pre_hooks or drop._forward_hooks or drop._forward_pre_hooks
+                         or conv._backward_hooks or drop._backward_hooks)):
+            # one autograd node for the pair: the keep mask is applied in the data-gradient GEMM's epilogue on the way back
+            return F_.dropout_pointwise_conv1d(enc_out, conv.weight, conv.bias, drop.p)
         x = F_.dropout(enc_out, drop.p, self.training, self._keep_mask)
         return conv(x)
 
@@ -76,6 +81,7 @@ class AudioToTextCTC(Voice100ModelBase):
         self.decoder = LinearCharDecoder(embed_size, vocab_size)
         self.criterion = nn.CTCLoss(zero_infinity=True)     # kept for API parity; the step uses functional.ctc_loss
         self.batch_augment = BatchSpectrogramAugumentation()
+        self.batch_augment.emit_transposed = True     # forward() opens with transpose(1, 2): the augmentation pass writes that layout too
         self.do_normalize = False
 
     def forward(self, audio: torch.Tensor) -> torch.Tensor:

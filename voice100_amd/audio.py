@@ -43,6 +43,7 @@ class BatchSpectrogramAugumentation(nn.Module):
         self.do_timestretch = do_timestretch
         self.log_offset = log_offset
         self.blank_audio = math.log(log_offset)
+        self.emit_transposed = False      # AudioToTextCTC turns this on: its forward() opens with the transpose
 
     def draw(self, audio: torch.Tensor) -> AugmentDecisions:
         """Consume `random` exactly as audio.py:34-49 does (shape-dependent draws included)."""
@@ -114,7 +115,9 @@ class BatchSpectrogramAugumentation(nn.Module):
                 uniform = torch.rand((B, Tout, F), device=audio.device)
             uniform = uniform.to(audio.device).contiguous()
         out = torch.empty((B, Tout, F), dtype=torch.float32, device=audio.device)
-        N.call("v100_augment_fused_len", audio, len_raw, len_pair[0], len_pair[1], uniform, out, B, Tin, Tout, F,
+        # the model that consumes the batch as [B, F, T] (asr.py:111) asks for that layout from the same pass (emit_transposed)
+        out_t = torch.empty((B, F, Tout), dtype=torch.float32, device=audio.device) if (self.emit_transposed and F == 64) else None
+        N.call("v100_augment_fused_len_t", audio, len_raw, len_pair[0], len_pair[1], uniform, out, out_t, B, Tin, Tout, F,
                int(d.stretch_rate), float(d.pitch_rate), float(d.amp), n, tm_s, tm_e, tm_a, fm_on, fm_s, fm_e, float(fm_a),
                int(d.noise is not None), float(low), float(high), float(std), int(d.mix), float(self.log_offset))
         if audio_len.device != audio.device:      # host lengths stay host lengths, computed there as the reference does (no sync)
@@ -123,4 +126,6 @@ class BatchSpectrogramAugumentation(nn.Module):
             out_len = len_pair[0] if audio_len.dtype == torch.int32 else len_pair[0].to(audio_len.dtype)
         if out_len.device == len_pair[1].device:  # host lengths get no device tag: output_length() then computes on the host like the reference
             F_.tag_half_length(out_len, len_pair[1])
+        if out_t is not None:
+            F_.tag_transposed(out, out_t)
         return out, out_len

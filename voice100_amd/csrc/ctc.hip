@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                                                        const int* __restrict__ tgt_len, const float* __restrict__ alpha,
                                                        const float* __restrict__ beta, float* nll,
                                                        float* __restrict__ grad, int B, int T, int V, int Lmax, int Smax, int blank,
-                                                       int mean_scale, const int* __restrict__ stall, float* __restrict__ loss) {
+                                                       int mean_scale, const int* __restrict__ stall, float* __restrict__ loss, int grad_bvt) {
     __shared__ float bins[8][CTC_MAXV];       // [0..3]: per-wave class sums; [4..7]: per-wave class references (as unsigned)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long w = (long)blockIdx.x * 4 + wave;
@@ -331,9 +331,12 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     }
     if (w >= (long)B * T) return;
     const int b = (int)(w / T), t = (int)(w % T);
-    float* g = grad + ((size_t)b * T + t) * V;
+    // grad_bvt: the gradient goes out as [B, V, T] (class c of this frame at g[c * T]) -- the layout of the tensor the logits were
+    // transposed FROM (asr.py:114), so that transpose's backward is a view instead of a launch
+    float* g = grad_bvt ? grad + (size_t)b * V * T + t : grad + ((size_t)b * T + t) * V;
+    const size_t gc = grad_bvt ? (size_t)T : 1;
     if (stall[b]) {                                   // see ctc_lattice_skew_kernel: poison instead of a silently wrong result
-        for (int c = lane; c < V; c += 64) g[c] = __builtin_nanf("");
+        for (int c = lane; c < V; c += 64) g[c * gc] = __builtin_nanf("");
         if (t == 0 && lane == 0) nll[b] = __builtin_nanf("");
         return;
     }
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     int Tb = in_len[b];
     if (Tb > T) Tb = T;
     if (t >= Tb || !(n < INFINITY)) {                 // padded frame, or zero_infinity
-        for (int c = lane; c < V; c += 64) g[c] = 0.f;
+        for (int c = lane; c < V; c += 64) g[c * gc] = 0.f;
         return;
     }
     int L = tgt_len[b];
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         const float dm = __builtin_bit_cast(float, dmin[c]);
         // log occupancy = (m - dm) + log(acc) + n - lpc, summed so that the two large terms (m - dm ~ -n + lpc) meet first
         const float occ = (acc > 0.f) ? expf(((m - dm) + n - lpc) + logf(acc)) : (acc != acc ? acc : 0.f);
-        g[c] = (expf(lpc) - occ) * gs;
+        g[c * gc] = (expf(lpc) - occ) * gs;
     }
 }
 
@@ -403,11 +406,11 @@ extern "C" int v100_ctc_workspace_floats(int B, int T, int Lmax) {      // alpha
 }
 
 static int ctc_run(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace, float* nll,
-                   float* loss, float* grad, int B, int T, int V, int Lmax, int blank, void* stream);
+                   float* loss, float* grad, int grad_bvt, int B, int T, int V, int Lmax, int blank, void* stream);
 
 extern "C" int v100_ctc_loss(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace,
                              float* nll, float* grad, int B, int T, int V, int Lmax, int blank, void* stream) {
-    return ctc_run(logits, targets, in_len, tgt_len, workspace, nll, nullptr, grad, B, T, V, Lmax, blank, stream);
+    return ctc_run(logits, targets, in_len, tgt_len, workspace, nll, nullptr, grad, 0, B, T, V, Lmax, blank, stream);
 }
 
 // The same plus the reduction of nn.CTCLoss(reduction='mean', zero_infinity=True): loss[0] = mean_b(nll_b / max(len_b, 1)) over
@@ -415,11 +418,20 @@ extern "C" int v100_ctc_loss(const float* logits, const long long* targets, cons
 extern "C" int v100_ctc_loss_mean(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace,
                                   float* nll, float* loss, float* grad, int B, int T, int V, int Lmax, int blank, void* stream) {
     if (!loss) return V100_ERR_NULL;
-    return ctc_run(logits, targets, in_len, tgt_len, workspace, nll, loss, grad, B, T, V, Lmax, blank, stream);
+    return ctc_run(logits, targets, in_len, tgt_len, workspace, nll, loss, grad, 0, B, T, V, Lmax, blank, stream);
+}
+
+// ... with the gradient written as [B, V, T] when grad_bvt != 0 (logits stay [B, T, V]): for a caller whose logits are the transpose of
+// a [B, V, T] tensor (asr.py:114) the backward of that transpose is then a view of this buffer.
+extern "C" int v100_ctc_loss_mean_t(const float* logits, const long long* targets, const int* in_len, const int* tgt_len,
+                                    float* workspace, float* nll, float* loss, float* grad, int grad_bvt, int B, int T, int V, int Lmax,
+                                    int blank, void* stream) {
+    if (!loss) return V100_ERR_NULL;
+    return ctc_run(logits, targets, in_len, tgt_len, workspace, nll, loss, grad, grad_bvt ? 1 : 0, B, T, V, Lmax, blank, stream);
 }
 
 static int ctc_run(const float* logits, const long long* targets, const int* in_len, const int* tgt_len, float* workspace, float* nll,
-                   float* loss, float* grad, int B, int T, int V, int Lmax, int blank, void* stream) {
+                   float* loss, float* grad, int grad_bvt, int B, int T, int V, int Lmax, int blank, void* stream) {
     if (!logits || !targets || !in_len || !tgt_len || !workspace || !nll || !grad) return V100_ERR_NULL;
     if (B <= 0 || T <= 0 || V <= 0 || V > CTC_MAXV || Lmax < 0 || 2 * Lmax + 1 > 4096 || blank < 0 || blank >= V) return V100_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -446,6 +458,6 @@ static int ctc_run(const float* logits, const long long* targets, const int* in_
     else { CTC_LATTICE(16); }
 #undef CTC_LATTICE
     V100_GGL(ctc_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len,
-                       alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank, loss ? 1 : 0, stall, loss);     // (the 'mean' reduction rides in block 0)
+                       alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank, loss ? 1 : 0, stall, loss, grad_bvt);     // (the 'mean' reduction rides in block 0)
     return v100_launch_status();
 }

@@ -116,7 +116,10 @@ extern "C" int v100_weight_prep_f16(const float* w, int rows, int cols, void* w1
 // (scalar-safe, K padded to 64) path at 34 us per step for 1 GFLOP.  29 FMAs per output are nothing; the kernel is the 33 MB store.
 // A workgroup owns a [64 m x 128 t] tile: A tile in LDS, a thread holds 8 m x 4 t accumulators.  fmt 0: fp32 operands (exact fp32,
 // fmaf chain in k order); fmt 1: operands rounded to bf16 like the MFMA path, fp32 accumulate.  T % 4 == 0.
-__global__ __launch_bounds__(256) void pw_smallk_kernel(PwParams p) {
+// MASK: the vocabulary head's data gradient with Dropout's backward in the epilogue (keep: the byte mask of v100_dropout_fwd over
+// Y's [B][M][T] elements; scale = 1 / (1 - p)) -- the separate pass read and wrote the 33 MB gradient once more.
+template <bool MASK>
+__global__ __launch_bounds__(256) void pw_smallk_kernel(PwParams p, const unsigned char* __restrict__ keep, float scale) {
     __shared__ float As[64][33];
     const int K = p.K, M = p.M, T = p.T;
     const int nmt = (M + 63) >> 6, ntt = (T + 127) >> 7;
@@ -164,6 +167,11 @@ __global__ __launch_bounds__(256) void pw_smallk_kernel(PwParams p) {
         if (m < M) {
             f32x4 o = acc[j];
             if (p.bias) { const float bs = p.bias[m]; o += f32x4{bs, bs, bs, bs}; }
+            if (MASK) {
+                const unsigned mk = *reinterpret_cast<const unsigned*>(keep + ((size_t)b * M + m) * T + t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ((mk >> (8 * e)) & 1u) ? o[e] * scale : 0.f;       // dropout_bwd_kernel's arithmetic
+            }
             *reinterpret_cast<f32x4*>(p.Y + ((size_t)b * M + m) * T + t) = o;
         }
     }
@@ -193,12 +201,32 @@ extern "C" int v100_pw_gemm(const float* A, const void* A_bf16, const float* X, 
     if (K <= 32 && use_bf16 != 2 && x_mode == PW_X_NONE && epi_mode == PW_EPI_STORE && (T & 3) == 0 && M >= 64 &&
         (size_t)B * K * T * 4 < 0x7fffff00ull) {                                             // see pw_smallk_kernel
         const long nw = (long)((M + 63) >> 6) * ((T + 127) >> 7) * B;
-        V100_GGL(pw_smallk_kernel, dim3((unsigned)nw), dim3(256), 0, st, p);
+        V100_GGL(pw_smallk_kernel<false>, dim3((unsigned)nw), dim3(256), 0, st, p, (const unsigned char*)nullptr, 1.f);
         return v100_launch_status();
     }
     if (use_bf16 == 2) { if (!pw_launch_gemm_f16(p, grid, st)) return V100_ERR_SHAPE; }     // fp16: inference combinations only
     else if (use_bf16) pw_launch_gemm_bf16(p, grid, st);
     else pw_launch_gemm_f32(p, grid, st);
+    return v100_launch_status();
+}
+
+static bool pw_smallk_ok(int B, int M, int K, int T, int use_bf16) {
+    return B > 0 && T > 0 && K > 0 && K <= 32 && (use_bf16 == 0 || use_bf16 == 1) && (T & 3) == 0 && M >= 64 && (size_t)B * K * T * 4 < 0x7fffff00ull &&
+           (long)((M + 63) >> 6) * ((T + 127) >> 7) * B <= 0x7fffffffL;
+}
+extern "C" int v100_pw_gemm_dropmask_supported(int B, int M, int K, int T, int use_bf16) { return pw_smallk_ok(B, M, K, T, use_bf16) ? 1 : 0; }
+
+extern "C" int v100_pw_gemm_dropmask(const float* A, const void* A_bf16, const float* X, float* Y, const void* keep, float pdrop, int B,
+                                     int M, int K, int T, int use_bf16, void* stream) {
+    if (!X || !Y || !keep) return V100_ERR_NULL;
+    if (use_bf16 ? !A_bf16 : !A) return V100_ERR_NULL;
+    if (!pw_smallk_ok(B, M, K, T, use_bf16) || !(pdrop >= 0.f && pdrop < 1.f)) return V100_ERR_SHAPE;
+    PwParams p{A, (const u16*)A_bf16, X, nullptr, nullptr, nullptr, nullptr, Y, nullptr, nullptr, nullptr, nullptr, nullptr, B, M, K, T,
+               PW_X_NONE, PW_EPI_STORE, ceil_div(M, PW_BM), ceil_div(T, PW_BN), use_bf16};
+    hipStream_t st = (hipStream_t)stream;
+    V100TimedRegion timed(V100_T_PW_GEMM, st);
+    const long nw = (long)((M + 63) >> 6) * ((T + 127) >> 7) * B;
+    V100_GGL(pw_smallk_kernel<true>, dim3((unsigned)nw), dim3(256), 0, st, p, (const unsigned char*)keep, 1.0f / (1.0f - pdrop));
     return v100_launch_status();
 }
 

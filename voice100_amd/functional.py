@@ -856,6 +856,8 @@ class TransposeLast2Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if not dy.is_contiguous() and dy.transpose(1, 2).is_contiguous():
+            return dy.transpose(1, 2)          # written in this op's INPUT layout by its producer (ctc_loss, grad_bvt): a view, no launch
         dy = dy.contiguous()
         B, C, R = dy.shape
         dx = _f32(B, R, C, like=dy)
@@ -863,8 +865,21 @@ class TransposeLast2Fn(torch.autograd.Function):
         return dx
 
 
+def tag_transposed(x: torch.Tensor, xt: torch.Tensor):
+    """Attach the [B, C, R] twin a kernel wrote beside x [B, R, C] (the augmentation pass, audio.py); transpose_last2() hands it out
+    instead of launching -- as long as x has not been written to since and no gradient is wanted through it."""
+    x._v100_T = (xt, x._version)
+
+
 def transpose_last2(x):
-    return TransposeLast2Fn.apply(x)
+    tag = getattr(x, "_v100_T", None)
+    if tag is not None and tag[1] == x._version and not x.requires_grad and tag[0].device == x.device \
+            and tag[0].shape == (x.shape[0], x.shape[2], x.shape[1]):
+        return tag[0]
+    y = TransposeLast2Fn.apply(x)
+    if y.requires_grad:
+        y._v100_grad_T = True      # a loss kernel that consumes y directly may write d loss / d y in x's layout (ctc_loss does)
+    return y
 
 
 class DropoutMaskFn(torch.autograd.Function):
@@ -911,6 +926,68 @@ class DropoutFn(torch.autograd.Function):
         dx = torch.empty_like(dy)
         N.call("v100_dropout_bwd", dy, mask, ctx.p, dx, dy.numel())
         return dx, None, None
+
+
+class DropoutPointwiseFn(torch.autograd.Function):
+    """nn.Dropout(p) then nn.Conv1d(kernel_size=1) (LinearCharDecoder, asr.py:85-94) as ONE autograd node: forward is DropoutFn's
+    kernel followed by PointwiseConvFn's GEMM; backward takes the weight / bias gradients from the saved dropped input and applies the
+    keep mask in the data-gradient GEMM's own epilogue (v100_pw_gemm_dropmask) instead of a pass over the [B, C, T] gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, p, seed, precision):
+        _check(x, "dropout_pointwise_conv1d")
+        x = x.contiguous()
+        B, cin, T = x.shape
+        cout = w.shape[0]
+        bf16 = _fmt(precision)
+        xd = torch.empty_like(x)
+        mask = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
+        N.call("v100_dropout_fwd", x, int(seed), float(p), xd, mask, x.numel())
+        W = _weights_of(w, cout, cin, bf16, False)
+        y = _f32(B, cout, T, like=x)
+        _pw_gemm(W.w, W.w_bf, xd, y, cout, cin, T, B, bf16, bias=bias.detach() if bias is not None else None, epi=0)
+        ctx.save_for_backward(xd, w, mask)
+        ctx.has_bias = bias is not None
+        ctx.bf16 = bf16
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xd, w, mask = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, cin, T = xd.shape
+        cout = w.shape[0]
+        bf16 = ctx.bf16
+        _no_fp16_training(bf16, "backward")
+        W = _weights_of(w, cout, cin, bf16, True)
+        S = N.helper("v100_pw_wgrad_splits", B, cout, cin)
+        partial = _f32(S, cout, cin, like=xd)
+        dW = _f32(cout, cin, like=xd)
+        N.call("v100_pw_wgrad", dy, None, None, None, None, 0, xd, None, None, 0, partial, dW, S, B, cout, cin, T, int(bf16))
+        db = None
+        if ctx.has_bias:
+            G = N.helper("v100_dw_num_groups", B, cout)
+            part = _f32(G, cout, 2, like=xd)
+            N.call("v100_chan_reduce2", dy, None, part, G, B, cout, T)
+            db = _f32(cout, like=xd)
+            N.call("v100_slab_sum0", part, G, db, cout)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _f32(B, cin, T, like=xd)
+            if N.helper("v100_pw_gemm_dropmask_supported", B, cin, cout, T, int(bf16)):
+                N.call("v100_pw_gemm_dropmask", W.wt, W.wt_bf, dy, dx, mask, ctx.p, B, cin, cout, T, int(bf16))
+            else:
+                dz = _f32(B, cin, T, like=xd)
+                _pw_gemm(W.wt, W.wt_bf, dy, dz, cin, cout, T, B, bf16, epi=0)
+                N.call("v100_dropout_bwd", dz, mask, ctx.p, dx, dx.numel())
+        return dx, dW.view_as(w), db, None, None, None
+
+
+def dropout_pointwise_conv1d(x, w, bias, p: float, precision: Optional[str] = None):
+    """Training-mode Dropout(p) -> Conv1d(k=1) with the in-kernel mask generator (0 < p < 1)."""
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())        # CPU generator: no device sync (as dropout())
+    return DropoutPointwiseFn.apply(x, w, bias, float(p), seed, precision or _PRECISION)
 
 
 def dropout(x, p: float, training: bool, keep: Optional[torch.Tensor] = None):
@@ -1334,7 +1411,7 @@ class CTCLossFn(torch.autograd.Function):
     characters).  Labels outside [0, V) count as blank unless VOICE100_CHECK_IDS=1 (then IndexError, like the reference)."""
 
     @staticmethod
-    def forward(ctx, logits, targets, input_lengths, target_lengths, blank):
+    def forward(ctx, logits, targets, input_lengths, target_lengths, blank, grad_bvt=False):
         _check(logits, "ctc_loss")
         logits = logits.contiguous()
         B, T, V = logits.shape
@@ -1351,11 +1428,14 @@ class CTCLossFn(torch.autograd.Function):
         ws = _f32(nws, like=logits)
         nll = _f32(B, like=logits)
         loss = _f32(1, like=logits)
-        grad = torch.empty_like(logits)
+        # grad_bvt: the gradient buffer is [B, V, T] -- the logits are the transpose of a [B, V, T] tensor (asr.py:114) and that
+        # transpose's backward then returns this buffer as it is (TransposeLast2Fn.backward)
+        grad = _f32(B, V, T, like=logits) if grad_bvt else torch.empty_like(logits)
         # the 'mean' reduction (finite utterances, / target length, / B) and its factor on the gradient happen in the library
-        N.call("v100_ctc_loss_mean", logits, targets, il, tl, ws, nll, loss, grad, B, T, V, lmax, int(blank))
+        N.call("v100_ctc_loss_mean_t", logits, targets, il, tl, ws, nll, loss, grad, int(bool(grad_bvt)), B, T, V, lmax, int(blank))
         ctx.save_for_backward(grad)
         ctx.handed_out = False
+        ctx.grad_bvt = bool(grad_bvt)
         return loss[0]
 
     @staticmethod
@@ -1366,10 +1446,12 @@ class CTCLossFn(torch.autograd.Function):
             # written in place): a second backward through this node (retain_graph=True) can no longer trust it
             raise RuntimeError("ctc_loss: second backward after the unit-root-gradient shortcut handed out the saved gradient; "
                                "call backward() with an explicit gradient tensor (not functional.unit_grad) when retaining the graph")
+        if ctx.grad_bvt:
+            grad = grad.transpose(1, 2)      # [B, T, V] as autograd expects, strided over the [B, V, T] buffer
         if is_unit_grad(gout):           # the root gradient TrainStep hands to backward(): the factor is exactly 1, no pass over grad
             ctx.handed_out = True
-            return grad, None, None, None, None
-        return grad * gout, None, None, None, None
+            return grad, None, None, None, None, None
+        return grad * gout, None, None, None, None, None
 
 
 _UNIT_GRADS = {}
@@ -1405,4 +1487,5 @@ def half_length(lengths: torch.Tensor):
 
 
 def ctc_loss(logits_btv, targets, input_lengths, target_lengths, blank: int = 0):
-    return CTCLossFn.apply(logits_btv, targets, input_lengths, target_lengths, blank)
+    grad_bvt = bool(getattr(logits_btv, "_v100_grad_T", False)) and logits_btv.requires_grad
+    return CTCLossFn.apply(logits_btv, targets, input_lengths, target_lengths, blank, grad_bvt)
