@@ -273,3 +273,15 @@ def test_bench_line_stays_under_3kb():
         assert k in line["roofline"], k
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in line["cpu_baseline"], k
+
+
+def test_trainer_precision_values_of_the_reference_recipes():
+    """`--trainer.precision` as the reference's README passes it (README.md:189, 212, 233, 284: `16`; Lightning's other spellings):
+    16 maps to "bf16" (INTEGRATION.md section 1), anything else Lightning does not know is refused."""
+    from voice100_amd.trainer import resolve_precision
+    for v, want in ((32, "fp32"), ("32", "fp32"), ("32-true", "fp32"), (16, "bf16"), ("16", "bf16"), ("16-mixed", "bf16"),
+                    ("bf16", "bf16"), ("bf16-mixed", "bf16"), ("BF16", "bf16")):
+        assert resolve_precision(v) == want
+    for bad in (64, "fp8", None, "half"):
+        with pytest.raises(ValueError):
+            resolve_precision(bad)

@@ -59,12 +59,32 @@ def launch_ranks(script: str, argv: List[str], nproc: int, timeout: Optional[flo
         raise
 
 
+_PRECISIONS = {"32": "fp32", "32-true": "fp32", "fp32": "fp32",
+               "bf16": "bf16", "bf16-mixed": "bf16",
+               # Lightning's fp16 AMP recipe (README.md:189, 212, 233, 284: `--trainer.precision 16`).  On MI355X the 16-bit matrix rate and
+               # the memory of bf16 and fp16 are the same and bf16 needs no loss scaling: the recipe trains in "bf16" here
+               "16": "bf16", "16-mixed": "bf16"}
+
+
+def resolve_precision(precision) -> str:
+    """The `--trainer.precision` values of the reference's training recipes (pytorch_lightning.Trainer: 32, 16, "bf16", and the
+    "-true" / "-mixed" spellings of later releases) -> this library's matmul precision ("fp32" | "bf16")."""
+    key = str(precision).lower()
+    if key not in _PRECISIONS:
+        raise ValueError(f"precision must be one of 32, 16, 'bf16' (or '32-true', '16-mixed', 'bf16-mixed'), got {precision!r}")
+    return _PRECISIONS[key]
+
+
 class TrainStep:
     """One optimisation step of a module exposing training_step(batch, idx) and configure_optimizers().
     With more than one rank the constructor first copies rank 0's parameters and buffers to every rank (DDP's
-    construction-time broadcast), so replicas cannot start from different weights."""
+    construction-time broadcast), so replicas cannot start from different weights.
+    precision: the reference recipes' `--trainer.precision` (32 | 16 | "bf16"; None = leave functional.set_matmul_precision as it is).
+    16 -- Lightning's fp16 autocast + GradScaler -- runs as "bf16" (same rate and memory here, no loss scaling needed)."""
 
-    def __init__(self, model: torch.nn.Module, bucket_bytes: int = 16 << 20, force_exchange: bool = False):
+    def __init__(self, model: torch.nn.Module, bucket_bytes: int = 16 << 20, force_exchange: bool = False, precision=None):
+        if precision is not None:
+            F_.set_matmul_precision(resolve_precision(precision))
         # force_exchange: run the bucketed all-reduce machinery even in a process group of ONE rank (bench.py's
         # `dp_path_single_rank`: what the data-parallel path costs at full size, measurable without a node)
         self.model = model
