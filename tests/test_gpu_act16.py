@@ -360,6 +360,10 @@ def test_block_act16_wide_shapes(cuda, cin, k, B, T):
     """Level-3 bf16 storage against fp32 storage (both with bf16 GEMM operands) on shapes that reach the kernels the small
     cases do not: 256-row backward-weight tiles with ragged rows and T tails, persistent expand GEMM (512 block tiles), one
     depthwise group with BatchNorm finalised in-kernel, time-stretched (odd) lengths."""
+    _wide_case(cuda, cin, k, B, T)
+
+
+def _wide_case(cuda, cin, k, B, T):
     from voice100_amd import functional as F_
     from voice100_amd.layers import InvertedResidual
     F_.set_matmul_precision("bf16")
@@ -385,6 +389,32 @@ def test_block_act16_wide_shapes(cuda, cin, k, B, T):
     finally:
         F_.set_activation_storage(keep)
         F_.set_matmul_precision("fp32")
+
+
+def _fuzz_seeds(default):
+    import os
+    env = os.environ.get("VOICE100_FUZZ_SEEDS")          # "1 2 3 ...": a wider sweep on demand
+    return [int(v) for v in env.split()] if env else [default]
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(606))
+def test_block_act16_random_shapes(cuda, seed):
+    """The wide-shape comparison above on seeded RANDOM shapes: widths 64 ... 512, every depthwise size of the encoder (and two the
+    streaming kernels do not specialise), batches up to 40, lengths 20 ... 1100 -- whatever row form, pitch, group count and
+    finalisation route the shape selects."""
+    import random
+    rng = random.Random(seed)
+    for _ in range(8):
+        cin = rng.choice([64, 128, 192, 256, 320, 384, 512])
+        k = rng.choice([11, 19, 27, 35, 51, 59, 67, 75, 83, 7, 33])
+        B = rng.choice([2, 3, 5, 8, 16, 33, 40])
+        T = rng.randint(20, 1100)
+        if B * cin * 4 * T > 48 * 2048 * 600:           # keep a case under ~0.25 GB per hidden tensor
+            T = max(20, (48 * 2048 * 600) // (B * cin * 4))
+        try:
+            _wide_case(cuda, cin, k, B, T)
+        except AssertionError as e:
+            raise AssertionError(f"shape (cin={cin}, k={k}, B={B}, T={T}): {e}") from e
 
 
 @pytest.mark.parametrize("cin,k,B,T", [(64, 19, 2, 133), (256, 51, 3, 512), (512, 83, 2, 640), (256, 35, 2, 1023), (128, 7, 4, 77)])

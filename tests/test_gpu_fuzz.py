@@ -1,6 +1,7 @@
 """Seeded random-shape parity sweep of the InvertedResidual block (training fp32: output + all gradients; eval: all
 three operand precisions) against the CPU oracle: specialised and generic kernel sizes, both strides, tiny and ragged
 lengths, channel counts that are not tile multiples."""
+import os
 import random
 import warnings
 
@@ -10,6 +11,12 @@ import torch
 from conftest import rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
+
+# VOICE100_FUZZ_SEEDS="1 2 3 ...": a wider sweep on demand (the default seeds are the ones the suite has always run)
+def _seeds(default):
+    env = os.environ.get("VOICE100_FUZZ_SEEDS")
+    return [int(v) for v in env.split()] if env else [default]
+
 
 KS = [5, 7, 11, 17, 19, 27, 29, 33, 35, 51, 59, 65, 67, 75, 83, 3, 9, 13, 21, 45]
 TS = [2, 3, 7, 8, 15, 16, 31, 33, 64, 100, 129, 255, 256, 257, 511, 513, 700]
@@ -29,10 +36,11 @@ def _block(cin, cout, k, stride, res, stats):
     return m
 
 
-def test_block_training_random_shapes(cuda):
+@pytest.mark.parametrize("seed", _seeds(123))
+def test_block_training_random_shapes(cuda, seed):
     from oracle import cnn
-    rng = random.Random(123)
-    torch.manual_seed(123)
+    rng = random.Random(seed)
+    torch.manual_seed(seed)
     for _ in range(40):
         k, stride = rng.choice(KS), rng.choice([1, 1, 1, 2])
         cin = rng.choice([1, 2, 3, 8, 16, 24])
@@ -65,11 +73,12 @@ def test_block_training_random_shapes(cuda):
         assert (num / max(den, 1e-30)) ** 0.5 < 5e-3, cfg
 
 
-def test_block_eval_random_shapes_all_precisions(cuda):
+@pytest.mark.parametrize("seed", _seeds(321))
+def test_block_eval_random_shapes_all_precisions(cuda, seed):
     from oracle import cnn
     from voice100_amd import functional as F_
-    rng = random.Random(321)
-    torch.manual_seed(321)
+    rng = random.Random(seed)
+    torch.manual_seed(seed)
     for _ in range(40):
         k, stride = rng.choice(KS), rng.choice([1, 1, 2])
         cin = rng.choice([1, 2, 3, 8, 16, 24, 40])
