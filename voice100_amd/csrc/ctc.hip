@@ -9,6 +9,7 @@
 // (log_softmax's backward is the identity here because that expression sums to zero over c) is formed by one
 // wave per frame with LDS float atomics into the <= 128 class bins.
 #include "common.h"
+#include <cstdlib>
 #include <math.h>
 #include <type_traits>
 
@@ -309,15 +310,21 @@ __global__ __launch_bounds__(1024) void ctc_lattice_skew_kernel(const float* __r
 }
 
 // one wave per (b, t): grad[b][t][c] = softmax - exp(lcab + nll - logprob); zero for padded frames / infeasible utterances
-__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
-                                                       const long long* __restrict__ targets, const int* __restrict__ in_len,
-                                                       const int* __restrict__ tgt_len, const float* __restrict__ alpha,
-                                                       const float* __restrict__ beta, float* nll,
-                                                       float* __restrict__ grad, int B, int T, int V, int Lmax, int Smax, int blank,
-                                                       int mean_scale, const int* __restrict__ stall, float* __restrict__ loss, int grad_bvt) {
-    __shared__ float bins[8][CTC_MAXV];       // [0..3]: per-wave class sums; [4..7]: per-wave class references (as unsigned)
+// BVT: the gradient goes out as [B, V, T] -- the layout of the tensor the logits were transposed FROM (asr.py:114), so that transpose's
+// backward is a view instead of a launch.  A wave's 29 values are then T floats apart: written by the wave itself they were 4-byte
+// stores into lines that seven other XCDs' workgroups fill at the same time (24.6 -> 31.5 us); so a workgroup is NW = 16 consecutive
+// frames, the values meet in LDS and each class's 16 frames leave as one 64-byte run.
+template <int NW, bool BVT>
+__global__ __launch_bounds__(64 * NW) void ctc_grad_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                           const long long* __restrict__ targets, const int* __restrict__ in_len,
+                                                           const int* __restrict__ tgt_len, const float* __restrict__ alpha,
+                                                           const float* __restrict__ beta, float* nll,
+                                                           float* __restrict__ grad, int B, int T, int V, int Lmax, int Smax, int blank,
+                                                           int mean_scale, const int* __restrict__ stall, float* __restrict__ loss) {
+    __shared__ float bins[2 * NW][CTC_MAXV];       // [0, NW): per-wave class sums; [NW, 2 NW): per-wave class references (as unsigned)
+    __shared__ float stage[BVT ? NW : 1][BVT ? CTC_MAXV : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long w = (long)blockIdx.x * 4 + wave;
+    const long w = (long)blockIdx.x * NW + wave;
     if (loss && blockIdx.x == 0 && wave == 0) {
         // loss = mean_b( finite(nll_b) ? nll_b / max(len_b, 1) : 0 )   (reduction='mean', zero_infinity=True: only +-inf is zeroed,
         // a NaN -- or a lattice whose pipeline wait hit its bound -- stays visible)
@@ -329,14 +336,11 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         s = wave_sum(s);
         if (lane == 0) loss[0] = s / (float)B;
     }
-    if (w >= (long)B * T) return;
+    const auto frame = [&]() {
     const int b = (int)(w / T), t = (int)(w % T);
-    // grad_bvt: the gradient goes out as [B, V, T] (class c of this frame at g[c * T]) -- the layout of the tensor the logits were
-    // transposed FROM (asr.py:114), so that transpose's backward is a view instead of a launch
-    float* g = grad_bvt ? grad + (size_t)b * V * T + t : grad + ((size_t)b * T + t) * V;
-    const size_t gc = grad_bvt ? (size_t)T : 1;
+    float* g = BVT ? &stage[wave][0] : grad + ((size_t)b * T + t) * V;
     if (stall[b]) {                                   // see ctc_lattice_skew_kernel: poison instead of a silently wrong result
-        for (int c = lane; c < V; c += 64) g[c * gc] = __builtin_nanf("");
+        for (int c = lane; c < V; c += 64) g[c] = __builtin_nanf("");
         if (t == 0 && lane == 0) nll[b] = __builtin_nanf("");
         return;
     }
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     int Tb = in_len[b];
     if (Tb > T) Tb = T;
     if (t >= Tb || !(n < INFINITY)) {                 // padded frame, or zero_infinity
-        for (int c = lane; c < V; c += 64) g[c * gc] = 0.f;
+        for (int c = lane; c < V; c += 64) g[c] = 0.f;
         return;
     }
     int L = tgt_len[b];
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     // gradient 100 % wrong; a diverged model -- the benchmark's own after ~40 steps on noise -- is in that regime at every frame).
     // Now each class has its own reference: dmin[c] = min over its states of (m - (alpha + beta)) (non-negative floats order like their
     // bit patterns: an LDS atomicMin on unsigned), the sums are relative to it, and it goes back into the exponent.
-    unsigned* dmin = reinterpret_cast<unsigned*>(&bins[wave][0]) + 4 * CTC_MAXV;      // (bins is [8][CTC_MAXV]: rows 4 .. 7 hold the references)
+    unsigned* dmin = reinterpret_cast<unsigned*>(&bins[NW + wave][0]);
     for (int c = lane; c < V; c += 64) { bins[wave][c] = 0.f; dmin[c] = 0x7f800000u; }
     float m = NEG_INF;
     for (int s = lane; s < S; s += 64) m = fmaxf(m, al[s] + be[s]);
@@ -396,7 +400,18 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         const float dm = __builtin_bit_cast(float, dmin[c]);
         // log occupancy = (m - dm) + log(acc) + n - lpc, summed so that the two large terms (m - dm ~ -n + lpc) meet first
         const float occ = (acc > 0.f) ? expf(((m - dm) + n - lpc) + logf(acc)) : (acc != acc ? acc : 0.f);
-        g[c * gc] = (expf(lpc) - occ) * gs;
+        g[c] = (expf(lpc) - occ) * gs;
+    }
+    };
+    if (w < (long)B * T) frame();
+    if constexpr (BVT) {
+        __syncthreads();
+        const long w0 = (long)blockIdx.x * NW;
+        for (int i = threadIdx.x; i < V * NW; i += 64 * NW) {
+            const int c = i / NW, j = i % NW;               // frame fastest: NW consecutive lanes write NW consecutive t of one class
+            const long wj = w0 + j;
+            if (wj < (long)B * T) grad[((size_t)(wj / T) * V + c) * T + (wj % T)] = stage[j][c];
+        }
     }
 }
 
@@ -457,7 +472,12 @@ static int ctc_run(const float* logits, const long long* targets, const int* in_
     else if (Smax <= 2048) { CTC_LATTICE(8); }
     else { CTC_LATTICE(16); }
 #undef CTC_LATTICE
-    V100_GGL(ctc_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len,
-                       alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank, loss ? 1 : 0, stall, loss, grad_bvt);     // (the 'mean' reduction rides in block 0)
+    static const int bvt_nw = [] { const char* e = getenv("V100_CTC_BVT_NW"); return e ? atoi(e) : 16; }();      // A/B: frames per workgroup of the [B, V, T] form
+    if (grad_bvt && bvt_nw == 4) V100_GGL((ctc_grad_kernel<4, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len,
+                           alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank, loss ? 1 : 0, stall, loss);
+    else if (grad_bvt) V100_GGL((ctc_grad_kernel<16, true>), dim3((unsigned)((rows + 15) / 16)), dim3(1024), 0, st, logits, lse, targets, in_len, tgt_len,
+                           alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank, loss ? 1 : 0, stall, loss);
+    else V100_GGL((ctc_grad_kernel<4, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, lse, targets, in_len, tgt_len,
+                  alpha, beta, nll, grad, B, T, V, Lmax, Smax, blank, loss ? 1 : 0, stall, loss);     // (the 'mean' reduction rides in block 0)
     return v100_launch_status();
 }

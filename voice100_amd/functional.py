@@ -1454,6 +1454,8 @@ class CTCLossFn(torch.autograd.Function):
         return grad * gout, None, None, None, None, None
 
 
+_CTC_BVT = os.environ.get("VOICE100_CTC_BVT", "1") != "0"      # A/B switch: 0 = the gradient in the logits' own layout + a transpose launch
+
 _UNIT_GRADS = {}
 
 
@@ -1487,5 +1489,5 @@ def half_length(lengths: torch.Tensor):
 
 
 def ctc_loss(logits_btv, targets, input_lengths, target_lengths, blank: int = 0):
-    grad_bvt = bool(getattr(logits_btv, "_v100_grad_T", False)) and logits_btv.requires_grad
+    grad_bvt = bool(getattr(logits_btv, "_v100_grad_T", False)) and logits_btv.requires_grad and _CTC_BVT
     return CTCLossFn.apply(logits_btv, targets, input_lengths, target_lengths, blank, grad_bvt)
