@@ -19,7 +19,7 @@ Families (the keys bench.py's `roofline_step` and DESIGN.md's table use, matched
   bn_pass    block-boundary passes (BatchNorm-3 forward affine + residual, BatchNorm-3 backward)
   bn_fin     BatchNorm finalisers (per-channel vectors only)                 ctc        log-sum-exp, lattice, gradient
   optim      fused Adam + per-step weight preparation (bf16 / transposed copies)
-  edge       model-edge passes: augmentation, [B,T,C] <-> [B,C,T] transposes, dropout, head bias / misc torch elementwise
+  edge       model-edge passes: augmentation (both layouts), the logit transpose, dropout forward, head bias / misc torch elementwise
 """
 import re
 
@@ -50,8 +50,8 @@ def step_rows(B=32, T=1024):
     def add(family, what, nbytes, flops=0.0, launches=1):
         rows.append({"family": family, "what": what, "launches": launches, "bytes": float(nbytes), "flops": float(flops)})
 
-    add("edge", "augmentation (audio.py:52-108): log-mel in, augmented log-mel out", 2 * 4 * B * T * N_MEL)
-    add("edge", "transpose [B,T,64] -> [B,64,T] (asr.py:111)", 2 * 4 * B * T * N_MEL)
+    # round 6: the augmentation pass also writes the [B, 64, T] twin the encoder takes (asr.py:111): no transpose launch
+    add("edge", "augmentation (audio.py:52-108): log-mel in, augmented log-mel out in both layouts ([B,T,64] and [B,64,T], asr.py:111)", 3 * 4 * B * T * N_MEL)
     add("optim", "weight preparation: fp32 weights -> bf16 + transposed bf16 copies (1x1 weights only)", 0)      # filled below
     t = T
     w_pw = 0
@@ -98,12 +98,14 @@ def step_rows(B=32, T=1024):
         t = tout
     # ---- head, loss
     Th = t
-    add("edge", "dropout forward + backward (asr.py:88)", 4 * 4 * B * 512 * Th, launches=2)
+    # round 6: dropout's backward rides in the head's backward-data GEMM (one byte of mask per element there), the CTC gradient is
+    # written in the pre-transpose layout (no backward transpose)
+    add("edge", "dropout forward (asr.py:88): x in, dropped x + byte mask out", (4 + 4 + 1) * B * 512 * Th, launches=1)
     flh = 2.0 * VOCAB * 512 * B * Th
     add("pw_gemm", "vocabulary head forward: [29 x 512] x [512 x T'] + bias", 4 * B * 512 * Th + 4 * B * VOCAB * Th, flh)
-    add("pw_gemm", "vocabulary head backward-data", 4 * B * VOCAB * Th + 4 * B * 512 * Th, flh)
+    add("pw_gemm", "vocabulary head backward-data with the dropout mask in its epilogue", 4 * B * VOCAB * Th + (4 + 1) * B * 512 * Th, flh)
     add("pw_wgrad", "vocabulary head weight gradient", 4 * B * VOCAB * Th + 4 * B * 512 * Th, flh)
-    add("edge", "logit transposes [B,V,T'] <-> [B,T',V] forward + backward (asr.py:114)", 4 * 4 * B * VOCAB * Th, launches=2)
+    add("edge", "logit transpose [B,V,T'] -> [B,T',V] (asr.py:114; its backward is a view of the CTC gradient)", 2 * 4 * B * VOCAB * Th, launches=1)
     S = 2 * TEXT_LEN + 1
     add("ctc", "log-sum-exp per frame, alpha / beta lattices, gradient (asr.py:148-152)",
         4 * B * Th * VOCAB * 3 + 2 * 4 * B * Th * S * 2, launches=3)
