@@ -554,6 +554,10 @@ constexpr int WS_MAXK = 2048;
 template <int XM, int EPI, int IO>
 __global__ __launch_bounds__(768) void pw_gemm_bf16_ws_kernel(PwParams p) {
     static_assert((IO & PW_IO_X) != 0 && (XM != PW_X_AFFINE2 || (IO & PW_IO_X2) != 0), "bf16-stored X operands only");
+    // PW_IO_F16 (inference at precision "fp16"): the stored words ARE the operand format -- the staging waves' decode / re-encode of a
+    // plain X (bf16 -> fp32 -> bf16) is the identity on every finite 16-bit pattern, so only the matrix instruction changes
+    constexpr bool F16 = (IO & PW_IO_F16) != 0;
+    static_assert(!F16 || XM == PW_X_NONE, "fp16 storage: plain X operand only (inference)");
     constexpr int BM = 256;
     constexpr int A_BYTES = BM * 128, X_BYTES = 128 * 128;
     constexpr int SMEM = BM * 128 * 4;                  // stages: A 2 x 32 KB + X 2 x 16 KB; the epilogue's [256][128] fp32 tile = 128 KB
@@ -753,10 +757,10 @@ __global__ __launch_bounds__(768) void pw_gemm_bf16_ws_kernel(PwParams p) {
                 const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ab + rdA0 + 32 * 128 + co);
                 const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + co);
                 const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bb + rdB0 + 32 * 128 + co);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+                acc[0][0] = mfma16<F16>(a0, b0, acc[0][0]);
+                acc[0][1] = mfma16<F16>(a0, b1, acc[0][1]);
+                acc[1][0] = mfma16<F16>(a1, b0, acc[1][0]);
+                acc[1][1] = mfma16<F16>(a1, b1, acc[1][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
             *reinterpret_cast<u32x4*>(Ad + ldsA[ks]) = ra[SG][ks];
@@ -2822,6 +2826,13 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
             else V100_GGL((pw_gemm_bf16_fast_kernel<0, EP, 128, true, false, (IOV)>), grid, dim3(256), 0, st, pb);                  \
             return true;                                                                                                            \
         }
+#if PW_WS
+        // the eval-mode project GEMM (fp16-stored h2 in, fp32 block output): the wave-specialised kernel, as at precision "bf16"
+        if (big16 && (PW_WS & 1) && p.epi_mode == 3 && p.io16 == (PW_IO_X | PW_IO_F16) && (p.K & 63) == 0 && p.K >= PW_WS_MINK && p.K <= WS_MAXK && (p.M & 255) == 0) {
+            V100_GGL((pw_gemm_bf16_ws_kernel<0, 3, (PW_IO_X | PW_IO_F16)>), grid, dim3(768), 0, st, pb);
+            return true;
+        }
+#endif
         XF(2, PW_IO_Y | PW_IO_F16) XF(3, PW_IO_X | PW_IO_F16)
 #undef XF
         return false;
