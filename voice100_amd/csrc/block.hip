@@ -186,9 +186,16 @@ extern "C" int v100_ir_fwd_train(const int* sh, const void* const* P, void* stre
     CK(v100_dwconv(a1, nullptr, wd, s1, t1, nullptr, 1, a2, nullptr, nullptr, nullptr, 0, st, G, B, hid, T, T2, K, S, pad, 0, 1, 0, stream));
     CK(finalize(st, G, (long long)B * T2, 8, s2, t2, m2, r2, hid));
     CK(v100_pw_gemm(w3, w3bf, a2, nullptr, s2, t2, nullptr, 1, a3, nullptr, nullptr, nullptr, nullptr, 1, st, B, cout, hid, T2, bf, stream));
-    CK(finalize(st, parts3, (long long)B * T2, 14, s3, t3, m3, r3, cout));
     // a block that itself keeps fp32 storage (the stride-2 first layer) still emits the shadow its successor reads: the caller
-    // passes P[27] only in bf16 precision at act16 level 4 (26 / 27 are not read otherwise)
+    // passes P[27] only in bf16 precision at act16 level 4 (26 / 27 are not read otherwise) -- and, like the 16-bit blocks, lets that
+    // pass finalise BatchNorm 3 itself (one launch fewer per step)
+    if (IR_FUSE_BN3 && !frozen && bf == 1 && (sh[IR_PREPPED] & 2) && P[27]) {
+        const DwPre pre{{1, (double)B * T2, (const float*)P[14], (const float*)P[15], nullptr, s3, t3, nullptr, m3, r3,
+                         (float*)P[16], (float*)P[17], (long long*)P[18], kMom, kEps}, st, parts3};
+        CK(chan_affine2_fin(a3, res ? x : nullptr, y, const_cast<void*>(P[27]), B, cout, T2, 0, pre, stream, 0));
+        return V100_OK;
+    }
+    CK(finalize(st, parts3, (long long)B * T2, 14, s3, t3, m3, r3, cout));
     if (bf == 1 && (sh[IR_PREPPED] & 2) && P[27]) CK(v100_chan_affine2_shadow(a3, res ? x : nullptr, s3, t3, y, const_cast<void*>(P[27]), B, cout, T2, 0, stream));
     else CK(v100_chan_affine2(a3, res ? x : nullptr, s3, nullptr, t3, y, B, cout, T2, stream));
     return V100_OK;
