@@ -196,9 +196,10 @@ def _bf(t):
 
 @pytest.mark.parametrize("B,C,T,K", [(2, 8, 48, 19), (3, 6, 133, 83), (2, 4, 700, 51), (5, 12, 512, 5), (2, 4, 1100, 35), (2, 3, 260, 27)])
 def test_dwconv_io_variants(cuda, B, C, T, K):
-    """Depthwise kernels with 16-bit storage.  In this mode the conv's data operand is a bf16 tensor by definition (as under
+    """Depthwise kernels with 16-bit storage.  In this mode the conv's operands are bf16 tensors by definition (as under
     autocast): the transformed input relu6(bn1(a1)) -- and in backward the BN2-backward affine g' and xin -- are rounded once
-    to bf16, taps and accumulation stay fp32.  Reference: torch on exactly those rounded operands (fp32 accumulate)."""
+    to bf16, and so are the taps (round 6: one digit, what F.conv1d sees under bf16 autocast; V100_DW_DIGITS=3 restores fp32-exact
+    taps); accumulation stays fp32.  Reference: torch on exactly those rounded operands (fp32 accumulate)."""
     import torch.nn.functional as F
     N = _native()
     g = torch.Generator().manual_seed(C * 7 + T + K)
@@ -206,18 +207,18 @@ def test_dwconv_io_variants(cuda, B, C, T, K):
     a1 = (torch.randn(B, C, T, generator=g) * 2).to(cuda)
     a116, a1r = to16(a1)
     w = (torch.randn(C, K, generator=g) * 0.2).to(cuda)
+    wq = _bf(w)                                                   # the taps as the kernels use them
     s1, t1 = torch.rand(C, generator=g).to(cuda) + 0.5, torch.randn(C, generator=g).to(cuda)
     G = N.helper("v100_dw_num_groups", B, C)
     pre = a1r * s1[None, :, None] + t1[None, :, None]
     xin = _bf(torch.clamp(pre, 0, 6))
     # forward: bf16 in, bf16 out, BN2 partial sums from the fp32 accumulators
-    ref = F.conv1d(xin, w[:, None, :], padding=pad, groups=C)
+    ref = F.conv1d(xin, wq[:, None, :], padding=pad, groups=C)
     y1 = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda)
     st1 = torch.zeros(G, C, 2, device=cuda)
     N.call("v100_dwconv_fwd_train_io", a116, w, s1, t1, y1, st1, G, B, C, T, K, DX | DY)
     assert rel_err(from16(y1, T), ref) < 6e-3                     # one bf16 rounding of the stored output
     assert float((from16(y1, T) - _bf(ref)).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())    # ... and nothing more
-    # (taps carry two bf16 digits in this mode: 2^-16 relative)
     assert rel_err(st1.sum(0)[:, 0], ref.sum((0, 2))) < 5e-5 and rel_err(st1.sum(0)[:, 1], (ref * ref).sum((0, 2))) < 5e-5
     # fused backward: dz2 fp32 | bf16, a2 bf16, a1 bf16 -> dz1 fp32 | bf16, BN1-backward sums, dW
     dz2 = torch.randn(B, C, T, generator=g).to(cuda)
@@ -227,7 +228,7 @@ def test_dwconv_io_variants(cuda, B, C, T, K):
     ga, gb, gc = torch.rand(C, generator=g).to(cuda) + 0.5, (torch.randn(C, generator=g) * 0.3).to(cuda), (torch.randn(C, generator=g) * 0.1).to(cuda)
     for mask, dzin16, dzref in ((DX2 | DAUX, dz2, dz2), (DX | DX2 | DAUX | DY, dz216, dz2r)):
         gp = _bf(ga[None, :, None] * dzref + gb[None, :, None] * a2r + gc[None, :, None])
-        xv, wv = xin.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        xv, wv = xin.clone().requires_grad_(True), wq.clone().requires_grad_(True)
         (F.conv1d(xv, wv[:, None, :], padding=pad, groups=C) * gp).sum().backward()
         dz1r = xv.grad * ((pre > 0) & (pre < 6))
         s0r, s1r = dz1r.sum((0, 2)), (dz1r * a1r).sum((0, 2))

@@ -231,7 +231,8 @@ def test_chan_passes_io_vs_float64(cuda, B, C, T):
                                      (1, 1, 5, 7), (2, 3, 8, 5), (4, 2, 1, 5), (7, 5, 257, 11), (33, 2, 40, 17)])      # tiny / degenerate rows, B > 32
 def test_dwconv_io_vs_float64(cuda, B, C, T, K):
     """Depthwise forward / fused backward with 16-bit storage (asr.py:49 and its autograd), elementwise against float64 on the
-    operands as the kernels define them (transformed data operand rounded once to bf16, fp32 taps)."""
+    operands as the kernels define them (transformed data operand and taps rounded once to bf16 -- F.conv1d under bf16 autocast;
+    V100_DW_DIGITS=3 restores fp32-exact taps)."""
     import torch.nn.functional as F
     N = _native()
     DX, DX2, DAUX, DY = 1, 2, 4, 8
@@ -244,7 +245,8 @@ def test_dwconv_io_vs_float64(cuda, B, C, T, K):
     G = N.helper("v100_dw_num_groups", B, C)
     pre = fma32(a1s, col(s1), col(t1))
     xin = bf(torch.clamp(pre, 0, 6).float()).double()
-    ref = F.conv1d(xin, w.double()[:, None, :], padding=pad, groups=C)
+    wq = bf(w).double()                                       # the taps as the kernels use them
+    ref = F.conv1d(xin, wq[:, None, :], padding=pad, groups=C)
     y = torch.full((B, C, pitch(T, B)), float("nan"), dtype=torch.bfloat16, device=cuda)
     st = torch.zeros(G, C, 2, device=cuda)
     N.call("v100_dwconv_fwd_train_io", a116, w, s1, t1, y, st, G, B, C, T, K, DX | DY)
@@ -256,7 +258,7 @@ def test_dwconv_io_vs_float64(cuda, B, C, T, K):
     a216, a2s = store16(rnd(B, C, T))
     ga, gb, gc = torch.rand(C, generator=g).to(cuda) + 0.5, rnd(C) * 0.3, rnd(C) * 0.1
     gp = bf(affine2(dz2s, a2s, ga, gb, gc).float()).double()
-    xv, wv = xin.clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+    xv, wv = xin.clone().requires_grad_(True), bf(w).double().clone().requires_grad_(True)
     (F.conv1d(xv, wv[:, None, :], padding=pad, groups=C) * gp).sum().backward()
     mask = ((pre > 0) & (pre < 6)).double()
     edge = torch.zeros_like(mask, dtype=torch.bool)          # pre is the kernel's own fmaf: no kink ambiguity
@@ -297,7 +299,7 @@ def test_dwconv_bwd_da1_vs_float64(cuda, B, C, T, K):
     a216, a2s = store16(rnd(B, C, T))
     ga, gb, gc = torch.rand(C, generator=g).to(cuda) + 0.5, rnd(C) * 0.3, rnd(C) * 0.1
     gp = bf(affine2(dz2s, a2s, ga, gb, gc).float()).double()
-    xv, wv = xin.clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+    xv, wv = xin.clone().requires_grad_(True), bf(w).double().clone().requires_grad_(True)
     (F.conv1d(xv, wv[:, None, :], padding=pad, groups=C) * gp).sum().backward()
     mask = ((pre > 0) & (pre < 6)).double()
     dz1r = xv.grad * mask

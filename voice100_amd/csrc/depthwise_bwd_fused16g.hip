@@ -56,7 +56,7 @@ bool dw_launch_bwd_fused16g(const DwParams& p, hipStream_t st, const V100TimedLa
     } while (0)
 #define X(KK)                                                                                                                     \
     if (p.K == KK) {                                                                                                              \
-        if (cfg.digits3) GO(KK, 3); else GO(KK, 2);                                                                               \
+        if (cfg.digits3) GO(KK, 3); else GO(KK, DW_DIGITS16);                                                                               \
         return true;                                                                                                              \
     }
         V100_DW_SPECIALISED(X)

@@ -532,8 +532,14 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwParams p) {
 // Stride-1 layers with a specialised kernel size run on the Toeplitz-MFMA kernels (round 3: the register-window VALU kernels they
 // replaced are no longer instantiated for those sizes -- they remain for the stride-2 opener and, as dwconv_generic_kernel, for
 // everything else).  Precision knob, read once: V100_DW_DIGITS = 2 | 3 bf16 digits per fp32 tap / sample (default 3: fp32-exact
-// products).  With 16-bit activation storage the taps default to TWO digits (16 mantissa bits against data rounded to 8):
-// V100_DW_DIGITS=3 restores the third.
+// products).  With 16-bit activation storage the taps default to DW_DIGITS16 (below).
+// Round 6: with 16-bit activation storage the taps are ONE digit by default -- rounded to bf16 (fp16 at precision "fp16") like the data
+// operand, which is what F.conv1d computes under the reference's 16-bit autocast (its weights are cast with its input); the second
+// digit bought nothing the rounded data could show and cost a second pass over the matrix pipe per Toeplitz block (step -0.9 %, the
+// depthwise family +0.02 of 8 TB/s, and power: profiles/r06_dw_digits_ab.txt).  V100_DW_DIGITS=3 restores fp32-exact taps.
+#ifndef DW_DIGITS16
+#define DW_DIGITS16 1
+#endif
 struct DwPathConfig { int digits; bool digits3; };
 static inline DwPathConfig dw_path_config() {
     static const DwPathConfig cfg = [] {
@@ -562,8 +568,13 @@ static bool dw_launch_specialised(const DwParams& p, hipStream_t st, const V100T
         if (p.stride == 1 && p.upsample == 1) {
 #define X(KK)                                                                                                           \
     if (p.K == KK) {                                                                                                    \
-        if (cfg.digits == 2 || (IO != 0 && !cfg.digits3)) V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 2, WG, IO>), grid, dim3(256), 0, st, p); \
-        else V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 3, WG, IO>), grid, dim3(256), 0, st, p);                  \
+        if constexpr (IO != 0) {                                                                                        \
+            if (!cfg.digits3) V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, DW_DIGITS16, WG, IO>), grid, dim3(256), 0, st, p); \
+            else V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 3, WG, IO>), grid, dim3(256), 0, st, p);              \
+        } else {                                                                                                        \
+            if (cfg.digits == 2) V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 2, WG, IO>), grid, dim3(256), 0, st, p); \
+            else V100_LAUNCH(tl, (dwconv_mfma_kernel<KK, IM, OM, 3, WG, IO>), grid, dim3(256), 0, st, p);              \
+        }                                                                                                               \
         return true;                                                                                                    \
     }
             V100_DW_SPECIALISED(X)

@@ -19,8 +19,8 @@ bool dw_launch_fwd_eval16(const DwParams& p, hipStream_t st, const V100TimedLaun
         // two fp16 digits per tap: 22 mantissa bits, far below the fp16 rounding of the stored activations
 #define X(KK)                                                                                                                           \
     if (p.K == KK) {                                                                                                                    \
-        if (p.Tin <= 512) V100_LAUNCH(tl, (dwconv_fwd16_stream_kernel<KK, 2, DWS_DEPTH, DWS_NT * 2, 2, true, true>), grid, dim3(256), 0, st, p);  \
-        else V100_LAUNCH(tl, (dwconv_fwd16_stream_kernel<KK, 2, DWS_DEPTH, DWS_NT * 2, 3, true, true>), grid, dim3(256), 0, st, p);         \
+        if (p.Tin <= 512) V100_LAUNCH(tl, (dwconv_fwd16_stream_kernel<KK, DW_DIGITS16, DWS_DEPTH, DWS_NT * 2, 2, true, true>), grid, dim3(256), 0, st, p);  \
+        else V100_LAUNCH(tl, (dwconv_fwd16_stream_kernel<KK, DW_DIGITS16, DWS_DEPTH, DWS_NT * 2, 3, true, true>), grid, dim3(256), 0, st, p);         \
         return true;                                                                                                                    \
     }
         V100_DW_SPECIALISED(X)
@@ -37,7 +37,7 @@ bool dw_launch_fwd_eval16(const DwParams& p, hipStream_t st, const V100TimedLaun
     } while (0)
 #define X(KK)                                                                                                                           \
     if (p.K == KK) {                                                                                                                    \
-        if (cfg.digits3) GO(KK, 3); else GO(KK, 2);                                                                                     \
+        if (cfg.digits3) GO(KK, 3); else GO(KK, DW_DIGITS16);                                                                                     \
         return true;                                                                                                                    \
     }
         V100_DW_SPECIALISED(X)

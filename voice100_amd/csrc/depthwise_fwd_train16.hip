@@ -32,7 +32,7 @@ bool dw_launch_fwd_train16(const DwParams& p, hipStream_t st, const V100TimedLau
     } while (0)
 #define X(KK)                                                                                                                     \
     if (p.K == KK) {                                                                                                              \
-        if (cfg.digits3) GO(KK, 3); else GO(KK, 2);                                                                               \
+        if (cfg.digits3) GO(KK, 3); else GO(KK, DW_DIGITS16);                                                                               \
         return true;                                                                                                              \
     }
         V100_DW_SPECIALISED(X)

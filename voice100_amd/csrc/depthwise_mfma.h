@@ -119,6 +119,14 @@ __device__ __forceinline__ unsigned dwm_pack_rne(float lo, float hi) {
     const dwm_f32x2 f = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f, dwm_bf16x2));
 }
+// the NT digits of a TAP: NT >= 2 the exact truncation split; NT == 1 (16-bit activation storage, round 6) the tap ROUNDED to bf16 to
+// nearest-even -- a truncated single digit would shrink every tap by 2^-9 on average, a gain error BatchNorm hides but a float64
+// check does not; rounded it is the operand F.conv1d sees under bf16 autocast
+template <int NT>
+__device__ __forceinline__ void dwm_split_taps(float v, unsigned (&d)[3]) {
+    if constexpr (NT == 1) { d[0] = dwm_pack_rne(v, 0.f) << 16; d[1] = 0u; d[2] = 0u; }
+    else dwm_split(v, d);
+}
 // two digits (high halves of lo / hi) -> one dword of two bf16
 __device__ __forceinline__ unsigned dwm_pack(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
@@ -207,8 +215,8 @@ __global__ __launch_bounds__(256, WG ? 3 : 4) void dwconv_mfma_kernel(DwParams p
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
             unsigned d0[3], d1[3];
-            dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp - n_ - off], d0);
-            dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp + 1 - n_ - off], d1);
+            dwm_split_taps<NT>(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp - n_ - off], d0);
+            dwm_split_taps<NT>(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp + 1 - n_ - off], d1);
 #pragma unroll
             for (int t = 0; t < NT; ++t) pk[t][jp] = dwm_pack(d0[t], d1[t]);
         }

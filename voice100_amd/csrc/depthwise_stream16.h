@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256, (NS == 2 && !EV) ? DWS_FWD_MINW : 4) void dwco
 #pragma unroll
                 for (int t = 0; t < NT; ++t) pk[t][jp] = d0[t] | (d1[t] << 16);
             } else {
-                dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp - n_ - off], d0);
-                dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp + 1 - n_ - off], d1);
+                dwm_split_taps<NT>(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp - n_ - off], d0);
+                dwm_split_taps<NT>(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp + 1 - n_ - off], d1);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) pk[t][jp] = dwm_pack(d0[t], d1[t]);
             }
@@ -462,8 +462,8 @@ __global__ __launch_bounds__(256, (DA1 && DWS_DA1_KEEP && NS == 2 && K > DWS_DA1
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
             unsigned d0[3], d1[3];
-            dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp - n_ - off], d0);
-            dwm_split(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp + 1 - n_ - off], d1);
+            dwm_split_taps<NT>(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp - n_ - off], d0);
+            dwm_split_taps<NT>(lds_w[WPAD + 32 * s + 8 * q_ + 2 * jp + 1 - n_ - off], d1);
 #pragma unroll
             for (int t = 0; t < NT; ++t) pk[t][jp] = dwm_pack(d0[t], d1[t]);
         }
