@@ -43,11 +43,27 @@ def test_stack_equals_blocks(cuda, precision, level):
             ref = _run(net, x, gy, "blocks")
             for seg in (None, 2, 1):
                 got = _run(net, x, gy, "stack", seg)
-                assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (T, seg)
-                for k in ref[2]:
-                    assert torch.equal(got[2][k], ref[2][k]), (T, seg, k)
+                # level 5 inside ONE stack call: the gradient between two capable residual blocks travels as bf16 (round 6) -- here
+                # between the last two blocks when they share a call; forward results and statistics stay bit-equal, gradients agree
+                # to the rounding of that one tensor.  Everything else: the same kernels in the same order, bit for bit.
+                g16 = level == 5 and seg is None          # (segments of 2: blocks 3 and 4 land in different calls)
+                assert torch.equal(got[0], ref[0]), (T, seg)
                 for k in ref[3]:
                     assert torch.equal(got[3][k], ref[3][k]), (T, seg, k)
+                if not g16:
+                    assert torch.equal(got[1], ref[1]), (T, seg)
+                    for k in ref[2]:
+                        assert torch.equal(got[2][k], ref[2][k]), (T, seg, k)
+                else:
+                    assert not torch.equal(got[1], ref[1])                               # the stream really is rounded
+                    assert float((got[1] - ref[1]).norm() / ref[1].norm()) < 1e-2, (T, seg)
+                    # (per parameter a BatchNorm bias gradient -- a sum over B T values of mixed sign -- amplifies the rounding by its
+                    # own cancellation: the bar is on all gradients together)
+                    num = sum(float((got[2][k].double() - ref[2][k].double()).pow(2).sum()) for k in ref[2])
+                    den = sum(float(ref[2][k].double().pow(2).sum()) for k in ref[2])
+                    assert (num / den) ** 0.5 < 1e-2, (T, seg, (num / den) ** 0.5)
+                    k_last = [k for k in ref[2] if k.startswith("4.")]                   # the last block's own gradients: upstream of the rounding
+                    assert all(torch.equal(got[2][k], ref[2][k]) for k in k_last)
     finally:
         F_.set_activation_storage(keep)
         F_.set_matmul_precision("fp32")

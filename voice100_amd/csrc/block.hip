@@ -252,6 +252,9 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
                 *m2 = coef + 6 * mc, *r2 = coef + 7 * mc, *m3 = coef + 10 * mc, *r3 = coef + 11 * mc;
     const float* dy = (const float*)P[11];
     float* dx = (float*)P[12];
+    // PREPPED bits 4 / 5 (set by the stack executor only, ir_grad16_ok): dy arrives / dx leaves as bf16 [B][C][pitch16(T)] -- the
+    // gradient stream between the blocks of a stack in the 16-bit form its forward stream has at level 5
+    const int dy16 = (sh[IR_PREPPED] & 16) ? 1 : 0, dx16 = (sh[IR_PREPPED] & 32) ? 1 : 0;
     IrBwdWs w;
     ir_bwd_carve(sh, const_cast<void*>(P[22]), w);
     float *pp = w.pqr, *qq = w.pqr + mc, *rr = w.pqr + 2 * mc;
@@ -269,11 +272,13 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
     if (a316 && IR_FUSE_BN3) {     // one workgroup per channel sums (dy, dy * a3) and finalises BatchNorm 3's backward itself ...
         const DwFin fin{2, (double)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], nullptr, nullptr, nullptr, 0.f, 0.f};
         // ... and, when the channel's samples fit its registers, applies the affine to them in the same launch
-        if (IR_FUSE_BN3 >= 2 && chan_bn3_bwd(dy, a3, w.part, w.da3, B, cout, T2, fin, stream)) {
+        if (IR_FUSE_BN3 >= 2 && chan_bn3_bwd(dy, a3, w.part, w.da3, B, cout, T2, fin, stream, dy16)) {
             if ((rc = v100_launch_status()) != V100_OK) return rc;
             da3_done = true;
-        } else CK(chan_reduce2_io_fin(dy, a3, w.part, B, cout, T2, fin, stream));
+        } else if (dy16) return V100_ERR_SHAPE;           // (the stack executor asks for a 16-bit dy only where the one-pass kernel applies)
+        else CK(chan_reduce2_io_fin(dy, a3, w.part, B, cout, T2, fin, stream));
     } else {
+        if (dy16) return V100_ERR_SHAPE;
         if (a316) CK(v100_chan_reduce2_io(dy, a3, w.part, Gr, B, cout, T2, 2, stream));
         else CK(v100_chan_reduce2(dy, a3, w.part, Gr, B, cout, T2, stream));
         CK(bwd_finalize(w.part, Gr, (long long)B * T2, g3, m3, r3, pp, qq, rr, (float*)P[20], (float*)P[21], cout, stream));
@@ -317,11 +322,13 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
         if (da1) {
             CK(v100_pw_wgrad_io(w.dz1, nullptr, nullptr, nullptr, nullptr, 0, x16 ? x16 : (const void*)x, nullptr, nullptr, 0, w.slab, (float*)P[13],
                                 v100_pw_wgrad_splits(B, hid, cin), B, hid, cin, T, WG_IO_G | (x16 ? WG_IO_X : 0), stream));
+            if ((dy16 || dx16) && !res) return V100_ERR_SHAPE;       // the 16-bit gradient stream runs through residual blocks only
             if (dx)
                 CK(v100_pw_gemm_io(pw.w1tbf, w.dz1, nullptr, nullptr, nullptr, nullptr, 0, dx, nullptr, nullptr, res ? dy : nullptr, res ? 5 : 0, nullptr,
-                                   B, cin, hid, T, PW_IO_X, stream));
+                                   B, cin, hid, T, PW_IO_X | (dy16 ? PW_IO_R : 0) | (dx16 ? PW_IO_Y : 0), stream));
             return V100_OK;
         }
+        if (dy16 || dx16) return V100_ERR_SHAPE;
         CK(v100_pw_wgrad_io(w.dz1, a1, pp, qq, rr, 2, x16 ? x16 : (const void*)x, nullptr, nullptr, 0, w.slab, (float*)P[13], v100_pw_wgrad_splits(B, hid, cin),
                             B, hid, cin, T, WG_IO_G2 | (g16 ? WG_IO_G : 0) | (x16 ? WG_IO_X : 0), stream));
         if (dx)
@@ -329,6 +336,7 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
                                B, cin, hid, T, PW_IO_X2 | (g16 ? PW_IO_X : 0), stream));
         return V100_OK;
     }
+    if (dy16 || dx16) return V100_ERR_SHAPE;
     // pw-linear: weight grad, then data grad through ReLU6 with BN2-backward sums
     CK(v100_pw_wgrad(w.da3, nullptr, nullptr, nullptr, nullptr, 0, a2, s2, t2, 1, w.slab, (float*)P[19], v100_pw_wgrad_splits(B, cout, hid),
                      B, cout, hid, T2, bf, stream));
@@ -670,8 +678,25 @@ extern "C" int v100_ir_stack_bwd(const int* desc, const void* const* params, con
     size_t goff = gf;
     const void* dyi = dy;
     int rc;
+    // Round 6: at level 5 the GRADIENT stream between two blocks is bf16 too (what autograd hands back for a bf16 residual stream under
+    // the reference's autocast) wherever both sides can take it: the producer a residual block on the finished-gradient path (its
+    // expand backward-data GEMM adds dy and stores dx through the 16-bit epilogue), the consumer a block whose one-pass BatchNorm-3
+    // backward covers the shape.  Half the bytes of the three passes that touch it (dx store, dy in BatchNorm-3 backward, dy as the
+    // residual gradient).  V100_IR_GRAD16=0: the fp32 stream (A/B).
+    static const bool grad16_on = [] { const char* e = getenv("V100_IR_GRAD16"); return !(e && e[0] == '0'); }();
+    auto grad16_ok = [&](int i) {                          // block i can consume a 16-bit dy AND produce a 16-bit dx
+        const int* sh = blk[i].sh;
+        return grad16_on && desc[ST_LEVEL] >= 5 && sh[IR_ACT16] >= 3 && sh[IR_RES] && sh[IR_STRIDE] == 1 && sh[IR_CIN] == sh[IR_COUT] && sh[IR_T] >= 8 &&
+               IR_FUSE_BN3 >= 2 && chan_bn3_bwd_fits(sh[IR_B], sh[IR_T]) && v100_ir_act16_supported(sh) &&
+               dw_bwd_da1_supported(sh[IR_B], sh[IR_HID], sh[IR_T], sh[IR_K], v100_dw_num_groups(sh[IR_B], sh[IR_HID])) && sh[IR_ACT16] >= 2;
+    };
+    bool dy_is16 = false;
     for (int i = n - 1; i >= 0; --i) {
-        const StackBlock& b = blk[i];
+        StackBlock b = blk[i];
+        // dx of block i is dy of block i - 1: 16-bit when both are capable residual blocks
+        const bool dx_is16 = i > 0 && grad16_ok(i) && grad16_ok(i - 1);
+        if (dy_is16 && !grad16_ok(i)) return V100_ERR_SHAPE;      // (cannot happen: dy_is16 was decided with this block's capability)
+        b.sh[IR_PREPPED] |= (dy_is16 ? 16 : 0) | (dx_is16 ? 32 : 0);
         goff -= b.grad_floats;
         float* g = (float*)grads + goff;
         const int cin = b.sh[IR_CIN], hid = b.sh[IR_HID], cout = b.sh[IR_COUT], k = b.sh[IR_K];
@@ -690,6 +715,7 @@ extern "C" int v100_ir_stack_bwd(const int* desc, const void* const* params, con
         P[24] = i > 0 ? (blk[i - 1].y16 >= 0 ? (const void*)(base + blk[i - 1].y16) : nullptr) : x16;
         CK(v100_ir_bwd(b.sh, P, stream));
         dyi = dxi;
+        dy_is16 = dx_is16;
     }
     return V100_OK;
 }

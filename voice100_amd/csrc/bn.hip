@@ -240,9 +240,10 @@ __global__ __launch_bounds__(1024) void chan_reduce2_fin_kernel(const void* __re
 // The whole BatchNorm-3 backward of a block in ONE pass over (dy, a3): the channel's B x T samples of both tensors stay in the
 // registers of its 1024-thread workgroup between the reduction (sum dy, sum dy*a3 -> p, q, r, dgamma, dbeta) and the affine
 // da3 = p*dy + q*a3 + r (bf16, pitched) that the two-kernel form re-read from memory.  NQ float4-quads per thread: B * ceil(T/4)
-// <= 1024 * NQ (the caller checks).  u = dy fp32, v = a3 bf16 (pitched), out = da3 bf16 (pitched).
-template <int NQ>
-__global__ __launch_bounds__(1024) void chan_bn3_bwd_kernel(const float* __restrict__ u, const void* __restrict__ v, float* __restrict__ partial,
+// <= 1024 * NQ (the caller checks).  u = dy fp32 -- or bf16 (pitched) when U16: the gradient stream between the blocks of a stack in its
+// 16-bit form (round 6, block.hip) --, v = a3 bf16 (pitched), out = da3 bf16 (pitched).
+template <int NQ, bool U16 = false>
+__global__ __launch_bounds__(1024) void chan_bn3_bwd_kernel(const void* __restrict__ u, const void* __restrict__ v, float* __restrict__ partial,
                                                             void* __restrict__ out, int B, int C, int T, DwFin fin) {
     __shared__ float red[16][2];
     __shared__ float coef[3];
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(1024) void chan_bn3_bwd_kernel(const float* __restr
         if (i < n) {
             const int b = i / T4, t = (i - b * T4) * 4;
             const size_t row = (size_t)b * C + c;
-            chan_load4<false>(u, row, T, P, t, a[k]);
+            chan_load4<U16>(u, row, T, P, t, a[k]);
             chan_load4<true>(v, row, T, P, t, w[k]);
         } else {
 #pragma unroll
@@ -671,11 +672,13 @@ int chan_affine2_fin(const void* u, const void* v, float* out, void* shadow, int
 }
 
 // block executor: BatchNorm-3 backward in one pass (sums, coefficients, da3); 0 = shape not covered (more than 8 quads per thread)
-int chan_bn3_bwd(const float* u, const void* v, float* partial, void* out, int B, int C, int T, const DwFin& fin, void* stream) {
+int chan_bn3_bwd_fits(int B, int T) { return (long)B * ((T + 3) / 4) <= 1024 * 8; }
+int chan_bn3_bwd(const void* u, const void* v, float* partial, void* out, int B, int C, int T, const DwFin& fin, void* stream, int u_bf16) {
     if (!u || !v || !partial || !out || fin.mode != 2) return 0;
     const long n = (long)B * ((T + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-#define CB3(NQ_) V100_GGL(chan_bn3_bwd_kernel<NQ_>, dim3(C), dim3(1024), 0, st, u, v, partial, out, B, C, T, fin)
+#define CB3(NQ_) do { if (u_bf16) V100_GGL((chan_bn3_bwd_kernel<NQ_, true>), dim3(C), dim3(1024), 0, st, u, v, partial, out, B, C, T, fin); \
+                      else V100_GGL((chan_bn3_bwd_kernel<NQ_, false>), dim3(C), dim3(1024), 0, st, u, v, partial, out, B, C, T, fin); } while (0)
     if (n <= 1024 * 2) CB3(2);
     else if (n <= 1024 * 4) CB3(4);
     else if (n <= 1024 * 6) CB3(6);

@@ -200,7 +200,8 @@ __device__ __forceinline__ void dw_pre_finish(const DwPre& pre, int c, int lane,
 
 int chan_affine2_fin(const void* u, const void* v, float* out, void* shadow, int B, int C, int T, int u_bf16, const DwPre& pre, void* stream,
                      int v_bf16 = 0);   // bn.hip
-int chan_bn3_bwd(const float* u, const void* v, float* partial, void* out, int B, int C, int T, const DwFin& fin, void* stream);   // bn.hip; 0 = not covered
+int chan_bn3_bwd(const void* u, const void* v, float* partial, void* out, int B, int C, int T, const DwFin& fin, void* stream, int u_bf16 = 0);   // bn.hip; 0 = not covered
+int chan_bn3_bwd_fits(int B, int T);     // 1 when chan_bn3_bwd covers the shape
 int chan_reduce2_io_fin(const void* u, const void* v, float* partial, int B, int C, int T, const DwFin& fin, void* stream);   // bn.hip
 // the act16 entry points with in-kernel BatchNorm finalisation (block executor; fin.mode != 0 requires G == 1)
 int dw_fwd_train_io_fin(const void* a1, const float* w, const float* in_a, const float* in_b, void* a2, float* stats, int G, int B, int C,

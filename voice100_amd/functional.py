@@ -60,7 +60,10 @@ def set_activation_storage(level: int) -> None:
     its gradient; 4: plus a bf16 shadow of every block output beside the fp32 tensor, which the next block's expand GEMM and
     expand weight gradient load as their X operand (bf16 precision only; block inputs / outputs themselves stay fp32 up to here);
     5: the forward residual stream of a stack in ONE 16-bit form -- a block's residual is read from that bf16 copy and interior blocks
-    of a stack do not write the fp32 copy of their output at all (what the reference's bf16 autocast run keeps; gradients stay fp32)."""
+    of a stack do not write the fp32 copy of their output at all (what the reference's bf16 autocast run keeps) -- and, since round 6,
+    the GRADIENT between two residual blocks of one stack call travels as bf16 too where both sides run the finished-gradient kernels
+    (what autograd hands back for a bf16 stream; V100_IR_GRAD16=0 keeps it fp32).  Weight gradients, statistics and the gradients
+    entering and leaving a stack stay fp32."""
     global _ACT16
     if level not in (0, 1, 2, 3, 4, 5):
         raise ValueError("activation storage level must be 0 ... 5")
