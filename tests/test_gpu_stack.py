@@ -287,10 +287,15 @@ def test_finished_gradient_path_is_bit_identical(cuda, tmp_path):
     script = tmp_path / "da1.py"
     script.write_text(_DA1_SCRIPT)
     res = {}
-    for v in ("1", "0"):
-        env = dict(os.environ, V100_IR_DA1=v)
-        subprocess.run([sys.executable, str(script), root, str(tmp_path / f"out{v}.pt")], check=True, env=env, timeout=600)
-        res[v] = torch.load(tmp_path / f"out{v}.pt")
-    for T in res["1"]:
-        for a, b in zip(res["1"][T], res["0"][T]):
+    # (the 16-bit gradient stream between blocks, round 6, exists on the finished-gradient path only: held off in both children so
+    # that the comparison isolates the da1 path; the third child has it on and is compared within the rounding of those tensors)
+    for v, g16 in (("1", "0"), ("0", "0"), ("1", "1")):
+        env = dict(os.environ, V100_IR_DA1=v, V100_IR_GRAD16=g16)
+        subprocess.run([sys.executable, str(script), root, str(tmp_path / f"out{v}{g16}.pt")], check=True, env=env, timeout=600)
+        res[v + g16] = torch.load(tmp_path / f"out{v}{g16}.pt")
+    for T in res["10"]:
+        for a, b in zip(res["10"][T], res["00"][T]):
             assert torch.equal(a, b), T
+        num = sum(float((a.double() - b.double()).pow(2).sum()) for a, b in zip(res["11"][T], res["10"][T]))
+        den = sum(float(b.double().pow(2).sum()) for b in res["10"][T])
+        assert (num / den) ** 0.5 < 1e-2, (T, (num / den) ** 0.5)

@@ -322,10 +322,9 @@ extern "C" int v100_ir_bwd(const int* sh, const void* const* P, void* stream) {
         if (da1) {
             CK(v100_pw_wgrad_io(w.dz1, nullptr, nullptr, nullptr, nullptr, 0, x16 ? x16 : (const void*)x, nullptr, nullptr, 0, w.slab, (float*)P[13],
                                 v100_pw_wgrad_splits(B, hid, cin), B, hid, cin, T, WG_IO_G | (x16 ? WG_IO_X : 0), stream));
-            if ((dy16 || dx16) && !res) return V100_ERR_SHAPE;       // the 16-bit gradient stream runs through residual blocks only
             if (dx)
                 CK(v100_pw_gemm_io(pw.w1tbf, w.dz1, nullptr, nullptr, nullptr, nullptr, 0, dx, nullptr, nullptr, res ? dy : nullptr, res ? 5 : 0, nullptr,
-                                   B, cin, hid, T, PW_IO_X | (dy16 ? PW_IO_R : 0) | (dx16 ? PW_IO_Y : 0), stream));
+                                   B, cin, hid, T, PW_IO_X | ((dy16 && res) ? PW_IO_R : 0) | (dx16 ? PW_IO_Y : 0), stream));
             return V100_OK;
         }
         if (dy16 || dx16) return V100_ERR_SHAPE;
@@ -679,21 +678,21 @@ extern "C" int v100_ir_stack_bwd(const int* desc, const void* const* params, con
     const void* dyi = dy;
     int rc;
     // Round 6: at level 5 the GRADIENT stream between two blocks is bf16 too (what autograd hands back for a bf16 residual stream under
-    // the reference's autocast) wherever both sides can take it: the producer a residual block on the finished-gradient path (its
-    // expand backward-data GEMM adds dy and stores dx through the 16-bit epilogue), the consumer a block whose one-pass BatchNorm-3
-    // backward covers the shape.  Half the bytes of the three passes that touch it (dx store, dy in BatchNorm-3 backward, dy as the
+    // the reference's autocast) wherever both sides can take it: the producer a block on the finished-gradient path (its expand
+    // backward-data GEMM adds dy, if it has a residual, and stores dx through the 16-bit epilogue), the consumer a block whose one-pass
+    // BatchNorm-3 backward covers the shape.  Half the bytes of the three passes that touch it (dx store, dy in BatchNorm-3 backward, dy as the
     // residual gradient).  V100_IR_GRAD16=0: the fp32 stream (A/B).
     static const bool grad16_on = [] { const char* e = getenv("V100_IR_GRAD16"); return !(e && e[0] == '0'); }();
     auto grad16_ok = [&](int i) {                          // block i can consume a 16-bit dy AND produce a 16-bit dx
         const int* sh = blk[i].sh;
-        return grad16_on && desc[ST_LEVEL] >= 5 && sh[IR_ACT16] >= 3 && sh[IR_RES] && sh[IR_STRIDE] == 1 && sh[IR_CIN] == sh[IR_COUT] && sh[IR_T] >= 8 &&
+        return grad16_on && desc[ST_LEVEL] >= 5 && sh[IR_ACT16] >= 3 && sh[IR_STRIDE] == 1 && sh[IR_T] >= 8 &&
                IR_FUSE_BN3 >= 2 && chan_bn3_bwd_fits(sh[IR_B], sh[IR_T]) && v100_ir_act16_supported(sh) &&
                dw_bwd_da1_supported(sh[IR_B], sh[IR_HID], sh[IR_T], sh[IR_K], v100_dw_num_groups(sh[IR_B], sh[IR_HID])) && sh[IR_ACT16] >= 2;
     };
     bool dy_is16 = false;
     for (int i = n - 1; i >= 0; --i) {
         StackBlock b = blk[i];
-        // dx of block i is dy of block i - 1: 16-bit when both are capable residual blocks
+        // dx of block i is dy of block i - 1: 16-bit when both are capable blocks (with or without a residual)
         const bool dx_is16 = i > 0 && grad16_ok(i) && grad16_ok(i - 1);
         if (dy_is16 && !grad16_ok(i)) return V100_ERR_SHAPE;      // (cannot happen: dy_is16 was decided with this block's capability)
         b.sh[IR_PREPPED] |= (dy_is16 ? 16 : 0) | (dx_is16 ? 32 : 0);

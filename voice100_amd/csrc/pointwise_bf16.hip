@@ -2894,7 +2894,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     XS(0, 1, PW_IO_X | PW_IO_Y)                                         // expand forward on the bf16 shadow
     XS(0, 3, PW_IO_X)                                                   // eval-mode project (K = the hidden width): y = bn3(W3 h2) (+ x)
     XS(0, 5, PW_IO_X) XS(0, 0, PW_IO_X)                                 // expand backward-data on the finished gradient da1 (round 5): plain bf16 X, fp32 dx (+ dy)
-    XS(0, 5, PW_IO_X | PW_IO_R | PW_IO_Y) XS(0, 5, PW_IO_X | PW_IO_Y) XS(0, 5, PW_IO_X | PW_IO_R)     // ... with the gradient stream between blocks in bf16 (round 6): dy in and / or dx out
+    XS(0, 5, PW_IO_X | PW_IO_R | PW_IO_Y) XS(0, 5, PW_IO_X | PW_IO_Y) XS(0, 5, PW_IO_X | PW_IO_R) XS(0, 0, PW_IO_X | PW_IO_Y)     // ... with the gradient stream between blocks in bf16 (round 6): dy in and / or dx out
 #undef XS
 #endif
 #if PW_PERSIST
@@ -2937,7 +2937,7 @@ bool pw_launch_gemm_bf16_io(const PwParams& p, hipStream_t st) {
     X(0, 2, PW_IO_Y)                      // eval-mode expand: h1 = relu6(bn1(W1 x)) stored as bf16 (inference, block executor)
     X(0, 3, PW_IO_X)                      // eval-mode project: y = bn3(W3 h2) (+ x), h2 bf16 in
     X(0, 5, PW_IO_X) X(0, 0, PW_IO_X)     // expand backward-data on da1 (plain bf16 X), fp32 out (+ residual gradient)
-    X(0, 5, PW_IO_X | PW_IO_R | PW_IO_Y) X(0, 5, PW_IO_X | PW_IO_Y) X(0, 5, PW_IO_X | PW_IO_R)     // ... bf16 residual gradient in / bf16 dx out (the stack's 16-bit gradient stream)
+    X(0, 5, PW_IO_X | PW_IO_R | PW_IO_Y) X(0, 5, PW_IO_X | PW_IO_Y) X(0, 5, PW_IO_X | PW_IO_R) X(0, 0, PW_IO_X | PW_IO_Y)     // ... bf16 residual gradient in / bf16 dx out (the stack's 16-bit gradient stream)
 #undef X
     return false;
 }
