@@ -78,7 +78,11 @@ def step_rows(B=32, T=1024):
         add("bn_fin", f"{L} BatchNorm finalisers forward (BN1, BN3; BN2 inside the depthwise kernel at >= 1024 channels)",
             parts_i * hid * 8 + parts_o * cout * 8 + 16 * (hid + cout), launches=2)
         # ---- backward
-        dy = B * cout * tout * 4                       # gradients between blocks stay fp32
+        # round 6: the gradient between two stride-1 blocks of the stack is bf16 (block.hip, v100_ir_stack_bwd); the gradient entering the
+        # stack (last block) and the opener's stay fp32
+        dy16 = 1 <= i <= len(SPEC) - 2
+        dx16 = 2 <= i <= len(SPEC) - 1
+        dy = B * cout * (pitch16(tout) * 2 if dy16 else tout * 4)
         add("bn_pass", f"{L} BatchNorm-3 backward: dy, a3 -> da3 (sums + affine in one launch)", dy + 2 * B * cout * Po * e)
         S3, S1 = wgrad_splits(B, cout, hid), wgrad_splits(B, hid, cin)
         add("pw_wgrad", f"{L} project weight gradient: da3, a2 -> dW3 (through {S3} partial slabs)", B * cout * Po * e + B * hid * Po * e + cout * hid * 4, fl3)
@@ -92,7 +96,7 @@ def step_rows(B=32, T=1024):
         add("slab", f"{L} dW1 slab reduction ({S1} slabs written + read: {(2 * S1) * hid * cin * 4 / 1e6:.0f} MB, not algorithmic)", 0)
         if i > 0:                                      # the first block's input gradient is not needed (the audio is a leaf without grad)
             add("pw_gemm", f"{L} expand backward-data: dz1, a1 (affine), W1^T (, dy) -> dx",
-                2 * B * hid * Pi * e + hid * cin * 2 + B * cin * t * 4 * (2 if res else 1), fl1)
+                2 * B * hid * Pi * e + hid * cin * 2 + B * cin * (pitch16(t) * 2 if dx16 else t * 4) + (dy if res else 0), fl1)
         add("bn_fin", f"{L} BatchNorm finalisers backward (BN2 from the GEMM slab; BN1 inside the depthwise kernel)",
             parts_o * hid * 8 + 24 * hid, launches=1)
         t = tout
